@@ -1,0 +1,109 @@
+/* libocrhip — C ABI of the MI355X (gfx950) CRNN-OCR hot path.
+ *
+ * Conventions (the same ones baidu warp-ctc's `compute_ctc_loss` uses, which is the only FFI the reference
+ * itself crosses — /root/reference/lib/networks/network.py:6,653-654):
+ *   - every pointer is a caller-owned DEVICE pointer (HBM) unless stated otherwise; the library keeps no state,
+ *     allocates nothing and never synchronises; all work is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - return value is an int status: 0 ok, 1 memory-op failed, 2 invalid argument, 3 launch failed
+ *     (warp-ctc's ctcStatus_t numbering); no exceptions, no torch types;
+ *   - "bf16" buffers hold raw bfloat16 bits (uint16_t); activations use the reference layout [N, W, H, C]
+ *     (image width W = time is TF's "height" axis, the 32-pixel feature axis H is TF's "width": gen.py:63-64).
+ *
+ * Each entry point cites the reference line whose computation it replaces.
+ */
+#ifndef OCR_HIP_H
+#define OCR_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { OCR_STATUS_OK = 0, OCR_STATUS_MEMOPS = 1, OCR_STATUS_INVALID = 2, OCR_STATUS_EXEC = 3 };
+
+/* epilogue flags of the GEMM / implicit-GEMM convolution engine */
+enum {
+    OCR_EPI_BIAS = 1, OCR_EPI_RELU = 2, OCR_EPI_OUT_F32 = 4, /* 8 reserved (split-K atomics, set internally) */
+    OCR_EPI_MASK = 16, OCR_EPI_ROWSWAP = 32, OCR_EPI_ACCUM = 64
+};
+
+const char* ocr_status_string(int status);           /* warp-ctc: ctcGetStatusString */
+int ocr_abi_version(void);
+
+/* ---- CTC (replaces warpctc_tensorflow.ctc, network.py:653-654; warp-ctc get_workspace_size/compute_ctc_loss) */
+int ocr_ctc_workspace_size(int max_label_len, int max_time, int minibatch, size_t* bytes);
+/* activations/gradients: f32 [max_time, minibatch, alphabet_size], unnormalised; gradients may be NULL (score only).
+ * flat_labels / label_lengths / input_lengths are DEVICE int32 arrays (warp-ctc's GPU path takes them from the host;
+ * keeping them in HBM removes the per-step host sync of train.py:130).  costs: f32 [minibatch]. */
+int ocr_ctc_loss(const float* activations, float* gradients, const int* flat_labels, const int* label_lengths,
+                 const int* input_lengths, int alphabet_size, int minibatch, int max_time, int max_label_len,
+                 int blank_label, float* costs, void* workspace, void* stream);
+/* best-path decode (argmax, collapse repeats, drop blank): the greedy counterpart of
+ * tf.nn.ctc_beam_search_decoder + sparse_tensor_to_dense(default 0) at network.py:656-657 / test.py:30-31.
+ * decoded: int32 [minibatch, max_time] padded with pad_value; decoded_lengths: int32 [minibatch]. */
+int ocr_ctc_greedy_decode(const float* activations, const int* input_lengths, int alphabet_size, int minibatch,
+                          int max_time, int blank_label, int pad_value, int* decoded, int* decoded_lengths,
+                          void* stream);
+
+/* ---- dense contractions (tf.nn.conv2d network.py:166, tf.matmul :126, LSTMCell matmul :104-107) ------------- */
+/* out[m][n] = sum_k P[m][k] * Q[n][k] (+bias[n]) ; bf16 operands, fp32 accumulate, K % 8 == 0, N % 4 == 0.
+ * physical P row = m + (m / row_group) * row_skip when row_group > 0 (conv5's overlapping 2x2 VALID windows). */
+int ocr_gemm_nt_bf16(const void* P, long ldp, const void* Q, long ldq, void* out, long ldo, int M, int N, int K,
+                     const float* bias, const void* mask, long ldmask, int flags, int splits, int row_group,
+                     int row_skip, int swap_inner, int swap_outer, void* stream);
+/* 3x3 SAME stride-1 convolution, x bf16 [Nb,W,H,Cin], wpack bf16 [Cout][3][3][Cin], y [Nb,W,H,Cout]
+ * (conv_single network.py:160-191; also its data gradient with flipped/transposed weights) */
+int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int Nb, int W, int H, int Cin, int Cout,
+                     const float* bias, const void* mask, int flags, void* stream);
+/* out[I][ldo] (f32) += scale * A^T B, A bf16 [Mk][lda], B bf16 [Mk][ldb]  (weight gradients of matmul layers) */
+int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* out, long ldo, int Mk, int I, int J,
+                     int row_group, int row_skip, long a_row_off, float scale, int splits, void* stream);
+/* dw f32 [3][3][Cin][Cout] (TF HWIO) += conv weight gradient */
+int ocr_conv3x3_wgrad_bf16(const void* x, const void* dy, float* dw, int Nb, int W, int H, int Cin, int Cout,
+                           int splits, void* stream);
+
+/* ---- conv1 (Cin = 1), pooling, batch-norm, reductions, packing (network.py:160-191, 343-350, 176-178) -------- */
+int ocr_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int Nb, int W, int H, int Cout,
+                  int relu, void* stream);
+int ocr_conv1_wgrad(const float* x, const void* dz, float* dw, float* db, int Nb, int W, int H, int Cout,
+                    void* stream);
+int ocr_maxpool_fwd(const void* x, void* y, int Nb, int W, int H, int C, int kw, int kh, void* stream);
+int ocr_maxpool_bwd(const void* x, const void* dy, void* dx, int Nb, int W, int H, int C, int kw, int kh,
+                    int relu_mask, void* stream);
+int ocr_bn_train_fwd(const void* x, void* y, const float* gamma, const float* beta, float* save_mean,
+                     float* save_rstd, long M, int C, float eps, int relu, void* workspace, void* stream);
+int ocr_bn_train_bwd(const void* x, const void* y, const void* dy, void* dx, const float* gamma,
+                     const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, long M, int C,
+                     int relu, void* workspace, void* stream);
+int ocr_colsum_bf16(const void* a, float* out, long M, int C, long lda, void* stream);
+int ocr_pack_transpose(const float* in, void* out, int R, int Cc, long ldin, int lstm_units, void* stream);
+int ocr_pack_conv_dgrad(const float* w, void* out, int Cin, int Cout, void* stream);
+int ocr_cast_f32_bf16(const float* in, void* out, long n, void* stream);
+int ocr_cast2d_f32_bf16(const float* in, long ldin, void* out, long ldout, int rows, int cols, void* stream);
+int ocr_tnc_to_ntc_bf16(const float* in, void* out, int T, int N, int C, float scale, void* stream);
+int ocr_conv5_col2im(const void* col, void* dx, int Nb, int W, int HC, void* stream);
+
+/* ---- bidirectional LSTM (bi_lstm network.py:97-129; TF-1.0 LSTMCell gate order i,j,f,o, forget_bias 1.0) ----- */
+int ocr_lstm_fwd_step(const float* xproj, const void* whT_packed, const int* seq_len, void* hout, float* gates,
+                      float* cell, int Nb, int T, int U, int step, float forget_bias, void* stream);
+int ocr_lstm_bwd_step(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
+                      const float* gates, const float* cell, void* dz, float* dc_state, int Nb, int T, int U,
+                      int step, void* stream);
+int ocr_lstm_hprev(const void* hout, const int* seq_len, void* hprev, int Nb, int T, int U, void* stream);
+int ocr_lstm_pack_bias(const float* b_fw, const float* b_bw, float* out, int U, void* stream);
+
+/* ---- optimiser (train.py:73-85: clip_by_global_norm 10.0 + Adam / Momentum / RMSProp; L2 of network.py:630-637) */
+int ocr_optim_init(void* scalars /* 8 doubles */, double lr, void* stream);
+int ocr_optim_set_lr(void* scalars, double lr, int multiply, void* stream);
+int ocr_optim_step(float* params, float* grads, float* state1, float* state2, long n, long n_reg,
+                   float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
+                   void* scalars, void* stream);
+
+/* ---- device probes used by the test-suite (not part of the hot path) ------------------------------------------ */
+/* ds_read_b64_tr_b16 lane-semantics probe: LDS holds shorts 0..8191 (value = element index); lane l reads at
+ * byte offset addr[l]; out[l*4+j] = element j returned to lane l. */
+int ocr_probe_tr16(const int* addr /* 64 */, int* out /* 64*4 */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,100 @@
+"""ctypes binding of libocrhip.so — the only way the Python host reaches the GPU kernels.
+
+There is deliberately NO fallback: if the shared library is missing or a call returns a non-zero status the
+caller gets an exception.  Pointers are raw device addresses (``tensor.data_ptr()``), the stream is the raw
+``hipStream_t`` of torch's current stream, exactly what a C/C++ caller of include/ocr_hip.h would pass.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libocrhip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ocr_hip.h")
+
+EPI_BIAS, EPI_RELU, EPI_OUT_F32, EPI_MASK, EPI_ROWSWAP, EPI_ACCUM = 1, 2, 4, 16, 32, 64
+
+_P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
+
+_SIGS = {
+    "ocr_abi_version": ([], _I),
+    "ocr_status_string": ([_I], ctypes.c_char_p),
+    "ocr_ctc_workspace_size": ([_I, _I, _I, ctypes.POINTER(ctypes.c_size_t)], _I),
+    "ocr_ctc_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P], _I),
+    "ocr_ctc_greedy_decode": ([_P, _P, _I, _I, _I, _I, _I, _P, _P, _P], _I),
+    "ocr_gemm_nt_bf16": ([_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P], _I),
+    "ocr_conv3x3_bf16": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P], _I),
+    "ocr_gemm_tn_bf16": ([_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _L, _F, _I, _P], _I),
+    "ocr_conv3x3_wgrad_bf16": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
+    "ocr_conv1_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
+    "ocr_conv1_wgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "ocr_maxpool_fwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
+    "ocr_maxpool_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "ocr_bn_train_fwd": ([_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P, _P], _I),
+    "ocr_bn_train_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P], _I),
+    "ocr_colsum_bf16": ([_P, _P, _L, _I, _L, _P], _I),
+    "ocr_pack_transpose": ([_P, _P, _I, _I, _L, _I, _P], _I),
+    "ocr_pack_conv_dgrad": ([_P, _P, _I, _I, _P], _I),
+    "ocr_cast_f32_bf16": ([_P, _P, _L, _P], _I),
+    "ocr_cast2d_f32_bf16": ([_P, _L, _P, _L, _I, _I, _P], _I),
+    "ocr_tnc_to_ntc_bf16": ([_P, _P, _I, _I, _I, _F, _P], _I),
+    "ocr_conv5_col2im": ([_P, _P, _I, _I, _I, _P], _I),
+    "ocr_lstm_fwd_step": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P], _I),
+    "ocr_lstm_bwd_step": ([_P, _L, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "ocr_lstm_hprev": ([_P, _P, _P, _I, _I, _I, _P], _I),
+    "ocr_lstm_pack_bias": ([_P, _P, _P, _I, _P], _I),
+    "ocr_optim_init": ([_P, _D, _P], _I),
+    "ocr_optim_set_lr": ([_P, _D, _I, _P], _I),
+    "ocr_optim_step": ([_P, _P, _P, _P, _L, _L, _F, _F, _I, _F, _F, _F, _P, _P], _I),
+    "ocr_probe_tr16": ([_P, _P, _P], _I),
+}
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def declared_symbols(header=HEADER_PATH):
+    """Entry points declared by include/ocr_hip.h (used by the no-GPU export test)."""
+    text = open(header).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ocr_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                "libocrhip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU/eager fallback for the hot path)" % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGS.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+    return _lib
+
+
+def status_string(code):
+    return lib().ocr_status_string(code).decode()
+
+
+def call(name, *args):
+    """Invoke an int-status entry point; raise on a non-zero status."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise NativeError("%s failed: status %d (%s)" % (name, rc, status_string(rc)))
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / None -> NULL."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

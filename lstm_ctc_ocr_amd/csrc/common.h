@@ -1,0 +1,58 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) CRNN-OCR kernels.
+// Everything in this directory is written for wave64 / MFMA / 160 KiB LDS only;
+// there is deliberately no other backend.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define OCR_WAVE 64
+
+// Status codes mirror warp-ctc's ctcStatus_t numbering (0 ok, 1 memops, 2 invalid
+// value, 3 execution failed) so a caller written against that ABI keeps working.
+enum {
+    OCR_OK = 0,
+    OCR_ERR_MEMOPS = 1,
+    OCR_ERR_INVALID = 2,
+    OCR_ERR_EXEC = 3,
+};
+
+#define OCR_CHECK_LAUNCH()                                        \
+    do {                                                          \
+        hipError_t e__ = hipGetLastError();                       \
+        if (e__ != hipSuccess) return OCR_ERR_EXEC;               \
+    } while (0)
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits in HBM
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// round-to-nearest-even fp32 -> bf16 (same rule as torch's .to(bfloat16)); NaN kept quiet.
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__host__ __device__ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

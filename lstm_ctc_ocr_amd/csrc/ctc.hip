@@ -1,0 +1,310 @@
+// CTC loss + gradient and greedy decode for gfx950: one 64-lane wavefront per sample.
+//
+// Replaces the un-vendored baidu warp-ctc kernels the reference reaches through
+// `warpctc_tensorflow.ctc(...)` (reference lib/networks/network.py:653-654) and the best-path
+// part of the decode at network.py:656-657 / lib/lstm/test.py:30-31.
+//
+// Semantics (SURVEY.md Appendix A "CTC (warp-ctc)"):
+//   y = softmax_C(act[t,n,:]);  l' = [b,l1,b,...,lL,b], S = 2L+1, b = blank_label
+//   cost_n = -log p(l|x);  d cost/d act[t,n,k] = y[t,n,k] - sum_{s: l'_s = k} gamma_t(s)
+//   for t < input_length, 0 beyond;  infeasible (L + repeats > T) => cost 0, grad 0.
+//
+// Mapping: lane s (+64*v) owns extended-label slot s; the alpha row lives in LDS so the
+// s-1 / s-2 neighbours are one ds_read away; a single wave per workgroup means the
+// step-to-step barrier is free. alpha[T][S] is parked in a caller-owned workspace in HBM
+// (L2-resident at these sizes); beta is consumed on the fly while the gradient row is
+// produced with all 64 lanes striding the class axis (one coalesced 256-B row at C = 64).
+#include "common.h"
+#include <math.h>
+
+#define NEG_INF (-INFINITY)
+
+__device__ __forceinline__ float lse2(float a, float b) {
+    float m = fmaxf(a, b);
+    if (m == NEG_INF) return NEG_INF;
+    return m + logf(expf(a - m) + expf(b - m));
+}
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+    float m = fmaxf(fmaxf(a, b), c);
+    if (m == NEG_INF) return NEG_INF;
+    return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+// VT = extended-label slots per lane (S <= 64*VT).
+template <int VT>
+__global__ __launch_bounds__(64) void ctc_loss_grad_kernel(
+    const float* __restrict__ act,      // [T, N, C] unnormalised
+    float* __restrict__ grad,           // [T, N, C] or nullptr
+    const int* __restrict__ flat_labels,
+    const int* __restrict__ label_off,  // [N] exclusive prefix sum of label_lengths
+    const int* __restrict__ label_len,  // [N]
+    const int* __restrict__ input_len,  // [N]
+    int T, int N, int C, int blank,
+    float* __restrict__ costs,          // [N]
+    float* __restrict__ ws,             // workspace: per sample T*(SMAX+1) floats
+    int SMAX) {
+    const int n = blockIdx.x;
+    const int lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // LDS carve-up: row[2][SMAX+2] (ping-pong alpha/beta rows, 2 guard slots in front),
+    //               acc[C] (posterior per class), lab[SMAX] (extended labels as int)
+    float* rowbuf = smem;                              // 2*(SMAX+2)
+    float* acc = rowbuf + 2 * (SMAX + 2);              // C
+    int* lab = (int*)(acc + C);                        // SMAX
+
+    const int L = label_len[n];
+    const int Tn = min(input_len[n], T);
+    const int S = 2 * L + 1;
+    const int* labels = flat_labels + label_off[n];
+    float* alpha_ws = ws + (size_t)n * T * (SMAX + 1);   // alpha[t][s]; slot SMAX of row t = lse[t]
+    const size_t tstride = (size_t)N * C;
+    const float* a_n = act + (size_t)n * C;
+    float* g_n = grad ? grad + (size_t)n * C : nullptr;
+
+    // zero-fill the gradient of frames this sample does not own (t >= Tn)
+    if (g_n) {
+        for (int t = Tn; t < T; ++t)
+            for (int k = lane; k < C; k += 64) g_n[t * tstride + k] = 0.f;
+    }
+
+    // extended labels + repeat count
+    int repeats = 0;
+    for (int s = lane; s < S; s += 64) {
+        int v = (s & 1) ? labels[s >> 1] : blank;
+        lab[s] = v;
+        if ((s & 1) && s >= 3 && labels[s >> 1] == labels[(s >> 1) - 1]) repeats++;
+    }
+    repeats = (int)wave_sum((float)repeats);
+    __syncthreads();
+
+    if (L + repeats > Tn || Tn <= 0) {   // infeasible alignment: warp-ctc reports cost 0, grad 0
+        if (lane == 0) costs[n] = 0.f;
+        if (g_n)
+            for (int t = 0; t < Tn; ++t)
+                for (int k = lane; k < C; k += 64) g_n[t * tstride + k] = 0.f;
+        return;
+    }
+
+    // ---- pass 1: log-sum-exp of every frame (softmax denominator), parked at alpha_ws[t][SMAX]
+    for (int t = 0; t < Tn; ++t) {
+        const float* row = a_n + t * tstride;
+        float m = NEG_INF;
+        for (int k = lane; k < C; k += 64) m = fmaxf(m, row[k]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int k = lane; k < C; k += 64) sum += expf(row[k] - m);
+        sum = wave_sum(sum);
+        if (lane == 0) alpha_ws[(size_t)t * (SMAX + 1) + SMAX] = m + logf(sum);
+    }
+    __syncthreads();
+
+    // per-slot constants
+    int my_lab[VT];
+    bool skip_fwd[VT], skip_bwd[VT];
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+        int s = lane + 64 * v;
+        my_lab[v] = (s < S) ? lab[s] : blank;
+        skip_fwd[v] = (s < S) && (s >= 2) && (my_lab[v] != blank) && (my_lab[v] != lab[s - 2]);
+        skip_bwd[v] = (s + 2 < S) && (lab[s + 2] != blank) && (lab[s + 2] != my_lab[v]);
+    }
+
+    // ---- pass 2: alpha recursion, rows kept in the workspace
+    float* cur = rowbuf + 2;                 // cur[-1], cur[-2] are guard slots (= -inf)
+    float* nxt = rowbuf + (SMAX + 2) + 2;
+    if (lane < 2) { cur[-1 - lane] = NEG_INF; nxt[-1 - lane] = NEG_INF; }
+    {
+        float lse0 = alpha_ws[SMAX];
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            int s = lane + 64 * v;
+            if (s < S) {
+                float a0 = (s < 2) ? (a_n[my_lab[v]] - lse0) : NEG_INF;
+                cur[s] = a0;
+                alpha_ws[s] = a0;
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = 1; t < Tn; ++t) {
+        const float* row = a_n + t * tstride;
+        float lse_t = alpha_ws[(size_t)t * (SMAX + 1) + SMAX];
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            int s = lane + 64 * v;
+            if (s < S) {
+                float p0 = cur[s], p1 = cur[s - 1];
+                float p2 = skip_fwd[v] ? cur[s - 2] : NEG_INF;
+                float a = lse3(p0, p1, p2);
+                if (a != NEG_INF) a += row[my_lab[v]] - lse_t;
+                nxt[s] = a;
+                alpha_ws[(size_t)t * (SMAX + 1) + s] = a;
+            }
+        }
+        __syncthreads();
+        float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    // log p(l|x)
+    float logp;
+    {
+        float e1 = cur[S - 1];
+        float e2 = (S >= 2) ? cur[S - 2] : NEG_INF;
+        logp = lse2(e1, e2);
+    }
+    if (lane == 0) costs[n] = -logp;
+    if (!g_n) return;
+    __syncthreads();
+
+    // ---- pass 3: beta recursion fused with the gradient rows (t = Tn-1 .. 0)
+    // rows here carry 2 guard slots BEHIND the data (s = S, S+1) instead of in front
+    float* bcur = rowbuf;
+    float* bnxt = rowbuf + (SMAX + 2);
+    for (int t = Tn - 1; t >= 0; --t) {
+        const float* row = a_n + t * tstride;
+        float lse_t = alpha_ws[(size_t)t * (SMAX + 1) + SMAX];
+        for (int k = lane; k < C; k += 64) acc[k] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            int s = lane + 64 * v;
+            if (s < S) {
+                float ly = row[my_lab[v]] - lse_t;
+                float b;
+                if (t == Tn - 1) {
+                    b = (s >= S - 2) ? ly : NEG_INF;
+                } else {
+                    float q0 = bcur[s];
+                    float q1 = (s + 1 < S) ? bcur[s + 1] : NEG_INF;
+                    float q2 = skip_bwd[v] ? bcur[s + 2] : NEG_INF;
+                    b = lse3(q0, q1, q2);
+                    if (b != NEG_INF) b += ly;
+                }
+                bnxt[s] = b;
+                float al = alpha_ws[(size_t)t * (SMAX + 1) + s];
+                if (al != NEG_INF && b != NEG_INF) {
+                    float gamma = expf(al + b - ly - logp);   // posterior of (t, s), <= 1
+                    atomicAdd(&acc[my_lab[v]], gamma);
+                }
+            }
+        }
+        __syncthreads();
+        float* grow = g_n + t * tstride;
+        for (int k = lane; k < C; k += 64) grow[k] = expf(row[k] - lse_t) - acc[k];
+        float* tmp = bcur; bcur = bnxt; bnxt = tmp;
+        __syncthreads();
+    }
+}
+
+// Greedy (best-path) decode: per frame argmax (lowest index wins ties, like numpy.argmax),
+// collapse repeats, drop `blank`. Output is dense [N, T] padded with `pad_value`, plus lengths.
+__global__ __launch_bounds__(64) void ctc_greedy_kernel(
+    const float* __restrict__ act, const int* __restrict__ input_len, int T, int N, int C,
+    int blank, int pad_value, int* __restrict__ out, int* __restrict__ out_len) {
+    const int n = blockIdx.x;
+    const int lane = threadIdx.x;
+    __shared__ int am[64];
+    const int Tn = min(input_len[n], T);
+    int* o = out + (size_t)n * T;
+    int prev = -1;
+    int count = 0;
+    for (int t0 = 0; t0 < Tn; t0 += 64) {
+        int tcnt = min(64, Tn - t0);
+        for (int tt = 0; tt < tcnt; ++tt) {
+            const float* row = act + ((size_t)(t0 + tt) * N + n) * C;
+            float bv = NEG_INF;
+            int bi = 0x7fffffff;
+            for (int k = lane; k < C; k += 64) {
+                float v = row[k];
+                if (v > bv) { bv = v; bi = k; }   // strict > keeps the lowest index per lane
+            }
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) {
+                float ov = __shfl_xor(bv, o2, 64);
+                int oi = __shfl_xor(bi, o2, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (lane == 0) am[tt] = bi;
+        }
+        __syncthreads();
+        int a = (lane < tcnt) ? am[lane] : blank;
+        int before = __shfl_up(a, 1, 64);
+        if (lane == 0) before = prev;
+        bool keep = (lane < tcnt) && (a != blank) && (a != before);
+        unsigned long long mask = __ballot(keep);
+        int pos = __popcll(mask & ((1ull << lane) - 1ull));
+        if (keep) o[count + pos] = a;
+        count += __popcll(mask);
+        prev = am[tcnt - 1];
+        __syncthreads();
+    }
+    for (int j = count + lane; j < T; j += 64) o[j] = pad_value;
+    if (lane == 0) out_len[n] = count;
+}
+
+__global__ void exclusive_scan_small(const int* __restrict__ in, int* __restrict__ out, int n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int s = 0;
+        for (int i = 0; i < n; ++i) { out[i] = s; s += in[i]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI (declared in include/ocr_hip.h)
+// ------------------------------------------------------------------------------------------
+static inline int smax_for(int max_label_len) { return 2 * max_label_len + 1; }
+
+extern "C" int ocr_ctc_workspace_size(int max_label_len, int max_time, int minibatch,
+                                      size_t* bytes) {
+    if (!bytes || max_label_len < 0 || max_time <= 0 || minibatch <= 0) return OCR_ERR_INVALID;
+    size_t smax = (size_t)smax_for(max_label_len);
+    // alpha rows (+1 slot per row for the frame log-sum-exp) + label offsets
+    *bytes = (size_t)minibatch * max_time * (smax + 1) * sizeof(float) +
+             (size_t)minibatch * sizeof(int);
+    *bytes = (*bytes + 255) & ~(size_t)255;
+    return OCR_OK;
+}
+
+extern "C" int ocr_ctc_loss(const float* activations, float* gradients, const int* flat_labels,
+                            const int* label_lengths, const int* input_lengths,
+                            int alphabet_size, int minibatch, int max_time, int max_label_len,
+                            int blank_label, float* costs, void* workspace, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!activations || !flat_labels || !label_lengths || !input_lengths || !costs || !workspace)
+        return OCR_ERR_INVALID;
+    if (alphabet_size <= 0 || minibatch <= 0 || max_time <= 0 || max_label_len < 0 ||
+        blank_label < 0 || blank_label >= alphabet_size)
+        return OCR_ERR_INVALID;
+    const int SMAX = smax_for(max_label_len);
+    if (SMAX > 256) return OCR_ERR_INVALID;   // 4 slots per lane is the largest instantiation
+    float* ws = (float*)workspace;
+    int* label_off = (int*)(ws + (size_t)minibatch * max_time * (SMAX + 1));
+    exclusive_scan_small<<<1, 64, 0, stream>>>(label_lengths, label_off, minibatch);
+    OCR_CHECK_LAUNCH();
+    size_t lds = (size_t)(2 * (SMAX + 2) + alphabet_size) * sizeof(float) + (size_t)SMAX * sizeof(int);
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) return OCR_ERR_INVALID;
+#define LAUNCH_CTC(VT)                                                                         \
+    ctc_loss_grad_kernel<VT><<<minibatch, 64, lds, stream>>>(                                  \
+        activations, gradients, flat_labels, label_off, label_lengths, input_lengths, max_time, \
+        minibatch, alphabet_size, blank_label, costs, ws, SMAX)
+    if (SMAX <= 64) LAUNCH_CTC(1);
+    else if (SMAX <= 128) LAUNCH_CTC(2);
+    else LAUNCH_CTC(4);
+#undef LAUNCH_CTC
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+
+extern "C" int ocr_ctc_greedy_decode(const float* activations, const int* input_lengths,
+                                     int alphabet_size, int minibatch, int max_time,
+                                     int blank_label, int pad_value, int* decoded,
+                                     int* decoded_lengths, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!activations || !input_lengths || !decoded || !decoded_lengths) return OCR_ERR_INVALID;
+    if (alphabet_size <= 0 || minibatch <= 0 || max_time <= 0) return OCR_ERR_INVALID;
+    ctc_greedy_kernel<<<minibatch, 64, 0, stream>>>(activations, input_lengths, max_time, minibatch,
+                                                    alphabet_size, blank_label, pad_value, decoded,
+                                                    decoded_lengths);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}

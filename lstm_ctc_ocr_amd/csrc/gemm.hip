@@ -1,0 +1,285 @@
+// bf16 MFMA tile engine for gfx950: C[m][n] = sum_k P[m][k] * Q[n][k]  (both operands K-contiguous)
+//
+// One engine serves every dense contraction on the CRNN hot path:
+//   * a2  conv_single 3x3 SAME  fwd / dgrad as an IMPLICIT GEMM: P rows are output pixels of the
+//         reference layout [N, W, H, C] (lib/networks/network.py:160-191), k = (tap, ci); the
+//         loader shifts the pixel by the tap and zero-fills the SAME-padding halo.
+//   * a2  conv5 2x2 VALID as a plain GEMM over overlapping rows (row-group skip, see below).
+//   * a6  the hoisted LSTM input projection, the FC logits (network.py:118-128) and their
+//         data-gradient GEMMs.
+//
+// MFMA orientation: v_mfma_f32_16x16x32_bf16 with A := Q tile (rows -> output channel n) and
+// B := P tile (cols -> output row m).  Each lane then owns 4 CONSECUTIVE n of one m, i.e. one
+// 8-byte bf16x4 (or 16-byte f32x4) store into the n-contiguous output — no LDS transpose in
+// the epilogue.
+//
+// Tile: 256 threads = 4 waves as 2(m) x 2(n); block tile (32*FM) x (32*FN), BK = 32 per step,
+// LDS rows padded to 80 B (5 x 16-B slots: gcd(5,16)=1 spreads a 16-row fragment read over all
+// 16 slots of the 256-B bank row).  Global -> register -> LDS staging, next tile's loads issued
+// before the current tile's MFMAs (T14-style split).
+#include "common.h"
+
+enum {
+    EPI_BIAS = 1,        // + bias[n]
+    EPI_RELU = 2,        // max(0, .)
+    EPI_OUT_F32 = 4,     // fp32 output (else bf16)
+    EPI_ATOMIC = 8,      // atomicAdd into fp32 output (split-K)
+    EPI_MASK = 16,       // zero where mask[m][n] <= 0 (ReLU backward fused into dgrad)
+    EPI_ROWSWAP = 32,    // out row = (m % inner) * outer + m / inner   ([N,T] -> [T,N])
+    EPI_ACCUM = 64,      // out += value (fp32, non-atomic; single split only)
+};
+
+struct GemmArgs {
+    const bf16_t* P;   // m rows
+    const bf16_t* Q;   // n rows
+    long ldp, ldq;
+    int M, N, K;       // K % 8 == 0
+    int k_per_split;   // multiple of 32; gridDim.z splits
+    // plain-mode row groups: physical row = m + (m / grp) * skip   (conv5's overlapping windows)
+    int grp, skip;
+    // conv-mode geometry (P = activations [Nb, cW, cH, cC], K = 9*cC, cC % 32 == 0)
+    int cW, cH, cC;
+    // epilogue
+    void* out;
+    long ldo;
+    const float* bias;
+    const bf16_t* mask;
+    long ldmask;
+    int flags;
+    int swap_inner, swap_outer;
+};
+
+#define LDS_ROW 40   // bf16 elements per LDS row: 32 payload + 8 pad  (80 B)
+
+template <int MODE /*0 plain, 1 conv3x3*/, int FM, int FN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
+    constexpr int BM = 32 * FM, BN = 32 * FN;
+    constexpr int NCP = BM * 4 / 256;   // 16-B chunks per thread for the P tile
+    constexpr int NCQ = BN * 4 / 256;
+    __shared__ __attribute__((aligned(16))) bf16_t Ps[BM * LDS_ROW];
+    __shared__ __attribute__((aligned(16))) bf16_t Qs[BN * LDS_ROW];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+
+    // ---- per-thread staging coordinates (fixed for the whole K loop)
+    const bf16_t* prow[NCP];
+    bool pvalid[NCP];
+    int pw[NCP], ph[NCP];
+#pragma unroll
+    for (int i = 0; i < NCP; ++i) {
+        int c = tid + i * 256;
+        int r = c >> 2;
+        int m = m0 + r;
+        pvalid[i] = m < g.M;
+        int mm = pvalid[i] ? m : 0;
+        if (MODE == 0) {
+            long phys = (long)mm + (g.grp > 0 ? (long)(mm / g.grp) * g.skip : 0);
+            prow[i] = g.P + phys * g.ldp + (c & 3) * 8;
+            pw[i] = ph[i] = 0;
+        } else {
+            int h = mm % g.cH;
+            int q = mm / g.cH;
+            int w = q % g.cW;
+            pw[i] = w; ph[i] = h;
+            prow[i] = g.P + (long)mm * g.cC + (c & 3) * 8;   // pixel (n,w,h), channel chunk
+        }
+    }
+    const bf16_t* qrow[NCQ];
+    bool qvalid[NCQ];
+#pragma unroll
+    for (int i = 0; i < NCQ; ++i) {
+        int c = tid + i * 256;
+        int r = c >> 2;
+        int n = n0 + r;
+        qvalid[i] = n < g.N;
+        qrow[i] = g.Q + (long)(qvalid[i] ? n : 0) * g.ldq + (c & 3) * 8;
+    }
+
+    u32x4 pst[NCP], qst[NCQ];
+    auto load_tiles = [&](int k0) {
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < NCP; ++i) {
+                int kc = k0 + ((tid + i * 256) & 3) * 8;
+                u32x4 v = {0, 0, 0, 0};
+                if (pvalid[i] && kc < kend) v = *(const u32x4*)(prow[i] + k0);
+                pst[i] = v;
+            }
+        } else {
+            int tap = k0 / g.cC;            // uniform: cC % 32 == 0 keeps a K tile inside one tap
+            int ci0 = k0 - tap * g.cC;
+            int dw = tap / 3 - 1, dh = tap % 3 - 1;
+            long shift = ((long)dw * g.cH + dh) * g.cC + ci0;
+#pragma unroll
+            for (int i = 0; i < NCP; ++i) {
+                int ww = pw[i] + dw, hh = ph[i] + dh;
+                bool ok = pvalid[i] && (unsigned)ww < (unsigned)g.cW && (unsigned)hh < (unsigned)g.cH;
+                u32x4 v = {0, 0, 0, 0};
+                if (ok) v = *(const u32x4*)(prow[i] + shift);
+                pst[i] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NCQ; ++i) {
+            int kc = k0 + ((tid + i * 256) & 3) * 8;
+            u32x4 v = {0, 0, 0, 0};
+            if (qvalid[i] && kc < kend) v = *(const u32x4*)(qrow[i] + k0);
+            qst[i] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) {
+            int c = tid + i * 256;
+            *(u32x4*)(&Ps[(c >> 2) * LDS_ROW + (c & 3) * 8]) = pst[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NCQ; ++i) {
+            int c = tid + i * 256;
+            *(u32x4*)(&Qs[(c >> 2) * LDS_ROW + (c & 3) * 8]) = qst[i];
+        }
+    };
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fk = (lane >> 4) * 8;
+    if (kbeg < kend) {
+        load_tiles(kbeg);
+        for (int k0 = kbeg; k0 < kend; k0 += 32) {
+            __syncthreads();            // previous tile's fragment reads are done
+            store_tiles();
+            __syncthreads();
+            if (k0 + 32 < kend) load_tiles(k0 + 32);   // in flight during the MFMAs below
+            bf16x8 af[FN], bfr[FM];
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+                af[a] = *(const bf16x8*)(&Qs[(wn * 16 * FN + a * 16 + frow) * LDS_ROW + fk]);
+#pragma unroll
+            for (int b = 0; b < FM; ++b)
+                bfr[b] = *(const bf16x8*)(&Ps[(wm * 16 * FM + b * 16 + frow) * LDS_ROW + fk]);
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int b = 0; b < FM; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane owns n = nb + (lane>>4)*4 .. +3 at m = mb + (lane&15)
+    const int flags = g.flags;
+    const bool add_bias = (flags & EPI_BIAS) && (!(flags & EPI_ATOMIC) || blockIdx.z == 0);
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+        int n = n0 + wn * 16 * FN + a * 16 + (lane >> 4) * 4;
+        if (n >= g.N) continue;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (add_bias) bv = *(const f32x4*)(g.bias + n);
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+            int m = m0 + wm * 16 * FM + b * 16 + (lane & 15);
+            if (m >= g.M) continue;
+            f32x4 v = acc[a][b] + bv;
+            if (flags & EPI_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            if (flags & EPI_MASK) {
+                u32x2 mk = *(const u32x2*)(g.mask + (long)m * g.ldmask + n);
+                if (!(bf_lo(mk.x) > 0.f)) v.x = 0.f;
+                if (!(bf_hi(mk.x) > 0.f)) v.y = 0.f;
+                if (!(bf_lo(mk.y) > 0.f)) v.z = 0.f;
+                if (!(bf_hi(mk.y) > 0.f)) v.w = 0.f;
+            }
+            long orow = m;
+            if (flags & EPI_ROWSWAP) orow = (long)(m % g.swap_inner) * g.swap_outer + m / g.swap_inner;
+            if (flags & EPI_OUT_F32) {
+                float* o = (float*)g.out + orow * g.ldo + n;
+                if (flags & EPI_ATOMIC) {
+                    atomicAdd(o + 0, v.x); atomicAdd(o + 1, v.y); atomicAdd(o + 2, v.z); atomicAdd(o + 3, v.w);
+                } else if (flags & EPI_ACCUM) {
+                    f32x4 old = *(f32x4*)o;
+                    *(f32x4*)o = old + v;
+                } else {
+                    *(f32x4*)o = v;
+                }
+            } else {
+                u32x2 pk;
+                pk.x = pack_bf2(v.x, v.y);
+                pk.y = pack_bf2(v.z, v.w);
+                *(u32x2*)((bf16_t*)g.out + orow * g.ldo + n) = pk;
+            }
+        }
+    }
+}
+
+template <int MODE, int FM, int FN>
+static int launch_gemm(const GemmArgs& g, hipStream_t stream) {
+    constexpr int BM = 32 * FM, BN = 32 * FN;
+    int splits = ceil_div(g.K, g.k_per_split);
+    dim3 grid(ceil_div(g.M, BM), ceil_div(g.N, BN), splits);
+    gemm_nt_kernel<MODE, FM, FN><<<grid, 256, 0, stream>>>(g);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+
+static int dispatch_gemm(GemmArgs& g, int mode, int splits, hipStream_t stream) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K & 7) || (g.N & 3)) return OCR_ERR_INVALID;
+    if (!g.P || !g.Q || !g.out) return OCR_ERR_INVALID;
+    if (splits < 1) splits = 1;
+    int kps = ceil_div(ceil_div(g.K, splits), 32) * 32;
+    g.k_per_split = kps;
+    if (ceil_div(g.K, kps) > 1) {
+        if (!(g.flags & EPI_OUT_F32) || (g.flags & (EPI_RELU | EPI_MASK | EPI_ACCUM))) return OCR_ERR_INVALID;
+        g.flags |= EPI_ATOMIC;
+    }
+    // big tiles when they still fill the chip, small tiles otherwise
+    long big_blocks = (long)ceil_div(g.M, 128) * ceil_div(g.N, 128) * ceil_div(g.K, kps);
+    bool big = big_blocks >= 192 && g.N >= 128;
+    if (mode == 1) {
+        if (g.cC % 32 || g.K != 9 * g.cC) return OCR_ERR_INVALID;
+        return big ? launch_gemm<1, 4, 4>(g, stream) : launch_gemm<1, 2, 2>(g, stream);
+    }
+    return big ? launch_gemm<0, 4, 4>(g, stream) : launch_gemm<0, 2, 2>(g, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" int ocr_gemm_nt_bf16(const void* P, long ldp, const void* Q, long ldq, void* out, long ldo,
+                                int M, int N, int K, const float* bias, const void* mask, long ldmask,
+                                int flags, int splits, int row_group, int row_skip, int swap_inner,
+                                int swap_outer, void* stream) {
+    GemmArgs g = {};
+    g.P = (const bf16_t*)P; g.Q = (const bf16_t*)Q; g.ldp = ldp; g.ldq = ldq;
+    g.M = M; g.N = N; g.K = K; g.grp = row_group; g.skip = row_skip;
+    g.out = out; g.ldo = ldo; g.bias = bias; g.mask = (const bf16_t*)mask; g.ldmask = ldmask;
+    g.flags = flags & ~EPI_ATOMIC; g.swap_inner = swap_inner; g.swap_outer = swap_outer;
+    if ((flags & EPI_BIAS) && !bias) return OCR_ERR_INVALID;
+    if ((flags & EPI_MASK) && !mask) return OCR_ERR_INVALID;
+    if ((flags & EPI_ROWSWAP) && (swap_inner <= 0 || swap_outer <= 0)) return OCR_ERR_INVALID;
+    return dispatch_gemm(g, 0, splits, (hipStream_t)stream);
+}
+
+// 3x3 SAME stride-1 convolution over the reference layout [Nb, W, H, C] as an implicit GEMM.
+// wpack is [Cout][3][3][Cin] bf16 (K-contiguous rows).  Used for the forward (wpack = packed
+// weights) and for dgrad (x := dY, wpack := flipped/transposed weights, Cin/Cout swapped).
+extern "C" int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int Nb, int W, int H,
+                                int Cin, int Cout, const float* bias, const void* mask, int flags,
+                                void* stream) {
+    GemmArgs g = {};
+    g.P = (const bf16_t*)x; g.Q = (const bf16_t*)wpack; g.ldp = Cin; g.ldq = 9L * Cin;
+    g.M = Nb * W * H; g.N = Cout; g.K = 9 * Cin; g.cW = W; g.cH = H; g.cC = Cin;
+    g.out = y; g.ldo = Cout; g.bias = bias; g.mask = (const bf16_t*)mask; g.ldmask = Cout;
+    g.flags = flags & ~(EPI_ATOMIC | EPI_ROWSWAP);
+    if ((flags & EPI_BIAS) && !bias) return OCR_ERR_INVALID;
+    if ((flags & EPI_MASK) && !mask) return OCR_ERR_INVALID;
+    return dispatch_gemm(g, 1, 1, (hipStream_t)stream);
+}

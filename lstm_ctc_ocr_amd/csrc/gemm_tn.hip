@@ -1,0 +1,201 @@
+// Weight-gradient contraction for gfx950: D[i][j] += sum_m A[m][i] * B[m][j]
+// (the contraction index m is the SLOW index of both operands: "TN" form).
+//
+// Serves every weight gradient of the reference graph (tf.gradients at lib/lstm/train.py:81):
+//   * conv_single 3x3 SAME (network.py:160-191):  dW[kh,kw,ci,co] = sum_pixels X[shifted][ci] * dY[pix][co]
+//     (implicit: the A row for pixel m and tap (kh,kw) is the pixel shifted by the tap, zero in the halo)
+//   * conv5 2x2 VALID, LSTM Wx / Wh, FC:  plain  dW[k_in][n_out] = X^T dY  (row-group skip for conv5)
+// The result is accumulated with fp32 atomics straight into the TF-layout gradient buffer
+// ([kh,kw,ci,co] resp. [in,out]), so split-M partial sums and the caller's "+=" are one mechanism.
+//
+// MFMA wants 8 consecutive k (= m) per lane, while HBM has the channel axis contiguous, so the
+// operands are transposed on the way through LDS.  TRANSPOSE_VIA = 0: 2-byte gathers from a row-major
+// tile (always correct, LDS-issue bound).  The hardware transposing read is layered on top in
+// gemm_tn_tr.hip once its lane semantics are pinned on the device.
+#include "common.h"
+
+struct TnArgs {
+    const bf16_t* A;  // [Mrows][lda]  (i contiguous)
+    const bf16_t* B;  // [Mrows][ldb]  (j contiguous)
+    long lda, ldb;
+    int Mk;           // contraction length (rows of B)
+    int I, J;         // output dims, I % 8 == 0, J % 8 == 0
+    int k_per_split;  // multiple of 32
+    int grp, skip;    // plain mode: physical A row = m + (m/grp)*skip ; A row offset added below
+    long a_row_off;   // plain mode: extra element offset applied to every A row (conv5 second tap row)
+    int cW, cH, cC;   // conv mode: A = activations [Nb, cW, cH, cC], taps = gridDim.x / itiles
+    float* out;       // conv: [9][cC][J] ; plain: [I][ldo]
+    long ldo;
+    float scale;      // multiply before accumulation (e.g. 1.0)
+};
+
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+
+template <int MODE /*0 plain, 1 conv3x3*/, int FI, int FJ>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
+    constexpr int BI = 32 * FI, BJ = 32 * FJ;
+    constexpr int LDA = BI + 8, LDB = BJ + 8;
+    constexpr int CPA = BI / 8, CPB = BJ / 8;          // 16-B chunks per tile row
+    constexpr int NCA = 32 * CPA / 256, NCB = 32 * CPB / 256;
+    static_assert(NCA >= 1 && NCB >= 1, "tile too small for 256 threads");
+    __shared__ __attribute__((aligned(16))) bf16_t As[32 * LDA];
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[32 * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int itiles = ceil_div(g.I, BI);
+    const int tap = (MODE == 1) ? (int)(blockIdx.x / itiles) : 0;
+    const int i0 = (int)(blockIdx.x % itiles) * BI;
+    const int j0 = blockIdx.y * BJ;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.Mk, kbeg + g.k_per_split);
+    const int dw = tap / 3 - 1, dh = tap % 3 - 1;
+
+    u32x4 ast[NCA], bst[NCB];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int t = 0; t < NCA; ++t) {
+            int c = tid + t * 256;
+            int r = c / CPA, col = (c % CPA) * 8;
+            int m = k0 + r;
+            u32x4 v = {0, 0, 0, 0};
+            bool ok = m < kend && (i0 + col) < g.I;
+            if (ok) {
+                if (MODE == 0) {
+                    long phys = (long)m + (g.grp > 0 ? (long)(m / g.grp) * g.skip : 0);
+                    v = *(const u32x4*)(g.A + phys * g.lda + g.a_row_off + i0 + col);
+                } else {
+                    int h = m % g.cH, q = m / g.cH, w = q % g.cW;
+                    int ww = w + dw, hh = h + dh;
+                    if ((unsigned)ww < (unsigned)g.cW && (unsigned)hh < (unsigned)g.cH)
+                        v = *(const u32x4*)(g.A + ((long)m + (long)dw * g.cH + dh) * g.cC + i0 + col);
+                }
+            }
+            ast[t] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < NCB; ++t) {
+            int c = tid + t * 256;
+            int r = c / CPB, col = (c % CPB) * 8;
+            int m = k0 + r;
+            u32x4 v = {0, 0, 0, 0};
+            if (m < kend && (j0 + col) < g.J) v = *(const u32x4*)(g.B + (long)m * g.ldb + j0 + col);
+            bst[t] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int t = 0; t < NCA; ++t) {
+            int c = tid + t * 256;
+            *(u32x4*)(&As[(c / CPA) * LDA + (c % CPA) * 8]) = ast[t];
+        }
+#pragma unroll
+        for (int t = 0; t < NCB; ++t) {
+            int c = tid + t * 256;
+            *(u32x4*)(&Bs[(c / CPB) * LDB + (c % CPB) * 8]) = bst[t];
+        }
+    };
+
+    f32x4 acc[FI][FJ];
+#pragma unroll
+    for (int a = 0; a < FI; ++a)
+#pragma unroll
+        for (int b = 0; b < FJ; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fcol = lane & 15, fk = (lane >> 4) * 8;
+    if (kbeg < kend) {
+        load_tiles(kbeg);
+        for (int k0 = kbeg; k0 < kend; k0 += 32) {
+            __syncthreads();
+            store_tiles();
+            __syncthreads();
+            if (k0 + 32 < kend) load_tiles(k0 + 32);
+            bf16x8 af[FI], bfr[FJ];
+#pragma unroll
+            for (int a = 0; a < FI; ++a) {
+                u16x8 t;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = As[(fk + j) * LDA + wi * 16 * FI + a * 16 + fcol];
+                af[a] = __builtin_bit_cast(bf16x8, t);
+            }
+#pragma unroll
+            for (int b = 0; b < FJ; ++b) {
+                u16x8 t;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = Bs[(fk + j) * LDB + wj * 16 * FJ + b * 16 + fcol];
+                bfr[b] = __builtin_bit_cast(bf16x8, t);
+            }
+#pragma unroll
+            for (int a = 0; a < FI; ++a)
+#pragma unroll
+                for (int b = 0; b < FJ; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // lane owns i = ib + (lane>>4)*4 + r, j = jb + (lane&15)
+    float* out = g.out;
+    long ldo = g.ldo;
+    if (MODE == 1) { out += (long)tap * g.cC * g.J; ldo = g.J; }
+#pragma unroll
+    for (int a = 0; a < FI; ++a) {
+#pragma unroll
+        for (int b = 0; b < FJ; ++b) {
+            int j = j0 + wj * 16 * FJ + b * 16 + (lane & 15);
+            if (j >= g.J) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int i = i0 + wi * 16 * FI + a * 16 + (lane >> 4) * 4 + r;
+                if (i < g.I) atomicAdd(out + (long)i * ldo + j, acc[a][b][r] * g.scale);
+            }
+        }
+    }
+}
+
+template <int MODE, int FI, int FJ>
+static int launch_tn(const TnArgs& g, int taps, hipStream_t stream) {
+    constexpr int BI = 32 * FI, BJ = 32 * FJ;
+    dim3 grid(ceil_div(g.I, BI) * taps, ceil_div(g.J, BJ), ceil_div(g.Mk, g.k_per_split));
+    gemm_tn_kernel<MODE, FI, FJ><<<grid, 256, 0, stream>>>(g);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+
+static int pick_splits(long tiles, int Mk) {
+    // aim for >= ~1024 workgroups, at least 4 K-steps (128 rows) per split
+    int s = (int)((1024 + tiles - 1) / tiles);
+    int maxs = Mk / 128; if (maxs < 1) maxs = 1;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    return s;
+}
+
+// out[I][ldo] += scale * A^T B   with A[Mk][lda] (row-group skip + fixed offset), B[Mk][ldb]
+extern "C" int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* out, long ldo,
+                                int Mk, int I, int J, int row_group, int row_skip, long a_row_off,
+                                float scale, int splits, void* stream) {
+    if (!A || !B || !out || Mk <= 0 || I <= 0 || J <= 0 || (I & 7) || (J & 7)) return OCR_ERR_INVALID;
+    TnArgs g = {};
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb; g.Mk = Mk; g.I = I; g.J = J;
+    g.grp = row_group; g.skip = row_skip; g.a_row_off = a_row_off; g.out = out; g.ldo = ldo; g.scale = scale;
+    bool big = (I >= 128 && J >= 128);
+    long tiles = big ? (long)ceil_div(I, 128) * ceil_div(J, 128) : (long)ceil_div(I, 64) * ceil_div(J, 64);
+    if (splits <= 0) splits = pick_splits(tiles, Mk);
+    g.k_per_split = ceil_div(ceil_div(Mk, splits), 32) * 32;
+    return big ? launch_tn<0, 4, 4>(g, 1, (hipStream_t)stream) : launch_tn<0, 2, 2>(g, 1, (hipStream_t)stream);
+}
+
+// dW[3][3][Cin][Cout] (fp32, TF layout) += sum over pixels of x[shifted pixel][ci] * dy[pixel][co]
+extern "C" int ocr_conv3x3_wgrad_bf16(const void* x, const void* dy, float* dw, int Nb, int W, int H,
+                                      int Cin, int Cout, int splits, void* stream) {
+    if (!x || !dy || !dw || Nb <= 0 || W <= 0 || H <= 0 || (Cin & 7) || (Cout & 7)) return OCR_ERR_INVALID;
+    TnArgs g = {};
+    g.A = (const bf16_t*)x; g.B = (const bf16_t*)dy; g.lda = Cin; g.ldb = Cout;
+    g.Mk = Nb * W * H; g.I = Cin; g.J = Cout; g.cW = W; g.cH = H; g.cC = Cin;
+    g.out = dw; g.ldo = Cout; g.scale = 1.0f;
+    bool big = (Cin >= 128 && Cout >= 128);
+    long tiles = 9L * (big ? (long)ceil_div(Cin, 128) * ceil_div(Cout, 128) : (long)ceil_div(Cin, 64) * ceil_div(Cout, 64));
+    if (splits <= 0) splits = pick_splits(tiles, g.Mk);
+    g.k_per_split = ceil_div(ceil_div(g.Mk, splits), 32) * 32;
+    return big ? launch_tn<1, 4, 4>(g, 9, (hipStream_t)stream) : launch_tn<1, 2, 2>(g, 9, (hipStream_t)stream);
+}

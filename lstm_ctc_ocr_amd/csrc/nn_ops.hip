@@ -1,0 +1,606 @@
+// HBM-bound layers of the reference graph for gfx950 (SURVEY.md §8a rows a2 conv1, a3, a4):
+// conv1 (C_in = 1, K = 9: VALU, not MFMA), max-pool fwd/bwd, training-mode batch-norm fwd/bwd,
+// bias-gradient column sums, weight (re)packing.  Everything moves 16 B per lane (8 bf16 / 4 f32),
+// coalesced along the channel axis of the reference layout [N, W, H, C].
+#include "common.h"
+
+// ============================================================================================
+// conv1: x f32 [Nb, W, H] (single channel) -> y bf16 [Nb, W, H, Cout], 3x3 SAME, + bias, ReLU
+//   reference: conv_single(3,3,64,1,1,'conv1',c_i=1)  lib/networks/LSTM_train.py:24, network.py:160-191
+// ============================================================================================
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ w,   // [9][Cout]
+                                                        const float* __restrict__ bias,
+                                                        bf16_t* __restrict__ y, int Nb, int W, int H,
+                                                        int Cout, int relu) {
+    extern __shared__ float wl[];   // [9][Cout] + [Cout]
+    for (int i = threadIdx.x; i < 9 * Cout; i += 256) wl[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += 256) wl[9 * Cout + i] = bias[i];
+    __syncthreads();
+    const int groups = Cout >> 3;
+    const long total = (long)Nb * W * H * groups;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        int gq = (int)(idx % groups);
+        long pix = idx / groups;
+        int h = (int)(pix % H);
+        long q = pix / H;
+        int wq = (int)(q % W);
+        const float* xn = x + (q - wq) * H;   // start of sample's [W][H] plane
+        float xv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            int ww = wq + t / 3 - 1, hh = h + t % 3 - 1;
+            xv[t] = ((unsigned)ww < (unsigned)W && (unsigned)hh < (unsigned)H) ? xn[(long)ww * H + hh] : 0.f;
+        }
+        float o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[c] = fmaf(xv[t], wl[t * Cout + gq * 8 + c], o[c]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            o[c] += wl[9 * Cout + gq * 8 + c];
+            if (relu) o[c] = fmaxf(o[c], 0.f);
+        }
+        u32x4 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+        *(u32x4*)(y + pix * Cout + gq * 8) = pk;
+    }
+}
+
+// conv1 weight/bias gradient: dW[9][Cout] += sum_pix x[shifted] * dz[pix][:],  db[Cout] += sum_pix dz
+// Each block owns a contiguous pixel chunk; thread = (channel group of 8) x (pixel lane of 32).
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x,
+                                                          const bf16_t* __restrict__ dz,
+                                                          float* __restrict__ dw, float* __restrict__ db,
+                                                          int Nb, int W, int H, int Cout, int pix_per_block) {
+    // requires Cout == 64: 8 channel groups x 32 pixel lanes = 256 threads
+    const int gq = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const long npix = (long)Nb * W * H;
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    const long p1 = min(npix, p0 + pix_per_block);
+    float acc[10][8];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[t][c] = 0.f;
+    for (long pix = p0 + pl; pix < p1; pix += 32) {
+        int h = (int)(pix % H);
+        long q = pix / H;
+        int wq = (int)(q % W);
+        const float* xn = x + (q - wq) * H;
+        u32x4 d = *(const u32x4*)(dz + pix * Cout + gq * 8);
+        float dv[8] = {bf_lo(d.x), bf_hi(d.x), bf_lo(d.y), bf_hi(d.y), bf_lo(d.z), bf_hi(d.z), bf_lo(d.w), bf_hi(d.w)};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            int ww = wq + t / 3 - 1, hh = h + t % 3 - 1;
+            float xv = ((unsigned)ww < (unsigned)W && (unsigned)hh < (unsigned)H) ? xn[(long)ww * H + hh] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[t][c] = fmaf(xv, dv[c], acc[t][c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[9][c] += dv[c];
+    }
+    // reduce the 32 pixel lanes: lanes of one wave hold pl = 8 consecutive values -> shuffle over pl bits,
+    // then 4 waves through LDS
+    __shared__ float red[4][10][64];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float v = acc[t][c];
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[t][c] = v;
+        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 8) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) red[wave][t][lane * 8 + c] = acc[t][c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 10 * 64; i += 256) {
+        int t = i / 64, c = i % 64;
+        float v = red[0][t][c] + red[1][t][c] + red[2][t][c] + red[3][t][c];
+        if (t < 9) atomicAdd(dw + t * Cout + c, v);
+        else atomicAdd(db + c, v);
+    }
+}
+
+// ============================================================================================
+// max-pool (VALID, window == stride, kw over axis W in {1,2}, kh over axis H in {1,2})
+//   reference: Network.max_pool  network.py:343-350 ; LSTM_train.py:25,27,30,33
+// ============================================================================================
+__device__ __forceinline__ void unpack8(u32x4 p, float* f) {
+    f[0] = bf_lo(p.x); f[1] = bf_hi(p.x); f[2] = bf_lo(p.y); f[3] = bf_hi(p.y);
+    f[4] = bf_lo(p.z); f[5] = bf_hi(p.z); f[6] = bf_lo(p.w); f[7] = bf_hi(p.w);
+}
+__device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) {
+    // bf16 max is exact: keep the raw bits of the larger half (first operand wins ties)
+    uint32_t lo = (bf_lo(b) > bf_lo(a)) ? (b & 0xffffu) : (a & 0xffffu);
+    uint32_t hi = (bf_hi(b) > bf_hi(a)) ? (b & 0xffff0000u) : (a & 0xffff0000u);
+    return lo | hi;
+}
+__device__ __forceinline__ u32x4 max8(u32x4 a, u32x4 b) {
+    u32x4 r = {max2(a.x, b.x), max2(a.y, b.y), max2(a.z, b.z), max2(a.w, b.w)};
+    return r;
+}
+
+template <int KW, int KH>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                          int Nb, int W, int H, int C) {
+    constexpr int kw = KW, kh = KH;
+    const int Wo = W / kw, Ho = H / kh, groups = C >> 3;
+    const long total = (long)Nb * Wo * Ho * groups;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        int gq = (int)(idx % groups);
+        long op = idx / groups;
+        int ho = (int)(op % Ho);
+        long q = op / Ho;
+        int wo = (int)(q % Wo);
+        long n = q / Wo;
+        const bf16_t* base = x + (((n * W + (long)wo * kw) * H) + (long)ho * kh) * C + gq * 8;
+        u32x4 m = *(const u32x4*)base;
+#pragma unroll
+        for (int a = 0; a < kw; ++a)
+#pragma unroll
+            for (int b = 0; b < kh; ++b) {
+                if (a == 0 && b == 0) continue;
+                m = max8(m, *(const u32x4*)(base + ((long)a * H + b) * C));
+            }
+        *(u32x4*)(y + op * C + gq * 8) = m;
+    }
+}
+
+// dx[pixel] = dy[window's output] if this pixel is the FIRST maximum of its window in TF scan order
+// (axis W outer, axis H inner), else 0; optionally multiplied by the ReLU mask (x > 0) so the
+// result is the gradient w.r.t. the pre-activation of the conv that produced x.
+template <int KW, int KH>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                          bf16_t* __restrict__ dx, int Nb, int W, int H, int C,
+                                                          int relu_mask) {
+    constexpr int kw = KW, kh = KH, cnt_all = KW * KH;
+    const int Wo = W / kw, Ho = H / kh, groups = C >> 3;
+    const long total = (long)Nb * Wo * Ho * groups;   // one thread per output window x channel group
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        int gq = (int)(idx % groups);
+        long op = idx / groups;
+        int ho = (int)(op % Ho);
+        long q = op / Ho;
+        int wo = (int)(q % Wo);
+        long n = q / Wo;
+        long boff = (((n * W + (long)wo * kw) * H) + (long)ho * kh) * C + gq * 8;
+        float xv[cnt_all][8];
+#pragma unroll
+        for (int a = 0; a < kw; ++a)
+#pragma unroll
+            for (int b = 0; b < kh; ++b) {
+                u32x4 v = *(const u32x4*)(x + boff + ((long)a * H + b) * C);
+                unpack8(v, xv[a * kh + b]);
+            }
+        float g[8];
+        unpack8(*(const u32x4*)(dy + op * C + gq * 8), g);
+        int win[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            int best = 0; float bv = xv[0][c];
+#pragma unroll
+            for (int e = 1; e < cnt_all; ++e) if (xv[e][c] > bv) { bv = xv[e][c]; best = e; }
+            win[c] = best;
+        }
+#pragma unroll
+        for (int a = 0; a < kw; ++a)
+#pragma unroll
+            for (int b = 0; b < kh; ++b) {
+                const int cnt = a * kh + b;
+                float o[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float v = (win[c] == cnt) ? g[c] : 0.f;
+                    if (relu_mask && !(xv[cnt][c] > 0.f)) v = 0.f;
+                    o[c] = v;
+                }
+                u32x4 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+                *(u32x4*)(dx + boff + ((long)a * H + b) * C) = pk;
+            }
+    }
+}
+
+// ============================================================================================
+// training-mode batch norm over rows of x[M][C] (bf16), biased variance, eps (TF contrib default 1e-3)
+//   reference: tf.contrib.layers.batch_norm(..., is_training=True)  network.py:176-178  (always batch stats)
+// ============================================================================================
+// Block-level reduction over the row lanes of a (row lane) x (channel group) thread layout, followed by one
+// atomic per channel per block.  red must hold 256*8 floats.
+template <typename AccT>
+__device__ __forceinline__ void block_channel_reduce(const float (&v)[8], float* red, AccT* dst, int C, int groups,
+                                                     int rl, int gq, int rlanes) {
+    __syncthreads();
+    if (rl < rlanes) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[rl * C + gq * 8 + c] = v[c];
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+        float t = 0.f;
+        for (int r = 0; r < rlanes; ++r) t += red[r * C + ch];
+        atomicAdd(&dst[ch], (AccT)t);
+    }
+}
+
+// pass 1: per-channel sum / sum of squares -> double accumulators stats[2][C] (pre-zeroed)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict__ x, double* __restrict__ stats,
+                                                       long M, int C, int rows_per_block) {
+    const int groups = C >> 3;                 // threads along channels (<= 256)
+    const int rl = threadIdx.x / groups;       // row lane
+    const int gq = threadIdx.x % groups;
+    const int rlanes = 256 / groups;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s[8], ss[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { s[c] = 0.f; ss[c] = 0.f; }
+    if (rl < rlanes) {
+        for (long r = r0 + rl; r < r1; r += rlanes) {
+            float v[8];
+            unpack8(*(const u32x4*)(x + r * C + gq * 8), v);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { s[c] += v[c]; ss[c] = fmaf(v[c], v[c], ss[c]); }
+        }
+    }
+    __shared__ float red[2048];
+    block_channel_reduce<double>(s, red, stats, C, groups, rl, gq, rlanes);
+    block_channel_reduce<double>(ss, red, stats + C, C, groups, rl, gq, rlanes);
+}
+// pass 2 (tiny): mean / rstd
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, float* __restrict__ mean, float* __restrict__ rstd,
+                                   long M, int C, float eps) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        double mu = stats[c] / (double)M;
+        double var = stats[C + c] / (double)M - mu * mu;
+        if (var < 0) var = 0;
+        mean[c] = (float)mu;
+        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+// pass 3: y = [relu](gamma * (x - mean) * rstd + beta)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       long M, int C, int relu) {
+    const int groups = C >> 3;
+    const long total = M * groups;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        int gq = (int)(idx % groups);
+        long r = idx / groups;
+        float v[8];
+        unpack8(*(const u32x4*)(x + r * C + gq * 8), v);
+        float o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            int ch = gq * 8 + c;
+            float t = (v[c] - mean[ch]) * rstd[ch] * gamma[ch] + beta[ch];
+            o[c] = relu ? fmaxf(t, 0.f) : t;
+        }
+        u32x4 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+        *(u32x4*)(y + r * C + gq * 8) = pk;
+    }
+}
+// backward pass 1: dz = dy * (y > 0) [if relu]; sums[0][C] = sum dz, sums[1][C] = sum dz * xhat  (double, pre-zeroed)
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
+                                                           const bf16_t* __restrict__ dy, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, double* __restrict__ sums,
+                                                           long M, int C, int rows_per_block, int relu) {
+    const int groups = C >> 3;
+    const int rl = threadIdx.x / groups, gq = threadIdx.x % groups, rlanes = 256 / groups;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s[8], sx[8], mu[8], rs[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { s[c] = 0.f; sx[c] = 0.f; mu[c] = mean[gq * 8 + c]; rs[c] = rstd[gq * 8 + c]; }
+    if (rl < rlanes) {
+        for (long r = r0 + rl; r < r1; r += rlanes) {
+            float xv[8], yv[8], g[8];
+            unpack8(*(const u32x4*)(x + r * C + gq * 8), xv);
+            unpack8(*(const u32x4*)(dy + r * C + gq * 8), g);
+            if (relu) {
+                unpack8(*(const u32x4*)(y + r * C + gq * 8), yv);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) if (!(yv[c] > 0.f)) g[c] = 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { s[c] += g[c]; sx[c] = fmaf(g[c], (xv[c] - mu[c]) * rs[c], sx[c]); }
+        }
+    }
+    __shared__ float red[2048];
+    block_channel_reduce<double>(s, red, sums, C, groups, rl, gq, rlanes);
+    block_channel_reduce<double>(sx, red, sums + C, C, groups, rl, gq, rlanes);
+}
+// backward pass 2: dx = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat));  dgamma += sum dz*xhat, dbeta += sum dz
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
+                                                           const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           long M, int C, int relu) {
+    const int groups = C >> 3;
+    const long total = M * groups;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            dbeta[c] += (float)sums[c];
+            dgamma[c] += (float)sums[C + c];
+        }
+    }
+    const double invM = 1.0 / (double)M;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        int gq = (int)(idx % groups);
+        long r = idx / groups;
+        float xv[8], yv[8], g[8], o[8];
+        unpack8(*(const u32x4*)(x + r * C + gq * 8), xv);
+        unpack8(*(const u32x4*)(dy + r * C + gq * 8), g);
+        if (relu) {
+            unpack8(*(const u32x4*)(y + r * C + gq * 8), yv);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) if (!(yv[c] > 0.f)) g[c] = 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            int ch = gq * 8 + c;
+            float xh = (xv[c] - mean[ch]) * rstd[ch];
+            float mdz = (float)(sums[ch] * invM), mdzx = (float)(sums[C + ch] * invM);
+            o[c] = gamma[ch] * rstd[ch] * (g[c] - mdz - xh * mdzx);
+        }
+        u32x4 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+        *(u32x4*)(dx + r * C + gq * 8) = pk;
+    }
+}
+
+// ============================================================================================
+// column sums: out[c] += sum_m a[m][c]   (bias gradients; a is bf16 [M][C], out fp32)
+// ============================================================================================
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ a, float* __restrict__ out, long M, int C,
+                                                     long lda, int rows_per_block) {
+    const int groups = C >> 3;
+    const int rl = threadIdx.x / groups, gq = threadIdx.x % groups, rlanes = 256 / groups;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s[c] = 0.f;
+    if (rl < rlanes) {
+        for (long r = r0 + rl; r < r1; r += rlanes) {
+            float v[8];
+            unpack8(*(const u32x4*)(a + r * lda + gq * 8), v);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) s[c] += v[c];
+        }
+    }
+    __shared__ float red[2048];
+    block_channel_reduce<float>(s, red, out, C, groups, rl, gq, rlanes);
+}
+
+// ============================================================================================
+// weight packing (fp32 master in TF layouts -> bf16 K-contiguous operand layouts)
+// ============================================================================================
+// generic: out[perm(c)][r] (bf16, ld = R) = in[r][c] (f32, [R][Cc]);  perm: TF gate-major column c = g*U + u ->
+// packed column (u/16)*64 + g*16 + u%16 (see lstm.hip) when lstm_units > 0, identity otherwise.
+__global__ void pack_transpose_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int R, int Cc, long ldin,
+                                      int lstm_units) {
+    __shared__ float tile[32][33];
+    int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Cc) ? in[(long)r * ldin + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int c = c0 + i, r = r0 + tx;
+        if (c < Cc && r < R) {
+            int pc = c;
+            if (lstm_units > 0) { int gidx = c / lstm_units, u = c % lstm_units; pc = (u >> 4) * 64 + gidx * 16 + (u & 15); }
+            out[(long)pc * R + r] = f2bf(tile[tx][i]);
+        }
+    }
+}
+// conv 3x3 dgrad operand: out[ci][8 - tap][co] = w[tap][ci][co]   (spatial flip, Cin<->Cout role swap)
+__global__ void pack_conv_dgrad_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cin, int Cout) {
+    long total = 9L * Cin * Cout;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int co = (int)(idx % Cout);
+        long q = idx / Cout;
+        int ci = (int)(q % Cin);
+        int tap = (int)(q / Cin);
+        out[((long)ci * 9 + (8 - tap)) * Cout + co] = f2bf(w[idx]);
+    }
+}
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    long stride = (long)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        f32x4 v = *(const f32x4*)(in + i);
+        u32x2 pk = {pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+        *(u32x2*)(out + i) = pk;
+    }
+    // tail (n % 4) handled by the last thread of the grid-stride pattern
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long t = n & ~3L; t < n; ++t) out[t] = f2bf(in[t]);
+}
+// strided 2-D cast: out[r][c] (bf16, ld = ldout) = in[r][c] (f32, ld = ldin), cols % 4 == 0
+__global__ void cast2d_f32_bf16_kernel(const float* __restrict__ in, long ldin, bf16_t* __restrict__ out, long ldout,
+                                       int rows, int cols) {
+    const int c4 = cols >> 2;
+    long total = (long)rows * c4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int c = (int)(idx % c4) * 4;
+        long r = idx / c4;
+        f32x4 v = *(const f32x4*)(in + r * ldin + c);
+        u32x2 pk = {pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+        *(u32x2*)(out + r * ldout + c) = pk;
+    }
+}
+// dlogits[T][N][C] f32  ->  [N][T][C] bf16, scaled (CTC gradient hand-off: mean over batch = 1/N)
+__global__ void tnc_to_ntc_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int T, int N, int C, float scale) {
+    long total = (long)T * N * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int c = (int)(idx % C);
+        long q = idx / C;
+        int n = (int)(q % N);
+        int t = (int)(q / N);
+        out[((long)n * T + t) * C + c] = f2bf(in[idx] * scale);
+    }
+}
+// conv5 dgrad overlap-add: dx[n][w][:] = col[n][w][0:HC] + col[n][w-1][HC:2HC]   (col rows exist for w < W-1)
+__global__ void conv5_col2im_kernel(const bf16_t* __restrict__ col, bf16_t* __restrict__ dx, int Nb, int W, int HC) {
+    long total = (long)Nb * W * HC;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int e = (int)(idx % HC);
+        long q = idx / HC;
+        int w = (int)(q % W);
+        long n = q / W;
+        float v = 0.f;
+        if (w < W - 1) v += bf2f(col[((n * (W - 1) + w) * 2L) * HC + e]);
+        if (w > 0) v += bf2f(col[((n * (W - 1) + w - 1) * 2L + 1) * HC + e]);
+        dx[idx] = f2bf(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+static inline int grid_for(long total, int cap = 4096) {
+    long b = (total + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int ocr_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int Nb, int W, int H,
+                             int Cout, int relu, void* stream) {
+    if (!x || !w || !bias || !y || (Cout & 7) || Cout > 1024) return OCR_ERR_INVALID;
+    long total = (long)Nb * W * H * (Cout >> 3);
+    conv1_fwd_kernel<<<grid_for(total, 8192), 256, (size_t)10 * Cout * sizeof(float), (hipStream_t)stream>>>(
+        x, w, bias, (bf16_t*)y, Nb, W, H, Cout, relu);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+extern "C" int ocr_conv1_wgrad(const float* x, const void* dz, float* dw, float* db, int Nb, int W, int H, int Cout,
+                               void* stream) {
+    if (!x || !dz || !dw || !db || Cout != 64) return OCR_ERR_INVALID;
+    long npix = (long)Nb * W * H;
+    int ppb = 1024;
+    conv1_wgrad_kernel<<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, (const bf16_t*)dz, dw, db, Nb, W, H, Cout, ppb);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+extern "C" int ocr_maxpool_fwd(const void* x, void* y, int Nb, int W, int H, int C, int kw, int kh, void* stream) {
+    if (!x || !y || (C & 7) || kw < 1 || kw > 2 || kh < 1 || kh > 2 || W % kw || H % kh) return OCR_ERR_INVALID;
+    long total = (long)Nb * (W / kw) * (H / kh) * (C >> 3);
+    const bf16_t* xi = (const bf16_t*)x; bf16_t* yo = (bf16_t*)y;
+    hipStream_t st = (hipStream_t)stream;
+    int gr = grid_for(total, 8192);
+    if (kw == 2 && kh == 2) maxpool_fwd_kernel<2, 2><<<gr, 256, 0, st>>>(xi, yo, Nb, W, H, C);
+    else if (kw == 1 && kh == 2) maxpool_fwd_kernel<1, 2><<<gr, 256, 0, st>>>(xi, yo, Nb, W, H, C);
+    else if (kw == 2 && kh == 1) maxpool_fwd_kernel<2, 1><<<gr, 256, 0, st>>>(xi, yo, Nb, W, H, C);
+    else return OCR_ERR_INVALID;
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+extern "C" int ocr_maxpool_bwd(const void* x, const void* dy, void* dx, int Nb, int W, int H, int C, int kw, int kh,
+                               int relu_mask, void* stream) {
+    if (!x || !dy || !dx || (C & 7) || kw < 1 || kw > 2 || kh < 1 || kh > 2 || W % kw || H % kh) return OCR_ERR_INVALID;
+    long total = (long)Nb * (W / kw) * (H / kh) * (C >> 3);
+    const bf16_t* xi = (const bf16_t*)x; const bf16_t* dyi = (const bf16_t*)dy; bf16_t* dxo = (bf16_t*)dx;
+    hipStream_t st = (hipStream_t)stream;
+    int gr = grid_for(total, 8192);
+    if (kw == 2 && kh == 2) maxpool_bwd_kernel<2, 2><<<gr, 256, 0, st>>>(xi, dyi, dxo, Nb, W, H, C, relu_mask);
+    else if (kw == 1 && kh == 2) maxpool_bwd_kernel<1, 2><<<gr, 256, 0, st>>>(xi, dyi, dxo, Nb, W, H, C, relu_mask);
+    else if (kw == 2 && kh == 1) maxpool_bwd_kernel<2, 1><<<gr, 256, 0, st>>>(xi, dyi, dxo, Nb, W, H, C, relu_mask);
+    else return OCR_ERR_INVALID;
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+// workspace: 2*C doubles (zeroed here)
+extern "C" int ocr_bn_train_fwd(const void* x, void* y, const float* gamma, const float* beta, float* save_mean,
+                                float* save_rstd, long M, int C, float eps, int relu, void* workspace, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !y || !gamma || !beta || !save_mean || !save_rstd || !workspace || (C & 7) || C > 2048 || M <= 0)
+        return OCR_ERR_INVALID;
+    if (hipMemsetAsync(workspace, 0, 2 * (size_t)C * sizeof(double), stream) != hipSuccess) return OCR_ERR_MEMOPS;
+    int rlanes = 256 / (C >> 3); if (rlanes < 1) return OCR_ERR_INVALID;
+    int rpb = 128;
+    bn_stats_kernel<<<ceil_div(M, rpb), 256, 0, stream>>>((const bf16_t*)x, (double*)workspace, M, C, rpb);
+    OCR_CHECK_LAUNCH();
+    bn_finalize_kernel<<<ceil_div(C, 256), 256, 0, stream>>>((const double*)workspace, save_mean, save_rstd, M, C, eps);
+    OCR_CHECK_LAUNCH();
+    bn_apply_kernel<<<grid_for(M * (C >> 3), 8192), 256, 0, stream>>>((const bf16_t*)x, (bf16_t*)y, save_mean, save_rstd, gamma,
+                                                                       beta, M, C, relu);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+extern "C" int ocr_bn_train_bwd(const void* x, const void* y, const void* dy, void* dx, const float* gamma,
+                                const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, long M,
+                                int C, int relu, void* workspace, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !y || !dy || !dx || !gamma || !save_mean || !save_rstd || !dgamma || !dbeta || !workspace || (C & 7) ||
+        C > 2048 || M <= 0)
+        return OCR_ERR_INVALID;
+    if (hipMemsetAsync(workspace, 0, 2 * (size_t)C * sizeof(double), stream) != hipSuccess) return OCR_ERR_MEMOPS;
+    int rpb = 128;
+    bn_bwd_stats_kernel<<<ceil_div(M, rpb), 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, save_mean,
+                                                              save_rstd, (double*)workspace, M, C, rpb, relu);
+    OCR_CHECK_LAUNCH();
+    bn_bwd_apply_kernel<<<grid_for(M * (C >> 3), 8192), 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy,
+                                                                           (bf16_t*)dx, save_mean, save_rstd, gamma,
+                                                                           (const double*)workspace, dgamma, dbeta, M, C, relu);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+extern "C" int ocr_colsum_bf16(const void* a, float* out, long M, int C, long lda, void* stream) {
+    if (!a || !out || (C & 7) || C > 2048 || M <= 0) return OCR_ERR_INVALID;
+    int rpb = 128;
+    colsum_kernel<<<ceil_div(M, rpb), 256, 0, (hipStream_t)stream>>>((const bf16_t*)a, out, M, C, lda, rpb);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+extern "C" int ocr_pack_transpose(const float* in, void* out, int R, int Cc, long ldin, int lstm_units, void* stream) {
+    if (!in || !out || R <= 0 || Cc <= 0) return OCR_ERR_INVALID;
+    if (lstm_units > 0 && Cc != 4 * lstm_units) return OCR_ERR_INVALID;
+    dim3 grid(ceil_div(Cc, 32), ceil_div(R, 32));
+    pack_transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(in, (bf16_t*)out, R, Cc, ldin, lstm_units);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+extern "C" int ocr_pack_conv_dgrad(const float* w, void* out, int Cin, int Cout, void* stream) {
+    if (!w || !out) return OCR_ERR_INVALID;
+    pack_conv_dgrad_kernel<<<grid_for(9L * Cin * Cout), 256, 0, (hipStream_t)stream>>>(w, (bf16_t*)out, Cin, Cout);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+extern "C" int ocr_cast_f32_bf16(const float* in, void* out, long n, void* stream) {
+    if (!in || !out || n < 0) return OCR_ERR_INVALID;
+    if (n == 0) return OCR_OK;
+    cast_f32_bf16_kernel<<<grid_for((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(in, (bf16_t*)out, n);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+extern "C" int ocr_cast2d_f32_bf16(const float* in, long ldin, void* out, long ldout, int rows, int cols, void* stream) {
+    if (!in || !out || rows <= 0 || cols <= 0 || (cols & 3) || (ldin & 3) || (ldout & 3)) return OCR_ERR_INVALID;
+    cast2d_f32_bf16_kernel<<<grid_for((long)rows * (cols >> 2)), 256, 0, (hipStream_t)stream>>>(in, ldin, (bf16_t*)out, ldout, rows, cols);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+extern "C" int ocr_tnc_to_ntc_bf16(const float* in, void* out, int T, int N, int C, float scale, void* stream) {
+    if (!in || !out) return OCR_ERR_INVALID;
+    tnc_to_ntc_bf16_kernel<<<grid_for((long)T * N * C), 256, 0, (hipStream_t)stream>>>(in, (bf16_t*)out, T, N, C, scale);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+extern "C" int ocr_conv5_col2im(const void* col, void* dx, int Nb, int W, int HC, void* stream) {
+    if (!col || !dx) return OCR_ERR_INVALID;
+    conv5_col2im_kernel<<<grid_for((long)Nb * W * HC), 256, 0, (hipStream_t)stream>>>((const bf16_t*)col, (bf16_t*)dx, Nb, W, HC);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}

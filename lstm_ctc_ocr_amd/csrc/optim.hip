@@ -1,0 +1,169 @@
+// Fused optimiser step for gfx950.
+//
+// Reference: lib/lstm/train.py:73-85 — tf.gradients -> tf.clip_by_global_norm(g, 10.0) -> Adam /
+// RMSProp / Momentum apply_gradients, with the L2 regulariser of lib/networks/network.py:630-637,660-662
+// (wd * ||w||^2 / 2 on conv + FC weights) folded in as g += wd * w.
+//
+// All parameters live in ONE flat fp32 buffer ordered [regularised tensors | the rest], so the whole
+// step is two HBM-bound grid-stride kernels over that buffer (+ a 1-thread "tick" that advances the
+// Adam bias correction on the device, which keeps the step replayable from a hipGraph with no host
+// scalars baked in).  The same flat gradient buffer is what the data-parallel all-reduce sees.
+#include "common.h"
+#include <math.h>
+
+// device scalar block layout (doubles): [0] sum g^2, [1] sum w^2 over regularised range,
+// [2] lr, [3] lr_t (bias-corrected), [4] beta1^t, [5] beta2^t, [6] step count, [7] last global norm
+#define SC_NORM2 0
+#define SC_REG2 1
+#define SC_LR 2
+#define SC_LRT 3
+#define SC_B1T 4
+#define SC_B2T 5
+#define SC_STEP 6
+#define SC_GNORM 7
+
+__global__ void optim_tick_kernel(double* sc, double beta1, double beta2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double b1t = sc[SC_B1T] * beta1, b2t = sc[SC_B2T] * beta2;
+        sc[SC_B1T] = b1t; sc[SC_B2T] = b2t;
+        sc[SC_STEP] += 1.0;
+        sc[SC_LRT] = sc[SC_LR] * sqrt(1.0 - b2t) / (1.0 - b1t);
+        sc[SC_NORM2] = 0.0; sc[SC_REG2] = 0.0;
+    }
+}
+
+// pass 1: g += wd * w on the regularised prefix; accumulate sum g^2 (all) and sum w^2 (prefix)
+__global__ __launch_bounds__(256) void optim_prep_kernel(const float* __restrict__ p, float* __restrict__ g, long n,
+                                                         long n_reg, float wd, double* sc) {
+    float s2 = 0.f, r2 = 0.f;
+    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (; i < n; i += stride) {   // n % 4 == 0, n_reg % 4 == 0
+        f32x4 gv = *(const f32x4*)(g + i);
+        if (i < n_reg) {
+            f32x4 pv = *(const f32x4*)(p + i);
+            gv = gv + pv * wd;
+            *(f32x4*)(g + i) = gv;
+            r2 += pv.x * pv.x + pv.y * pv.y + pv.z * pv.z + pv.w * pv.w;
+        }
+        s2 += gv.x * gv.x + gv.y * gv.y + gv.z * gv.z + gv.w * gv.w;
+    }
+    s2 = wave_sum(s2); r2 = wave_sum(r2);
+    __shared__ float red[2][4];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = s2; red[1][wave] = r2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sc[SC_NORM2], (double)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+        atomicAdd(&sc[SC_REG2], (double)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
+    }
+}
+
+// pass 2, Adam (TF form): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_t m / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, long n,
+                                                          float beta1, float beta2, float eps, float clip,
+                                                          double* sc) {
+    const float gnorm = (float)sqrt(sc[SC_NORM2]);
+    const float scale = (clip > 0.f) ? clip / fmaxf(gnorm, clip) : 1.f;
+    const float lrt = (float)sc[SC_LRT];
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[SC_GNORM] = (double)gnorm;
+    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (; i < n; i += stride) {
+        f32x4 gv = *(const f32x4*)(g + i) * scale;
+        f32x4 mv = *(const f32x4*)(m + i), vv = *(const f32x4*)(v + i), pv = *(const f32x4*)(p + i);
+        mv = mv * beta1 + gv * (1.f - beta1);
+        vv = vv * beta2 + gv * gv * (1.f - beta2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r] -= lrt * mv[r] / (sqrtf(vv[r]) + eps);
+        *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv; *(f32x4*)(p + i) = pv;
+    }
+}
+// Momentum (TF MomentumOptimizer): acc = mom*acc + g; w -= lr*acc
+__global__ __launch_bounds__(256) void momentum_update_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                              float* __restrict__ m, long n, float mom, float clip,
+                                                              double* sc) {
+    const float gnorm = (float)sqrt(sc[SC_NORM2]);
+    const float scale = (clip > 0.f) ? clip / fmaxf(gnorm, clip) : 1.f;
+    const float lr = (float)sc[SC_LR];
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[SC_GNORM] = (double)gnorm;
+    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (; i < n; i += stride) {
+        f32x4 gv = *(const f32x4*)(g + i) * scale;
+        f32x4 mv = *(const f32x4*)(m + i) * mom + gv;
+        f32x4 pv = *(const f32x4*)(p + i) - mv * lr;
+        *(f32x4*)(m + i) = mv; *(f32x4*)(p + i) = pv;
+    }
+}
+// RMSProp (TF RMSPropOptimizer defaults: decay .9, momentum 0, eps 1e-10): ms = d ms + (1-d) g^2; w -= lr g / sqrt(ms + eps)
+__global__ __launch_bounds__(256) void rmsprop_update_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                             float* __restrict__ ms, long n, float decay, float eps,
+                                                             float clip, double* sc) {
+    const float gnorm = (float)sqrt(sc[SC_NORM2]);
+    const float scale = (clip > 0.f) ? clip / fmaxf(gnorm, clip) : 1.f;
+    const float lr = (float)sc[SC_LR];
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[SC_GNORM] = (double)gnorm;
+    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (; i < n; i += stride) {
+        f32x4 gv = *(const f32x4*)(g + i) * scale;
+        f32x4 sv = *(const f32x4*)(ms + i) * decay + gv * gv * (1.f - decay);
+        f32x4 pv = *(const f32x4*)(p + i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r] -= lr * gv[r] / sqrtf(sv[r] + eps);
+        *(f32x4*)(ms + i) = sv; *(f32x4*)(p + i) = pv;
+    }
+}
+__global__ void optim_init_kernel(double* sc, double lr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        sc[SC_NORM2] = 0; sc[SC_REG2] = 0; sc[SC_LR] = lr; sc[SC_LRT] = lr; sc[SC_B1T] = 1.0; sc[SC_B2T] = 1.0;
+        sc[SC_STEP] = 0; sc[SC_GNORM] = 0;
+    }
+}
+__global__ void optim_set_lr_kernel(double* sc, double lr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) sc[SC_LR] = lr;
+}
+__global__ void optim_scale_lr_kernel(double* sc, double gamma) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) sc[SC_LR] *= gamma;
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI.  `scalars` is a caller-owned device block of 8 doubles (layout above).
+// ------------------------------------------------------------------------------------------
+extern "C" int ocr_optim_init(void* scalars, double lr, void* stream) {
+    if (!scalars) return OCR_ERR_INVALID;
+    optim_init_kernel<<<1, 64, 0, (hipStream_t)stream>>>((double*)scalars, lr);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+extern "C" int ocr_optim_set_lr(void* scalars, double lr, int multiply, void* stream) {
+    if (!scalars) return OCR_ERR_INVALID;
+    if (multiply) optim_scale_lr_kernel<<<1, 64, 0, (hipStream_t)stream>>>((double*)scalars, lr);
+    else optim_set_lr_kernel<<<1, 64, 0, (hipStream_t)stream>>>((double*)scalars, lr);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+// solver: 0 Adam (beta1, beta2, eps), 1 Momentum (beta1 = momentum), 2 RMSProp (beta1 = decay, eps)
+// state1/state2: Adam m, v ; Momentum accumulator (state2 unused) ; RMSProp mean-square (state2 unused)
+extern "C" int ocr_optim_step(float* params, float* grads, float* state1, float* state2, long n, long n_reg,
+                              float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
+                              void* scalars, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!params || !grads || !state1 || !scalars || n <= 0 || (n & 3) || (n_reg & 3) || n_reg < 0 || n_reg > n)
+        return OCR_ERR_INVALID;
+    if (solver == 0 && !state2) return OCR_ERR_INVALID;
+    double* sc = (double*)scalars;
+    optim_tick_kernel<<<1, 64, 0, stream>>>(sc, (double)beta1, (double)beta2);
+    OCR_CHECK_LAUNCH();
+    int blocks = (int)((n / 4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+    optim_prep_kernel<<<blocks, 256, 0, stream>>>(params, grads, n, weight_decay > 0.f ? n_reg : 0, weight_decay, sc);
+    OCR_CHECK_LAUNCH();
+    if (solver == 0) adam_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, state2, n, beta1, beta2, eps, clip_norm, sc);
+    else if (solver == 1) momentum_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, n, beta1, clip_norm, sc);
+    else if (solver == 2) rmsprop_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, n, beta1, eps, clip_norm, sc);
+    else return OCR_ERR_INVALID;
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}

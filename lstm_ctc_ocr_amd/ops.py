@@ -1,0 +1,242 @@
+"""Thin tensor-level wrappers over the C ABI (include/ocr_hip.h).
+
+torch is used for allocation and stream handles only; every function enqueues hand-written HIP kernels on torch's
+current stream and returns device tensors.  No function here has a CPU or eager fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _native as nat
+from ._native import EPI_ACCUM, EPI_BIAS, EPI_MASK, EPI_OUT_F32, EPI_RELU, EPI_ROWSWAP, call, ptr
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _st():
+    return nat.stream()
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise nat.NativeError("hot-path operators take device tensors only (got a CPU tensor)")
+    return t
+
+
+# ----------------------------------------------------------------------------------------------- CTC
+def ctc_workspace_bytes(max_label_len, max_time, minibatch):
+    sz = ctypes.c_size_t(0)
+    call("ocr_ctc_workspace_size", max_label_len, max_time, minibatch, ctypes.byref(sz))
+    return sz.value
+
+
+def ctc_loss(acts, flat_labels, label_lengths, input_lengths, max_label_len, blank=0, want_grad=True,
+             workspace=None, costs=None, grads=None):
+    """warp-ctc shaped: acts f32 [T, N, C] unnormalised; labels/lengths int32 device tensors."""
+    T, N, C = acts.shape
+    _dev(acts)
+    if workspace is None:
+        workspace = torch.empty(ctc_workspace_bytes(max_label_len, T, N), dtype=torch.uint8, device=acts.device)
+    if costs is None:
+        costs = torch.empty(N, dtype=F32, device=acts.device)
+    if want_grad and grads is None:
+        grads = torch.empty_like(acts)
+    call("ocr_ctc_loss", ptr(acts), ptr(grads) if want_grad else None, ptr(flat_labels), ptr(label_lengths),
+         ptr(input_lengths), C, N, T, max_label_len, blank, ptr(costs), ptr(workspace), _st())
+    return costs, (grads if want_grad else None)
+
+
+def ctc_greedy_decode(acts, input_lengths, blank=0, pad_value=0):
+    T, N, C = acts.shape
+    out = torch.empty((N, T), dtype=torch.int32, device=acts.device)
+    lens = torch.empty(N, dtype=torch.int32, device=acts.device)
+    call("ocr_ctc_greedy_decode", ptr(_dev(acts)), ptr(input_lengths), C, N, T, blank, pad_value, ptr(out), ptr(lens), _st())
+    return out, lens
+
+
+# ----------------------------------------------------------------------------------------------- GEMMs
+def gemm_nt(P, Q, out=None, *, M=None, N=None, K=None, ldp=None, ldq=None, ldo=None, bias=None, relu=False,
+            out_f32=False, mask=None, accumulate=False, splits=1, row_group=0, row_skip=0, rowswap=None):
+    """out[m][n] = sum_k P[m][k] Q[n][k]; P, Q bf16 (K contiguous)."""
+    M = P.shape[0] if M is None else M
+    K = P.shape[1] if K is None else K
+    N = Q.shape[0] if N is None else N
+    ldp = P.stride(0) if ldp is None else ldp
+    ldq = Q.stride(0) if ldq is None else ldq
+    if out is None:
+        out = torch.empty((M, N), dtype=F32 if out_f32 else BF16, device=P.device)
+    ldo = out.stride(0) if ldo is None else ldo
+    flags = 0
+    if bias is not None: flags |= EPI_BIAS
+    if relu: flags |= EPI_RELU
+    if out.dtype == F32: flags |= EPI_OUT_F32
+    if mask is not None: flags |= EPI_MASK
+    if accumulate: flags |= EPI_ACCUM
+    si = so = 0
+    if rowswap is not None:
+        flags |= EPI_ROWSWAP
+        si, so = rowswap
+    call("ocr_gemm_nt_bf16", ptr(_dev(P)), ldp, ptr(Q), ldq, ptr(out), ldo, M, N, K, ptr(bias), ptr(mask),
+         mask.stride(0) if mask is not None else 0, flags, splits, row_group, row_skip, si, so, _st())
+    return out
+
+
+def conv3x3(x, wpack, out=None, *, bias=None, relu=False, mask=None):
+    """x bf16 [Nb, W, H, Cin]; wpack bf16 [Cout, 3, 3, Cin] -> bf16 [Nb, W, H, Cout]."""
+    Nb, W, H, Cin = x.shape
+    Cout = wpack.shape[0]
+    if out is None:
+        out = torch.empty((Nb, W, H, Cout), dtype=BF16, device=x.device)
+    flags = (EPI_BIAS if bias is not None else 0) | (EPI_RELU if relu else 0) | (EPI_MASK if mask is not None else 0)
+    call("ocr_conv3x3_bf16", ptr(_dev(x)), ptr(wpack), ptr(out), Nb, W, H, Cin, Cout, ptr(bias), ptr(mask), flags, _st())
+    return out
+
+
+def gemm_tn(A, B, out, *, Mk=None, I=None, J=None, lda=None, ldb=None, ldo=None, row_group=0, row_skip=0,
+            a_row_off=0, scale=1.0, splits=0):
+    """out[I][J] (f32) += scale * A^T B."""
+    Mk = B.shape[0] if Mk is None else Mk
+    I = A.shape[1] if I is None else I
+    J = B.shape[1] if J is None else J
+    lda = A.stride(0) if lda is None else lda
+    ldb = B.stride(0) if ldb is None else ldb
+    ldo = out.stride(0) if ldo is None else ldo
+    call("ocr_gemm_tn_bf16", ptr(_dev(A)), lda, ptr(B), ldb, ptr(out), ldo, Mk, I, J, row_group, row_skip, a_row_off,
+         float(scale), splits, _st())
+    return out
+
+
+def conv3x3_wgrad(x, dy, dw, splits=0):
+    Nb, W, H, Cin = x.shape
+    Cout = dy.shape[-1]
+    call("ocr_conv3x3_wgrad_bf16", ptr(_dev(x)), ptr(dy), ptr(dw), Nb, W, H, Cin, Cout, splits, _st())
+    return dw
+
+
+# ----------------------------------------------------------------------------------------------- HBM-bound layers
+def conv1_fwd(x, w, bias, relu=True, out=None):
+    Nb, W, H = x.shape
+    Cout = w.shape[-1]
+    if out is None:
+        out = torch.empty((Nb, W, H, Cout), dtype=BF16, device=x.device)
+    call("ocr_conv1_fwd", ptr(_dev(x)), ptr(w), ptr(bias), ptr(out), Nb, W, H, Cout, int(relu), _st())
+    return out
+
+
+def conv1_wgrad(x, dz, dw, db):
+    Nb, W, H = x.shape
+    call("ocr_conv1_wgrad", ptr(_dev(x)), ptr(dz), ptr(dw), ptr(db), Nb, W, H, dz.shape[-1], _st())
+
+
+def maxpool_fwd(x, kw, kh, out=None):
+    Nb, W, H, C = x.shape
+    if out is None:
+        out = torch.empty((Nb, W // kw, H // kh, C), dtype=BF16, device=x.device)
+    call("ocr_maxpool_fwd", ptr(_dev(x)), ptr(out), Nb, W, H, C, kw, kh, _st())
+    return out
+
+
+def maxpool_bwd(x, dy, kw, kh, relu_mask, out=None):
+    Nb, W, H, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    call("ocr_maxpool_bwd", ptr(_dev(x)), ptr(dy), ptr(out), Nb, W, H, C, kw, kh, int(relu_mask), _st())
+    return out
+
+
+def bn_train_fwd(x2d, gamma, beta, eps, relu, workspace, out=None, save_mean=None, save_rstd=None):
+    M, C = x2d.shape
+    if out is None: out = torch.empty_like(x2d)
+    if save_mean is None: save_mean = torch.empty(C, dtype=F32, device=x2d.device)
+    if save_rstd is None: save_rstd = torch.empty(C, dtype=F32, device=x2d.device)
+    call("ocr_bn_train_fwd", ptr(_dev(x2d)), ptr(out), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_rstd), M, C,
+         float(eps), int(relu), ptr(workspace), _st())
+    return out, save_mean, save_rstd
+
+
+def bn_train_bwd(x2d, y2d, dy2d, gamma, save_mean, save_rstd, dgamma, dbeta, relu, workspace, out=None):
+    M, C = x2d.shape
+    if out is None: out = torch.empty_like(x2d)
+    call("ocr_bn_train_bwd", ptr(_dev(x2d)), ptr(y2d), ptr(dy2d), ptr(out), ptr(gamma), ptr(save_mean), ptr(save_rstd),
+         ptr(dgamma), ptr(dbeta), M, C, int(relu), ptr(workspace), _st())
+    return out
+
+
+def colsum(a2d, out, M=None, C=None, lda=None):
+    M = a2d.shape[0] if M is None else M
+    C = a2d.shape[1] if C is None else C
+    lda = a2d.stride(0) if lda is None else lda
+    call("ocr_colsum_bf16", ptr(_dev(a2d)), ptr(out), M, C, lda, _st())
+    return out
+
+
+def pack_transpose(w2d, out, lstm_units=0, R=None, Cc=None, ldin=None):
+    R = w2d.shape[0] if R is None else R
+    Cc = w2d.shape[1] if Cc is None else Cc
+    ldin = w2d.stride(0) if ldin is None else ldin
+    call("ocr_pack_transpose", ptr(_dev(w2d)), ptr(out), R, Cc, ldin, lstm_units, _st())
+    return out
+
+
+def pack_conv_dgrad(w, out):
+    kh, kw, cin, cout = w.shape
+    call("ocr_pack_conv_dgrad", ptr(_dev(w)), ptr(out), cin, cout, _st())
+    return out
+
+
+def cast_bf16(src, dst):
+    call("ocr_cast_f32_bf16", ptr(_dev(src)), ptr(dst), src.numel(), _st())
+    return dst
+
+
+def cast2d_bf16(src, ldin, dst, ldout, rows, cols):
+    call("ocr_cast2d_f32_bf16", ptr(_dev(src)), ldin, ptr(dst), ldout, rows, cols, _st())
+    return dst
+
+
+def tnc_to_ntc_bf16(src_tnc, dst_ntc, scale):
+    T, N, C = src_tnc.shape
+    call("ocr_tnc_to_ntc_bf16", ptr(_dev(src_tnc)), ptr(dst_ntc), T, N, C, float(scale), _st())
+    return dst_ntc
+
+
+def conv5_col2im(col, dx, Nb, W, HC):
+    call("ocr_conv5_col2im", ptr(_dev(col)), ptr(dx), Nb, W, HC, _st())
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------- LSTM
+def lstm_fwd_step(xproj, whT, seq_len, hout, gates, cell, Nb, T, U, step, forget_bias=1.0):
+    call("ocr_lstm_fwd_step", ptr(_dev(xproj)), ptr(whT), ptr(seq_len), ptr(hout), ptr(gates), ptr(cell), Nb, T, U, step,
+         float(forget_bias), _st())
+
+
+def lstm_bwd_step(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, dc_state, Nb, T, U, step):
+    call("ocr_lstm_bwd_step", ptr(_dev(wh)), ldw, w_dir_stride, ptr(seq_len), ptr(dhout), ptr(gates), ptr(cell), ptr(dz),
+         ptr(dc_state), Nb, T, U, step, _st())
+
+
+def lstm_hprev(hout, seq_len, hprev, Nb, T, U):
+    call("ocr_lstm_hprev", ptr(_dev(hout)), ptr(seq_len), ptr(hprev), Nb, T, U, _st())
+
+
+def lstm_pack_bias(b_fw, b_bw, out, U):
+    call("ocr_lstm_pack_bias", ptr(_dev(b_fw)), ptr(b_bw), ptr(out), U, _st())
+
+
+# ----------------------------------------------------------------------------------------------- optimiser
+SOLVERS = {"Adam": 0, "Momentum": 1, "RMS": 2}
+
+
+def optim_init(scalars, lr):
+    call("ocr_optim_init", ptr(_dev(scalars)), float(lr), _st())
+
+
+def optim_set_lr(scalars, lr, multiply=False):
+    call("ocr_optim_set_lr", ptr(_dev(scalars)), float(lr), int(multiply), _st())
+
+
+def optim_step(params, grads, state1, state2, n_reg, weight_decay, clip_norm, solver, beta1, beta2, eps, scalars):
+    call("ocr_optim_step", ptr(_dev(params)), ptr(grads), ptr(state1), ptr(state2), params.numel(), n_reg,
+         float(weight_decay), float(clip_norm), solver, float(beta1), float(beta2), float(eps), ptr(scalars), _st())

@@ -1,0 +1,411 @@
+"""-m gpu: every HIP kernel against an independent CPU computation on the same (bf16-rounded) inputs.
+
+Tolerances: integer/index outputs bit-exact; fp32-accumulated contractions of bf16 operands within 2e-3 of the
+operand-scale (fp32 summation order only) when the output is fp32 and within bf16 output quantisation (2^-8
+relative) when the output is stored as bf16; CTC loss 1e-4 relative (north star asks 1e-3), gradients 1e-4 abs.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from lstm_ctc_ocr_amd import ops
+from oracle import ctc as octc
+from oracle import decode as odec
+from oracle import graph as og
+
+BF = torch.bfloat16
+
+
+def bf(x):
+    return x.to(BF).to(torch.float32)
+
+
+def maxerr(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+def relerr(a, b):
+    return maxerr(a, b) / max(float(b.double().abs().max()), 1e-12)
+
+
+def gen(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+# ------------------------------------------------------------------------------------------- probe
+def test_probe_tr16(dev):
+    """Records the lane semantics of ds_read_b64_tr_b16 for two address patterns (evidence for gemm_tn's
+    transposing read); asserts the hypothesis used by the TR path."""
+    res = {}
+    lanes = np.arange(64)
+    tables = {
+        "lane_linear": lanes * 8,
+        # hypothesis H: group g = l>>4 reads a 4(k) x 16(col) row-major block with row stride 64 elements;
+        # lane L=l&15 supplies the 8-byte chunk (row L>>2, cols 4*(L&3)..+3)
+        "rowmajor64": (((lanes >> 4) * 4 + ((lanes & 15) >> 2)) * 64 + (lanes & 3) * 4) * 2,
+    }
+    for name, tab in tables.items():
+        addr = torch.tensor(tab, dtype=torch.int32, device=dev)
+        out = torch.zeros(256, dtype=torch.int32, device=dev)
+        from lstm_ctc_ocr_amd import _native as nat
+        nat.call("ocr_probe_tr16", addr.data_ptr(), out.data_ptr(), nat.stream())
+        torch.cuda.synchronize()
+        res[name] = out.cpu().numpy().reshape(64, 4).tolist()
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(res, open("gpurun_out/probe_tr16.json", "w"))
+    got = np.array(res["rowmajor64"])
+    exp = np.array([[((l >> 4) * 4 + j) * 64 + (l & 15) for j in range(4)] for l in range(64)])
+    print("tr16 rowmajor64 lane0..3:", got[:4].tolist(), "expected", exp[:4].tolist())
+    print("tr16 lane_linear lane0..3,16,17:", [res["lane_linear"][i] for i in (0, 1, 2, 3, 16, 17)])
+    assert (got == exp).all(), "hypothesis H about ds_read_b64_tr_b16 does not hold — see gpurun_out/probe_tr16.json"
+
+
+# ------------------------------------------------------------------------------------------- CTC
+def _ctc_case(dev, T, N, C, lens, in_lens, seed, blank=0, labels=None):
+    rng = np.random.RandomState(seed)
+    acts = (rng.randn(T, N, C) * 2).astype(np.float32)
+    if labels is None:
+        labels = [rng.randint(1, C, size=l).tolist() for l in lens]
+    flat = np.array([v for l in labels for v in l], np.int32)
+    ll = np.array([len(l) for l in labels], np.int32)
+    il = np.array(in_lens, np.int32)
+    ref_c, ref_g = octc.ctc_loss_c(acts, flat, ll, il, blank)
+    a = torch.from_numpy(acts).to(dev)
+    fl = torch.from_numpy(flat if len(flat) else np.zeros(1, np.int32)).to(dev)
+    costs, grads = ops.ctc_loss(a, fl, torch.from_numpy(ll).to(dev), torch.from_numpy(il).to(dev), int(max(ll.max(), 1)), blank)
+    torch.cuda.synchronize()
+    c = costs.cpu().numpy(); g = grads.cpu().numpy()
+    assert np.allclose(c, ref_c, rtol=1e-4, atol=1e-4), (c, ref_c)
+    assert np.abs(g - ref_g).max() < 1e-4, np.abs(g - ref_g).max()
+    # score-only call must not touch gradients and give the same costs
+    costs2, _ = ops.ctc_loss(a, fl, torch.from_numpy(ll).to(dev), torch.from_numpy(il).to(dev), int(max(ll.max(), 1)), blank,
+                             want_grad=False)
+    assert np.allclose(costs2.cpu().numpy(), ref_c, rtol=1e-4, atol=1e-4)
+
+
+def test_ctc_known_answer(dev):
+    acts = torch.tensor([[[0.1, 0.6, 0.1, 0.1, 0.1]], [[0.1, 0.1, 0.6, 0.1, 0.1]]], device=dev)
+    lab = torch.tensor([1, 2], dtype=torch.int32, device=dev)
+    one = torch.tensor([2], dtype=torch.int32, device=dev)
+    costs, grads = ops.ctc_loss(acts, lab, one, one, 2)
+    assert abs(float(costs[0]) - 2.46286) < 1e-5
+    g = grads.cpu().numpy().reshape(2, 5)
+    exp = np.full((2, 5), 0.177031); exp[0, 1] = exp[1, 2] = -0.708125
+    assert np.abs(g - exp).max() < 1e-5
+
+
+def test_ctc_c2_shape(dev):
+    rng = np.random.RandomState(0)
+    _ctc_case(dev, 63, 64, 64, [10] * 64, [63] * 64, 1)
+    _ctc_case(dev, 63, 64, 64, rng.randint(4, 11, 64).tolist(), rng.randint(30, 64, 64).tolist(), 2)
+
+
+def test_ctc_edge_cases(dev):
+    # repeated characters, infeasible samples (L + repeats > T), empty label, T = 1
+    labels = [[5, 5, 5, 5], [1, 2, 3], [], [7], [9, 9]]
+    _ctc_case(dev, 8, 5, 16, None, [8, 2, 8, 1, 3], 3, labels=labels)
+    _ctc_case(dev, 8, 5, 16, None, [7, 3, 5, 1, 2], 4, labels=labels)
+    # long labels: S = 2L+1 > 64 exercises two / four slots per lane; large alphabet exercises strided classes
+    _ctc_case(dev, 90, 3, 96, [40, 33, 5], [90, 80, 90], 5)
+    _ctc_case(dev, 200, 2, 200, [100, 70], [200, 199], 6)
+    # non-zero blank
+    _ctc_case(dev, 20, 4, 10, [3, 4, 5, 2], [20, 18, 15, 9], 7, blank=9,
+              labels=[[1, 2, 3], [0, 0, 4, 8], [5, 6, 7, 8, 0], [2, 2]])
+
+
+def test_ctc_greedy(dev):
+    rng = np.random.RandomState(5)
+    for (T, N, C) in [(63, 64, 64), (130, 7, 96), (5, 3, 4)]:
+        acts = rng.randn(T, N, C).astype(np.float32)
+        acts[rng.rand(T, N) < 0.4, 0] += 6.0      # plenty of blanks and repeats
+        acts[:, :, 3] += (rng.rand(T, N) < 0.3) * 6.0
+        il = rng.randint(1, T + 1, N).astype(np.int32)
+        out, lens = ops.ctc_greedy_decode(torch.from_numpy(acts).to(dev), torch.from_numpy(il).to(dev))
+        ref = odec.greedy_decode(acts, il)
+        out = out.cpu().numpy(); lens = lens.cpu().numpy()
+        for n in range(N):
+            assert lens[n] == len(ref[n])
+            assert out[n, :lens[n]].tolist() == ref[n]
+            assert (out[n, lens[n]:] == 0).all()
+    # hand cases from SURVEY §8c(5)
+    am = [5, 5, 0, 5, 0, 0, 7]
+    acts = np.full((7, 2, 8), -5.0, np.float32)
+    for t, a in enumerate(am): acts[t, 0, a] = 5.0
+    acts[:, 1, 0] = 5.0
+    out, lens = ops.ctc_greedy_decode(torch.from_numpy(acts).to(dev), torch.tensor([7, 7], dtype=torch.int32, device=dev))
+    assert out[0, :3].tolist() == [5, 5, 7] and int(lens[0]) == 3 and int(lens[1]) == 0
+
+
+# ------------------------------------------------------------------------------------------- GEMM NT
+@pytest.mark.parametrize("M,N,K", [(4032, 1024, 512), (4032, 64, 512), (300, 132, 72), (128, 128, 32), (70, 520, 2048)])
+def test_gemm_nt(dev, M, N, K):
+    P = bf(gen((M, K), 1)); Q = bf(gen((N, K), 2)); bias = gen((N,), 3)
+    ref = P @ Q.t()
+    Pd, Qd, bd = P.to(dev).to(BF), Q.to(dev).to(BF), bias.to(dev)
+    out = ops.gemm_nt(Pd, Qd, out_f32=True)
+    assert relerr(out.cpu(), ref) < 2e-5
+    out = ops.gemm_nt(Pd, Qd, bias=bd, relu=True)
+    assert relerr(out.float().cpu(), bf(torch.relu(ref + bias))) < 1e-2
+    # split-K with atomics accumulates onto the existing fp32 content
+    base = gen((M, N), 4).to(dev)
+    out = ops.gemm_nt(Pd, Qd, out=base.clone(), splits=3, bias=bd)
+    assert relerr(out.cpu(), ref + bias + base.cpu()) < 2e-5
+    # mask (ReLU backward fused) and accumulate
+    mask = gen((M, N), 5)
+    out = ops.gemm_nt(Pd, Qd, mask=mask.to(dev).to(BF))
+    assert relerr(out.float().cpu(), bf(ref * (bf(mask) > 0))) < 1e-2
+    acc = ops.gemm_nt(Pd, Qd, out=base.clone(), accumulate=True)
+    assert relerr(acc.cpu(), ref + base.cpu()) < 2e-5
+
+
+def test_gemm_nt_rowswap_and_rowgroups(dev):
+    Nb, T, K, N = 5, 7, 64, 64
+    P = bf(gen((Nb * T, K), 1)); Q = bf(gen((N, K), 2))
+    out = torch.empty((T * Nb, N), dtype=torch.float32, device=dev)
+    ops.gemm_nt(P.to(dev).to(BF), Q.to(dev).to(BF), out=out, rowswap=(T, Nb))
+    ref = (P @ Q.t()).reshape(Nb, T, N).permute(1, 0, 2).reshape(T * Nb, N)
+    assert relerr(out.cpu(), ref) < 2e-5
+    # conv5-style overlapping rows: x [Nb, W, HC], window = rows w and w+1 -> K = 2*HC, W-1 rows per sample
+    Nb, W, HC, Co = 3, 9, 64, 128
+    x = bf(gen((Nb, W, HC), 3)); Wt = bf(gen((Co, 2 * HC), 4))
+    rows = torch.stack([torch.cat([x[n, w], x[n, w + 1]]) for n in range(Nb) for w in range(W - 1)])
+    out = ops.gemm_nt(x.to(dev).to(BF), Wt.to(dev).to(BF), M=Nb * (W - 1), N=Co, K=2 * HC, ldp=HC, row_group=W - 1,
+                      row_skip=1, out_f32=True)
+    assert relerr(out.cpu(), rows @ Wt.t()) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------- conv 3x3
+def _conv_ref(x, w, b):   # x [N,W,H,C], w HWIO
+    y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), None, padding=1).permute(0, 2, 3, 1)
+    return y + b
+
+
+@pytest.mark.parametrize("Nb,W,H,Ci,Co", [(4, 16, 8, 64, 128), (2, 12, 4, 256, 512), (64, 64, 4, 256, 512), (3, 20, 16, 64, 128)])
+def test_conv3x3_fwd_dgrad_wgrad(dev, Nb, W, H, Ci, Co):
+    x = bf(gen((Nb, W, H, Ci), 1)); w = bf(gen((3, 3, Ci, Co), 2, 0.05)); b = gen((Co,), 3)
+    ref = _conv_ref(x, w, b)
+    wpack = torch.empty((Co, 3, 3, Ci), dtype=BF, device=dev)
+    ops.pack_transpose(w.reshape(9 * Ci, Co).to(dev), wpack)          # [9Ci][Co] -> [Co][9Ci]
+    y = ops.conv3x3(x.to(dev).to(BF), wpack, bias=b.to(dev), relu=True)
+    assert relerr(y.float().cpu(), bf(torch.relu(ref))) < 1e-2
+    # data gradient == conv with flipped / transposed weights, with the ReLU mask of the layer below fused
+    dy = bf(gen((Nb, W, H, Co), 4))
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    _conv_ref(xr, wr, b).backward(dy)
+    wd = torch.empty((Ci, 3, 3, Co), dtype=BF, device=dev)
+    ops.pack_conv_dgrad(w.to(dev), wd)
+    below = gen((Nb, W, H, Ci), 5)
+    dx = ops.conv3x3(dy.to(dev).to(BF), wd, mask=below.to(dev).to(BF))
+    assert relerr(dx.float().cpu(), bf(xr.grad * (bf(below) > 0))) < 1e-2
+    # weight gradient accumulates into the fp32 TF-layout buffer
+    dw = torch.zeros((3, 3, Ci, Co), dtype=torch.float32, device=dev)
+    ops.conv3x3_wgrad(x.to(dev).to(BF), dy.to(dev).to(BF), dw)
+    assert relerr(dw.cpu(), wr.grad) < 1e-4
+    ops.conv3x3_wgrad(x.to(dev).to(BF), dy.to(dev).to(BF), dw, splits=2)
+    assert relerr(dw.cpu(), 2 * wr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("Mk,I,J", [(4032, 512, 2048), (4032, 256, 1024), (4032, 512, 64), (100, 72, 136)])
+def test_gemm_tn(dev, Mk, I, J):
+    A = bf(gen((Mk, I), 1)); B = bf(gen((Mk, J), 2))
+    out = torch.zeros((I, J), dtype=torch.float32, device=dev)
+    ops.gemm_tn(A.to(dev).to(BF), B.to(dev).to(BF), out)
+    assert relerr(out.cpu(), A.t() @ B) < 1e-4
+    ops.gemm_tn(A.to(dev).to(BF), B.to(dev).to(BF), out, scale=0.5, splits=1)
+    assert relerr(out.cpu(), 1.5 * (A.t() @ B)) < 1e-4
+
+
+def test_gemm_tn_conv5_rows(dev):
+    Nb, W, HC, Co = 3, 9, 64, 128
+    x = bf(gen((Nb, W, HC), 3)); dy = bf(gen((Nb * (W - 1), Co), 4))
+    rows = torch.stack([torch.cat([x[n, w], x[n, w + 1]]) for n in range(Nb) for w in range(W - 1)])
+    out = torch.zeros((2 * HC, Co), dtype=torch.float32, device=dev)
+    ops.gemm_tn(x.to(dev).to(BF), dy.to(dev).to(BF), out, Mk=Nb * (W - 1), I=2 * HC, J=Co, lda=HC, row_group=W - 1, row_skip=1)
+    assert relerr(out.cpu(), rows.t() @ dy) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- conv1 / pool / bn
+def test_conv1(dev):
+    Nb, W, H, Co = 5, 24, 32, 64
+    x = gen((Nb, W, H), 1).abs(); w = gen((3, 3, 1, Co), 2, 0.3); b = gen((Co,), 3, 0.1)
+    ref = torch.relu(_conv_ref(x.unsqueeze(3), w, b))
+    y = ops.conv1_fwd(x.to(dev), w.to(dev), b.to(dev))
+    assert relerr(y.float().cpu(), bf(ref)) < 1e-2
+    dz = bf(gen((Nb, W, H, Co), 4))
+    wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    _conv_ref(x.unsqueeze(3), wr, br).backward(dz)
+    dw = torch.zeros_like(w, device=dev); db = torch.zeros(Co, device=dev)
+    ops.conv1_wgrad(x.to(dev), dz.to(dev).to(BF), dw, db)
+    assert relerr(dw.cpu(), wr.grad) < 1e-4 and relerr(db.cpu(), br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("kw,kh", [(2, 2), (1, 2)])
+def test_maxpool(dev, kw, kh):
+    Nb, W, H, C = 3, 8, 8, 64
+    x = bf(gen((Nb, W, H, C), 1))
+    x[x.abs() < 0.3] = 0.0                    # ties (ReLU zeros) exercise first-max routing
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr.permute(0, 3, 1, 2), (kw, kh), (kw, kh)).permute(0, 2, 3, 1)
+    y = ops.maxpool_fwd(x.to(dev).to(BF), kw, kh)
+    assert maxerr(y.float().cpu(), yr.detach()) == 0.0
+    dy = bf(gen(tuple(yr.shape), 2))
+    yr.backward(dy)
+    dx = ops.maxpool_bwd(x.to(dev).to(BF), dy.to(dev).to(BF), kw, kh, relu_mask=False)
+    assert maxerr(dx.float().cpu(), xr.grad) == 0.0
+    dx = ops.maxpool_bwd(x.to(dev).to(BF), dy.to(dev).to(BF), kw, kh, relu_mask=True)
+    assert maxerr(dx.float().cpu(), xr.grad * (x > 0)) == 0.0
+
+
+@pytest.mark.parametrize("M,C", [(16384, 512), (1000, 64)])
+def test_batchnorm(dev, M, C):
+    x = bf(gen((M, C), 1) * 2 + 0.5); gamma = gen((C,), 2) + 1.5; beta = gen((C,), 3)
+    xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    mu = xr.mean(0); var = xr.var(0, unbiased=False)
+    yr = torch.relu((xr - mu) * torch.rsqrt(var + 1e-3) * gr + br)
+    ws = torch.empty(2 * C, dtype=torch.float64, device=dev)
+    xd = x.to(dev).to(BF)
+    y, sm, sr = ops.bn_train_fwd(xd, gamma.to(dev), beta.to(dev), 1e-3, True, ws)
+    assert relerr(sm.cpu(), mu.detach()) < 1e-4 and relerr(sr.cpu(), torch.rsqrt(var + 1e-3).detach()) < 1e-4
+    assert relerr(y.float().cpu(), bf(yr.detach())) < 1e-2
+    dy = bf(gen((M, C), 4))
+    # use the device's own (bf16) y for the mask so both sides agree on which outputs are exactly zero
+    ydev = y.float().cpu()
+    (yr * (ydev > 0)).backward(dy)
+    dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+    dx = ops.bn_train_bwd(xd, y, dy.to(dev).to(BF), gamma.to(dev), sm, sr, dg, db, True, ws)
+    assert relerr(dg.cpu(), gr.grad) < 1e-3 and relerr(db.cpu(), br.grad) < 1e-3
+    assert relerr(dx.float().cpu(), bf(xr.grad)) < 2e-2
+
+
+def test_small_ops(dev):
+    a = bf(gen((1000, 512), 1))
+    out = torch.ones(512, device=dev)
+    ops.colsum(a.to(dev).to(BF), out)
+    assert relerr(out.cpu(), a.sum(0) + 1) < 1e-4
+    src = gen((1031,), 2).to(dev); dst = torch.empty(1031, dtype=BF, device=dev)
+    ops.cast_bf16(src, dst)
+    assert maxerr(dst.float().cpu(), bf(src.cpu())) == 0.0
+    s2 = gen((10, 24), 3).to(dev); d2 = torch.zeros((10, 32), dtype=BF, device=dev)
+    ops.cast2d_bf16(s2, 24, d2[:, 8:], 32, 10, 24)
+    assert maxerr(d2[:, 8:].float().cpu(), bf(s2.cpu())) == 0.0 and float(d2[:, :8].float().abs().sum()) == 0.0
+    g = gen((7, 5, 64), 4).to(dev); o = torch.empty((5, 7, 64), dtype=BF, device=dev)
+    ops.tnc_to_ntc_bf16(g, o, 0.25)
+    assert maxerr(o.float().cpu(), bf(g.cpu().permute(1, 0, 2) * 0.25)) == 0.0
+    # LSTM packing: gate-major column g*U+u -> packed (u/16)*64 + g*16 + u%16, transposed
+    U, D = 32, 24
+    w = gen((D, 4 * U), 5)
+    packed = torch.empty((4 * U, D), dtype=BF, device=dev)
+    ops.pack_transpose(w.to(dev), packed, lstm_units=U)
+    ref = torch.empty(4 * U, D)
+    for gte in range(4):
+        for u in range(U):
+            ref[(u // 16) * 64 + gte * 16 + u % 16] = w[:, gte * U + u]
+    assert maxerr(packed.float().cpu(), bf(ref)) == 0.0
+    col = bf(gen((3 * 8, 2, 64), 6)); dx = torch.empty((3, 9, 64), dtype=BF, device=dev)
+    ops.conv5_col2im(col.to(dev).to(BF), dx, 3, 9, 64)
+    c = col.reshape(3, 8, 2, 64); ref = torch.zeros(3, 9, 64)
+    ref[:, :8] += c[:, :, 0]; ref[:, 1:] += c[:, :, 1]
+    assert maxerr(dx.float().cpu(), bf(ref)) == 0.0
+
+
+# ------------------------------------------------------------------------------------------- LSTM
+def _lstm_device_forward(dev, x, seq_len, Ws, bs, U):
+    """Runs the hoisted projection + per-step kernels exactly as the executor does. x: [N,T,D] bf16-rounded fp32."""
+    N, T, D = x.shape
+    R = N * T
+    wxT = torch.empty((8 * U, D), dtype=BF, device=dev)
+    whT = torch.empty((2, 4 * U, U), dtype=BF, device=dev)
+    for d in range(2):
+        Wd = Ws[d].to(dev)
+        ops.pack_transpose(Wd[:D], wxT[d * 4 * U:(d + 1) * 4 * U], lstm_units=U, R=D, Cc=4 * U, ldin=4 * U)
+        ops.pack_transpose(Wd[D:], whT[d], lstm_units=U, R=U, Cc=4 * U, ldin=4 * U)
+    bias = torch.empty(8 * U, device=dev)
+    ops.lstm_pack_bias(bs[0].to(dev), bs[1].to(dev), bias, U)
+    xd = x.to(dev).to(BF).reshape(R, D)
+    xproj = ops.gemm_nt(xd, wxT, bias=bias, out_f32=True)
+    sl = torch.tensor(seq_len, dtype=torch.int32, device=dev)
+    hout = torch.full((R, 2 * U), 7.0, dtype=BF, device=dev)          # poison: kernels must overwrite every row
+    gates = torch.zeros((2, R, 4 * U), device=dev); cell = torch.zeros((2, R, U), device=dev)
+    for s in range(T):
+        ops.lstm_fwd_step(xproj, whT, sl, hout, gates, cell, N, T, U, s)
+    return dict(xd=xd, sl=sl, hout=hout, gates=gates, cell=cell)
+
+
+@pytest.mark.parametrize("N,T,D,U,lens", [(64, 21, 512, 256, None), (5, 9, 64, 32, [9, 4, 1, 7, 9]), (70, 6, 64, 32, None)])
+def test_lstm_fwd_bwd(dev, N, T, D, U, lens):
+    rng = np.random.RandomState(1)
+    seq_len = lens if lens is not None else rng.randint(max(1, T // 2), T + 1, N).tolist()
+    x = bf(gen((N, T, D), 1))
+    Ws = [gen((D + U, 4 * U), 2 + d, 0.08) for d in range(2)]
+    bs = [gen((4 * U,), 4 + d, 0.1) for d in range(2)]
+    xr = x.clone().requires_grad_(True)
+    Wr = [w.clone().requires_grad_(True) for w in Ws]
+    br = [b.clone().requires_grad_(True) for b in bs]
+    fw = og.lstm_direction(xr, seq_len, Wr[0], br[0], False, True)
+    bw = og.lstm_direction(xr, seq_len, Wr[1], br[1], True, True)
+    ref = torch.cat([fw, bw], 2)
+    st = _lstm_device_forward(dev, x, seq_len, Ws, bs, U)
+    got = st["hout"].float().cpu().reshape(N, T, 2 * U)
+    assert maxerr(got, ref.detach()) < 2e-2, maxerr(got, ref.detach())
+    # ---- backward
+    dh = bf(gen((N, T, 2 * U), 9))
+    ref.backward(dh)
+    R = N * T
+    whb = torch.empty((2, D + U, 4 * U), dtype=BF, device=dev)
+    for d in range(2):
+        ops.cast_bf16(Ws[d].to(dev).contiguous(), whb[d])
+    dz = torch.full((R, 8 * U), 3.0, dtype=BF, device=dev)
+    dc = torch.zeros((2, N, U), device=dev)
+    dhd = dh.to(dev).to(BF).reshape(R, 2 * U)
+    for s in range(T - 1, -1, -1):
+        ops.lstm_bwd_step(whb[:, D:], 4 * U, (D + U) * 4 * U, st["sl"], dhd, st["gates"], st["cell"], dz, dc, N, T, U, s)
+    hprev = torch.empty((2, R, U), dtype=BF, device=dev)
+    ops.lstm_hprev(st["hout"], st["sl"], hprev, N, T, U)
+    for d in range(2):
+        dW = torch.zeros((D + U, 4 * U), device=dev); dbias = torch.zeros(4 * U, device=dev)
+        ops.gemm_tn(st["xd"], dz[:, d * 4 * U:(d + 1) * 4 * U], dW[:D], Mk=R, I=D, J=4 * U, lda=D, ldb=8 * U, ldo=4 * U)
+        ops.gemm_tn(hprev[d], dz[:, d * 4 * U:(d + 1) * 4 * U], dW[D:], Mk=R, I=U, J=4 * U, lda=U, ldb=8 * U, ldo=4 * U)
+        ops.colsum(dz[:, d * 4 * U:(d + 1) * 4 * U], dbias, M=R, C=4 * U, lda=8 * U)
+        assert relerr(dW.cpu(), Wr[d].grad) < 3e-2, ("dW", d, relerr(dW.cpu(), Wr[d].grad))
+        assert relerr(dbias.cpu(), br[d].grad) < 3e-2, ("db", d, relerr(dbias.cpu(), br[d].grad))
+    wcat = torch.empty((D, 8 * U), dtype=BF, device=dev)
+    for d in range(2):
+        ops.cast2d_bf16(Ws[d].to(dev), 4 * U, wcat[:, d * 4 * U:], 8 * U, D, 4 * U)
+    dx = ops.gemm_nt(dz, wcat)
+    assert relerr(dx.float().cpu().reshape(N, T, D), xr.grad) < 3e-2
+
+
+# ------------------------------------------------------------------------------------------- optimiser
+@pytest.mark.parametrize("solver", ["Adam", "Momentum", "RMS"])
+def test_optimizer(dev, solver):
+    n, n_reg = 4096 + 512, 4096
+    p = gen((n,), 1); lr, wd, clip = 1e-2, 1e-3, 10.0
+    pd = p.to(dev); s1 = torch.zeros(n, device=dev); s2 = torch.zeros(n, device=dev)
+    sc = torch.zeros(8, dtype=torch.float64, device=dev)
+    ops.optim_init(sc, lr)
+    pr = p.double().clone(); m = torch.zeros(n, dtype=torch.float64); v = torch.zeros(n, dtype=torch.float64)
+    for step in range(1, 4):
+        g = gen((n,), 10 + step, 30.0 if step == 2 else 0.01)       # step 2 triggers the clip
+        gd = g.to(dev).clone()
+        b1, b2, eps = (0.9, 0.999, 1e-8) if solver == "Adam" else ((0.9, 0.0, 0.0) if solver == "Momentum" else (0.9, 0.0, 1e-10))
+        ops.optim_step(pd, gd, s1, s2, n_reg, wd, clip, ops.SOLVERS[solver], b1, b2, eps, sc)
+        gg = g.double().clone(); gg[:n_reg] += wd * pr[:n_reg]
+        norm = float(gg.norm()); gg *= clip / max(norm, clip)
+        if solver == "Adam":
+            m = 0.9 * m + 0.1 * gg; v = 0.999 * v + 0.001 * gg * gg
+            lrt = lr * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+            pr = pr - lrt * m / (v.sqrt() + 1e-8)
+        elif solver == "Momentum":
+            m = 0.9 * m + gg; pr = pr - lr * m
+        else:
+            m = 0.9 * m + 0.1 * gg * gg; pr = pr - lr * gg / (m + 1e-10).sqrt()
+        torch.cuda.synchronize()
+        assert abs(float(sc[7]) - norm) / norm < 1e-5
+        assert relerr(pd.cpu().double(), pr) < 1e-5, (solver, step)

@@ -1,0 +1,123 @@
+"""Per-kernel timing at BASELINE config 2 shapes (N=64, W=256): prints one line per kernel with achieved
+TFLOP/s or GB/s.  Run on the GPU box:  python tools/kernel_bench.py [--json gpurun_out/kernels.json]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lstm_ctc_ocr_amd import ops  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--batch", type=int, default=64)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    Nb = args.batch
+    res = []
+
+    def rec(name, secs, flops=None, bytes_=None):
+        line = {"kernel": name, "us": secs * 1e6}
+        if flops: line["tflops"] = flops / secs / 1e12
+        if bytes_: line["gbps"] = bytes_ / secs / 1e9
+        res.append(line)
+        print(json.dumps(line), flush=True)
+
+    convs = [("conv2", 128, 16, 64, 128), ("conv3_1", 64, 8, 128, 256), ("conv3_2", 64, 8, 256, 256),
+             ("conv4_1", 64, 4, 256, 512), ("conv4_2", 64, 4, 512, 512)]
+    for name, W, H, Ci, Co in convs:
+        x = torch.randn(Nb, W, H, Ci, device=dev).to(BF)
+        wp = (torch.randn(Co, 3, 3, Ci, device=dev) * 0.05).to(BF)
+        b = torch.zeros(Co, device=dev)
+        y = torch.empty(Nb, W, H, Co, dtype=BF, device=dev)
+        fl = 2.0 * Nb * W * H * 9 * Ci * Co
+        rec(name + ".fwd", timeit(lambda: ops.conv3x3(x, wp, out=y, bias=b, relu=True)), fl)
+        wd = (torch.randn(Ci, 3, 3, Co, device=dev) * 0.05).to(BF)
+        dx = torch.empty_like(x)
+        rec(name + ".dgrad", timeit(lambda: ops.conv3x3(y, wd, out=dx, mask=x)), fl)
+        dw = torch.zeros(3, 3, Ci, Co, device=dev)
+        rec(name + ".wgrad", timeit(lambda: ops.conv3x3_wgrad(x, y, dw)), fl)
+    # conv5 as GEMM, LSTM projection, FC
+    T = 63
+    x5 = torch.randn(Nb, 64, 1024, device=dev).to(BF); w5 = torch.randn(512, 2048, device=dev).to(BF)
+    rec("conv5.fwd", timeit(lambda: ops.gemm_nt(x5, w5, M=Nb * T, N=512, K=2048, ldp=1024, row_group=T, row_skip=1)),
+        2.0 * Nb * T * 2048 * 512)
+    xl = torch.randn(Nb * T, 512, device=dev).to(BF); wx = torch.randn(2048, 512, device=dev).to(BF)
+    rec("lstm.xproj", timeit(lambda: ops.gemm_nt(xl, wx, out_f32=True)), 2.0 * Nb * T * 512 * 2048)
+    dz = torch.randn(Nb * T, 2048, device=dev).to(BF); dwx = torch.zeros(512, 2048, device=dev)
+    rec("lstm.dWx", timeit(lambda: ops.gemm_tn(xl, dz, dwx)), 2.0 * Nb * T * 512 * 2048)
+    # LSTM steps
+    U = 256
+    whT = (torch.randn(2, 4 * U, U, device=dev) * 0.05).to(BF)
+    xproj = torch.randn(Nb * T, 8 * U, device=dev)
+    sl = torch.full((Nb,), T, dtype=torch.int32, device=dev)
+    hout = torch.zeros(Nb * T, 2 * U, dtype=BF, device=dev)
+    gates = torch.zeros(2, Nb * T, 4 * U, device=dev); cell = torch.zeros(2, Nb * T, U, device=dev)
+
+    def lstm_fwd():
+        for s in range(T):
+            ops.lstm_fwd_step(xproj, whT, sl, hout, gates, cell, Nb, T, U, s)
+    rec("lstm.fwd_63steps", timeit(lstm_fwd, iters=5))
+    whb = (torch.randn(2, 768, 4 * U, device=dev) * 0.05).to(BF)
+    dzb = torch.zeros(Nb * T, 8 * U, dtype=BF, device=dev); dc = torch.zeros(2, Nb, U, device=dev)
+    dh = torch.randn(Nb * T, 2 * U, device=dev).to(BF)
+
+    def lstm_bwd():
+        for s in range(T - 1, -1, -1):
+            ops.lstm_bwd_step(whb[:, 512:], 4 * U, 768 * 4 * U, sl, dh, gates, cell, dzb, dc, Nb, T, U, s)
+    rec("lstm.bwd_63steps", timeit(lstm_bwd, iters=5))
+    # CTC
+    acts = torch.randn(T, Nb, 64, device=dev)
+    lab = torch.randint(1, 63, (Nb * 10,), dtype=torch.int32, device=dev)
+    ll = torch.full((Nb,), 10, dtype=torch.int32, device=dev)
+    ws = torch.empty(ops.ctc_workspace_bytes(10, T, Nb), dtype=torch.uint8, device=dev)
+    costs = torch.empty(Nb, device=dev); grads = torch.empty_like(acts)
+    rec("ctc.loss_grad", timeit(lambda: ops.ctc_loss(acts, lab, ll, sl, 10, workspace=ws, costs=costs, grads=grads)))
+    rec("ctc.greedy", timeit(lambda: ops.ctc_greedy_decode(acts, sl)))
+    # HBM-bound
+    x1 = torch.rand(Nb, 256, 32, device=dev); w1 = torch.randn(3, 3, 1, 64, device=dev); b1 = torch.zeros(64, device=dev)
+    y1 = torch.empty(Nb, 256, 32, 64, dtype=BF, device=dev)
+    rec("conv1.fwd", timeit(lambda: ops.conv1_fwd(x1, w1, b1, out=y1)), bytes_=y1.numel() * 2 + x1.numel() * 4)
+    p1 = torch.empty(Nb, 128, 16, 64, dtype=BF, device=dev)
+    rec("pool1.fwd", timeit(lambda: ops.maxpool_fwd(y1, 2, 2, out=p1)), bytes_=y1.numel() * 2 + p1.numel() * 2)
+    d1 = torch.empty_like(y1)
+    rec("pool1.bwd", timeit(lambda: ops.maxpool_bwd(y1, p1, 2, 2, True, out=d1)), bytes_=y1.numel() * 4 + p1.numel() * 2)
+    dw1 = torch.zeros(3, 3, 1, 64, device=dev); db1 = torch.zeros(64, device=dev)
+    rec("conv1.wgrad", timeit(lambda: ops.conv1_wgrad(x1, d1, dw1, db1)), bytes_=d1.numel() * 2)
+    xb = torch.randn(Nb * 256, 512, device=dev).to(BF); g = torch.ones(512, device=dev); be = torch.zeros(512, device=dev)
+    wsb = torch.empty(1024, dtype=torch.float64, device=dev); yb = torch.empty_like(xb)
+    sm = torch.empty(512, device=dev); sr = torch.empty(512, device=dev)
+    rec("bn.fwd", timeit(lambda: ops.bn_train_fwd(xb, g, be, 1e-3, True, wsb, out=yb, save_mean=sm, save_rstd=sr)),
+        bytes_=xb.numel() * 6)
+    dg = torch.zeros(512, device=dev); dbb = torch.zeros(512, device=dev); dxb = torch.empty_like(xb)
+    rec("bn.bwd", timeit(lambda: ops.bn_train_bwd(xb, yb, xb, g, sm, sr, dg, dbb, True, wsb, out=dxb)), bytes_=xb.numel() * 14)
+    n = 7158592
+    p = torch.randn(n, device=dev); gr = torch.randn(n, device=dev); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    sc = torch.zeros(8, dtype=torch.float64, device=dev); ops.optim_init(sc, 1e-4)
+    rec("adam.step", timeit(lambda: ops.optim_step(p, gr, m, v, 5579328, 1e-5, 10.0, 0, 0.9, 0.999, 1e-8, sc)), bytes_=n * 4 * 9)
+    if args.json:
+        os.makedirs(os.path.dirname(args.json), exist_ok=True)
+        json.dump(res, open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
