@@ -236,7 +236,7 @@ static int dispatch_gemm(GemmArgs& g, int mode, int splits, hipStream_t stream) 
     if (splits < 1) splits = 1;
     int kps = ceil_div(ceil_div(g.K, splits), 32) * 32;
     g.k_per_split = kps;
-    if (ceil_div(g.K, kps) > 1) {
+    if (splits > 1) {   // a split request always means "accumulate into the fp32 output with atomics"
         if (!(g.flags & EPI_OUT_F32) || (g.flags & (EPI_RELU | EPI_MASK | EPI_ACCUM))) return OCR_ERR_INVALID;
         g.flags |= EPI_ATOMIC;
     }

@@ -9,9 +9,14 @@
 // ([kh,kw,ci,co] resp. [in,out]), so split-M partial sums and the caller's "+=" are one mechanism.
 //
 // MFMA wants 8 consecutive k (= m) per lane, while HBM has the channel axis contiguous, so the
-// operands are transposed on the way through LDS.  TRANSPOSE_VIA = 0: 2-byte gathers from a row-major
-// tile (always correct, LDS-issue bound).  The hardware transposing read is layered on top in
-// gemm_tn_tr.hip once its lane semantics are pinned on the device.
+// operands are transposed on the way through LDS with gfx950's transposing read ds_read_b64_tr_b16:
+// a 16-lane group hands in 16 x 8-byte chunks covering a 4(k) x 16(col) row-major block (lane L supplies row
+// L>>2, columns 4*(L&3)..+3) and lane L receives column L, i.e. 4 consecutive k of ITS output column
+// (semantics pinned on the device by tests/test_gpu_kernels.py::test_probe_tr16).  Two reads give the 8 k
+// slots of a v_mfma_f32_16x16x32_bf16 operand.  Lane group g reads tile rows 4g..4g+3 and 16+4g..16+4g+3 — a
+// k permutation applied identically to A and B, so the contraction is unchanged — which, with LDS rows of
+// (tile width + 16) bf16 (row stride = 8 dwords mod 64), makes every 32-lane half of the read hit 64
+// distinct banks.  USE_TR = false keeps the plain 2-byte gather (same k order) for A/B comparison.
 #include "common.h"
 
 struct TnArgs {
@@ -31,10 +36,35 @@ struct TnArgs {
 
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 
-template <int MODE /*0 plain, 1 conv3x3*/, int FI, int FJ>
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+// 8 k-slots of output column (col0 + lane&15) from a row-major [32][ld] bf16 tile.
+// slot j<4 <-> tile row 4g+j, slot 4+j <-> tile row 16+4g+j  (g = lane>>4)
+template <bool USE_TR>
+__device__ __forceinline__ bf16x8 load_frag(const bf16_t* tile, int ld, int col0, int lane) {
+    const int g = lane >> 4, L = lane & 15;
+    if (USE_TR) {
+        const bf16_t* p0 = tile + (4 * g + (L >> 2)) * ld + col0 + (L & 3) * 4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * ld));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    } else {
+        u16x8 t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[j] = tile[(4 * g + j) * ld + col0 + L];
+            t[4 + j] = tile[(16 + 4 * g + j) * ld + col0 + L];
+        }
+        return __builtin_bit_cast(bf16x8, t);
+    }
+}
+
+template <int MODE /*0 plain, 1 conv3x3*/, int FI, int FJ, bool USE_TR = true>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
     constexpr int BI = 32 * FI, BJ = 32 * FJ;
-    constexpr int LDA = BI + 8, LDB = BJ + 8;
+    constexpr int LDA = BI + 16, LDB = BJ + 16;
     constexpr int CPA = BI / 8, CPB = BJ / 8;          // 16-B chunks per tile row
     constexpr int NCA = 32 * CPA / 256, NCB = 32 * CPB / 256;
     static_assert(NCA >= 1 && NCB >= 1, "tile too small for 256 threads");
@@ -102,7 +132,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
         for (int b = 0; b < FJ; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int fcol = lane & 15, fk = (lane >> 4) * 8;
     if (kbeg < kend) {
         load_tiles(kbeg);
         for (int k0 = kbeg; k0 < kend; k0 += 32) {
@@ -112,19 +141,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
             if (k0 + 32 < kend) load_tiles(k0 + 32);
             bf16x8 af[FI], bfr[FJ];
 #pragma unroll
-            for (int a = 0; a < FI; ++a) {
-                u16x8 t;
+            for (int a = 0; a < FI; ++a) af[a] = load_frag<USE_TR>(As, LDA, wi * 16 * FI + a * 16, lane);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) t[j] = As[(fk + j) * LDA + wi * 16 * FI + a * 16 + fcol];
-                af[a] = __builtin_bit_cast(bf16x8, t);
-            }
-#pragma unroll
-            for (int b = 0; b < FJ; ++b) {
-                u16x8 t;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) t[j] = Bs[(fk + j) * LDB + wj * 16 * FJ + b * 16 + fcol];
-                bfr[b] = __builtin_bit_cast(bf16x8, t);
-            }
+            for (int b = 0; b < FJ; ++b) bfr[b] = load_frag<USE_TR>(Bs, LDB, wj * 16 * FJ + b * 16, lane);
 #pragma unroll
             for (int a = 0; a < FI; ++a)
 #pragma unroll

