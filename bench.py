@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""Headline benchmark: captcha images/sec in TRAINING (forward + CTC + backward + all-reduce + clip + Adam) of the
+VGG-7 + BiLSTM(256) + CTC CRNN at H=32, W=256, 10-char labels, batch 64 per GPU (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0.  `roofline` is the dominant kernel (implicit-GEMM 3x3 convolution, MFMA-bound), timed
+live with HIP events on the launch stream; `cpu_baseline` is the CPU oracle (a torch-CPU restatement of the
+reference TF1 graph — the TF reference itself cannot run here) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH, WIDTH, LABEL_LEN = 64, 256, 10
+MFMA_BF16_PEAK = 2.5e15      # dense bf16, MI355X_MICROARCH.md
+TRAIN_GFLOP_PER_IMG = 10.09
+
+
+def synth_batches(n_batches, seed, device):
+    rng = np.random.RandomState(seed)
+    out = []
+    T = WIDTH // 4 - 1
+    for _ in range(n_batches):
+        x = torch.from_numpy(rng.rand(BATCH, WIDTH, 32).astype(np.float32)).to(device)
+        labels = torch.from_numpy(rng.randint(1, 63, BATCH * LABEL_LEN).astype(np.int32)).to(device)
+        ll = torch.full((BATCH,), LABEL_LEN, dtype=torch.int32, device=device)
+        sl = torch.full((BATCH,), T, dtype=torch.int32, device=device)
+        out.append((x, labels, ll, sl))
+    return out
+
+
+def conv_roofline(eng, device):
+    """Every launch of the dominant kernel (gemm_nt_kernel<conv3x3>: 5 forward + 5 data-gradient convolutions per
+    step) timed with events on the launch stream; achieved = sum(algorithmic flop) / sum(time)."""
+    from lstm_ctc_ocr_amd import ops
+    shapes = [(128, 16, 64, 128), (64, 8, 128, 256), (64, 8, 256, 256), (64, 4, 256, 512), (64, 4, 512, 512)]
+    tot_fl, tot_t, n_launch = 0.0, 0.0, 0
+    for (W, H, Ci, Co) in shapes:
+        x = torch.randn(BATCH, W, H, Ci, device=device).to(torch.bfloat16)
+        y = torch.randn(BATCH, W, H, Co, device=device).to(torch.bfloat16)
+        wf = (torch.randn(Co, 3, 3, Ci, device=device) * 0.05).to(torch.bfloat16)
+        wd = (torch.randn(Ci, 3, 3, Co, device=device) * 0.05).to(torch.bfloat16)
+        b = torch.zeros(Co, device=device)
+        oy, ox = torch.empty_like(y), torch.empty_like(x)
+        for fn in (lambda: ops.conv3x3(x, wf, out=oy, bias=b, relu=True), lambda: ops.conv3x3(y, wd, out=ox, mask=x)):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            tot_t += e0.elapsed_time(e1) * 1e-3 / 10
+            tot_fl += 2.0 * BATCH * W * H * 9 * Ci * Co
+            n_launch += 1
+    ach = tot_fl / tot_t
+    return {"bound": "mfma", "kernel": "gemm_nt_kernel<conv3x3> (implicit-GEMM 3x3 conv fwd + dgrad, 10 launches/step)",
+            "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK,
+            "avg_launch_us": tot_t / n_launch * 1e6, "traffic": None}
+
+
+def cpu_baseline(budget_s=20.0):
+    """The CPU oracle's training step (fp32 torch-CPU restatement of the TF1 graph) on a bounded sample."""
+    from oracle import graph as og
+    torch.set_num_threads(os.cpu_count() or 1)
+    n = 8
+    rng = np.random.RandomState(0)
+    x = torch.from_numpy(rng.rand(n, WIDTH, 32).astype(np.float32))
+    labels = rng.randint(1, 63, n * LABEL_LEN).astype(np.int32)
+    ll = np.full(n, LABEL_LEN, np.int32)
+    sl = [WIDTH // 4 - 1] * n
+    params = og.init_params()
+    state = {}
+    t0 = time.time()
+    steps = 0
+    while True:
+        params, *_ = og.train_step(params, state, (x, labels, ll, sl), 1e-4, 1e-5)
+        steps += 1
+        if time.time() - t0 > budget_s or steps >= 8:
+            break
+    dt = time.time() - t0
+    return {"value": n * steps / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d training steps of %d images (W=256, L=10) with the fp32 CPU oracle" % (steps, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from lstm_ctc_ocr_amd.config import cfg
+    from lstm_ctc_ocr_amd.engine import Engine
+    from lstm_ctc_ocr_amd.models import get_network
+    cfg.TRAIN.SOLVER, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.WEIGHT_DECAY = 'Adam', 1e-4, 1e-5     # lstm/lstm.yml
+    eng = Engine(get_network('LSTM_train'), device=device, seed=cfg.RNG_SEED, use_graphs=not args.no_graphs)
+    eng.setup_optimizer()
+    batches = synth_batches(8, cfg.RNG_SEED + rank, device)
+
+    def step(i):
+        x, labels, ll, sl = batches[i % len(batches)]
+        eng.train_step(x, labels, ll, sl, fetch_loss=False)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = eng.last_loss()
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = BATCH * world * args.steps / dt
+        line = {
+            "metric": "captcha images/sec training (32x256, bs=64/GPU)", "value": value, "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "VGG-7 + BiLSTM(256) + CTC train step, H=32 W=256, 10-char labels, C=64, bs=64/GPU "
+                                   "(BASELINE.json configs[1]), Adam lr 1e-4 wd 1e-5 clip 10",
+                       "global_batch": BATCH * world, "parallelism": "dp%d" % world, "hipgraph": not args.no_graphs},
+            "final_loss": loss,
+            "model_tflops_per_gpu": value / world * TRAIN_GFLOP_PER_IMG * 1e9 / 1e12,
+        }
+        line["roofline"] = conv_roofline(eng, device)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

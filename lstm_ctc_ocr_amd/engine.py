@@ -38,6 +38,7 @@ class _Op(object):
 
     def __init__(self, eng, node, prev):
         self.eng, self.node, self.prev, self.name = eng, node, prev, node.name
+        self.key = node.name          # buffer key; made unique by Engine._lower (the reference reuses layer names)
 
     def out_shape(self, in_shape):
         raise NotImplementedError
@@ -56,15 +57,16 @@ class _Op(object):
 
     # gradient w.r.t. this op's output (written by the consumer)
     def y(self, sp):
-        return sp.buf[self.name + '/y']
+        return sp.buf[self.key + '/y']
 
     def dy(self, sp):
-        return sp.buf[self.name + '/dy']
+        return sp.buf[self.key + '/dy']
 
 
 class _InputOp(_Op):
     def __init__(self, eng):
         self.eng, self.name, self.prev, self.node = eng, 'data', None, None
+        self.key = 'data'
 
     def y(self, sp):
         return sp.x
@@ -118,18 +120,18 @@ class _ConvOp(_Op):
     def alloc(self, sp, s):
         o = self.out_shape(s)
         dev = self.eng.device
-        sp.shape[self.name] = (s, o)
-        sp.buf[self.name + '/y'] = torch.empty(o, dtype=BF16, device=dev)
-        sp.buf[self.name + '/dy'] = torch.empty(o, dtype=BF16, device=dev)
+        sp.shape[self.key] = (s, o)
+        sp.buf[self.key + '/y'] = torch.empty(o, dtype=BF16, device=dev)
+        sp.buf[self.key + '/dy'] = torch.empty(o, dtype=BF16, device=dev)
         if self.bn:
-            sp.buf[self.name + '/z'] = torch.empty(o, dtype=BF16, device=dev)
-            sp.buf[self.name + '/dz'] = torch.empty(o, dtype=BF16, device=dev)
-            sp.buf[self.name + '/mean'] = torch.empty(self.co, dtype=F32, device=dev)
-            sp.buf[self.name + '/rstd'] = torch.empty(self.co, dtype=F32, device=dev)
-            sp.buf[self.name + '/bnws'] = torch.empty(2 * self.co, dtype=torch.float64, device=dev)
+            sp.buf[self.key + '/z'] = torch.empty(o, dtype=BF16, device=dev)
+            sp.buf[self.key + '/dz'] = torch.empty(o, dtype=BF16, device=dev)
+            sp.buf[self.key + '/mean'] = torch.empty(self.co, dtype=F32, device=dev)
+            sp.buf[self.key + '/rstd'] = torch.empty(self.co, dtype=F32, device=dev)
+            sp.buf[self.key + '/bnws'] = torch.empty(2 * self.co, dtype=torch.float64, device=dev)
         if self.kind == 'full':
             N, W, H, C = s
-            sp.buf[self.name + '/col'] = torch.empty((N * o[1], self.kh * H * C), dtype=BF16, device=dev)
+            sp.buf[self.key + '/col'] = torch.empty((N * o[1], self.kh * H * C), dtype=BF16, device=dev)
 
     def refresh(self):
         if self.kind == 'c1':
@@ -143,13 +145,13 @@ class _ConvOp(_Op):
     def fwd(self, sp):
         e = self.eng
         x = self.prev.y(sp)
-        s, o = sp.shape[self.name]
+        s, o = sp.shape[self.key]
         bias = e.param(self.name + '/biases')
         y = self.y(sp)
         if self.kind == 'c1':
             ops.conv1_fwd(x, e.param(self.name + '/weights'), bias, relu=self.relu, out=y)
             return
-        tgt = sp.buf[self.name + '/z'] if self.bn else y
+        tgt = sp.buf[self.key + '/z'] if self.bn else y
         relu_now = self.relu and not self.bn
         if self.kind == '3x3':
             ops.conv3x3(x, self.wpack.view(self.co, 3, 3, self.ci), out=tgt, bias=bias, relu=relu_now)
@@ -162,22 +164,22 @@ class _ConvOp(_Op):
             M = o[0] * o[1] * o[2]
             ops.bn_train_fwd(tgt.view(M, self.co), e.param('%s/%s/gamma' % (self.name, self.name)),
                              e.param('%s/%s/beta' % (self.name, self.name)), BN_EPS, self.relu,
-                             sp.buf[self.name + '/bnws'], out=y.view(M, self.co),
-                             save_mean=sp.buf[self.name + '/mean'], save_rstd=sp.buf[self.name + '/rstd'])
+                             sp.buf[self.key + '/bnws'], out=y.view(M, self.co),
+                             save_mean=sp.buf[self.key + '/mean'], save_rstd=sp.buf[self.key + '/rstd'])
 
     def bwd(self, sp):
         e = self.eng
-        s, o = sp.shape[self.name]
+        s, o = sp.shape[self.key]
         x = self.prev.y(sp)
         dy = self.dy(sp)                    # already ReLU-masked by the consumer unless this layer has BN
         M = o[0] * o[1] * o[2]
         dz = dy
         if self.bn:
-            dz = sp.buf[self.name + '/dz']
-            ops.bn_train_bwd(sp.buf[self.name + '/z'].view(M, self.co), self.y(sp).view(M, self.co), dy.view(M, self.co),
-                             e.param('%s/%s/gamma' % (self.name, self.name)), sp.buf[self.name + '/mean'],
-                             sp.buf[self.name + '/rstd'], e.grad('%s/%s/gamma' % (self.name, self.name)),
-                             e.grad('%s/%s/beta' % (self.name, self.name)), self.relu, sp.buf[self.name + '/bnws'],
+            dz = sp.buf[self.key + '/dz']
+            ops.bn_train_bwd(sp.buf[self.key + '/z'].view(M, self.co), self.y(sp).view(M, self.co), dy.view(M, self.co),
+                             e.param('%s/%s/gamma' % (self.name, self.name)), sp.buf[self.key + '/mean'],
+                             sp.buf[self.key + '/rstd'], e.grad('%s/%s/gamma' % (self.name, self.name)),
+                             e.grad('%s/%s/beta' % (self.name, self.name)), self.relu, sp.buf[self.key + '/bnws'],
                              out=dz.view(M, self.co))
         dw = e.grad(self.name + '/weights')
         db = e.grad(self.name + '/biases')
@@ -201,7 +203,7 @@ class _ConvOp(_Op):
                 if pmask is not None or self.kh != 2:
                     raise NotImplementedError('%s: data gradient of a full-height VALID conv is lowered for k_h = 2 '
                                               'behind a non-ReLU producer' % self.name)
-                col = sp.buf[self.name + '/col']
+                col = sp.buf[self.key + '/col']
                 wsh = e.shadow(self.name + '/weights').view(K, self.co)      # [K][co] bf16, k = co contiguous
                 ops.gemm_nt(dz.view(M, self.co), wsh, out=col, M=M, N=K, K=self.co)
                 ops.conv5_col2im(col, pdy, N, W, H * C)
@@ -227,9 +229,9 @@ class _PoolOp(_Op):
 
     def alloc(self, sp, s):
         o = self.out_shape(s)
-        sp.shape[self.name] = (s, o)
-        sp.buf[self.name + '/y'] = torch.empty(o, dtype=BF16, device=self.eng.device)
-        sp.buf[self.name + '/dy'] = torch.empty(o, dtype=BF16, device=self.eng.device)
+        sp.shape[self.key] = (s, o)
+        sp.buf[self.key + '/y'] = torch.empty(o, dtype=BF16, device=self.eng.device)
+        sp.buf[self.key + '/dy'] = torch.empty(o, dtype=BF16, device=self.eng.device)
 
     def fwd(self, sp):
         ops.maxpool_fwd(self.prev.y(sp), self.kw_t, self.kh_f, out=self.y(sp))
@@ -257,14 +259,14 @@ class _ViewOp(_Op):
         return s
 
     def alloc(self, sp, s):
-        sp.shape[self.name] = (s, self.out_shape(s))
+        sp.shape[self.key] = (s, self.out_shape(s))
 
     def y(self, sp):
-        return self.prev.y(sp).view(sp.shape[self.name][1])
+        return self.prev.y(sp).view(sp.shape[self.key][1])
 
     def dy(self, sp):
         d = self.prev.dy(sp)
-        return None if d is None else d.view(sp.shape[self.name][1])
+        return None if d is None else d.view(sp.shape[self.key][1])
 
 
 class _BiLstmOp(_Op):
@@ -289,18 +291,18 @@ class _BiLstmOp(_Op):
         N, T, D = s
         U, C, dev = self.U, self.C, self.eng.device
         R = N * T
-        sp.shape[self.name] = (s, (T, N, C))
+        sp.shape[self.key] = (s, (T, N, C))
         b = sp.buf
-        b[self.name + '/xproj'] = torch.empty((R, 8 * U), dtype=F32, device=dev)
-        b[self.name + '/hout'] = torch.zeros((R, 2 * U), dtype=BF16, device=dev)
-        b[self.name + '/gates'] = torch.zeros((2, R, 4 * U), dtype=F32, device=dev)
-        b[self.name + '/cell'] = torch.zeros((2, R, U), dtype=F32, device=dev)
-        b[self.name + '/y'] = torch.empty((T, N, C), dtype=F32, device=dev)          # logits, time-major
-        b[self.name + '/dy'] = torch.empty((R, C), dtype=BF16, device=dev)           # d loss / d logits, [N,T,C]
-        b[self.name + '/dhout'] = torch.empty((R, 2 * U), dtype=BF16, device=dev)
-        b[self.name + '/dz'] = torch.zeros((R, 8 * U), dtype=BF16, device=dev)
-        b[self.name + '/dc'] = torch.zeros((2, N, U), dtype=F32, device=dev)
-        b[self.name + '/hprev'] = torch.empty((2, R, U), dtype=BF16, device=dev)
+        b[self.key + '/xproj'] = torch.empty((R, 8 * U), dtype=F32, device=dev)
+        b[self.key + '/hout'] = torch.zeros((R, 2 * U), dtype=BF16, device=dev)
+        b[self.key + '/gates'] = torch.zeros((2, R, 4 * U), dtype=F32, device=dev)
+        b[self.key + '/cell'] = torch.zeros((2, R, U), dtype=F32, device=dev)
+        b[self.key + '/y'] = torch.empty((T, N, C), dtype=F32, device=dev)          # logits, time-major
+        b[self.key + '/dy'] = torch.empty((R, C), dtype=BF16, device=dev)           # d loss / d logits, [N,T,C]
+        b[self.key + '/dhout'] = torch.empty((R, 2 * U), dtype=BF16, device=dev)
+        b[self.key + '/dz'] = torch.zeros((R, 8 * U), dtype=BF16, device=dev)
+        b[self.key + '/dc'] = torch.zeros((2, N, U), dtype=F32, device=dev)
+        b[self.key + '/hprev'] = torch.empty((2, R, U), dtype=BF16, device=dev)
 
     def refresh(self):
         e, U, D = self.eng, self.U, self.D
@@ -314,43 +316,43 @@ class _BiLstmOp(_Op):
 
     def fwd(self, sp):
         e, U, C = self.eng, self.U, self.C
-        (N, T, D), _ = sp.shape[self.name]
+        (N, T, D), _ = sp.shape[self.key]
         R = N * T
         b = sp.buf
         x = self.prev.y(sp).view(R, D)
-        ops.gemm_nt(x, self.wxT, out=b[self.name + '/xproj'], bias=self.bias)
+        ops.gemm_nt(x, self.wxT, out=b[self.key + '/xproj'], bias=self.bias)
         for s in range(T):
-            ops.lstm_fwd_step(b[self.name + '/xproj'], self.whT, sp.seq_len, b[self.name + '/hout'], b[self.name + '/gates'],
-                              b[self.name + '/cell'], N, T, U, s, 1.0)
-        ops.gemm_nt(b[self.name + '/hout'], self.wfcT, out=b[self.name + '/y'].view(R, C),
+            ops.lstm_fwd_step(b[self.key + '/xproj'], self.whT, sp.seq_len, b[self.key + '/hout'], b[self.key + '/gates'],
+                              b[self.key + '/cell'], N, T, U, s, 1.0)
+        ops.gemm_nt(b[self.key + '/hout'], self.wfcT, out=b[self.key + '/y'].view(R, C),
                     bias=e.param(self.name + '/biases'), rowswap=(T, N))
 
     def bwd(self, sp):
         e, U, C, D = self.eng, self.U, self.C, self.D
-        (N, T, _), _ = sp.shape[self.name]
+        (N, T, _), _ = sp.shape[self.key]
         R = N * T
         b = sp.buf
-        dl = b[self.name + '/dy']
-        hout = b[self.name + '/hout']
+        dl = b[self.key + '/dy']
+        hout = b[self.key + '/hout']
         # FC: dW += H^T dL, db += colsum dL, dH = dL Wfc^T
         ops.gemm_tn(hout, dl, e.grad(self.name + '/weights'))
         ops.colsum(dl, e.grad(self.name + '/biases'))
-        ops.gemm_nt(dl, e.shadow(self.name + '/weights'), out=b[self.name + '/dhout'])
+        ops.gemm_nt(dl, e.shadow(self.name + '/weights'), out=b[self.key + '/dhout'])
         # BPTT, both directions per launch
         wsh = e.shadow(self.name + '/fw/weights')
         stride = e.offset(self.name + '/bw/weights') - e.offset(self.name + '/fw/weights')
-        b[self.name + '/dc'].zero_()
+        b[self.key + '/dc'].zero_()
         for s in range(T - 1, -1, -1):
-            ops.lstm_bwd_step(wsh[D:], 4 * U, stride, sp.seq_len, b[self.name + '/dhout'], b[self.name + '/gates'],
-                              b[self.name + '/cell'], b[self.name + '/dz'], b[self.name + '/dc'], N, T, U, s)
-        ops.lstm_hprev(hout, sp.seq_len, b[self.name + '/hprev'], N, T, U)
-        dz = b[self.name + '/dz']
+            ops.lstm_bwd_step(wsh[D:], 4 * U, stride, sp.seq_len, b[self.key + '/dhout'], b[self.key + '/gates'],
+                              b[self.key + '/cell'], b[self.key + '/dz'], b[self.key + '/dc'], N, T, U, s)
+        ops.lstm_hprev(hout, sp.seq_len, b[self.key + '/hprev'], N, T, U)
+        dz = b[self.key + '/dz']
         x = self.prev.y(sp).view(R, D)
         for d, tag in enumerate(('fw', 'bw')):
             dW = e.grad('%s/%s/weights' % (self.name, tag))
             dzd = dz[:, d * 4 * U:(d + 1) * 4 * U]
             ops.gemm_tn(x, dzd, dW[:D], Mk=R, I=D, J=4 * U, lda=D, ldb=8 * U, ldo=4 * U)
-            ops.gemm_tn(b[self.name + '/hprev'][d], dzd, dW[D:], Mk=R, I=U, J=4 * U, lda=U, ldb=8 * U, ldo=4 * U)
+            ops.gemm_tn(b[self.key + '/hprev'][d], dzd, dW[D:], Mk=R, I=U, J=4 * U, lda=U, ldb=8 * U, ldo=4 * U)
             ops.colsum(dzd, e.grad('%s/%s/biases' % (self.name, tag)), M=R, C=4 * U, lda=8 * U)
         pdy = self.prev.dy(sp)
         if pdy is not None:
@@ -511,6 +513,7 @@ class Engine(object):
             if nd.op not in table:
                 raise NotImplementedError('layer %r (%s) has no gfx950 lowering yet' % (nd.op, nd.name))
             op = table[nd.op](self, nd, prev)
+            op.key = '%02d:%s' % (len(self.ops), nd.name)
             self.ops.append(op)
             prev = op
 
