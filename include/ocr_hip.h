@@ -88,6 +88,15 @@ int ocr_lstm_fwd_step(const float* xproj, const void* whT_packed, const int* seq
 int ocr_lstm_bwd_step(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
                       const float* gates, const float* cell, void* dz, float* dc_state, int Nb, int T, int U,
                       int step, void* stream);
+/* whole-sequence (persistent) variants: one launch for all T steps, workgroups of a (direction, 64-row batch tile)
+ * group exchange h_t / dz_t through write-through stores + an agent-scope counter.  `sync`: >= 2*ceil(Nb/64)+1
+ * int32 words (zeroed by the call; last word = spin-timeout error flag).  ocr_lstm_seq_supported() tells whether
+ * the shape is covered (U == 256 and the grid fits one workgroup per CU); otherwise use the step entry points. */
+int ocr_lstm_seq_supported(int Nb, int U);
+int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, const int* seq_len, void* hout, float* gates,
+                     float* cell, int Nb, int T, int U, float forget_bias, void* sync, void* stream);
+int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
+                     const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync, void* stream);
 int ocr_lstm_hprev(const void* hout, const int* seq_len, void* hprev, int Nb, int T, int U, void* stream);
 int ocr_lstm_pack_bias(const float* b_fw, const float* b_bw, float* out, int U, void* stream);
 

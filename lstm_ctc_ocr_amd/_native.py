@@ -41,6 +41,9 @@ _SIGS = {
     "ocr_conv5_col2im": ([_P, _P, _I, _I, _I, _P], _I),
     "ocr_lstm_fwd_step": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P], _I),
     "ocr_lstm_bwd_step": ([_P, _L, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "ocr_lstm_seq_supported": ([_I, _I], _I),
+    "ocr_lstm_fwd_seq": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P], _I),
+    "ocr_lstm_bwd_seq": ([_P, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
     "ocr_lstm_hprev": ([_P, _P, _P, _I, _I, _I, _P], _I),
     "ocr_lstm_pack_bias": ([_P, _P, _P, _I, _P], _I),
     "ocr_optim_init": ([_P, _D, _P], _I),

@@ -53,6 +53,12 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// hardware-rate gate non-linearities: v_exp_f32 + v_rcp_f32 (relative error ~1e-6, far below the bf16 storage of h)
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    float e = __expf(-2.0f * fabsf(x));          // in (0, 1]: no overflow
+    float t = (1.0f - e) * __frcp_rn(1.0f + e);
+    return copysignf(t, x);
+}
 
 __host__ __device__ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -53,43 +53,52 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdArgs a) {
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // prefetch the operands that do not depend on the MFMA result
+    const int ul0 = q * 4;
+    const float* xp = a.xproj + row * (8L * U) + (long)d * 4 * U + (long)ub * 64 + ul0;
+    f32x4 xi = {0.f, 0.f, 0.f, 0.f}, xj = xi, xf = xi, xo = xi, cprev = xi;
+    if (active) {
+        xi = *(const f32x4*)(xp + 0); xj = *(const f32x4*)(xp + 16); xf = *(const f32x4*)(xp + 32); xo = *(const f32x4*)(xp + 48);
+        if (s > 0) cprev = *(const f32x4*)(a.cell + ((long)d * R + rowp) * U + ub * 16 + ul0);
+    }
     if (s > 0) {
         const bf16_t* wbase = a.whT + ((long)d * 4 * U + (long)ub * 64 + nl) * U + q * 8;
         const bf16_t* hbase = a.hout + rowp * (2L * U) + (long)d * U + q * 8;
-#pragma unroll 2
-        for (int k0 = 0; k0 < U; k0 += 32) {
-            bf16x8 b = *(const bf16x8*)(hbase + k0);
+        // K = U is consumed in chunks of 128 with all 20 operand loads of a chunk in flight at once
+        for (int kc = 0; kc < U; kc += 128) {
+            bf16x8 b[4], w[4][4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x8 w = *(const bf16x8*)(wbase + (long)g * 16 * U + k0);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b, acc[g], 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk) {
+                const bool in = kc + kk * 32 < U;          // U % 32 == 0; tail chunks contribute zeros
+                const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                b[kk] = in ? *(const bf16x8*)(hbase + kc + kk * 32) : zero;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) w[g][kk] = in ? *(const bf16x8*)(wbase + (long)g * 16 * U + kc + kk * 32) : zero;
             }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g][kk], b[kk], acc[g], 0, 0, 0);
         }
     }
     // lane owns units u = ub*16 + q*4 + r (r = 0..3) of batch row n, gate g in acc[g][r]
-    const int ul0 = q * 4;
     if (!nvalid) return;
     bf16_t* hdst = a.hout + row * (2L * U) + (long)d * U + ub * 16 + ul0;
     if (!active) {
         if (s < T) { u32x2 z = {0u, 0u}; *(u32x2*)hdst = z; }
         return;
     }
-    const float* xp = a.xproj + row * (8L * U) + (long)d * 4 * U + (long)ub * 64 + ul0;
-    f32x4 zi = *(const f32x4*)(xp + 0) + acc[0];
-    f32x4 zj = *(const f32x4*)(xp + 16) + acc[1];
-    f32x4 zf = *(const f32x4*)(xp + 32) + acc[2];
-    f32x4 zo = *(const f32x4*)(xp + 48) + acc[3];
-    f32x4 cprev = {0.f, 0.f, 0.f, 0.f};
-    if (s > 0) cprev = *(const f32x4*)(a.cell + ((long)d * R + rowp) * U + ub * 16 + ul0);
+    f32x4 zi = xi + acc[0], zj = xj + acc[1], zf = xf + acc[2], zo = xo + acc[3];
     f32x4 gi, gj, gf, go, cn, hn;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        gi[r] = 1.f / (1.f + expf(-zi[r]));
-        gj[r] = tanhf(zj[r]);
-        gf[r] = 1.f / (1.f + expf(-(zf[r] + a.forget_bias)));
-        go[r] = 1.f / (1.f + expf(-zo[r]));
+        gi[r] = sigmoidf_(zi[r]);
+        gj[r] = tanhf_(zj[r]);
+        gf[r] = sigmoidf_(zf[r] + a.forget_bias);
+        go[r] = sigmoidf_(zo[r]);
         cn[r] = gf[r] * cprev[r] + gi[r] * gj[r];
-        hn[r] = go[r] * tanhf(cn[r]);
+        hn[r] = go[r] * tanhf_(cn[r]);
     }
     float* gdst = a.gates + ((long)d * R + row) * (4L * U) + (long)ub * 64 + ul0;
     *(f32x4*)(gdst + 0) = gi;
@@ -135,19 +144,28 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdArgs a) {
     const long rown = (long)nn * T + (has_next ? tnext : 0);
 
     // dh_rec[u][n] = sum_k Wh[u][k] * dz_{s+1}[n][k],  k over the 4U gate columns (master order)
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
     if (s + 1 < T) {
         const bf16_t* wbase = a.wh + (long)d * a.w_dir_stride + ((long)ub * 16 + nl) * a.ldw + q * 8;
         const bf16_t* zbase = a.dz + rown * (8L * U) + (long)d * 4 * U + q * 8;
         const int K = 4 * U;
-#pragma unroll 2
-        for (int k0 = 0; k0 < K; k0 += 64) {
-            bf16x8 w0 = *(const bf16x8*)(wbase + k0);
-            bf16x8 z0 = *(const bf16x8*)(zbase + k0);
-            bf16x8 w1 = *(const bf16x8*)(wbase + k0 + 32);
-            bf16x8 z1 = *(const bf16x8*)(zbase + k0 + 32);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, z0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, z1, acc1, 0, 0, 0);
+        for (int k0 = 0; k0 < K; k0 += 256) {
+            bf16x8 w[8], z[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const bool in = k0 + kk * 32 < K;
+                const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                w[kk] = in ? *(const bf16x8*)(wbase + k0 + kk * 32) : zero;
+                z[kk] = in ? *(const bf16x8*)(zbase + k0 + kk * 32) : zero;
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], z[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], z[1], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], z[2], acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[3], z[3], acc3, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[4], z[4], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[5], z[5], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[6], z[6], acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[7], z[7], acc3, 0, 0, 0);
         }
     }
     if (!nvalid) return;
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdArgs a) {
         }
         return;
     }
-    f32x4 dh = acc0 + acc1;
+    f32x4 dh = (acc0 + acc1) + (acc2 + acc3);
     if (!has_next) dh = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
         u32x2 g2 = *(const u32x2*)(a.dhout + row * (2L * U) + (long)d * U + u0);
@@ -179,7 +197,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdArgs a) {
     f32x4 di, dj, df, dov, dcn;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float tc = tanhf(c[r]);
+        float tc = tanhf_(c[r]);
         float dc = dcv[r] + dh[r] * go[r] * (1.f - tc * tc);
         dov[r] = dh[r] * tc * go[r] * (1.f - go[r]);
         di[r] = dc * gj[r] * gi[r] * (1.f - gi[r]);

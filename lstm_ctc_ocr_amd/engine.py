@@ -303,6 +303,9 @@ class _BiLstmOp(_Op):
         b[self.key + '/dz'] = torch.zeros((R, 8 * U), dtype=BF16, device=dev)
         b[self.key + '/dc'] = torch.zeros((2, N, U), dtype=F32, device=dev)
         b[self.key + '/hprev'] = torch.empty((2, R, U), dtype=BF16, device=dev)
+        b[self.key + '/sync_f'] = torch.zeros(2 * ((N + 63) // 64) + 1, dtype=I32, device=dev)
+        b[self.key + '/sync_b'] = torch.zeros(2 * ((N + 63) // 64) + 1, dtype=I32, device=dev)
+        sp.lstm_sync = (b[self.key + '/sync_f'], b[self.key + '/sync_b'])
 
     def refresh(self):
         e, U, D = self.eng, self.U, self.D
@@ -321,9 +324,13 @@ class _BiLstmOp(_Op):
         b = sp.buf
         x = self.prev.y(sp).view(R, D)
         ops.gemm_nt(x, self.wxT, out=b[self.key + '/xproj'], bias=self.bias)
-        for s in range(T):
-            ops.lstm_fwd_step(b[self.key + '/xproj'], self.whT, sp.seq_len, b[self.key + '/hout'], b[self.key + '/gates'],
-                              b[self.key + '/cell'], N, T, U, s, 1.0)
+        if self.eng.persistent_lstm and ops.lstm_seq_supported(N, U):
+            ops.lstm_fwd_seq(b[self.key + '/xproj'], self.whT, sp.seq_len, b[self.key + '/hout'], b[self.key + '/gates'],
+                             b[self.key + '/cell'], N, T, U, b[self.key + '/sync_f'], 1.0)
+        else:
+            for s in range(T):
+                ops.lstm_fwd_step(b[self.key + '/xproj'], self.whT, sp.seq_len, b[self.key + '/hout'],
+                                  b[self.key + '/gates'], b[self.key + '/cell'], N, T, U, s, 1.0)
         ops.gemm_nt(b[self.key + '/hout'], self.wfcT, out=b[self.key + '/y'].view(R, C),
                     bias=e.param(self.name + '/biases'), rowswap=(T, N))
 
@@ -341,10 +348,14 @@ class _BiLstmOp(_Op):
         # BPTT, both directions per launch
         wsh = e.shadow(self.name + '/fw/weights')
         stride = e.offset(self.name + '/bw/weights') - e.offset(self.name + '/fw/weights')
-        b[self.key + '/dc'].zero_()
-        for s in range(T - 1, -1, -1):
-            ops.lstm_bwd_step(wsh[D:], 4 * U, stride, sp.seq_len, b[self.key + '/dhout'], b[self.key + '/gates'],
-                              b[self.key + '/cell'], b[self.key + '/dz'], b[self.key + '/dc'], N, T, U, s)
+        if self.eng.persistent_lstm and ops.lstm_seq_supported(N, U):
+            ops.lstm_bwd_seq(wsh[D:], 4 * U, stride, sp.seq_len, b[self.key + '/dhout'], b[self.key + '/gates'],
+                             b[self.key + '/cell'], b[self.key + '/dz'], N, T, U, b[self.key + '/sync_b'])
+        else:
+            b[self.key + '/dc'].zero_()
+            for s in range(T - 1, -1, -1):
+                ops.lstm_bwd_step(wsh[D:], 4 * U, stride, sp.seq_len, b[self.key + '/dhout'], b[self.key + '/gates'],
+                                  b[self.key + '/cell'], b[self.key + '/dz'], b[self.key + '/dc'], N, T, U, s)
         ops.lstm_hprev(hout, sp.seq_len, b[self.key + '/hprev'], N, T, U)
         dz = b[self.key + '/dz']
         x = self.prev.y(sp).view(R, D)
@@ -390,7 +401,8 @@ class ShapePlan(object):
 class Engine(object):
     """Owns parameters, optimiser state and per-shape plans for one Network on one GPU."""
 
-    def __init__(self, net, device='cuda:0', seed=None, max_label_len=31, use_graphs=True, group=None):
+    def __init__(self, net, device='cuda:0', seed=None, max_label_len=31, use_graphs=True, group=None,
+                 persistent_lstm=True):
         from .config import cfg
         if not torch.cuda.is_available():
             raise NativeError('Engine needs a ROCm GPU: the hot path has no CPU implementation')
@@ -401,6 +413,7 @@ class Engine(object):
         self.num_features = cfg.NUM_FEATURES
         self.max_label_len = max_label_len
         self.use_graphs = use_graphs
+        self.persistent_lstm = persistent_lstm
         self.group = group
         self.world = 1
         if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -661,4 +674,7 @@ class Engine(object):
         ctc = float(sp.costs.cpu().numpy().mean())
         reg = 0.5 * float(self.cfg.TRAIN.WEIGHT_DECAY) * float(sc[1]) if self.cfg.TRAIN.WEIGHT_DECAY > 0 else 0.0
         self.last_ctc, self.last_reg, self.last_gnorm = ctc, reg, float(sc[7])
+        for word in getattr(sp, 'lstm_sync', ()):
+            if int(word[-1].item()) != 0:
+                raise NativeError('persistent LSTM kernel: inter-workgroup wait timed out (results invalid)')
         return ctc + reg

@@ -217,6 +217,20 @@ def lstm_bwd_step(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, dc_sta
          ptr(dc_state), Nb, T, U, step, _st())
 
 
+def lstm_seq_supported(Nb, U):
+    return bool(nat.lib().ocr_lstm_seq_supported(Nb, U))
+
+
+def lstm_fwd_seq(xproj, whT, seq_len, hout, gates, cell, Nb, T, U, sync, forget_bias=1.0):
+    call("ocr_lstm_fwd_seq", ptr(_dev(xproj)), ptr(whT), ptr(seq_len), ptr(hout), ptr(gates), ptr(cell), Nb, T, U,
+         float(forget_bias), ptr(sync), _st())
+
+
+def lstm_bwd_seq(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, Nb, T, U, sync):
+    call("ocr_lstm_bwd_seq", ptr(_dev(wh)), ldw, w_dir_stride, ptr(seq_len), ptr(dhout), ptr(gates), ptr(cell), ptr(dz),
+         Nb, T, U, ptr(sync), _st())
+
+
 def lstm_hprev(hout, seq_len, hprev, Nb, T, U):
     call("ocr_lstm_hprev", ptr(_dev(hout)), ptr(seq_len), ptr(hprev), Nb, T, U, _st())
 

@@ -316,7 +316,7 @@ def test_small_ops(dev):
 
 
 # ------------------------------------------------------------------------------------------- LSTM
-def _lstm_device_forward(dev, x, seq_len, Ws, bs, U):
+def _lstm_device_forward(dev, x, seq_len, Ws, bs, U, persistent=False):
     """Runs the hoisted projection + per-step kernels exactly as the executor does. x: [N,T,D] bf16-rounded fp32."""
     N, T, D = x.shape
     R = N * T
@@ -333,13 +333,22 @@ def _lstm_device_forward(dev, x, seq_len, Ws, bs, U):
     sl = torch.tensor(seq_len, dtype=torch.int32, device=dev)
     hout = torch.full((R, 2 * U), 7.0, dtype=BF, device=dev)          # poison: kernels must overwrite every row
     gates = torch.zeros((2, R, 4 * U), device=dev); cell = torch.zeros((2, R, U), device=dev)
-    for s in range(T):
-        ops.lstm_fwd_step(xproj, whT, sl, hout, gates, cell, N, T, U, s)
+    if persistent:
+        assert ops.lstm_seq_supported(N, U)
+        sync = torch.zeros(2 * ((N + 63) // 64) + 1, dtype=torch.int32, device=dev)
+        ops.lstm_fwd_seq(xproj, whT, sl, hout, gates, cell, N, T, U, sync)
+        torch.cuda.synchronize()
+        assert int(sync[-1]) == 0, "persistent LSTM forward: spin timeout"
+    else:
+        for s in range(T):
+            ops.lstm_fwd_step(xproj, whT, sl, hout, gates, cell, N, T, U, s)
     return dict(xd=xd, sl=sl, hout=hout, gates=gates, cell=cell)
 
 
-@pytest.mark.parametrize("N,T,D,U,lens", [(64, 21, 512, 256, None), (5, 9, 64, 32, [9, 4, 1, 7, 9]), (70, 6, 64, 32, None)])
-def test_lstm_fwd_bwd(dev, N, T, D, U, lens):
+@pytest.mark.parametrize("N,T,D,U,lens,persistent", [(64, 21, 512, 256, None, False), (5, 9, 64, 32, [9, 4, 1, 7, 9], False),
+                                                        (70, 6, 64, 32, None, False), (64, 63, 512, 256, None, True),
+                                                        (100, 12, 64, 256, None, True), (3, 5, 64, 256, [5, 1, 3], True)])
+def test_lstm_fwd_bwd(dev, N, T, D, U, lens, persistent):
     rng = np.random.RandomState(1)
     seq_len = lens if lens is not None else rng.randint(max(1, T // 2), T + 1, N).tolist()
     x = bf(gen((N, T, D), 1))
@@ -351,7 +360,7 @@ def test_lstm_fwd_bwd(dev, N, T, D, U, lens):
     fw = og.lstm_direction(xr, seq_len, Wr[0], br[0], False, True)
     bw = og.lstm_direction(xr, seq_len, Wr[1], br[1], True, True)
     ref = torch.cat([fw, bw], 2)
-    st = _lstm_device_forward(dev, x, seq_len, Ws, bs, U)
+    st = _lstm_device_forward(dev, x, seq_len, Ws, bs, U, persistent)
     got = st["hout"].float().cpu().reshape(N, T, 2 * U)
     assert maxerr(got, ref.detach()) < 2e-2, maxerr(got, ref.detach())
     # ---- backward
@@ -364,8 +373,14 @@ def test_lstm_fwd_bwd(dev, N, T, D, U, lens):
     dz = torch.full((R, 8 * U), 3.0, dtype=BF, device=dev)
     dc = torch.zeros((2, N, U), device=dev)
     dhd = dh.to(dev).to(BF).reshape(R, 2 * U)
-    for s in range(T - 1, -1, -1):
-        ops.lstm_bwd_step(whb[:, D:], 4 * U, (D + U) * 4 * U, st["sl"], dhd, st["gates"], st["cell"], dz, dc, N, T, U, s)
+    if persistent:
+        sync = torch.zeros(2 * ((N + 63) // 64) + 1, dtype=torch.int32, device=dev)
+        ops.lstm_bwd_seq(whb[:, D:], 4 * U, (D + U) * 4 * U, st["sl"], dhd, st["gates"], st["cell"], dz, N, T, U, sync)
+        torch.cuda.synchronize()
+        assert int(sync[-1]) == 0, "persistent LSTM backward: spin timeout"
+    else:
+        for s in range(T - 1, -1, -1):
+            ops.lstm_bwd_step(whb[:, D:], 4 * U, (D + U) * 4 * U, st["sl"], dhd, st["gates"], st["cell"], dz, dc, N, T, U, s)
     hprev = torch.empty((2, R, U), dtype=BF, device=dev)
     ops.lstm_hprev(st["hout"], st["sl"], hprev, N, T, U)
     for d in range(2):

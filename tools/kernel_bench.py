@@ -85,6 +85,10 @@ def main():
         for s in range(T - 1, -1, -1):
             ops.lstm_bwd_step(whb[:, 512:], 4 * U, 768 * 4 * U, sl, dh, gates, cell, dzb, dc, Nb, T, U, s)
     rec("lstm.bwd_63steps", timeit(lstm_bwd, iters=5))
+    syn = torch.zeros(3, dtype=torch.int32, device=dev)
+    rec("lstm.fwd_seq_persistent", timeit(lambda: ops.lstm_fwd_seq(xproj, whT, sl, hout, gates, cell, Nb, T, U, syn), iters=10))
+    rec("lstm.bwd_seq_persistent", timeit(lambda: ops.lstm_bwd_seq(whb[:, 512:], 4 * U, 768 * 4 * U, sl, dh, gates, cell, dzb, Nb, T, U, syn), iters=10))
+    print("persistent spin-timeout flag:", int(syn[-1]))
     # CTC
     acts = torch.randn(T, Nb, 64, device=dev)
     lab = torch.randint(1, 63, (Nb * 10,), dtype=torch.int32, device=dev)
