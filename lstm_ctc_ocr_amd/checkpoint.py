@@ -1,0 +1,72 @@
+"""Checkpoint I/O with the reference's Saver protocol (lib/lstm/train.py:23-37, 96-106) on a portable container.
+
+The reference writes TF-1.0 `.ckpt` bundles through tf.train.Saver(max_to_keep=100); TensorFlow is not available
+here, so a snapshot is a single `.npz` holding every variable under its TF name and layout
+(conv*/weights [kh,kw,ci,co], conv4_x/conv4_x/{beta,gamma}, logits/{fw,bw}/{weights[768,1024],biases},
+logits/{weights,biases}) plus the optimiser slots and step counters, and a text file `checkpoint` naming the
+latest one — the same naming (`lstm_ctc[_infix]_iter_<n>.ckpt`), resume rule (iteration parsed from the file
+name) and retention as the reference.  A dict of arrays converted from a real TF checkpoint loads through
+Engine.load_arrays unchanged.
+"""
+import os
+
+import numpy as np
+
+MAX_TO_KEEP = 100
+
+
+def _index_path(output_dir):
+    return os.path.join(output_dir, 'checkpoint')
+
+
+def save(engine, path):
+    arrays = {'var/' + k: v for k, v in engine.state_arrays().items()}
+    if engine.opt_ready:
+        arrays['opt/state1'] = engine.state1.cpu().numpy()
+        if engine.state2 is not None:
+            arrays['opt/state2'] = engine.state2.cpu().numpy()
+        arrays['opt/scalars'] = engine.scalars.cpu().numpy()
+        arrays['opt/solver'] = np.int64(engine.solver)
+    arrays['meta/iteration'] = np.int64(engine.iteration)
+    tmp = path + '.tmp.npz'
+    np.savez(tmp, **arrays)
+    os.replace(tmp, path)
+    out_dir = os.path.dirname(path)
+    idx = _index_path(out_dir)
+    kept = []
+    if os.path.exists(idx):
+        kept = [l.strip() for l in open(idx) if l.strip()]
+    base = os.path.basename(path)
+    kept = [k for k in kept if k != base] + [base]
+    while len(kept) > MAX_TO_KEEP:
+        old = kept.pop(0)
+        try:
+            os.remove(os.path.join(out_dir, old))
+        except OSError:
+            pass
+    with open(idx, 'w') as f:
+        f.write("\n".join(kept) + "\n")
+    return path
+
+
+def latest_checkpoint(output_dir):
+    idx = _index_path(output_dir)
+    if not os.path.exists(idx):
+        return None
+    kept = [l.strip() for l in open(idx) if l.strip()]
+    return os.path.join(output_dir, kept[-1]) if kept else None
+
+
+def restore(engine, path):
+    import torch
+    data = np.load(path)
+    engine.load_arrays({k[4:]: data[k] for k in data.files if k.startswith('var/')})
+    if 'opt/state1' in data.files:
+        if not engine.opt_ready:
+            engine.setup_optimizer()
+        engine.state1.copy_(torch.from_numpy(data['opt/state1']))
+        if engine.state2 is not None and 'opt/state2' in data.files:
+            engine.state2.copy_(torch.from_numpy(data['opt/state2']))
+        engine.scalars.copy_(torch.from_numpy(data['opt/scalars']))
+    engine.iteration = int(data['meta/iteration']) if 'meta/iteration' in data.files else 0
+    return engine
