@@ -1,0 +1,27 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed over RCCL/xGMI (backend "nccl") on the GPU box,
+gloo in the CPU test-suite.  The path has exactly ONE exchange per step — the flat fp32 gradient buffer — so this
+module is deliberately tiny."""
+import os
+
+
+def env_world():
+    return int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+
+
+def loss_scale(local_batch, world):
+    """d(total loss)/d(cost_n): the reference's loss is the MEAN cost over the batch (network.py:655); with the
+    global batch sharded over `world` ranks every rank scales its local gradient by 1/(local_batch*world) so that a
+    plain SUM all-reduce yields the global-batch mean gradient."""
+    return 1.0 / (float(local_batch) * float(world))
+
+
+def allreduce_sum_(flat, group=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
+def rank_seed(base_seed, rank):
+    """Independent, reproducible data stream per rank."""
+    return int(base_seed) + 1000003 * int(rank)

@@ -20,6 +20,7 @@ import math
 import numpy as np
 import torch
 
+from . import dist as ocr_dist
 from . import ops
 from ._native import NativeError
 
@@ -559,7 +560,7 @@ class Engine(object):
         ops.ctc_loss(logits, sp.labels, sp.labels_len, sp.seq_len, self.max_label_len, blank=0, want_grad=True,
                      workspace=sp.ctc_ws, costs=sp.costs, grads=sp.ctc_grad)
         # loss = mean over the GLOBAL batch -> d loss / d cost_n = 1 / (N * world)   (network.py:655)
-        ops.tnc_to_ntc_bf16(sp.ctc_grad, self.ops[-1].dy(sp), 1.0 / (sp.N * self.world))
+        ops.tnc_to_ntc_bf16(sp.ctc_grad, self.ops[-1].dy(sp), ocr_dist.loss_scale(sp.N, self.world))
         for op in reversed(self.ops):
             op.bwd(sp)
 
@@ -652,7 +653,7 @@ class Engine(object):
         factor is already folded into the CTC gradient hand-off, so the sum IS the global-batch mean gradient; the
         clip then sees the same global norm a single GPU would see at the global batch size."""
         if self.world > 1:
-            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.group)
+            ocr_dist.allreduce_sum_(self.grads, self.group)
 
     def train_step(self, data, labels, labels_len, seq_len, fetch_loss=True):
         """One optimisation step on a batch laid out as gen.py:41-67 produces it.  Returns the total loss

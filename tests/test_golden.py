@@ -1,0 +1,77 @@
+"""Golden vectors (tests/golden/*.npz, written by tests/golden/make_golden.py from the pinned oracle).
+CPU leg: the oracle still reproduces them bit-for-bit-ish (freezes the checker).  GPU leg: the HIP path against the
+same fixed vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctc as octc
+from oracle import decode as odec
+from oracle import graph as og
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_graph_fixture():
+    d = np.load(os.path.join(G, 'graph_small.npz'))
+    params = og.init_params(seed=11)
+    for k in d.files:
+        if k.startswith('p/'):
+            params[k[2:]] = torch.from_numpy(d[k])
+    chk = sum(float(v.double().abs().sum()) for k, v in params.items() if k.endswith('weights'))
+    assert abs(chk - float(d['weight_checksum'])) < 1e-6 * chk, 'seeded weights differ from the ones the fixture was made with'
+    return d, params
+
+
+def test_oracle_reproduces_ctc_fixture():
+    d = np.load(os.path.join(G, 'ctc_small.npz'))
+    costs, grads = octc.ctc_loss_c(d['acts'], d['flat_labels'], d['label_lengths'], d['input_lengths'])
+    assert np.allclose(costs, d['costs'], rtol=1e-6, atol=1e-6) and np.abs(grads - d['grads']).max() < 1e-6
+    assert d['costs'][3] == 0 and np.all(d['grads'][:, 3] == 0)                 # the infeasible sample
+    assert np.array_equal(odec.dense(odec.greedy_decode(d['acts'], d['input_lengths'])), d['greedy'])
+    assert np.array_equal(odec.dense(odec.reference_decode(d['acts'], d['input_lengths'])), d['beam'])
+
+
+def test_oracle_reproduces_graph_fixture():
+    d, params = load_graph_fixture()
+    l32 = og.forward(params, torch.from_numpy(d['x']), d['seq_len'].tolist(), sim_bf16=False).numpy()
+    assert np.abs(l32 - d['logits_fp32']).max() < 1e-4
+    total, ctc, _ = og.loss_fn(params, torch.from_numpy(d['x']), d['labels'], d['label_lengths'], d['seq_len'].tolist(), 1e-5,
+                               sim_bf16=True)
+    assert abs(float(total) - float(d['loss_total'])) < 1e-3 * float(d['loss_total'])
+
+
+@pytest.mark.gpu
+def test_device_ctc_matches_fixture(dev):
+    from lstm_ctc_ocr_amd import ops
+    d = np.load(os.path.join(G, 'ctc_small.npz'))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    costs, grads = ops.ctc_loss(t(d['acts']), t(d['flat_labels']), t(d['label_lengths']), t(d['input_lengths']), 7)
+    assert np.allclose(costs.cpu().numpy(), d['costs'], rtol=1e-4, atol=1e-4)          # bar: 1e-3 relative
+    assert np.abs(grads.cpu().numpy() - d['grads']).max() < 1e-4
+    out, lens = ops.ctc_greedy_decode(t(d['acts']), t(d['input_lengths']))
+    out, lens = out.cpu().numpy(), lens.cpu().numpy()
+    for n in range(out.shape[0]):
+        want = [v for v in d['greedy'][n] if v != 0]
+        assert out[n, :lens[n]].tolist() == want                                       # bar: identical
+
+
+@pytest.mark.gpu
+def test_device_graph_matches_fixture(dev):
+    from lstm_ctc_ocr_amd.config import cfg
+    from lstm_ctc_ocr_amd.engine import Engine
+    from lstm_ctc_ocr_amd.models import get_network
+    d, params = load_graph_fixture()
+    cfg.TRAIN.WEIGHT_DECAY = 1e-5
+    eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=1, use_graphs=False)
+    eng.load_arrays({k: v.numpy() for k, v in params.items()})
+    sl = d['seq_len']
+    logits = eng.forward(d['x'], sl).float().cpu().numpy()
+    for n in range(len(sl)):
+        assert np.abs(logits[:sl[n], n] - d['logits_bf16sim'][:sl[n], n]).max() < 5e-3
+    print('max |device - fp32 oracle| logits:', np.abs(logits - d['logits_fp32']).max())
+    eng.setup_optimizer('Adam', 1e-4)
+    loss = eng.train_step(d['x'], d['labels'], d['label_lengths'], sl)
+    assert abs(loss - float(d['loss_total'])) < 1e-3 * float(d['loss_total'])         # bar: CTC loss within 1e-3 relative

@@ -1,0 +1,98 @@
+"""Pins the CTC oracle (oracle/ctc_ref.c, oracle/ctc.py) — the checker every device-side CTC claim rests on.
+The reference holds no vectors for this path; the pins are warp-ctc's published known-answer test, exact
+path enumeration, and torch's independent CPU implementation."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ctc as octc
+from oracle import decode as odec
+
+
+def test_warpctc_known_answer_vector():
+    # warp-ctc tests/test_cpu.cpp::small_test == tensorflow_binding/tests/test_warpctc_op.py::_testBasic
+    acts = np.array([[[0.1, 0.6, 0.1, 0.1, 0.1]], [[0.1, 0.1, 0.6, 0.1, 0.1]]], np.float32)
+    for fn in (octc.ctc_loss_c, octc.ctc_loss_numpy):
+        costs, grads = fn(acts, [1, 2], [2], [2])
+        assert abs(float(costs[0]) - 2.46286) < 1e-5
+        exp = np.full((2, 5), 0.177031); exp[0, 1] = exp[1, 2] = -0.708125
+        assert np.abs(np.asarray(grads).reshape(2, 5) - exp).max() < 1e-5
+    p = np.exp(acts[:, 0, :]) / np.exp(acts[:, 0, :]).sum(-1, keepdims=True)
+    assert abs(-np.log(p[0, 1] * p[1, 2]) - 2.4628585) < 1e-6        # analytic: the only path is (1, 2)
+
+
+@pytest.mark.parametrize("T,C,label", [(4, 3, [1, 2]), (5, 3, [1, 1]), (5, 4, [3]), (3, 3, []), (4, 4, [2, 2, 1][:2])])
+def test_against_path_enumeration(T, C, label):
+    rng = np.random.RandomState(T * 10 + C)
+    acts = rng.randn(T, 1, C).astype(np.float32) * 1.5
+    cost_bf, table = octc.ctc_brute_force(acts[:, 0, :], label)
+    assert abs(sum(table.values()) - 1.0) < 1e-9
+    costs, grads = octc.ctc_loss_c(acts, label, [len(label)], [T])
+    assert abs(costs[0] - cost_bf) < 1e-5
+    # gradient by central differences of the enumerated loss
+    eps = 1e-3
+    for t in range(T):
+        for k in range(C):
+            ap, am = acts.copy().astype(np.float64), acts.copy().astype(np.float64)
+            ap[t, 0, k] += eps; am[t, 0, k] -= eps
+            num = (octc.ctc_brute_force(ap[:, 0, :], label)[0] - octc.ctc_brute_force(am[:, 0, :], label)[0]) / (2 * eps)
+            assert abs(num - grads[t, 0, k]) < 2e-4
+
+
+def test_against_torch_ctc_loss_c2_shape():
+    rng = np.random.RandomState(7)
+    T, N, C = 63, 64, 64
+    acts = rng.randn(T, N, C).astype(np.float32) * 2
+    ll = rng.randint(4, 11, N)
+    il = rng.randint(40, T + 1, N)
+    labels = [rng.randint(1, C, l) for l in ll]
+    labels[3][1] = labels[3][0]; labels[5][:] = labels[5][0]          # repeats
+    flat = np.concatenate(labels).astype(np.int32)
+    costs, grads = octc.ctc_loss_c(acts, flat, ll, il)
+    a = torch.from_numpy(acts).requires_grad_(True)
+    ref = F.ctc_loss(F.log_softmax(a, -1), torch.from_numpy(flat).long(), torch.from_numpy(il), torch.from_numpy(ll),
+                     blank=0, reduction='none')
+    ref.sum().backward()
+    assert np.allclose(costs, ref.detach().numpy(), rtol=1e-5, atol=1e-4)
+    assert np.abs(grads - a.grad.numpy()).max() < 3e-4      # torch runs the recursion in fp32, the oracle in fp64
+    c2, g2 = octc.ctc_loss_numpy(acts[:, :4], np.concatenate(labels[:4]), ll[:4], il[:4])
+    assert np.allclose(c2, costs[:4], rtol=1e-6) and np.abs(g2 - grads[:, :4]).max() < 1e-6
+
+
+def test_infeasible_and_padding_semantics():
+    rng = np.random.RandomState(1)
+    acts = rng.randn(6, 3, 5).astype(np.float32)
+    # sample 0: L + repeats = 4 + 3 > T = 6 -> cost 0, grad 0 (warp-ctc); sample 1 uses only 3 frames
+    costs, grads = octc.ctc_loss_c(acts, [2, 2, 2, 2, 1, 3, 4], [4, 2, 1], [6, 3, 6])
+    assert costs[0] == 0 and np.all(grads[:, 0] == 0)
+    assert costs[1] > 0 and np.all(grads[3:, 1] == 0) and np.abs(grads[:3, 1]).sum() > 0
+    assert np.allclose(grads[:, 2].sum(-1), 0, atol=1e-6)               # softmax - posterior sums to 0 per frame
+
+
+def test_decoders_on_hand_cases_and_enumeration():
+    # the two-blanks quirk — loss blank is 0, TF's decoder blank is C-1 and zeros are stripped later
+    am = [5, 5, 0, 5, 0, 0, 7]
+    logits = np.full((7, 1, 9), -9.0, np.float32)       # C = 9: class 8 is the TF decoder's blank
+    for t, a in enumerate(am): logits[t, 0, a] = 9.0
+    assert odec.greedy_decode(logits, [7]) == [[5, 5, 7]]
+    assert odec.reference_decode(logits, [7]) == [[5, 5, 7]]
+    logits[:, 0, :] = -9.0; logits[:, 0, 0] = 9.0
+    assert odec.greedy_decode(logits, [7]) == [[]]
+    # class C-1 frames act as the TF decoder's blank: the search itself keeps both fives of [5, blank, 5], and
+    # merge_repeated=True (the reference's setting) then collapses them in the OUTPUT — TF's documented quirk; real
+    # doubles survive in the reference only because they are separated by the symbol 0
+    logits = np.full((3, 1, 8), -9.0, np.float32)
+    logits[0, 0, 5] = logits[1, 0, 7] = logits[2, 0, 5] = 9.0
+    assert odec.beam_search_tf(logits, [3], merge_repeated=False)[0] == [[5, 5]]
+    assert odec.beam_search_tf(logits, [3], merge_repeated=True)[0] == [[5]]
+    # exhaustive beam == most probable labelling from path enumeration (blank = C-1, no post-merge)
+    rng = np.random.RandomState(3)
+    for trial in range(5):
+        T, C = 5, 4
+        x = rng.randn(T, 1, C) * 2
+        _, table = octc.ctc_brute_force(x[:, 0, :], [], blank=C - 1)
+        best = max(table.items(), key=lambda kv: kv[1])
+        seqs, scores = odec.beam_search_tf(x, [T], beam_width=10000, merge_repeated=False)
+        assert tuple(seqs[0]) == best[0]
+        assert abs(np.exp(scores[0]) - best[1]) < 1e-9

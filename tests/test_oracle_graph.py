@@ -1,0 +1,94 @@
+"""Pins the layer-level oracle (oracle/graph.py) on independent implementations: a re-packed torch.nn.LSTM for the
+TF-1.0 LSTMCell restatement, plain numpy loops for conv / pool / batch-norm, and TF's documented sequence-length rules."""
+import numpy as np
+import torch
+
+from oracle import graph as og
+
+
+def test_lstm_cell_matches_repacked_torch_lstm():
+    torch.manual_seed(0)
+    N, T, D, U = 3, 7, 12, 8
+    x = torch.randn(N, T, D)
+    W = torch.randn(D + U, 4 * U) * 0.3       # TF layout, gate order i, j, f, o
+    b = torch.randn(4 * U) * 0.1
+    out = og.lstm_direction(x, [T] * N, W, b, reverse=False, sim=False, forget_bias=1.0)
+    ref = torch.nn.LSTM(D, U, batch_first=True)           # torch gate order i, f, g, o; two biases; no forget bias
+    i, j, f, o = W.split(U, dim=1)
+    bi, bj, bf_, bo = b.split(U)
+    Wt = torch.cat([i, f, j, o], 1)
+    with torch.no_grad():
+        ref.weight_ih_l0.copy_(Wt[:D].t()); ref.weight_hh_l0.copy_(Wt[D:].t())
+        ref.bias_ih_l0.copy_(torch.cat([bi, bf_ + 1.0, bj, bo])); ref.bias_hh_l0.zero_()
+    exp, _ = ref(x)
+    assert float((out - exp).abs().max()) < 1e-5
+
+
+def test_bidirectional_sequence_length_semantics():
+    torch.manual_seed(1)
+    N, T, D, U = 2, 6, 5, 4
+    x = torch.randn(N, T, D)
+    W = torch.randn(D + U, 4 * U) * 0.3; b = torch.zeros(4 * U)
+    lens = [6, 3]
+    fw = og.lstm_direction(x, lens, W, b, False, False)
+    bw = og.lstm_direction(x, lens, W, b, True, False)
+    # outputs past the length are zero (dynamic_rnn), and the padded tail never influences valid frames
+    assert float(fw[1, 3:].abs().max()) == 0 and float(bw[1, 3:].abs().max()) == 0
+    x2 = x.clone(); x2[1, 3:] = 99.0
+    assert torch.equal(og.lstm_direction(x2, lens, W, b, False, False)[1, :3], fw[1, :3])
+    assert torch.equal(og.lstm_direction(x2, lens, W, b, True, False)[1, :3], bw[1, :3])
+    # backward direction == forward direction on the sequence reversed WITHIN its length
+    xr = x.clone(); xr[1, :3] = x[1, :3].flip(0); xr[0] = x[0].flip(0)
+    fr = og.lstm_direction(xr, lens, W, b, False, False)
+    assert float((fr[1, :3].flip(0) - bw[1, :3]).abs().max()) < 1e-6
+    assert float((fr[0].flip(0) - bw[0]).abs().max()) < 1e-6
+
+
+def test_conv_pool_bn_against_numpy_loops():
+    rng = np.random.RandomState(0)
+    N, W, H, Ci, Co = 2, 5, 4, 3, 2
+    x = rng.randn(N, W, H, Ci).astype(np.float32); w = rng.randn(3, 3, Ci, Co).astype(np.float32); b = rng.randn(Co).astype(np.float32)
+    got = og.conv_single(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 'SAME', False).numpy()
+    exp = np.zeros((N, W, H, Co), np.float32)
+    for n in range(N):
+        for i in range(W):
+            for j in range(H):
+                for a in range(3):
+                    for c in range(3):
+                        ii, jj = i + a - 1, j + c - 1
+                        if 0 <= ii < W and 0 <= jj < H:
+                            exp[n, i, j] += x[n, ii, jj] @ w[a, c]
+    assert np.abs(got - (exp + b)).max() < 1e-4
+    # VALID 2x2 (conv5): output [W-1, H-1]
+    w2 = rng.randn(2, 2, Ci, Co).astype(np.float32)
+    got = og.conv_single(torch.from_numpy(x), torch.from_numpy(w2), torch.zeros(Co), 'VALID', False).numpy()
+    assert got.shape == (N, W - 1, H - 1, Co)
+    assert abs(got[0, 1, 2, 0] - sum(x[0, 1 + a, 2 + c] @ w2[a, c, :, 0] for a in range(2) for c in range(2))) < 1e-4
+    # pooling: first argument pools the time axis W, second the feature axis H (network.py:343-350 with TF height = W)
+    p = og.max_pool(torch.from_numpy(x[:, :4]), 1, 2).numpy()
+    assert p.shape == (N, 4, 2, Ci) and np.allclose(p[0, 1, 1], np.maximum(x[0, 1, 2], x[0, 1, 3]))
+    # batch norm: biased variance over (N, W, H), eps 1e-3
+    y = og.batch_norm_train(torch.from_numpy(x), torch.ones(Ci) * 2, torch.ones(Ci) * 0.5).numpy()
+    flat = x.reshape(-1, Ci)
+    exp = (flat - flat.mean(0)) / np.sqrt(flat.var(0) + 1e-3) * 2 + 0.5
+    assert np.abs(y.reshape(-1, Ci) - exp).max() < 1e-4
+
+
+def test_full_graph_shapes_loss_and_optimizer_formulas():
+    p = og.init_params()
+    assert sum(v.numel() for v in p.values()) == 7158592          # SURVEY §8d parameter count
+    x = torch.rand(2, 32, 32)
+    logits = og.forward(p, x, [7, 5])
+    assert tuple(logits.shape) == (7, 2, 64)                      # T = W/4 - 1, time-major
+    # frames past a sample's length carry the FC bias only
+    assert float((logits[5:, 1] - p['logits/biases']).abs().max()) < 1e-6
+    total, ctc, _ = og.loss_fn(p, x, [1, 2, 3], [2, 1], [7, 5], 1e-5)
+    reg = sum(0.5e-5 * float((v ** 2).sum()) for k, v in p.items() if og.REGULARISED(k))
+    assert abs(float(total) - float(ctc) - reg) < 1e-5
+    # clip_by_global_norm + Adam (TF form) on a toy problem
+    g = {'a': torch.tensor([30.0, 40.0])}
+    clipped, norm = og.clip_by_global_norm(g, 10.0)
+    assert abs(norm - 50.0) < 1e-6 and torch.allclose(clipped['a'], torch.tensor([6.0, 8.0]))
+    st = {}
+    new = og.adam_step({'a': torch.zeros(2)}, clipped, st, lr=0.1)
+    assert torch.allclose(new['a'], torch.tensor([-0.1, -0.1]), atol=1e-6)   # first Adam step = -lr * sign(g)
