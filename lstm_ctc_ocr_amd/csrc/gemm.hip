@@ -250,6 +250,13 @@ static int dispatch_gemm(GemmArgs& g, int mode, int splits, hipStream_t stream) 
     return big ? launch_gemm<0, 4, 4>(g, stream) : launch_gemm<0, 2, 2>(g, stream);
 }
 
+// large-tile LDS-DMA engine (igemm.hip); returns -1 when it does not cover the shape
+int ig_try_dispatch(const void* P, long ldp, const void* Q, long ldq, void* out, long ldo, int M, int N, int K,
+                    const float* bias, const void* mask, long ldmask, int flags, int mode, int grp, int skip, int cW,
+                    int cH, int cC, int swap_inner, int swap_outer, hipStream_t stream);
+static int g_use_igemm = 1;
+extern "C" int ocr_set_gemm_engine(int use_large_tile) { g_use_igemm = use_large_tile; return OCR_OK; }
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -265,6 +272,11 @@ extern "C" int ocr_gemm_nt_bf16(const void* P, long ldp, const void* Q, long ldq
     if ((flags & EPI_BIAS) && !bias) return OCR_ERR_INVALID;
     if ((flags & EPI_MASK) && !mask) return OCR_ERR_INVALID;
     if ((flags & EPI_ROWSWAP) && (swap_inner <= 0 || swap_outer <= 0)) return OCR_ERR_INVALID;
+    if (g_use_igemm && splits <= 1 && P && Q && out && M > 0 && N > 0 && K > 0) {
+        int rc = ig_try_dispatch(P, ldp, Q, ldq, out, ldo, M, N, K, bias, mask, ldmask, g.flags, 0, row_group, row_skip, 0, 0, 0,
+                                 swap_inner, swap_outer, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     return dispatch_gemm(g, 0, splits, (hipStream_t)stream);
 }
 
@@ -281,5 +293,10 @@ extern "C" int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int N
     g.flags = flags & ~(EPI_ATOMIC | EPI_ROWSWAP);
     if ((flags & EPI_BIAS) && !bias) return OCR_ERR_INVALID;
     if ((flags & EPI_MASK) && !mask) return OCR_ERR_INVALID;
+    if (g_use_igemm && x && wpack && y && g.M > 0 && Cout > 0 && Cin > 0) {
+        int rc = ig_try_dispatch(x, Cin, wpack, 9L * Cin, y, Cout, g.M, Cout, 9 * Cin, bias, mask, Cout, g.flags, 1, 0, 0, W, H, Cin,
+                                 0, 0, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     return dispatch_gemm(g, 1, 1, (hipStream_t)stream);
 }
