@@ -91,10 +91,12 @@ int ocr_lstm_bwd_step(const void* wh, long ldw, long w_dir_stride, const int* se
                       const float* gates, const float* cell, void* dz, float* dc_state, int Nb, int T, int U,
                       int step, void* stream);
 /* whole-sequence (persistent) variants: one launch for all T steps, workgroups of a (direction, 64-row batch tile)
- * group exchange h_t / dz_t through write-through stores + an agent-scope counter.  `sync`: >= 2*ceil(Nb/64)+1
+ * group exchange h_t / dz_t through write-through stores + an agent-scope counter.  `sync`: ocr_lstm_seq_sync_words(Nb)
  * int32 words (zeroed by the call; last word = spin-timeout error flag).  ocr_lstm_seq_supported() tells whether
  * the shape is covered (U == 256 and the grid fits one workgroup per CU); otherwise use the step entry points. */
 int ocr_lstm_seq_supported(int Nb, int U);
+int ocr_lstm_seq_sync_words(int Nb);
+int ocr_lstm_seq_debug(void* dbg /* device int64[4*T] phase stamps of workgroup 0, NULL = off */);
 int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, const int* seq_len, void* hout, float* gates,
                      float* cell, int Nb, int T, int U, float forget_bias, void* sync, void* stream);
 int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,

@@ -10,16 +10,21 @@
 //     that the 16 workgroups of a (direction, batch-tile) group exchange.  Hand-off protocol (placement
 //     independent, MI355X guide G16/R1): write-through (sc1, agent-scope relaxed atomic) 8-byte payload stores ->
 //     every wave drains vmcnt -> __syncthreads -> one lane bumps a monotonic agent-scope counter; consumers:
-//     one lane polls the counter relaxed (bounded, s_sleep) -> ONE agent-scope acquire fence -> __syncthreads ->
-//     plain 16-byte loads.  Every step writes fresh rows, so there is no write-after-read hazard.
-//   * residency: the grid is (U/16) x 2 x ceil(N/64) workgroups of 256 threads, one per CU; the C entry point
+//     one lane polls the counter relaxed (bounded, s_sleep) -> __syncthreads -> 16-byte `buffer_load ... sc1`
+//     loads of the exchanged rows (write-through stores + L1-bypassing loads on both sides: no ~1.7 us
+//     buffer_inv acquire per step).  Every step writes fresh rows, so there is no write-after-read hazard.
+//   * residency: the grid is (U/16) x 2 x ceil(N/16) one-wave workgroups (or ceil(N/64) four-wave ones), one per CU; the C entry point
 //     refuses grids above 256 workgroups (the caller then uses the per-step kernels).  Spins are bounded and
 //     report through an error word instead of hanging the device.
 #include "common.h"
+#include <stdlib.h>
 
 typedef unsigned long long u64;
 
 #define SPIN_LIMIT (1u << 22)
+#define CNT_STRIDE 64     // 32-bit words between group counters: pollers of different groups never share a cache line
+// optional phase timestamps (wall_clock64, 100 MHz) of workgroup 0: dbg[step*4 + {0 loop top, 1 after wait, 2 after MFMA, 3 after arrive}]
+#define DBG_STAMP(slot) do { if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) a.dbg[dbgi * 4 + (slot)] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ void store_wt8(void* p, u32x2 v) {
     u64 x = ((u64)v.y << 32) | (u64)v.x;
@@ -32,7 +37,7 @@ __device__ __forceinline__ void group_arrive(unsigned* counter) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// wait until `counter` >= target, then make other workgroups' write-through stores visible to plain loads
+// wait until `counter` >= target; the exchanged rows are then read with sc1 (L1-bypassing) loads
 __device__ __forceinline__ void group_wait(unsigned* counter, unsigned target, int* err) {
     if (threadIdx.x == 0) {
         unsigned spins = 0;
@@ -40,30 +45,33 @@ __device__ __forceinline__ void group_wait(unsigned* counter, unsigned target, i
             __builtin_amdgcn_s_sleep(1);
             if (++spins > SPIN_LIMIT) { atomicExch(err, 1); break; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+}
+__device__ __forceinline__ bf16x8 load_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, /*sc1*/ 16);
+    return __builtin_bit_cast(bf16x8, v);
 }
 
 struct LstmSeqFwdArgs {
     const float* xproj; const bf16_t* whT; const int* seq_len; bf16_t* hout; float* gates; float* cell;
     unsigned* counters; int* err;
-    int Nb, T, U; float forget_bias;
+    int Nb, T, U; float forget_bias; long long* dbg;
 };
 
-template <int KS /* U / 32 */>
-__global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqFwdArgs a) {
+template <int KS /* U / 32 */, int WPB /* waves (16-row batch tiles) per workgroup */>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_seq_kernel(LstmSeqFwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ub = blockIdx.x, d = blockIdx.y, zb = blockIdx.z;
     const int U = KS * 32, T = a.T;
     const int nl = lane & 15, q = lane >> 4;
-    const int n = zb * 64 + wave * 16 + nl;
+    const int n = zb * (16 * WPB) + wave * 16 + nl;
     const bool nvalid = n < a.Nb;
     const int nn = nvalid ? n : 0;
     const int len = min(a.seq_len[nn], T);
     const long R = (long)a.Nb * T;
     const int ul0 = q * 4;
-    unsigned* counter = a.counters + (d * gridDim.z + zb);
+    unsigned* counter = a.counters + (d * gridDim.z + zb) * CNT_STRIDE;   // one 256-B line per group counter
     const unsigned group = gridDim.x;
 
     // W_h^T slice: 4 gate fragments x KS k-steps, resident for the whole sequence
@@ -76,7 +84,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqFwdArgs a) {
             for (int kk = 0; kk < KS; ++kk) w[g][kk] = *(const bf16x8*)(wbase + (long)g * 16 * U + kk * 32);
     }
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.hout, 0, (int)(R * 2 * U * 2), 0x00020000);
     for (int s = 0; s < T; ++s) {
+        const int dbgi = s;
+        DBG_STAMP(0);
         const bool active = nvalid && s < len;
         const int t = active ? (d == 0 ? s : len - 1 - s) : s;
         const int tprev = (d == 0) ? t - 1 : t + 1;
@@ -91,16 +102,19 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqFwdArgs a) {
         for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
             group_wait(counter, group * (unsigned)s, a.err);
-            const bf16_t* hbase = a.hout + rowp * (2L * U) + (long)d * U + q * 8;
+            DBG_STAMP(1);
+            const unsigned hoff = (unsigned)((rowp * (2L * U) + (long)d * U + q * 8) * 2);
             bf16x8 b[KS];
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) b[kk] = *(const bf16x8*)(hbase + kk * 32);
+            for (int kk = 0; kk < KS; ++kk) b[kk] = load_sc1(hrsrc, hoff + kk * 64);
+            __builtin_amdgcn_sched_barrier(0);      // keep ALL loads in flight before the first MFMA: one round trip, not KS
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g][kk], b[kk], acc[g], 0, 0, 0);
         }
+        DBG_STAMP(2);
         if (nvalid) {
             bf16_t* hdst = a.hout + row * (2L * U) + (long)d * U + ub * 16 + ul0;
             if (!active) {
@@ -126,28 +140,29 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(LstmSeqFwdArgs a) {
             }
         }
         if (s + 1 < T) group_arrive(counter);
+        DBG_STAMP(3);
     }
 }
 
 struct LstmSeqBwdArgs {
     const bf16_t* wh; long ldw; long w_dir_stride; const int* seq_len; const bf16_t* dhout; const float* gates;
     const float* cell; bf16_t* dz; unsigned* counters; int* err;
-    int Nb, T, U;
+    int Nb, T, U; long long* dbg;
 };
 
-template <int KS /* 4U / 32 */>
-__global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(LstmSeqBwdArgs a) {
+template <int KS /* 4U / 32 */, int WPB>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_seq_kernel(LstmSeqBwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ub = blockIdx.x, d = blockIdx.y, zb = blockIdx.z;
     const int U = KS * 8, T = a.T;
     const int nl = lane & 15, q = lane >> 4;
-    const int n = zb * 64 + wave * 16 + nl;
+    const int n = zb * (16 * WPB) + wave * 16 + nl;
     const bool nvalid = n < a.Nb;
     const int nn = nvalid ? n : 0;
     const int len = min(a.seq_len[nn], T);
     const long R = (long)a.Nb * T;
     const int u0 = ub * 16 + q * 4;
-    unsigned* counter = a.counters + (d * gridDim.z + zb);
+    unsigned* counter = a.counters + (d * gridDim.z + zb) * CNT_STRIDE;   // one 256-B line per group counter
     const unsigned group = gridDim.x;
 
     bf16x8 w[KS];   // W_h rows (16 units of this workgroup) x K = 4U, resident
@@ -157,7 +172,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(LstmSeqBwdArgs a) {
         for (int kk = 0; kk < KS; ++kk) w[kk] = *(const bf16x8*)(wbase + kk * 32);
     }
     f32x4 dcs = {0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, (int)(R * 8 * U * 2), 0x00020000);
     for (int s = T - 1, it = 0; s >= 0; --s, ++it) {
+        const int dbgi = it;
+        DBG_STAMP(0);
         const bool active = nvalid && s < len;
         const bool has_next = nvalid && (s + 1 < len);
         const int t = active ? (d == 0 ? s : len - 1 - s) : s;
@@ -178,11 +196,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(LstmSeqBwdArgs a) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
         if (it > 0) {
             group_wait(counter, group * (unsigned)it, a.err);
-            const bf16_t* zbase = a.dz + rown * (8L * U) + (long)d * 4 * U + q * 8;
+            DBG_STAMP(1);
+            const unsigned zoff = (unsigned)((rown * (8L * U) + (long)d * 4 * U + q * 8) * 2);
             // all K/32 operand loads in flight at once: one L2 round trip per step instead of four
             bf16x8 z[KS];
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) z[kk] = *(const bf16x8*)(zbase + kk * 32);
+            for (int kk = 0; kk < KS; ++kk) z[kk] = load_sc1(zrsrc, zoff + kk * 64);
+            __builtin_amdgcn_sched_barrier(0);      // hipcc otherwise ping-pongs two registers: 16 serial sc1 round trips
 #pragma unroll
             for (int k0 = 0; k0 < KS; k0 += 4) {
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[k0 + 0], z[k0 + 0], acc0, 0, 0, 0);
@@ -191,6 +211,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(LstmSeqBwdArgs a) {
                 acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[k0 + 3], z[k0 + 3], acc3, 0, 0, 0);
             }
         }
+        DBG_STAMP(2);
         if (nvalid) {
             bf16_t* zdst = a.dz + row * (8L * U) + (long)d * 4 * U + u0;
             if (!active) {
@@ -220,6 +241,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(LstmSeqBwdArgs a) {
             }
         }
         if (s > 0) group_arrive(counter);
+        DBG_STAMP(3);
     }
 }
 
@@ -228,11 +250,39 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(LstmSeqBwdArgs a) {
 // counters followed by an error word; it is zeroed on the stream before every launch (hipGraph-replayable).
 // Returns OCR_ERR_INVALID for shapes the persistent kernels do not cover (caller falls back to the step kernels).
 // ------------------------------------------------------------------------------------------
-extern "C" int ocr_lstm_seq_supported(int Nb, int U) {
-    if (U != 256) return 0;
-    int groups = 2 * ceil_div(Nb, 64);
-    return (U / 16) * groups <= 256;
+// counters are cleared by a kernel, not hipMemsetAsync: under hipGraph replay a memset NODE of these sizes was observed to
+// fill the block with a stale non-zero pattern (ROCm 7.2), which makes every wait time out
+__global__ void zero_words_kernel(unsigned* p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
 }
+
+static long long* g_lstm_dbg = nullptr;
+// test/diagnostic hook: device buffer of 4*T int64 receiving wall-clock stamps of workgroup 0 (NULL = off)
+extern "C" int ocr_lstm_seq_debug(void* dbg) { g_lstm_dbg = (long long*)dbg; return OCR_OK; }
+
+// batch rows per workgroup: 16 (one wave, 4x the CUs, 4x less hand-off payload per CU and step) while the grid still
+// fits one workgroup per CU, else 64
+static int seq_rows_per_wg_default(int Nb, int U) {
+    for (int rows = 16; rows <= 64; rows *= 2)
+        if ((U / 16) * 2 * ceil_div(Nb, rows) <= 256) return rows;
+    return 0;
+}
+static int seq_rows_per_wg(int Nb, int U) {
+    // measured at N = 64 (us per step fwd / bwd, group counters on separate cache lines): 16 rows 2.6 / 3.2, 32 rows
+    // 3.0 / 4.1, 64 rows 3.6 / 6.2 - the per-step cost is the hand-off payload a CU has to pull (about 65 GB/s per CU)
+    // plus a fixed ~2 us of store-drain + counter + poll, so the smallest batch tile that still fits one WG per CU wins.
+    const char* e = getenv("OCR_LSTM_ROWS");            // experiment knob: force 16 / 32 / 64 rows per workgroup
+    int want = e ? atoi(e) : 0;
+    for (int rows = 16; rows <= 64; rows *= 2) {
+        if (want && rows != want) continue;
+        if ((U / 16) * 2 * ceil_div(Nb, rows) <= 256) return rows;
+    }
+    if (want) return seq_rows_per_wg_default(Nb, U);
+    return 0;
+}
+extern "C" int ocr_lstm_seq_supported(int Nb, int U) { return U == 256 && seq_rows_per_wg(Nb, U) != 0; }
+// int32 words the caller must provide in `sync` (group counters + error word)
+extern "C" int ocr_lstm_seq_sync_words(int Nb) { return (2 * ceil_div(Nb, 16) + 1) * CNT_STRIDE; }
 
 extern "C" int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, const int* seq_len, void* hout,
                                 float* gates, float* cell, int Nb, int T, int U, float forget_bias, void* sync,
@@ -240,12 +290,16 @@ extern "C" int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, cons
     hipStream_t stream = (hipStream_t)stream_;
     if (!xproj || !whT_packed || !seq_len || !hout || !gates || !cell || !sync) return OCR_ERR_INVALID;
     if (Nb <= 0 || T <= 0 || !ocr_lstm_seq_supported(Nb, U)) return OCR_ERR_INVALID;
-    int nz = ceil_div(Nb, 64);
-    if (hipMemsetAsync(sync, 0, (size_t)(2 * nz + 1) * sizeof(unsigned), stream) != hipSuccess) return OCR_ERR_MEMOPS;
+    const int rows = seq_rows_per_wg(Nb, U);
+    const int nz = ceil_div(Nb, rows), words = ocr_lstm_seq_sync_words(Nb);
+    zero_words_kernel<<<1, 256, 0, stream>>>((unsigned*)sync, words);
+    OCR_CHECK_LAUNCH();
     LstmSeqFwdArgs a = {xproj, (const bf16_t*)whT_packed, seq_len, (bf16_t*)hout, gates, cell, (unsigned*)sync,
-                        (int*)sync + 2 * nz, Nb, T, U, forget_bias};
+                        (int*)sync + words - 1, Nb, T, U, forget_bias, g_lstm_dbg};
     dim3 grid(U / 16, 2, nz);
-    lstm_fwd_seq_kernel<8><<<grid, 256, 0, stream>>>(a);
+    if (rows == 16) lstm_fwd_seq_kernel<8, 1><<<grid, 64, 0, stream>>>(a);
+    else if (rows == 32) lstm_fwd_seq_kernel<8, 2><<<grid, 128, 0, stream>>>(a);
+    else lstm_fwd_seq_kernel<8, 4><<<grid, 256, 0, stream>>>(a);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
@@ -256,12 +310,16 @@ extern "C" int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, con
     hipStream_t stream = (hipStream_t)stream_;
     if (!wh || !seq_len || !dhout || !gates || !cell || !dz || !sync) return OCR_ERR_INVALID;
     if (Nb <= 0 || T <= 0 || !ocr_lstm_seq_supported(Nb, U)) return OCR_ERR_INVALID;
-    int nz = ceil_div(Nb, 64);
-    if (hipMemsetAsync(sync, 0, (size_t)(2 * nz + 1) * sizeof(unsigned), stream) != hipSuccess) return OCR_ERR_MEMOPS;
+    const int rows = seq_rows_per_wg(Nb, U);
+    const int nz = ceil_div(Nb, rows), words = ocr_lstm_seq_sync_words(Nb);
+    zero_words_kernel<<<1, 256, 0, stream>>>((unsigned*)sync, words);
+    OCR_CHECK_LAUNCH();
     LstmSeqBwdArgs a = {(const bf16_t*)wh, ldw, w_dir_stride, seq_len, (const bf16_t*)dhout, gates, cell, (bf16_t*)dz,
-                        (unsigned*)sync, (int*)sync + 2 * nz, Nb, T, U};
+                        (unsigned*)sync, (int*)sync + words - 1, Nb, T, U, g_lstm_dbg};
     dim3 grid(U / 16, 2, nz);
-    lstm_bwd_seq_kernel<32><<<grid, 256, 0, stream>>>(a);
+    if (rows == 16) lstm_bwd_seq_kernel<32, 1><<<grid, 64, 0, stream>>>(a);
+    else if (rows == 32) lstm_bwd_seq_kernel<32, 2><<<grid, 128, 0, stream>>>(a);
+    else lstm_bwd_seq_kernel<32, 4><<<grid, 256, 0, stream>>>(a);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }

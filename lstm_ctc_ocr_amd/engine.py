@@ -304,8 +304,8 @@ class _BiLstmOp(_Op):
         b[self.key + '/dz'] = torch.zeros((R, 8 * U), dtype=BF16, device=dev)
         b[self.key + '/dc'] = torch.zeros((2, N, U), dtype=F32, device=dev)
         b[self.key + '/hprev'] = torch.empty((2, R, U), dtype=BF16, device=dev)
-        b[self.key + '/sync_f'] = torch.zeros(2 * ((N + 63) // 64) + 1, dtype=I32, device=dev)
-        b[self.key + '/sync_b'] = torch.zeros(2 * ((N + 63) // 64) + 1, dtype=I32, device=dev)
+        b[self.key + '/sync_f'] = torch.zeros(ops.lstm_seq_sync_words(N), dtype=I32, device=dev)
+        b[self.key + '/sync_b'] = torch.zeros(ops.lstm_seq_sync_words(N), dtype=I32, device=dev)
         sp.lstm_sync = (b[self.key + '/sync_f'], b[self.key + '/sync_b'])
 
     def refresh(self):
@@ -675,7 +675,8 @@ class Engine(object):
         ctc = float(sp.costs.cpu().numpy().mean())
         reg = 0.5 * float(self.cfg.TRAIN.WEIGHT_DECAY) * float(sc[1]) if self.cfg.TRAIN.WEIGHT_DECAY > 0 else 0.0
         self.last_ctc, self.last_reg, self.last_gnorm = ctc, reg, float(sc[7])
-        for word in getattr(sp, 'lstm_sync', ()):
+        for i, word in enumerate(getattr(sp, 'lstm_sync', ())):
             if int(word[-1].item()) != 0:
-                raise NativeError('persistent LSTM kernel: inter-workgroup wait timed out (results invalid)')
+                raise NativeError('persistent LSTM %s kernel: inter-workgroup wait timed out (results invalid); counters %s'
+                                  % (('forward', 'backward')[i], word[::64].tolist()))
         return ctc + reg

@@ -221,6 +221,10 @@ def lstm_seq_supported(Nb, U):
     return bool(nat.lib().ocr_lstm_seq_supported(Nb, U))
 
 
+def lstm_seq_sync_words(Nb):
+    return int(nat.lib().ocr_lstm_seq_sync_words(Nb))
+
+
 def lstm_fwd_seq(xproj, whT, seq_len, hout, gates, cell, Nb, T, U, sync, forget_bias=1.0):
     call("ocr_lstm_fwd_seq", ptr(_dev(xproj)), ptr(whT), ptr(seq_len), ptr(hout), ptr(gates), ptr(cell), Nb, T, U,
          float(forget_bias), ptr(sync), _st())

@@ -336,7 +336,7 @@ def _lstm_device_forward(dev, x, seq_len, Ws, bs, U, persistent=False):
     gates = torch.zeros((2, R, 4 * U), device=dev); cell = torch.zeros((2, R, U), device=dev)
     if persistent:
         assert ops.lstm_seq_supported(N, U)
-        sync = torch.zeros(2 * ((N + 63) // 64) + 1, dtype=torch.int32, device=dev)
+        sync = torch.zeros(ops.lstm_seq_sync_words(N), dtype=torch.int32, device=dev)
         ops.lstm_fwd_seq(xproj, whT, sl, hout, gates, cell, N, T, U, sync)
         torch.cuda.synchronize()
         assert int(sync[-1]) == 0, "persistent LSTM forward: spin timeout"
@@ -348,7 +348,7 @@ def _lstm_device_forward(dev, x, seq_len, Ws, bs, U, persistent=False):
 
 @pytest.mark.parametrize("N,T,D,U,lens,persistent", [(64, 21, 512, 256, None, False), (5, 9, 64, 32, [9, 4, 1, 7, 9], False),
                                                         (70, 6, 64, 32, None, False), (64, 63, 512, 256, None, True),
-                                                        (100, 12, 64, 256, None, True), (3, 5, 64, 256, [5, 1, 3], True)])
+                                                        (100, 12, 64, 256, None, True), (3, 5, 64, 256, [5, 1, 3], True), (200, 4, 64, 256, None, True), (8, 21, 512, 256, None, True)])
 def test_lstm_fwd_bwd(dev, N, T, D, U, lens, persistent):
     rng = np.random.RandomState(1)
     seq_len = lens if lens is not None else rng.randint(max(1, T // 2), T + 1, N).tolist()
@@ -375,7 +375,7 @@ def test_lstm_fwd_bwd(dev, N, T, D, U, lens, persistent):
     dc = torch.zeros((2, N, U), device=dev)
     dhd = dh.to(dev).to(BF).reshape(R, 2 * U)
     if persistent:
-        sync = torch.zeros(2 * ((N + 63) // 64) + 1, dtype=torch.int32, device=dev)
+        sync = torch.zeros(ops.lstm_seq_sync_words(N), dtype=torch.int32, device=dev)
         ops.lstm_bwd_seq(whb[:, D:], 4 * U, (D + U) * 4 * U, st["sl"], dhd, st["gates"], st["cell"], dz, N, T, U, sync)
         torch.cuda.synchronize()
         assert int(sync[-1]) == 0, "persistent LSTM backward: spin timeout"

@@ -85,10 +85,22 @@ def main():
         for s in range(T - 1, -1, -1):
             ops.lstm_bwd_step(whb[:, 512:], 4 * U, 768 * 4 * U, sl, dh, gates, cell, dzb, dc, Nb, T, U, s)
     rec("lstm.bwd_63steps", timeit(lstm_bwd, iters=5))
-    syn = torch.zeros(3, dtype=torch.int32, device=dev)
+    syn = torch.zeros(ops.lstm_seq_sync_words(Nb), dtype=torch.int32, device=dev)
     rec("lstm.fwd_seq_persistent", timeit(lambda: ops.lstm_fwd_seq(xproj, whT, sl, hout, gates, cell, Nb, T, U, syn), iters=10))
     rec("lstm.bwd_seq_persistent", timeit(lambda: ops.lstm_bwd_seq(whb[:, 512:], 4 * U, 768 * 4 * U, sl, dh, gates, cell, dzb, Nb, T, U, syn), iters=10))
     print("persistent spin-timeout flag:", int(syn[-1]))
+    from lstm_ctc_ocr_amd import _native as nat
+    dbg = torch.zeros(4 * T, dtype=torch.int64, device=dev)
+    nat.call("ocr_lstm_seq_debug", dbg.data_ptr())
+    for nm, fn in (("fwd", lambda: ops.lstm_fwd_seq(xproj, whT, sl, hout, gates, cell, Nb, T, U, syn)),
+                   ("bwd", lambda: ops.lstm_bwd_seq(whb[:, 512:], 4 * U, 768 * 4 * U, sl, dh, gates, cell, dzb, Nb, T, U, syn))):
+        fn(); torch.cuda.synchronize()
+        d = dbg.cpu().numpy().reshape(T, 4).astype(float) * 10.0      # wall_clock64 ticks are 10 ns
+        steps = d[5:-2]
+        print("lstm.%s phases (ns, median over steps): wait %.0f  loads+mfma %.0f  math+stores+arrive %.0f  step total %.0f" % (
+            nm, __import__("numpy").median(steps[:, 1] - steps[:, 0]), __import__("numpy").median(steps[:, 2] - steps[:, 1]),
+            __import__("numpy").median(steps[:, 3] - steps[:, 2]), __import__("numpy").median(steps[1:, 0] - steps[:-1, 0])))
+    nat.call("ocr_lstm_seq_debug", None)
     # CTC
     acts = torch.randn(T, Nb, 64, device=dev)
     lab = torch.randint(1, 63, (Nb * 10,), dtype=torch.int32, device=dev)
