@@ -56,12 +56,13 @@ int ocr_set_gemm_engine(int use_large_tile);
  * (conv_single network.py:160-191; also its data gradient with flipped/transposed weights) */
 int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int Nb, int W, int H, int Cin, int Cout,
                      const float* bias, const void* mask, int flags, void* stream);
-/* out[I][ldo] (f32) += scale * A^T B, A bf16 [Mk][lda], B bf16 [Mk][ldb]  (weight gradients of matmul layers) */
+/* out[I][ldo] (f32) += scale * A^T B, A bf16 [Mk][lda], B bf16 [Mk][ldb]  (weight gradients of matmul layers);
+ * colsum (may be NULL): colsum[j] += scale * sum_m B[m][j] — the bias gradient, produced by the same pass */
 int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* out, long ldo, int Mk, int I, int J,
-                     int row_group, int row_skip, long a_row_off, float scale, int splits, void* stream);
-/* dw f32 [3][3][Cin][Cout] (TF HWIO) += conv weight gradient */
-int ocr_conv3x3_wgrad_bf16(const void* x, const void* dy, float* dw, int Nb, int W, int H, int Cin, int Cout,
-                           int splits, void* stream);
+                     int row_group, int row_skip, long a_row_off, float scale, int splits, float* colsum, void* stream);
+/* dw f32 [3][3][Cin][Cout] (TF HWIO) += conv weight gradient; dbias (may be NULL) += sum over pixels of dy */
+int ocr_conv3x3_wgrad_bf16(const void* x, const void* dy, float* dw, float* dbias, int Nb, int W, int H, int Cin,
+                           int Cout, int splits, void* stream);
 
 /* ---- conv1 (Cin = 1), pooling, batch-norm, reductions, packing (network.py:160-191, 343-350, 176-178) -------- */
 int ocr_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int Nb, int W, int H, int Cout,
@@ -79,6 +80,10 @@ int ocr_bn_train_bwd(const void* x, const void* y, const void* dy, void* dx, con
 int ocr_colsum_bf16(const void* a, float* out, long M, int C, long lda, void* stream);
 int ocr_pack_transpose(const float* in, void* out, int R, int Cc, long ldin, int lstm_units, void* stream);
 int ocr_pack_conv_dgrad(const float* w, void* out, int Cin, int Cout, void* stream);
+/* all weight re-packs of a step in ONE launch.  jobs: device array of 64-byte records
+ * {int type(0 transpose+perm,1 conv-dgrad flip,2 strided cast,3 flat cast); int R, Cc, lstm_units; long ldin, ldout;
+ *  const float* src; bf16* dst; long n; int block_start, nblocks;}  with block_start ascending */
+int ocr_pack_jobs(const void* jobs, int njobs, int total_blocks, void* stream);
 int ocr_cast_f32_bf16(const float* in, void* out, long n, void* stream);
 int ocr_cast2d_f32_bf16(const float* in, long ldin, void* out, long ldout, int rows, int cols, void* stream);
 int ocr_tnc_to_ntc_bf16(const float* in, void* out, int T, int N, int C, float scale, void* stream);

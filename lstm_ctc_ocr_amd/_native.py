@@ -25,8 +25,8 @@ _SIGS = {
     "ocr_gemm_nt_bf16": ([_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P], _I),
     "ocr_set_gemm_engine": ([_I], _I),
     "ocr_conv3x3_bf16": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P], _I),
-    "ocr_gemm_tn_bf16": ([_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _L, _F, _I, _P], _I),
-    "ocr_conv3x3_wgrad_bf16": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
+    "ocr_gemm_tn_bf16": ([_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _L, _F, _I, _P, _P], _I),
+    "ocr_conv3x3_wgrad_bf16": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "ocr_conv1_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "ocr_conv1_wgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "ocr_maxpool_fwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
@@ -36,6 +36,7 @@ _SIGS = {
     "ocr_colsum_bf16": ([_P, _P, _L, _I, _L, _P], _I),
     "ocr_pack_transpose": ([_P, _P, _I, _I, _L, _I, _P], _I),
     "ocr_pack_conv_dgrad": ([_P, _P, _I, _I, _P], _I),
+    "ocr_pack_jobs": ([_P, _I, _I, _P], _I),
     "ocr_cast_f32_bf16": ([_P, _P, _L, _P], _I),
     "ocr_cast2d_f32_bf16": ([_P, _L, _P, _L, _I, _I, _P], _I),
     "ocr_tnc_to_ntc_bf16": ([_P, _P, _I, _I, _I, _F, _P], _I),

@@ -32,6 +32,7 @@ struct TnArgs {
     float* out;       // conv: [9][cC][J] ; plain: [I][ldo]
     long ldo;
     float scale;      // multiply before accumulation (e.g. 1.0)
+    float* colsum;    // optional: colsum[j] += sum_m B[m][j]  (bias gradient fused into the weight-gradient pass)
 };
 
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
@@ -80,6 +81,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
     const int kbeg = blockIdx.z * g.k_per_split;
     const int kend = min(g.Mk, kbeg + g.k_per_split);
     const int dw = tap / 3 - 1, dh = tap % 3 - 1;
+    // the blocks that see every B row exactly once (first i-tile, centre tap) also produce the column sums of B
+    const bool do_cs = g.colsum != nullptr && i0 == 0 && (MODE == 0 || tap == 4);
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     u32x4 ast[NCA], bst[NCB];
     auto load_tiles = [&](int k0) {
@@ -137,6 +141,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
         for (int k0 = kbeg; k0 < kend; k0 += 32) {
             __syncthreads();
             store_tiles();
+            if (do_cs) {
+#pragma unroll
+                for (int t = 0; t < NCB; ++t) {
+                    cs[0] += bf_lo(bst[t].x); cs[1] += bf_hi(bst[t].x); cs[2] += bf_lo(bst[t].y); cs[3] += bf_hi(bst[t].y);
+                    cs[4] += bf_lo(bst[t].z); cs[5] += bf_hi(bst[t].z); cs[6] += bf_lo(bst[t].w); cs[7] += bf_hi(bst[t].w);
+                }
+            }
             __syncthreads();
             if (k0 + 32 < kend) load_tiles(k0 + 32);
             bf16x8 af[FI], bfr[FJ];
@@ -152,6 +163,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
         }
     }
 
+    if (do_cs) {   // every thread's 8 columns are (tid % CPB)*8 .. +7; reduce the 256/CPB row lanes through LDS
+        __shared__ float red[256 * 8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = cs[e];
+        __syncthreads();
+        if (tid < BJ && j0 + tid < g.J) {
+            float t = 0.f;
+            for (int u = tid >> 3; u < 256; u += CPB) t += red[u * 8 + (tid & 7)];
+            atomicAdd(g.colsum + j0 + tid, t * g.scale);
+        }
+    }
     // lane owns i = ib + (lane>>4)*4 + r, j = jb + (lane&15)
     float* out = g.out;
     long ldo = g.ldo;
@@ -192,11 +214,11 @@ static int pick_splits(long tiles, int Mk) {
 // out[I][ldo] += scale * A^T B   with A[Mk][lda] (row-group skip + fixed offset), B[Mk][ldb]
 extern "C" int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* out, long ldo,
                                 int Mk, int I, int J, int row_group, int row_skip, long a_row_off,
-                                float scale, int splits, void* stream) {
+                                float scale, int splits, float* colsum, void* stream) {
     if (!A || !B || !out || Mk <= 0 || I <= 0 || J <= 0 || (I & 7) || (J & 7)) return OCR_ERR_INVALID;
     TnArgs g = {};
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb; g.Mk = Mk; g.I = I; g.J = J;
-    g.grp = row_group; g.skip = row_skip; g.a_row_off = a_row_off; g.out = out; g.ldo = ldo; g.scale = scale;
+    g.grp = row_group; g.skip = row_skip; g.a_row_off = a_row_off; g.out = out; g.ldo = ldo; g.scale = scale; g.colsum = colsum;
     bool big = (I >= 128 && J >= 128);
     long tiles = big ? (long)ceil_div(I, 128) * ceil_div(J, 128) : (long)ceil_div(I, 64) * ceil_div(J, 64);
     if (splits <= 0) splits = pick_splits(tiles, Mk);
@@ -205,13 +227,13 @@ extern "C" int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb
 }
 
 // dW[3][3][Cin][Cout] (fp32, TF layout) += sum over pixels of x[shifted pixel][ci] * dy[pixel][co]
-extern "C" int ocr_conv3x3_wgrad_bf16(const void* x, const void* dy, float* dw, int Nb, int W, int H,
+extern "C" int ocr_conv3x3_wgrad_bf16(const void* x, const void* dy, float* dw, float* dbias, int Nb, int W, int H,
                                       int Cin, int Cout, int splits, void* stream) {
     if (!x || !dy || !dw || Nb <= 0 || W <= 0 || H <= 0 || (Cin & 7) || (Cout & 7)) return OCR_ERR_INVALID;
     TnArgs g = {};
     g.A = (const bf16_t*)x; g.B = (const bf16_t*)dy; g.lda = Cin; g.ldb = Cout;
     g.Mk = Nb * W * H; g.I = Cin; g.J = Cout; g.cW = W; g.cH = H; g.cC = Cin;
-    g.out = dw; g.ldo = Cout; g.scale = 1.0f;
+    g.out = dw; g.ldo = Cout; g.scale = 1.0f; g.colsum = dbias;
     bool big = (Cin >= 128 && Cout >= 128);
     long tiles = 9L * (big ? (long)ceil_div(Cin, 128) * ceil_div(Cout, 128) : (long)ceil_div(Cin, 64) * ceil_div(Cout, 64));
     if (splits <= 0) splits = pick_splits(tiles, g.Mk);

@@ -467,6 +467,72 @@ __global__ void conv5_col2im_kernel(const bf16_t* __restrict__ col, bf16_t* __re
     }
 }
 
+// ============================================================================================
+// one-launch weight refresh: a table of pack jobs executed by a single grid (the per-tensor pack kernels above cost
+// ~4.5 us each as separate launches - 15 of them per step were ~90 us of pure launch latency)
+// ============================================================================================
+struct PackJob {            // 64 bytes, mirrored by lstm_ctc_ocr_amd/engine.py (numpy structured dtype)
+    int type;               // 0 transpose(+lstm perm), 1 conv dgrad flip, 2 strided cast, 3 flat cast
+    int R, Cc;              // type 0/2: rows, cols of the fp32 source ; type 1: Cin, Cout ; type 3: unused
+    int lstm_units;         // type 0
+    long ldin, ldout;       // type 0: ldin ; type 2: ldin, ldout
+    const float* src;
+    bf16_t* dst;
+    long n;                 // type 1/3: element count
+    int block_start, nblocks;
+};
+
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    __shared__ float tile[32][33];
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block_start) ++j;
+    const PackJob jb = jobs[j];
+    const int b = blockIdx.x - jb.block_start;
+    if (jb.type == 0) {
+        const int ctiles = (jb.Cc + 31) / 32;
+        const int c0 = (b % ctiles) * 32, r0 = (b / ctiles) * 32;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int i = ty; i < 32; i += 8) {
+            int r = r0 + i, c = c0 + tx;
+            tile[i][tx] = (r < jb.R && c < jb.Cc) ? jb.src[(long)r * jb.ldin + c] : 0.f;
+        }
+        __syncthreads();
+        for (int i = ty; i < 32; i += 8) {
+            int c = c0 + i, r = r0 + tx;
+            if (c < jb.Cc && r < jb.R) {
+                int pc = c;
+                if (jb.lstm_units > 0) { int gidx = c / jb.lstm_units, u = c % jb.lstm_units; pc = (u >> 4) * 64 + gidx * 16 + (u & 15); }
+                jb.dst[(long)pc * jb.R + r] = f2bf(tile[tx][i]);
+            }
+        }
+    } else if (jb.type == 1) {
+        const int Cin = jb.R, Cout = jb.Cc;
+        for (long idx = (long)b * 256 + threadIdx.x; idx < jb.n; idx += (long)jb.nblocks * 256) {
+            int co = (int)(idx % Cout);
+            long q = idx / Cout;
+            int ci = (int)(q % Cin);
+            int tap = (int)(q / Cin);
+            jb.dst[((long)ci * 9 + (8 - tap)) * Cout + co] = f2bf(jb.src[idx]);
+        }
+    } else if (jb.type == 2) {
+        const int c4 = jb.Cc >> 2;
+        const long total = (long)jb.R * c4;
+        for (long idx = (long)b * 256 + threadIdx.x; idx < total; idx += (long)jb.nblocks * 256) {
+            int c = (int)(idx % c4) * 4;
+            long r = idx / c4;
+            f32x4 v = *(const f32x4*)(jb.src + r * jb.ldin + c);
+            u32x2 pk = {pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+            *(u32x2*)(jb.dst + r * jb.ldout + c) = pk;
+        }
+    } else {
+        for (long i = ((long)b * 256 + threadIdx.x) * 4; i + 3 < jb.n; i += (long)jb.nblocks * 256 * 4) {
+            f32x4 v = *(const f32x4*)(jb.src + i);
+            u32x2 pk = {pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+            *(u32x2*)(jb.dst + i) = pk;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -576,6 +642,13 @@ extern "C" int ocr_pack_transpose(const float* in, void* out, int R, int Cc, lon
 extern "C" int ocr_pack_conv_dgrad(const float* w, void* out, int Cin, int Cout, void* stream) {
     if (!w || !out) return OCR_ERR_INVALID;
     pack_conv_dgrad_kernel<<<grid_for(9L * Cin * Cout), 256, 0, (hipStream_t)stream>>>(w, (bf16_t*)out, Cin, Cout);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+// jobs: device array of `njobs` PackJob records (layout above), block_start ascending, total_blocks = sum of nblocks
+extern "C" int ocr_pack_jobs(const void* jobs, int njobs, int total_blocks, void* stream) {
+    if (!jobs || njobs <= 0 || total_blocks <= 0) return OCR_ERR_INVALID;
+    pack_jobs_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>((const PackJob*)jobs, njobs);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }

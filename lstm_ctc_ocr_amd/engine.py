@@ -47,8 +47,11 @@ class _Op(object):
     def alloc(self, sp, in_shape):
         pass
 
-    def refresh(self):            # re-pack weights after a parameter update
+    def refresh(self):            # re-pack work that is not expressible as a pack job
         pass
+
+    def pack_jobs(self):          # bf16 operand re-packs after a parameter update (executed by ONE launch)
+        return []
 
     def fwd(self, sp):
         pass
@@ -134,14 +137,15 @@ class _ConvOp(_Op):
             N, W, H, C = s
             sp.buf[self.key + '/col'] = torch.empty((N * o[1], self.kh * H * C), dtype=BF16, device=dev)
 
-    def refresh(self):
+    def pack_jobs(self):
         if self.kind == 'c1':
-            return
+            return []
         w = self.eng.param(self.name + '/weights')
         K = self.kh * self.kw * self.ci
-        ops.pack_transpose(w.view(K, self.co), self.wpack)
+        jobs = [dict(type=0, R=K, Cc=self.co, ldin=self.co, src=w, dst=self.wpack)]
         if hasattr(self, 'wdgrad'):
-            ops.pack_conv_dgrad(w, self.wdgrad)
+            jobs.append(dict(type=1, R=self.ci, Cc=self.co, src=w, dst=self.wdgrad, n=w.numel()))
+        return jobs
 
     def fwd(self, sp):
         e = self.eng
@@ -187,11 +191,10 @@ class _ConvOp(_Op):
         if self.kind == 'c1':
             ops.conv1_wgrad(x, dz, dw, db)
             return
-        ops.colsum(dz.view(M, self.co), db)
         pdy = self.prev.dy(sp)
         pmask = self.prev.y(sp) if self.prev.mask_in_consumer else None
         if self.kind == '3x3':
-            ops.conv3x3_wgrad(x, dz, dw)
+            ops.conv3x3_wgrad(x, dz, dw, dbias=db)      # bias gradient rides on the weight-gradient pass
             if pdy is not None:
                 ops.conv3x3(dz, self.wdgrad.view(self.ci, 3, 3, self.co), out=pdy, mask=pmask)
         else:
@@ -199,7 +202,7 @@ class _ConvOp(_Op):
             Wo = o[1]
             K = self.kh * H * C
             ops.gemm_tn(x, dz.view(M, self.co), dw.view(K, self.co), Mk=M, I=K, J=self.co, lda=H * C, ldb=self.co,
-                        ldo=self.co, row_group=Wo, row_skip=self.kh - 1)
+                        ldo=self.co, row_group=Wo, row_skip=self.kh - 1, colsum=db)
             if pdy is not None:
                 if pmask is not None or self.kh != 2:
                     raise NotImplementedError('%s: data gradient of a full-height VALID conv is lowered for k_h = 2 '
@@ -308,15 +311,21 @@ class _BiLstmOp(_Op):
         b[self.key + '/sync_b'] = torch.zeros(ops.lstm_seq_sync_words(N), dtype=I32, device=dev)
         sp.lstm_sync = (b[self.key + '/sync_f'], b[self.key + '/sync_b'])
 
-    def refresh(self):
+    def pack_jobs(self):
         e, U, D = self.eng, self.U, self.D
+        jobs = []
         for d, tag in enumerate(('fw', 'bw')):
             w = e.param('%s/%s/weights' % (self.name, tag))                  # [D+U, 4U], gate-major columns
-            ops.pack_transpose(w[:D], self.wxT[d * 4 * U:(d + 1) * 4 * U], lstm_units=U, R=D, Cc=4 * U, ldin=4 * U)
-            ops.pack_transpose(w[D:], self.whT[d], lstm_units=U, R=U, Cc=4 * U, ldin=4 * U)
-            ops.cast2d_bf16(w, 4 * U, self.wcat[:, d * 4 * U:], 8 * U, D, 4 * U)
-        ops.lstm_pack_bias(e.param(self.name + '/fw/biases'), e.param(self.name + '/bw/biases'), self.bias, U)
-        ops.pack_transpose(e.param(self.name + '/weights'), self.wfcT)
+            jobs.append(dict(type=0, R=D, Cc=4 * U, ldin=4 * U, lstm_units=U, src=w[:D], dst=self.wxT[d * 4 * U:(d + 1) * 4 * U]))
+            jobs.append(dict(type=0, R=U, Cc=4 * U, ldin=4 * U, lstm_units=U, src=w[D:], dst=self.whT[d]))
+            jobs.append(dict(type=2, R=D, Cc=4 * U, ldin=4 * U, ldout=8 * U, src=w, dst=self.wcat[:, d * 4 * U:]))
+        wf = e.param(self.name + '/weights')
+        jobs.append(dict(type=0, R=wf.shape[0], Cc=wf.shape[1], ldin=wf.shape[1], src=wf, dst=self.wfcT))
+        return jobs
+
+    def refresh(self):
+        e = self.eng
+        ops.lstm_pack_bias(e.param(self.name + '/fw/biases'), e.param(self.name + '/bw/biases'), self.bias, self.U)
 
     def fwd(self, sp):
         e, U, C = self.eng, self.U, self.C
@@ -343,8 +352,7 @@ class _BiLstmOp(_Op):
         dl = b[self.key + '/dy']
         hout = b[self.key + '/hout']
         # FC: dW += H^T dL, db += colsum dL, dH = dL Wfc^T
-        ops.gemm_tn(hout, dl, e.grad(self.name + '/weights'))
-        ops.colsum(dl, e.grad(self.name + '/biases'))
+        ops.gemm_tn(hout, dl, e.grad(self.name + '/weights'), colsum=e.grad(self.name + '/biases'))
         ops.gemm_nt(dl, e.shadow(self.name + '/weights'), out=b[self.key + '/dhout'])
         # BPTT, both directions per launch
         wsh = e.shadow(self.name + '/fw/weights')
@@ -363,9 +371,9 @@ class _BiLstmOp(_Op):
         for d, tag in enumerate(('fw', 'bw')):
             dW = e.grad('%s/%s/weights' % (self.name, tag))
             dzd = dz[:, d * 4 * U:(d + 1) * 4 * U]
-            ops.gemm_tn(x, dzd, dW[:D], Mk=R, I=D, J=4 * U, lda=D, ldb=8 * U, ldo=4 * U)
+            ops.gemm_tn(x, dzd, dW[:D], Mk=R, I=D, J=4 * U, lda=D, ldb=8 * U, ldo=4 * U,
+                        colsum=e.grad('%s/%s/biases' % (self.name, tag)))
             ops.gemm_tn(b[self.key + '/hprev'][d], dzd, dW[D:], Mk=R, I=U, J=4 * U, lda=U, ldb=8 * U, ldo=4 * U)
-            ops.colsum(dzd, e.grad('%s/%s/biases' % (self.name, tag)), M=R, C=4 * U, lda=8 * U)
         pdy = self.prev.dy(sp)
         if pdy is not None:
             pmask = self.prev.y(sp).view(R, D) if self.prev.mask_in_consumer else None
@@ -506,8 +514,37 @@ class Engine(object):
     def state_arrays(self):
         return {name: self.param(name).detach().cpu().numpy().copy() for name in self.specs}
 
+    PACK_DTYPE = np.dtype([('type', '<i4'), ('R', '<i4'), ('Cc', '<i4'), ('lstm_units', '<i4'), ('ldin', '<i8'),
+                           ('ldout', '<i8'), ('src', '<u8'), ('dst', '<u8'), ('n', '<i8'), ('block_start', '<i4'),
+                           ('nblocks', '<i4')])       # == struct PackJob in csrc/nn_ops.hip (64 bytes)
+
+    def _build_pack_table(self):
+        jobs = [dict(type=3, src=self.params, dst=self.params_bf16, n=self.n_total)]
+        for op in self.ops:
+            jobs.extend(op.pack_jobs())
+        tab = np.zeros(len(jobs), self.PACK_DTYPE)
+        start = 0
+        for i, j in enumerate(jobs):
+            t = j['type']
+            if t == 0:
+                nb = ((j['Cc'] + 31) // 32) * ((j['R'] + 31) // 32)
+            elif t == 1:
+                nb = min((j['n'] + 255) // 256, 512)
+            elif t == 2:
+                nb = min((j['R'] * j['Cc'] // 4 + 255) // 256, 512)
+            else:
+                nb = min((j['n'] // 4 + 255) // 256, 2048)
+            tab[i] = (t, j.get('R', 0), j.get('Cc', 0), j.get('lstm_units', 0), j.get('ldin', 0), j.get('ldout', 0),
+                      j['src'].data_ptr(), j['dst'].data_ptr(), j.get('n', 0), start, nb)
+            start += nb
+        assert tab.itemsize == 64
+        self._pack_table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
+        self._pack_njobs, self._pack_blocks = len(jobs), start
+
     def refresh_weights(self):
-        ops.cast_bf16(self.params, self.params_bf16)
+        if not hasattr(self, '_pack_table'):
+            self._build_pack_table()
+        ops.pack_jobs(self._pack_table, self._pack_njobs, self._pack_blocks)
         for op in self.ops:
             op.refresh()
 

@@ -94,8 +94,8 @@ def conv3x3(x, wpack, out=None, *, bias=None, relu=False, mask=None):
 
 
 def gemm_tn(A, B, out, *, Mk=None, I=None, J=None, lda=None, ldb=None, ldo=None, row_group=0, row_skip=0,
-            a_row_off=0, scale=1.0, splits=0):
-    """out[I][J] (f32) += scale * A^T B."""
+            a_row_off=0, scale=1.0, splits=0, colsum=None):
+    """out[I][J] (f32) += scale * A^T B;  colsum[J] += scale * column sums of B (bias gradient) when given."""
     Mk = B.shape[0] if Mk is None else Mk
     I = A.shape[1] if I is None else I
     J = B.shape[1] if J is None else J
@@ -103,14 +103,14 @@ def gemm_tn(A, B, out, *, Mk=None, I=None, J=None, lda=None, ldb=None, ldo=None,
     ldb = B.stride(0) if ldb is None else ldb
     ldo = out.stride(0) if ldo is None else ldo
     call("ocr_gemm_tn_bf16", ptr(_dev(A)), lda, ptr(B), ldb, ptr(out), ldo, Mk, I, J, row_group, row_skip, a_row_off,
-         float(scale), splits, _st())
+         float(scale), splits, ptr(colsum), _st())
     return out
 
 
-def conv3x3_wgrad(x, dy, dw, splits=0):
+def conv3x3_wgrad(x, dy, dw, splits=0, dbias=None):
     Nb, W, H, Cin = x.shape
     Cout = dy.shape[-1]
-    call("ocr_conv3x3_wgrad_bf16", ptr(_dev(x)), ptr(dy), ptr(dw), Nb, W, H, Cin, Cout, splits, _st())
+    call("ocr_conv3x3_wgrad_bf16", ptr(_dev(x)), ptr(dy), ptr(dw), ptr(dbias), Nb, W, H, Cin, Cout, splits, _st())
     return dw
 
 
@@ -183,6 +183,10 @@ def pack_conv_dgrad(w, out):
     kh, kw, cin, cout = w.shape
     call("ocr_pack_conv_dgrad", ptr(_dev(w)), ptr(out), cin, cout, _st())
     return out
+
+
+def pack_jobs(table, njobs, total_blocks):
+    call("ocr_pack_jobs", ptr(_dev(table)), njobs, total_blocks, _st())
 
 
 def cast_bf16(src, dst):

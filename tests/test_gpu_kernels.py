@@ -207,18 +207,21 @@ def test_conv3x3_fwd_dgrad_wgrad(dev, Nb, W, H, Ci, Co):
     assert relerr(dx.float().cpu(), bf(xr.grad * (bf(below) > 0))) < 1e-2
     # weight gradient accumulates into the fp32 TF-layout buffer
     dw = torch.zeros((3, 3, Ci, Co), dtype=torch.float32, device=dev)
-    ops.conv3x3_wgrad(x.to(dev).to(BF), dy.to(dev).to(BF), dw)
+    dbias = torch.zeros(Co, dtype=torch.float32, device=dev)
+    ops.conv3x3_wgrad(x.to(dev).to(BF), dy.to(dev).to(BF), dw, dbias=dbias)
     assert relerr(dw.cpu(), wr.grad) < 1e-4
-    ops.conv3x3_wgrad(x.to(dev).to(BF), dy.to(dev).to(BF), dw, splits=2)
-    assert relerr(dw.cpu(), 2 * wr.grad) < 1e-4
+    assert relerr(dbias.cpu(), dy.reshape(-1, Co).sum(0)) < 1e-4          # bias gradient fused into the same pass
+    ops.conv3x3_wgrad(x.to(dev).to(BF), dy.to(dev).to(BF), dw, splits=2, dbias=dbias)
+    assert relerr(dw.cpu(), 2 * wr.grad) < 1e-4 and relerr(dbias.cpu(), 2 * dy.reshape(-1, Co).sum(0)) < 1e-4
 
 
 @pytest.mark.parametrize("Mk,I,J", [(4032, 512, 2048), (4032, 256, 1024), (4032, 512, 64), (100, 72, 136)])
 def test_gemm_tn(dev, Mk, I, J):
     A = bf(gen((Mk, I), 1)); B = bf(gen((Mk, J), 2))
     out = torch.zeros((I, J), dtype=torch.float32, device=dev)
-    ops.gemm_tn(A.to(dev).to(BF), B.to(dev).to(BF), out)
-    assert relerr(out.cpu(), A.t() @ B) < 1e-4
+    cs = torch.zeros(J, dtype=torch.float32, device=dev)
+    ops.gemm_tn(A.to(dev).to(BF), B.to(dev).to(BF), out, colsum=cs)
+    assert relerr(out.cpu(), A.t() @ B) < 1e-4 and relerr(cs.cpu(), B.sum(0)) < 1e-4
     ops.gemm_tn(A.to(dev).to(BF), B.to(dev).to(BF), out, scale=0.5, splits=1)
     assert relerr(out.cpu(), 1.5 * (A.t() @ B)) < 1e-4
 
@@ -386,9 +389,8 @@ def test_lstm_fwd_bwd(dev, N, T, D, U, lens, persistent):
     ops.lstm_hprev(st["hout"], st["sl"], hprev, N, T, U)
     for d in range(2):
         dW = torch.zeros((D + U, 4 * U), device=dev); dbias = torch.zeros(4 * U, device=dev)
-        ops.gemm_tn(st["xd"], dz[:, d * 4 * U:(d + 1) * 4 * U], dW[:D], Mk=R, I=D, J=4 * U, lda=D, ldb=8 * U, ldo=4 * U)
+        ops.gemm_tn(st["xd"], dz[:, d * 4 * U:(d + 1) * 4 * U], dW[:D], Mk=R, I=D, J=4 * U, lda=D, ldb=8 * U, ldo=4 * U, colsum=dbias)
         ops.gemm_tn(hprev[d], dz[:, d * 4 * U:(d + 1) * 4 * U], dW[D:], Mk=R, I=U, J=4 * U, lda=U, ldb=8 * U, ldo=4 * U)
-        ops.colsum(dz[:, d * 4 * U:(d + 1) * 4 * U], dbias, M=R, C=4 * U, lda=8 * U)
         assert relerr(dW.cpu(), Wr[d].grad) < 3e-2, ("dW", d, relerr(dW.cpu(), Wr[d].grad))
         assert relerr(dbias.cpu(), br[d].grad) < 3e-2, ("db", d, relerr(dbias.cpu(), br[d].grad))
     wcat = torch.empty((D, 8 * U), dtype=BF, device=dev)
