@@ -36,8 +36,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return (bf16_t)(u >> 16);
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two floats -> packed bf16 pair with ONE v_cvt_pk_bf16_f32 (gfx950 native, round-to-nearest-even like f2bf)
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }

@@ -13,15 +13,21 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
                                                         const float* __restrict__ bias,
                                                         bf16_t* __restrict__ y, int Nb, int W, int H,
                                                         int Cout, int relu) {
-    extern __shared__ float wl[];   // [9][Cout] + [Cout]
-    for (int i = threadIdx.x; i < 9 * Cout; i += 256) wl[i] = w[i];
-    for (int i = threadIdx.x; i < Cout; i += 256) wl[9 * Cout + i] = bias[i];
-    __syncthreads();
-    const int groups = Cout >> 3;
-    const long total = (long)Nb * W * H * groups;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        int gq = (int)(idx % groups);
-        long pix = idx / groups;
+    // thread = (channel group of 8, pixel lane); its 72 weights + 8 biases stay in registers for the whole grid-stride
+    // loop (the first version re-read them from LDS per pixel: 80 ds_reads per 16-B store, 1.3 TB/s)
+    const int groups = Cout >> 3;                 // 8 at Cout = 64
+    const int gq = threadIdx.x % groups;
+    const int plane = threadIdx.x / groups;
+    const int planes = 256 / groups;
+    float wr[9][8], br[8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) wr[t][c] = w[t * Cout + gq * 8 + c];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) br[c] = bias[gq * 8 + c];
+    const long npix = (long)Nb * W * H;
+    for (long pix = (long)blockIdx.x * planes + plane; pix < npix; pix += (long)gridDim.x * planes) {
         int h = (int)(pix % H);
         long q = pix / H;
         int wq = (int)(q % W);
@@ -38,10 +44,10 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) o[c] = fmaf(xv[t], wl[t * Cout + gq * 8 + c], o[c]);
+            for (int c = 0; c < 8; ++c) o[c] = fmaf(xv[t], wr[t][c], o[c]);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            o[c] += wl[9 * Cout + gq * 8 + c];
+            o[c] += br[c];
             if (relu) o[c] = fmaxf(o[c], 0.f);
         }
         u32x4 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
@@ -546,8 +552,9 @@ static inline int grid_for(long total, int cap = 4096) {
 extern "C" int ocr_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int Nb, int W, int H,
                              int Cout, int relu, void* stream) {
     if (!x || !w || !bias || !y || (Cout & 7) || Cout > 1024) return OCR_ERR_INVALID;
+    if (256 % (Cout >> 3)) return OCR_ERR_INVALID;
     long total = (long)Nb * W * H * (Cout >> 3);
-    conv1_fwd_kernel<<<grid_for(total, 8192), 256, (size_t)10 * Cout * sizeof(float), (hipStream_t)stream>>>(
+    conv1_fwd_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(
         x, w, bias, (bf16_t*)y, Nb, W, H, Cout, relu);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
@@ -596,7 +603,7 @@ extern "C" int ocr_bn_train_fwd(const void* x, void* y, const float* gamma, cons
         return OCR_ERR_INVALID;
     if (hipMemsetAsync(workspace, 0, 2 * (size_t)C * sizeof(double), stream) != hipSuccess) return OCR_ERR_MEMOPS;
     int rlanes = 256 / (C >> 3); if (rlanes < 1) return OCR_ERR_INVALID;
-    int rpb = 128;
+    int rpb = 32;
     bn_stats_kernel<<<ceil_div(M, rpb), 256, 0, stream>>>((const bf16_t*)x, (double*)workspace, M, C, rpb);
     OCR_CHECK_LAUNCH();
     bn_finalize_kernel<<<ceil_div(C, 256), 256, 0, stream>>>((const double*)workspace, save_mean, save_rstd, M, C, eps);
@@ -614,7 +621,7 @@ extern "C" int ocr_bn_train_bwd(const void* x, const void* y, const void* dy, vo
         C > 2048 || M <= 0)
         return OCR_ERR_INVALID;
     if (hipMemsetAsync(workspace, 0, 2 * (size_t)C * sizeof(double), stream) != hipSuccess) return OCR_ERR_MEMOPS;
-    int rpb = 128;
+    int rpb = 32;
     bn_bwd_stats_kernel<<<ceil_div(M, rpb), 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, save_mean,
                                                               save_rstd, (double*)workspace, M, C, rpb, relu);
     OCR_CHECK_LAUNCH();

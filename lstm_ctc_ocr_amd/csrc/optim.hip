@@ -158,7 +158,10 @@ extern "C" int ocr_optim_step(float* params, float* grads, float* state1, float*
     optim_tick_kernel<<<1, 64, 0, stream>>>(sc, (double)beta1, (double)beta2);
     OCR_CHECK_LAUNCH();
     int blocks = (int)((n / 4 + 255) / 256); if (blocks > 2048) blocks = 2048;
-    optim_prep_kernel<<<blocks, 256, 0, stream>>>(params, grads, n, weight_decay > 0.f ? n_reg : 0, weight_decay, sc);
+    // the norm pass ends in two same-address double atomics per block (~12 ns each, serialised): 2048 blocks were 50 us
+    // of pure atomic tail; 384 blocks keep HBM busy and cost < 10 us of it
+    int pblocks = blocks > 384 ? 384 : blocks;
+    optim_prep_kernel<<<pblocks, 256, 0, stream>>>(params, grads, n, weight_decay > 0.f ? n_reg : 0, weight_decay, sc);
     OCR_CHECK_LAUNCH();
     if (solver == 0) adam_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, state2, n, beta1, beta2, eps, clip_norm, sc);
     else if (solver == 1) momentum_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, n, beta1, clip_norm, sc);
