@@ -24,6 +24,7 @@ _SIGS = {
     "ocr_ctc_greedy_decode": ([_P, _P, _I, _I, _I, _I, _I, _P, _P, _P], _I),
     "ocr_gemm_nt_bf16": ([_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P], _I),
     "ocr_set_gemm_engine": ([_I], _I),
+    "ocr_set_wgrad_engine": ([_I], _I),
     "ocr_conv3x3_bf16": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P], _I),
     "ocr_gemm_tn_bf16": ([_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _L, _F, _I, _P, _P], _I),
     "ocr_conv3x3_wgrad_bf16": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),

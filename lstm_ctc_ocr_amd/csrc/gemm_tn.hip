@@ -211,6 +211,13 @@ static int pick_splits(long tiles, int Mk) {
     return s;
 }
 
+// LDS-DMA generation (gemm_tn2.hip); -1 = shape not covered
+int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* out, long ldo, int Mk, int I, int J, int mode,
+                     int grp, int skip, long a_row_off, int cW, int cH, int cC, float scale, int splits, float* colsum,
+                     hipStream_t stream);
+static int g_use_tn2 = 1;
+extern "C" int ocr_set_wgrad_engine(int use_dma_tiles) { g_use_tn2 = use_dma_tiles; return OCR_OK; }
+
 // out[I][ldo] += scale * A^T B   with A[Mk][lda] (row-group skip + fixed offset), B[Mk][ldb]
 extern "C" int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* out, long ldo,
                                 int Mk, int I, int J, int row_group, int row_skip, long a_row_off,
@@ -218,6 +225,11 @@ extern "C" int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb
     if (!A || !B || !out || Mk <= 0 || I <= 0 || J <= 0 || (I & 7) || (J & 7)) return OCR_ERR_INVALID;
     TnArgs g = {};
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb; g.Mk = Mk; g.I = I; g.J = J;
+    if (g_use_tn2) {
+        int rc = tn2_try_dispatch(A, lda, B, ldb, out, ldo, Mk, I, J, 0, row_group, row_skip, a_row_off, 0, 0, 0, scale, splits,
+                                  colsum, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     g.grp = row_group; g.skip = row_skip; g.a_row_off = a_row_off; g.out = out; g.ldo = ldo; g.scale = scale; g.colsum = colsum;
     bool big = (I >= 128 && J >= 128);
     long tiles = big ? (long)ceil_div(I, 128) * ceil_div(J, 128) : (long)ceil_div(I, 64) * ceil_div(J, 64);
@@ -230,6 +242,11 @@ extern "C" int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb
 extern "C" int ocr_conv3x3_wgrad_bf16(const void* x, const void* dy, float* dw, float* dbias, int Nb, int W, int H,
                                       int Cin, int Cout, int splits, void* stream) {
     if (!x || !dy || !dw || Nb <= 0 || W <= 0 || H <= 0 || (Cin & 7) || (Cout & 7)) return OCR_ERR_INVALID;
+    if (g_use_tn2) {
+        int rc = tn2_try_dispatch(x, Cin, dy, Cout, dw, Cout, Nb * W * H, Cin, Cout, 1, 0, 0, 0, W, H, Cin, 1.0f, splits, dbias,
+                                  (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     TnArgs g = {};
     g.A = (const bf16_t*)x; g.B = (const bf16_t*)dy; g.lda = Cin; g.ldb = Cout;
     g.Mk = Nb * W * H; g.I = Cin; g.J = Cout; g.cW = W; g.cH = H; g.cC = Cin;

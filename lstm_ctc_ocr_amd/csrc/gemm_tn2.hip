@@ -1,0 +1,231 @@
+// Second-generation weight-gradient kernel for gfx950 (same contract as gemm_tn.hip):
+//     out[i][j] += scale * sum_m A[m][i] * B[m][j]        (contraction over the slow index of both operands)
+// for the 3x3 SAME convolution weight gradient (A = activations shifted by the tap, B = dY — reference
+// tf.gradients of network.py:166 at train.py:81) and the plain X^T dY products of conv5 / LSTM / FC.
+//
+// Changes against gemm_tn.hip (measured 250-495 TFLOP/s, register-staged 128x128x32 steps, 2 barriers per step):
+//   * BK = 64 rows of m per step and LDS-DMA (`global_load_lds_dwordx4`) into two stages: half the barriers per flop,
+//     no staging VGPRs / ds_write pass, the next step streams in under the MFMAs;
+//   * the tile stays row-major [m][channel] (what DMA can write); the transposing read ds_read_b64_tr_b16 still
+//     delivers 4 consecutive m of one channel per lane.  Bank conflicts are removed by XOR-ing the 32-byte slot index
+//     of a row with (row & 7) — applied to the SOURCE chunk of the DMA and again in the read address — together with
+//     the k-permutation "lane group g owns tile rows 4g..4g+3 and 16+4g..16+4g+3" of every 32-row MFMA step (identical
+//     for A and B, so the contraction is unchanged): each 32-lane half of a read then touches 8 rows x 32 B = 64 banks;
+//   * halo pixels / tails come from a zero page; bias-gradient column sums are taken from the LDS tile by the blocks
+//     that see every B row once (first i-tile, centre tap).
+// Requires I % 128 == 0 and J % 128 == 0 (256-byte tile rows); other shapes stay on gemm_tn.hip.
+#include "common.h"
+
+struct Tn2Args {
+    const bf16_t* A; const bf16_t* B;
+    long lda, ldb;
+    int Mk, I, J, k_per_split;     // k_per_split % 64 == 0
+    int grp, skip; long a_row_off;
+    int cW, cH, cC;
+    float* out; long ldo; float scale; float* colsum;
+    __device__ int cH_or1() const { return cH > 0 ? cH : 1; }
+};
+
+__device__ u32x4 tn2_zero_page[4];
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+// byte offset (inside a swizzled [64][128] tile, k-step 0) of the first transposing read of channel block cb:
+// tile rows {4g..4g+3} (+16 for the second read, +32 per k-step), channel cb*16 + lane&15
+__device__ __forceinline__ int tn2_frag_off(int cb, int lane) {
+    const int g = lane >> 4, L = lane & 15;
+    const int r0 = 4 * g + (L >> 2);                     // (r0 + 16) & 7 and (r0 + 32) & 7 equal r0 & 7
+    const int q = cb * 2 + ((L & 3) >> 1);
+    const int p = q ^ ((r0 & 7) << 1);
+    return r0 * 256 + p * 16 + (L & 1) * 8;
+}
+__device__ __forceinline__ bf16x8 tn2_frag(const unsigned char* a0) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 16 * 256));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int MODE /*0 plain, 1 conv3x3*/>
+__global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
+    constexpr int TILE = 64 * 256;                   // bytes of one operand tile: 64 rows x 128 channels bf16
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 stages x (A tile | B tile) = 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int itiles = g.I / 128;
+    const int tap = (MODE == 1) ? (int)(blockIdx.x / itiles) : 0;
+    const int i0 = (int)(blockIdx.x % itiles) * 128;
+    const int j0 = blockIdx.y * 128;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.Mk, kbeg + g.k_per_split);
+    const int dw = tap / 3 - 1, dh = tap % 3 - 1;
+    const bool do_cs = g.colsum != nullptr && i0 == 0 && (MODE == 0 || tap == 4);
+    const bf16_t* zero = (const bf16_t*)tn2_zero_page;
+
+    // DMA geometry: instruction j of wave w covers tile rows (w*4 + j)*4 .. +3, lane -> (row lane>>4, 16-B position lane&15).
+    // Everything that does not change along the K loop is hoisted: per (lane, j) the row, the swizzled source chunk, the
+    // operand base pointers; the pixel coordinates (w, h) of the row are advanced incrementally (+64 rows per step)
+    // instead of being re-derived with two integer divisions per DMA instruction (that version spent 8.5 VALU
+    // instructions per MFMA and was VALU-bound).
+    const int rsub = lane >> 4, pos = lane & 15;
+    int trow[4];
+    const bf16_t* pa[4];
+    const bf16_t* pb[4];
+    int pw[4], ph[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 4 + rsub;
+        const int q = pos ^ ((r & 7) << 1);                 // source chunk held at LDS position `pos`
+        trow[j] = r;
+        const long m = (long)kbeg + r;
+        pb[j] = g.B + m * g.ldb + j0 + q * 8;
+        if (MODE == 0) {
+            pa[j] = g.A + g.a_row_off + i0 + q * 8;          // row term added per step (row-group skip is not affine)
+            pw[j] = ph[j] = 0;
+        } else {
+            pa[j] = g.A + (m + (long)dw * g.cH + dh) * g.cC + i0 + q * 8;
+            ph[j] = (int)(m % g.cH);
+            pw[j] = (int)((m / g.cH) % g.cW);
+        }
+    }
+    const int step_h = 64 % g.cH_or1(), step_w = 64 / g.cH_or1();
+    auto stage_load = [&](int k0, int buf) {
+        unsigned char* sa = smem + buf * (2 * TILE);
+        unsigned char* sb = sa + TILE;
+        const long koff = (long)(k0 - kbeg);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = k0 + trow[j];
+            const bf16_t* srca = zero;
+            const bf16_t* srcb = zero;
+            if (m < kend) {
+                srcb = pb[j] + koff * g.ldb;
+                if (MODE == 0) {
+                    long phys = (long)m + (g.grp > 0 ? (long)(m / g.grp) * g.skip : 0);
+                    srca = pa[j] + phys * g.lda;
+                } else if ((unsigned)(pw[j] + dw) < (unsigned)g.cW && (unsigned)(ph[j] + dh) < (unsigned)g.cH) {
+                    srca = pa[j] + koff * g.cC;
+                }
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)srca, (lptr_t)(sa + (wave * 4 + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)srcb, (lptr_t)(sb + (wave * 4 + j) * 1024), 16, 0, 0);
+            if (MODE == 1) {                                  // advance this row's pixel by 64 rows for the next step
+                int h = ph[j] + step_h, w = pw[j] + step_w;
+                if (h >= g.cH) { h -= g.cH; ++w; }
+                while (w >= g.cW) w -= g.cW;
+                ph[j] = h; pw[j] = w;
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    int offa[4], offb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { offa[a] = tn2_frag_off(wi * 4 + a, lane); offb[a] = tn2_frag_off(wj * 4 + a, lane); }
+
+    if (kbeg < kend) {
+        stage_load(kbeg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int cur = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += 64) {
+            if (k0 + 64 < kend) stage_load(k0 + 64, cur ^ 1);
+            const unsigned char* ta = smem + cur * (2 * TILE);
+            const unsigned char* tb = ta + TILE;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[4], bfr[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) af[a] = tn2_frag(ta + offa[a] + kk * (32 * 256));
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bfr[b] = tn2_frag(tb + offb[b] + kk * (32 * 256));
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+            }
+            if (do_cs) {      // thread -> source chunk q = tid & 15 (8 columns), rows (tid >> 4) + 16 * i
+                const int q = tid & 15;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = (tid >> 4) + 16 * i;
+                    u32x4 v = *(const u32x4*)(tb + r * 256 + ((q ^ ((r & 7) << 1)) << 4));
+                    cs[0] += bf_lo(v.x); cs[1] += bf_hi(v.x); cs[2] += bf_lo(v.y); cs[3] += bf_hi(v.y);
+                    cs[4] += bf_lo(v.z); cs[5] += bf_hi(v.z); cs[6] += bf_lo(v.w); cs[7] += bf_hi(v.w);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    if (do_cs) {
+        float* red = (float*)smem;                     // all tiles are dead after the last barrier
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = cs[e];
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+            for (int u = tid >> 3; u < 256; u += 16) t += red[u * 8 + (tid & 7)];
+            atomicAdd(g.colsum + j0 + tid, t * g.scale);
+        }
+    }
+    // lane owns i = ib + (lane>>4)*4 + r, j = jb + (lane&15)
+    float* out = g.out;
+    long ldo = g.ldo;
+    if (MODE == 1) { out += (long)tap * g.cC * g.J; ldo = g.J; }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = j0 + wj * 64 + b * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + wi * 64 + a * 16 + (lane >> 4) * 4 + r;
+                atomicAdd(out + (long)i * ldo + j, acc[a][b][r] * g.scale);
+            }
+        }
+}
+
+// returns -1 if the shape is not covered
+int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* out, long ldo, int Mk, int I, int J, int mode,
+                     int grp, int skip, long a_row_off, int cW, int cH, int cC, float scale, int splits, float* colsum,
+                     hipStream_t stream) {
+    if ((I & 127) || (J & 127) || Mk < 256) return -1;
+    Tn2Args g = {};
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb; g.Mk = Mk; g.I = I; g.J = J;
+    g.grp = grp; g.skip = skip; g.a_row_off = a_row_off; g.cW = cW; g.cH = cH; g.cC = cC;
+    g.out = out; g.ldo = ldo; g.scale = scale; g.colsum = colsum;
+    const int taps = mode == 1 ? 9 : 1;
+    const long tiles = (long)taps * (I / 128) * (J / 128);
+    if (splits <= 0) {                       // ~300 workgroups measured best (split sweep in tools/wgrad_probe.py): enough to
+        splits = (int)((300 + tiles - 1) / tiles);   // fill 256 CUs, few enough that the fp32 atomic epilogue stays small
+        int maxs = Mk / 256; if (maxs < 1) maxs = 1;
+        if (splits > maxs) splits = maxs;
+        if (splits < 1) splits = 1;
+    }
+    g.k_per_split = ceil_div(ceil_div(Mk, splits), 64) * 64;
+    static bool attr_set[2] = {false, false};
+    const void* fn = mode == 1 ? (const void*)gemm_tn2_kernel<1> : (const void*)gemm_tn2_kernel<0>;
+    if (!attr_set[mode]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) return OCR_ERR_EXEC;
+        attr_set[mode] = true;
+    }
+    dim3 grid((I / 128) * taps, J / 128, ceil_div(Mk, g.k_per_split));
+    if (mode == 1) gemm_tn2_kernel<1><<<grid, 256, 65536, stream>>>(g);
+    else gemm_tn2_kernel<0><<<grid, 256, 65536, stream>>>(g);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}

@@ -215,7 +215,7 @@ def test_conv3x3_fwd_dgrad_wgrad(dev, Nb, W, H, Ci, Co):
     assert relerr(dw.cpu(), 2 * wr.grad) < 1e-4 and relerr(dbias.cpu(), 2 * dy.reshape(-1, Co).sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("Mk,I,J", [(4032, 512, 2048), (4032, 256, 1024), (4032, 512, 64), (100, 72, 136)])
+@pytest.mark.parametrize("Mk,I,J", [(4032, 512, 2048), (4032, 256, 1024), (4032, 512, 64), (100, 72, 136), (300, 128, 128), (1000, 256, 384)])
 def test_gemm_tn(dev, Mk, I, J):
     A = bf(gen((Mk, I), 1)); B = bf(gen((Mk, J), 2))
     out = torch.zeros((I, J), dtype=torch.float32, device=dev)
