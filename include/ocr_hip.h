@@ -44,6 +44,14 @@ int ocr_ctc_greedy_decode(const float* activations, const int* input_lengths, in
                           int max_time, int blank_label, int pad_value, int* decoded, int* decoded_lengths,
                           void* stream);
 
+/* TF-semantics prefix beam search: tf.nn.ctc_beam_search_decoder(inputs, seq_len, beam_width=100, top_paths=1,
+ * merge_repeated=True) as called at network.py:656 / test.py:30 — BLANK = alphabet_size-1, output dense + padded.
+ * beam_width <= 128; neg_log_prob (may be NULL): f32 [minibatch].  Workspace from ocr_ctc_beam_workspace_size. */
+int ocr_ctc_beam_workspace_size(int alphabet_size, int minibatch, int max_time, int beam_width, size_t* bytes);
+int ocr_ctc_beam_decode(const float* activations, const int* input_lengths, int alphabet_size, int minibatch,
+                        int max_time, int beam_width, int merge_repeated, int pad_value, int* decoded,
+                        int* decoded_lengths, float* neg_log_prob, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- dense contractions (tf.nn.conv2d network.py:166, tf.matmul :126, LSTMCell matmul :104-107) ------------- */
 /* out[m][n] = sum_k P[m][k] * Q[n][k] (+bias[n]) ; bf16 operands, fp32 accumulate, K % 8 == 0, N % 4 == 0.
  * physical P row = m + (m / row_group) * row_skip when row_group > 0 (conv5's overlapping 2x2 VALID windows). */

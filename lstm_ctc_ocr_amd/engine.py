@@ -634,15 +634,23 @@ class Engine(object):
         self._run(sp, 'fwd')
         return self.ops[-1].y(sp)
 
-    def decode(self, data, seq_len):
-        """Greedy best-path decode (blank 0, zeros dropped): returns list of label lists."""
+    def decode(self, data, seq_len, method='beam', beam_width=100):
+        """Decoded label lists with zeros dropped (what accuracy_calculation / decodeRes see).
+        method='beam'  : the reference's decoder — tf.nn.ctc_beam_search_decoder(beam 100, merge_repeated=True), whose
+                         blank is class C-1; class 0 is an ordinary symbol that sparse_to_dense/ignore_value=0 strip later
+                         (network.py:656-657, training.py:32).
+        method='greedy': best path with blank 0."""
         sp = self.plan(data.shape[0], data.shape[1])
         self._bind(sp, data, seq_len)
         self._run(sp, 'fwd')
-        out, lens = ops.ctc_greedy_decode(self.ops[-1].y(sp), sp.seq_len, blank=0, pad_value=0)
+        logits = self.ops[-1].y(sp)
+        if method == 'greedy':
+            out, lens = ops.ctc_greedy_decode(logits, sp.seq_len, blank=0, pad_value=0)
+        else:
+            out, lens, _ = ops.ctc_beam_decode(logits, sp.seq_len, beam_width=beam_width, merge_repeated=True, pad_value=0)
         out = out.cpu().numpy()
         lens = lens.cpu().numpy()
-        return [out[i, :lens[i]].tolist() for i in range(out.shape[0])]
+        return [[int(v) for v in out[i, :lens[i]] if v != 0] for i in range(out.shape[0])]
 
     def setup_optimizer(self, solver=None, lr=None):
         c = self.cfg.TRAIN

@@ -55,6 +55,21 @@ def ctc_greedy_decode(acts, input_lengths, blank=0, pad_value=0):
     return out, lens
 
 
+def ctc_beam_decode(acts, input_lengths, beam_width=100, merge_repeated=True, pad_value=0, workspace=None):
+    """tf.nn.ctc_beam_search_decoder semantics (blank = C-1).  Returns (dense [N, T] int32, lengths, neg_log_prob)."""
+    T, N, C = acts.shape
+    sz = ctypes.c_size_t(0)
+    call("ocr_ctc_beam_workspace_size", C, N, T, beam_width, ctypes.byref(sz))
+    if workspace is None or workspace.numel() < sz.value:
+        workspace = torch.empty(sz.value, dtype=torch.uint8, device=acts.device)
+    out = torch.empty((N, T), dtype=torch.int32, device=acts.device)
+    lens = torch.empty(N, dtype=torch.int32, device=acts.device)
+    nlp = torch.empty(N, dtype=F32, device=acts.device)
+    call("ocr_ctc_beam_decode", ptr(_dev(acts)), ptr(input_lengths), C, N, T, beam_width, int(merge_repeated), pad_value,
+         ptr(out), ptr(lens), ptr(nlp), ptr(workspace), workspace.numel(), _st())
+    return out, lens, nlp
+
+
 # ----------------------------------------------------------------------------------------------- GEMMs
 def gemm_nt(P, Q, out=None, *, M=None, N=None, K=None, ldp=None, ldq=None, ldo=None, bias=None, relu=False,
             out_f32=False, mask=None, accumulate=False, splits=1, row_group=0, row_skip=0, rowswap=None):

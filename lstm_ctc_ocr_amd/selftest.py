@@ -28,8 +28,9 @@ def smoke():
     ref = og.forward(params, torch.from_numpy(x), sl.tolist(), sim_bf16=True)
     err = float((logits - ref).abs().max())
     assert err < 5e-3, 'logits differ from the oracle by %g' % err
-    dec = eng.decode(x, sl)
+    dec = eng.decode(x, sl, method='greedy')
     assert dec == odec.greedy_decode(logits.numpy(), sl), 'greedy decode differs from the oracle'
+    assert eng.decode(x, sl, method='beam') == odec.reference_decode(logits.numpy(), sl), 'beam decode differs from the oracle'
     # one optimisation step: loss against the oracle's loss on the same batch
     wd = float(eng.cfg.TRAIN.WEIGHT_DECAY)
     loss = eng.train_step(x, labels, ll, sl)

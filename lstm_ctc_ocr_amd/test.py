@@ -4,8 +4,8 @@ per-file result and the exact-match accuracy in the reference's format.
 
 Deviations: images are read with PIL (cv2 is not available); `time_step_len` is
 W // POOL_SCALE + OFFSET_TIME_STEP — the reference feeds W // POOL_SCALE, one more than the graph produces
-(SURVEY Q3), which TF's sequence ops reject; decode is the greedy best path (blank 0), or the TF-semantics beam
-search when cfg-independent flag `beam=True` is passed.
+(SURVEY Q3), which TF's sequence ops reject; decode is the device implementation of the reference's
+ctc_beam_search_decoder (beam 100, blank C-1, merge_repeated) followed by the same zero stripping.
 """
 import math
 import os

@@ -56,6 +56,11 @@ def test_device_ctc_matches_fixture(dev):
     for n in range(out.shape[0]):
         want = [v for v in d['greedy'][n] if v != 0]
         assert out[n, :lens[n]].tolist() == want                                       # bar: identical
+    out, lens, _ = ops.ctc_beam_decode(t(d['acts']), t(d['input_lengths']), beam_width=100)
+    out, lens = out.cpu().numpy(), lens.cpu().numpy()
+    for n in range(out.shape[0]):
+        got = [v for v in out[n, :lens[n]] if v != 0]
+        assert got == [v for v in d['beam'][n] if v != 0]                              # the reference's decode + zero stripping
 
 
 @pytest.mark.gpu

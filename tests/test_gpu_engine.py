@@ -58,9 +58,10 @@ def test_forward_parity(engine, N, W, varlen):
         assert float((logits[:t, n] - ref[:t, n]).abs().max()) < 5e-3
     ref32 = og.forward(params, torch.from_numpy(x), sl.tolist(), sim_bf16=False)
     print('max |logits(bf16 path) - logits(fp32 oracle)| =', float((logits - ref32).abs().max()))
-    dec = engine.decode(x, sl)
-    # kernel-level: bit-exact best path of the device's own logits
+    dec = engine.decode(x, sl, method='greedy')
+    # kernel-level: bit-exact best path of the device's own logits, and the reference's beam decode (blank C-1, zeros stripped)
     assert dec == odec.greedy_decode(logits.numpy(), sl)
+    assert engine.decode(x, sl, method='beam') == odec.reference_decode(logits.numpy(), sl, beam_width=100)
     # end-to-end: identical strings wherever the oracle's per-frame top-2 margin exceeds the logit tolerance
     # (random-init weights give near-uniform posteriors, so sub-tolerance ties exist and are excluded)
     ref_dec = odec.greedy_decode(ref.numpy(), sl)

@@ -143,6 +143,24 @@ def test_ctc_greedy(dev):
     assert out[0, :3].tolist() == [5, 5, 7] and int(lens[0]) == 3 and int(lens[1]) == 0
 
 
+@pytest.mark.parametrize("T,N,C,beam", [(12, 6, 8, 100), (20, 5, 16, 4), (63, 8, 64, 100), (30, 3, 96, 25), (7, 4, 5, 2)])
+def test_ctc_beam_search_matches_tf_semantics_oracle(dev, T, N, C, beam):
+    rng = np.random.RandomState(T + C)
+    acts = (rng.randn(T, N, C) * 3).astype(np.float32)
+    acts[rng.rand(T, N) < 0.3, C - 1] += 5.0                    # TF blank (C-1) frames
+    acts[rng.rand(T, N) < 0.3, 0] += 5.0                        # class-0 frames (the loss's blank, a normal symbol here)
+    il = rng.randint(max(1, T // 2), T + 1, N).astype(np.int32)
+    for merge in (True, False):
+        out, lens, nlp = ops.ctc_beam_decode(torch.from_numpy(acts).to(dev), torch.from_numpy(il).to(dev), beam_width=beam,
+                                             merge_repeated=merge)
+        ref, scores = odec.beam_search_tf(acts, il, beam_width=beam, merge_repeated=merge)
+        out, lens, nlp = out.cpu().numpy(), lens.cpu().numpy(), nlp.cpu().numpy()
+        for n in range(N):
+            assert out[n, :lens[n]].tolist() == ref[n], (n, out[n, :lens[n]].tolist(), ref[n])
+            assert (out[n, lens[n]:] == 0).all()
+            assert abs(-nlp[n] - scores[n]) < 1e-3 * max(1.0, abs(scores[n]))
+
+
 # ------------------------------------------------------------------------------------------- GEMM NT
 @pytest.mark.parametrize("M,N,K", [(4032, 1024, 512), (4032, 64, 512), (300, 132, 72), (128, 128, 32), (70, 520, 2048)])
 def test_gemm_nt(dev, M, N, K):
