@@ -255,7 +255,9 @@ int ig_try_dispatch(const void* P, long ldp, const void* Q, long ldq, void* out,
                     const float* bias, const void* mask, long ldmask, int flags, int mode, int grp, int skip, int cW,
                     int cH, int cC, int swap_inner, int swap_outer, hipStream_t stream);
 static int g_use_igemm = 1;
-extern "C" int ocr_set_gemm_engine(int use_large_tile) { g_use_igemm = use_large_tile; return OCR_OK; }
+extern int g_ig_stages;
+// 0 = 128x128 register-staged tiles only, 1 = LDS-DMA 256-row tiles (three-stage pipeline), 2 = same with two stages
+extern "C" int ocr_set_gemm_engine(int mode) { g_use_igemm = mode != 0; g_ig_stages = (mode == 2) ? 2 : 3; return OCR_OK; }
 
 // ------------------------------------------------------------------------------------------
 // C ABI

@@ -35,7 +35,7 @@ __device__ u32x4 ig_zero_page[4];   // 64 B of zeros (device globals are zero-in
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BN, int MODE /*0 plain, 1 conv3x3*/>
+template <int BN, int MODE /*0 plain, 1 conv3x3*/, int STAGES /*2 or 3 LDS stages*/>
 __global__ __launch_bounds__(512) void igemm_kernel(IgArgs g) {
     constexpr int BM = 256, BK = 64;
     constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N;
@@ -117,13 +117,9 @@ __global__ __launch_bounds__(512) void igemm_kernel(IgArgs g) {
     // fragment read offsets: row (lane&15) of a 16-row block, 16-B chunk (kk*4 + lane>>4) ^ (row & 7)
     const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
     const int ntk = g.K / BK;
-    stage_load(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int t = 0; t < ntk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < ntk) stage_load((t + 1) * BK, cur ^ 1);
-        const unsigned char* ps = smem + cur * STAGE;
+    constexpr int NI = 4 + QI;        // DMA instructions one wave issues per stage
+    auto compute = [&](int buf) {
+        const unsigned char* ps = smem + buf * STAGE;
         const unsigned char* qs = ps + PB;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -139,8 +135,36 @@ __global__ __launch_bounds__(512) void igemm_kernel(IgArgs g) {
                 for (int b = 0; b < FM; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage has landed (this wave's DMA pieces)
-        __syncthreads();                                     // everyone's pieces landed, everyone done reading `cur`
+    };
+    if (STAGES == 2) {
+        stage_load(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int t = 0; t < ntk; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < ntk) stage_load((t + 1) * BK, cur ^ 1);
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage has landed (this wave's DMA pieces)
+            __syncthreads();                                     // everyone's pieces landed, everyone done reading `cur`
+        }
+    } else {
+        // three stages, two K tiles in flight: the wait at the top of step t only retires stage t (counted vmcnt leaves the
+        // NI DMA instructions of stage t+1 outstanding), and the barrier is a RAW s_barrier — __syncthreads() would drain
+        // the DMA queue (an LDS-DMA is a pending LDS write on the VM counter).  The same barrier orders "everyone finished
+        // reading stage t-1" before stage t+2 is streamed into that buffer.
+        stage_load(0, 0);
+        if (ntk > 1) stage_load(BK, 1);
+        int cur = 0;
+        for (int t = 0; t < ntk; ++t) {
+            if (t + 1 < ntk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + 2 < ntk) { int nb = cur + 2; if (nb >= 3) nb -= 3; stage_load((t + 2) * BK, nb); }
+            compute(cur);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of `cur` are complete
+            cur = (cur == 2) ? 0 : cur + 1;
+        }
     }
 
     // ---- epilogue: lane owns n = nb + (lane>>4)*4 .. +3 at m = mb + (lane&15)
@@ -180,19 +204,26 @@ __global__ __launch_bounds__(512) void igemm_kernel(IgArgs g) {
     }
 }
 
-template <int BN, int MODE>
-static int launch_ig(const IgArgs& g, hipStream_t stream) {
-    constexpr int LDS = 2 * (256 * 128 + BN * 128);
+int g_ig_stages = 3;     // A/B knob (ocr_set_gemm_engine): 3 = three-stage counted-vmcnt pipeline where LDS allows, 2 = two-stage
+
+template <int BN, int MODE, int STAGES>
+static int launch_ig2(const IgArgs& g, hipStream_t stream) {
+    constexpr int LDS = STAGES * (256 * 128 + BN * 128);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kernel<BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)igemm_kernel<BN, MODE, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return OCR_ERR_EXEC;
         attr_set = true;
     }
     int mt = (g.M + 255) / 256, nt = (g.N + BN - 1) / BN;
-    igemm_kernel<BN, MODE><<<mt * nt, 512, LDS, stream>>>(g);
+    igemm_kernel<BN, MODE, STAGES><<<mt * nt, 512, LDS, stream>>>(g);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
+}
+template <int BN, int MODE>
+static int launch_ig(const IgArgs& g, hipStream_t stream) {
+    if (BN <= 128 && g_ig_stages == 3) return launch_ig2<(BN <= 128 ? BN : 128), MODE, 3>(g, stream);   // 3 x 48 KiB fits, 3 x 64 KiB does not
+    return launch_ig2<BN, MODE, 2>(g, stream);
 }
 
 // Shared with gemm.hip's entry points: returns -1 when the shape is not covered (caller uses the small-tile kernel).
