@@ -37,6 +37,7 @@ int ocr_ctc_workspace_size(int max_label_len, int max_time, int minibatch, size_
 int ocr_ctc_loss(const float* activations, float* gradients, const int* flat_labels, const int* label_lengths,
                  const int* input_lengths, int alphabet_size, int minibatch, int max_time, int max_label_len,
                  int blank_label, float* costs, void* workspace, void* stream);
+int ocr_set_ctc_engine(int fast);   /* 1 (default): 4-wave LDS-resident kernel where it fits; 0: one-wave general kernel */
 /* best-path decode (argmax, collapse repeats, drop blank): the greedy counterpart of
  * tf.nn.ctc_beam_search_decoder + sparse_tensor_to_dense(default 0) at network.py:656-657 / test.py:30-31.
  * decoded: int32 [minibatch, max_time] padded with pad_value; decoded_lengths: int32 [minibatch]. */

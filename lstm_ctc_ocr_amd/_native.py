@@ -21,6 +21,7 @@ _SIGS = {
     "ocr_status_string": ([_I], ctypes.c_char_p),
     "ocr_ctc_workspace_size": ([_I, _I, _I, ctypes.POINTER(ctypes.c_size_t)], _I),
     "ocr_ctc_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P], _I),
+    "ocr_set_ctc_engine": ([_I], _I),
     "ocr_ctc_greedy_decode": ([_P, _P, _I, _I, _I, _I, _I, _P, _P, _P], _I),
     "ocr_ctc_beam_workspace_size": ([_I, _I, _I, _I, ctypes.POINTER(ctypes.c_size_t)], _I),
     "ocr_ctc_beam_decode": ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, ctypes.c_size_t, _P], _I),

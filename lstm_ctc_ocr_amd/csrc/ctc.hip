@@ -195,6 +195,129 @@ __global__ __launch_bounds__(64) void ctc_loss_grad_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fast path (S = 2L+1 <= 64 and 3*T*S floats fit in LDS — every configuration of the reference): 4 waves per sample.
+//   phase 1  all waves: softmax denominators of their frames (t = wave, wave+4, ...)
+//   phase 2  all threads: logy[t][s] = act[t][l'_s] - lse[t] gathered into LDS — the recursion below never waits on HBM/L2
+//   phase 3  wave 0 runs the alpha recursion, wave 1 the beta recursion CONCURRENTLY; the row lives in registers and the
+//            s-1 / s-2 (s+1 / s+2) neighbours come from wave shuffles, so a step is ~60 VALU cycles with no barrier
+//   phase 4  all waves: gradient rows of their frames (posterior per class via LDS float atomics, coalesced row store)
+// The first version did all of this in one wave with a barrier and an L2 round trip per step: 3 x 63 serial steps,
+// ~0.8 us each (152 us at T = 63).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ctc_fast_kernel(
+    const float* __restrict__ act, float* __restrict__ grad, const int* __restrict__ flat_labels,
+    const int* __restrict__ label_off, const int* __restrict__ label_len, const int* __restrict__ input_len,
+    int T, int N, int C, int blank, float* __restrict__ costs, int SMAX) {
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float* lse = fsm;                          // [T]
+    float* logy = lse + T;                     // [T][SMAX]
+    float* alpha = logy + T * SMAX;            // [T][SMAX]
+    float* beta = alpha + T * SMAX;            // [T][SMAX]
+    float* acc = beta + T * SMAX;              // [4][C]   per-wave posterior accumulators
+    int* lab = (int*)(acc + 4 * C);            // [SMAX]
+    __shared__ float s_logp;
+    __shared__ int s_repeats;
+
+    const int L = label_len[n];
+    const int Tn = min(input_len[n], T);
+    const int S = 2 * L + 1;
+    const int* labels = flat_labels + label_off[n];
+    const size_t tstride = (size_t)N * C;
+    const float* a_n = act + (size_t)n * C;
+    float* g_n = grad ? grad + (size_t)n * C : nullptr;
+
+    if (tid == 0) s_repeats = 0;
+    __syncthreads();
+    int rep = 0;
+    for (int s = tid; s < S; s += 256) {
+        lab[s] = (s & 1) ? labels[s >> 1] : blank;
+        if ((s & 1) && s >= 3 && labels[s >> 1] == labels[(s >> 1) - 1]) rep++;
+    }
+    if (rep) atomicAdd(&s_repeats, rep);
+    __syncthreads();
+    const bool feasible = (Tn > 0) && (L + s_repeats <= Tn);
+    if (g_n) {          // frames this sample does not own (and everything when infeasible): zero gradient
+        const int t0 = feasible ? Tn : 0;
+        for (int t = t0 + wave; t < T; t += 4)
+            for (int k = lane; k < C; k += 64) g_n[t * tstride + k] = 0.f;
+    }
+    if (!feasible) { if (tid == 0) costs[n] = 0.f; return; }
+
+    // phase 1
+    for (int t = wave; t < Tn; t += 4) {
+        const float* row = a_n + t * tstride;
+        float m = NEG_INF;
+        for (int k = lane; k < C; k += 64) m = fmaxf(m, row[k]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int k = lane; k < C; k += 64) sum += expf(row[k] - m);
+        sum = wave_sum(sum);
+        if (lane == 0) lse[t] = m + logf(sum);
+    }
+    __syncthreads();
+    // phase 2
+    for (int i = tid; i < Tn * S; i += 256) {
+        const int t = i / S, s = i - t * S;
+        logy[t * SMAX + s] = a_n[t * tstride + lab[s]] - lse[t];
+    }
+    __syncthreads();
+    // phase 3
+    if (wave == 0) {
+        const int s = lane;
+        const bool in = s < S;
+        const int my = in ? lab[s] : blank;
+        const bool skip = in && s >= 2 && my != blank && my != lab[s - 2];
+        float a = (in && s < 2) ? logy[s] : NEG_INF;
+        if (in) alpha[s] = a;
+        for (int t = 1; t < Tn; ++t) {
+            float p1 = __shfl_up(a, 1, 64), p2 = __shfl_up(a, 2, 64);
+            if (lane < 1) p1 = NEG_INF;
+            if (!skip) p2 = NEG_INF;
+            float v = lse3(a, p1, p2);
+            if (v != NEG_INF && in) v += logy[t * SMAX + s]; else if (!in) v = NEG_INF;
+            a = v;
+            if (in) alpha[t * SMAX + s] = a;
+        }
+        float e1 = __shfl(a, S - 1, 64);
+        float e2 = (S >= 2) ? __shfl(a, S - 2, 64) : NEG_INF;
+        if (lane == 0) { s_logp = lse2(e1, e2); costs[n] = -s_logp; }
+    } else if (wave == 1 && g_n) {
+        const int s = lane;
+        const bool in = s < S;
+        const int my = in ? lab[s] : blank;
+        const bool skip = (s + 2 < S) && lab[s + 2] != blank && lab[s + 2] != my;
+        float b = (in && s >= S - 2) ? logy[(Tn - 1) * SMAX + s] : NEG_INF;
+        if (in) beta[(Tn - 1) * SMAX + s] = b;
+        for (int t = Tn - 2; t >= 0; --t) {
+            float q1 = __shfl_down(b, 1, 64), q2 = __shfl_down(b, 2, 64);
+            if (s + 1 >= S) q1 = NEG_INF;
+            if (!skip) q2 = NEG_INF;
+            float v = lse3(b, q1, q2);
+            if (v != NEG_INF && in) v += logy[t * SMAX + s]; else if (!in) v = NEG_INF;
+            b = v;
+            if (in) beta[t * SMAX + s] = b;
+        }
+    }
+    __syncthreads();
+    if (!g_n) return;
+    // phase 4
+    const float logp = s_logp;
+    float* wacc = acc + wave * C;
+    for (int t = wave; t < Tn; t += 4) {
+        for (int k = lane; k < C; k += 64) wacc[k] = 0.f;
+        if (lane < S) {
+            const float al = alpha[t * SMAX + lane], be = beta[t * SMAX + lane];
+            if (al != NEG_INF && be != NEG_INF) atomicAdd(&wacc[lab[lane]], expf(al + be - logy[t * SMAX + lane] - logp));
+        }
+        const float* row = a_n + t * tstride;
+        float* grow = g_n + t * tstride;
+        const float l = lse[t];
+        for (int k = lane; k < C; k += 64) grow[k] = expf(row[k] - l) - wacc[k];
+    }
+}
+
 // Greedy (best-path) decode: per frame argmax (lowest index wins ties, like numpy.argmax),
 // collapse repeats, drop `blank`. Output is dense [N, T] padded with `pad_value`, plus lengths.
 __global__ __launch_bounds__(64) void ctc_greedy_kernel(
@@ -252,6 +375,8 @@ __global__ void exclusive_scan_small(const int* __restrict__ in, int* __restrict
 // C ABI (declared in include/ocr_hip.h)
 // ------------------------------------------------------------------------------------------
 static inline int smax_for(int max_label_len) { return 2 * max_label_len + 1; }
+static int g_ctc_fast = 1;
+extern "C" int ocr_set_ctc_engine(int fast) { g_ctc_fast = fast; return OCR_OK; }   // A/B + test knob: 0 = one-wave reference kernel
 
 extern "C" int ocr_ctc_workspace_size(int max_label_len, int max_time, int minibatch,
                                       size_t* bytes) {
@@ -280,6 +405,18 @@ extern "C" int ocr_ctc_loss(const float* activations, float* gradients, const in
     int* label_off = (int*)(ws + (size_t)minibatch * max_time * (SMAX + 1));
     exclusive_scan_small<<<1, 64, 0, stream>>>(label_lengths, label_off, minibatch);
     OCR_CHECK_LAUNCH();
+    // fast path: S <= 64 and the three [T][S] tables fit in LDS
+    {
+        size_t flds = ((size_t)max_time * (1 + 3 * SMAX) + 4 * (size_t)alphabet_size) * sizeof(float) + (size_t)SMAX * sizeof(int);
+        flds = (flds + 15) & ~(size_t)15;
+        if (SMAX <= 64 && flds <= 64 * 1024 && g_ctc_fast) {
+            ctc_fast_kernel<<<minibatch, 256, flds, stream>>>(activations, gradients, flat_labels, label_off, label_lengths,
+                                                             input_lengths, max_time, minibatch, alphabet_size, blank_label, costs,
+                                                             SMAX);
+            OCR_CHECK_LAUNCH();
+            return OCR_OK;
+        }
+    }
     size_t lds = (size_t)(2 * (SMAX + 2) + alphabet_size) * sizeof(float) + (size_t)SMAX * sizeof(int);
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return OCR_ERR_INVALID;

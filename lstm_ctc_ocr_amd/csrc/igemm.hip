@@ -167,19 +167,28 @@ __global__ __launch_bounds__(512) void igemm_kernel(IgArgs g) {
         }
     }
 
-    // ---- epilogue: lane owns n = nb + (lane>>4)*4 .. +3 at m = mb + (lane&15)
+    // ---- epilogue: lane owns n = nb + (lane>>4)*4 .. +3 at m = mb + (lane&15).  Loop order m-block outer / n-fragment inner:
+    // the FN stores that complete one 128-byte run of a pixel row are issued back to back (with n outer the same lines
+    // were revisited FM stores apart and reached HBM as partial-line writes — WRITE_SIZE 2.5x the output bytes).
     const int flags = g.flags;
+    f32x4 bv[FN];
 #pragma unroll
     for (int a = 0; a < FN; ++a) {
-        int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
-        if (n >= g.N) continue;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (flags & IG_BIAS) bv = *(const f32x4*)(g.bias + n);
+        const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+        bv[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if ((flags & IG_BIAS) && n < g.N) bv[a] = *(const f32x4*)(g.bias + n);
+    }
 #pragma unroll
-        for (int b = 0; b < FM; ++b) {
-            int m = m0 + wm * WM + b * 16 + (lane & 15);
-            if (m >= g.M) continue;
-            f32x4 v = acc[a][b] + bv;
+    for (int b = 0; b < FM; ++b) {
+        const int m = m0 + wm * WM + b * 16 + (lane & 15);
+        if (m >= g.M) continue;
+        long orow = m;
+        if (flags & IG_ROWSWAP) orow = (long)(m % g.swap_inner) * g.swap_outer + m / g.swap_inner;
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+            if (n >= g.N) continue;
+            f32x4 v = acc[a][b] + bv[a];
             if (flags & IG_RELU) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
@@ -190,8 +199,6 @@ __global__ __launch_bounds__(512) void igemm_kernel(IgArgs g) {
                 if (!(bf_lo(mk.y) > 0.f)) v.z = 0.f;
                 if (!(bf_hi(mk.y) > 0.f)) v.w = 0.f;
             }
-            long orow = m;
-            if (flags & IG_ROWSWAP) orow = (long)(m % g.swap_inner) * g.swap_outer + m / g.swap_inner;
             if (flags & IG_OUT_F32) {
                 *(f32x4*)((float*)g.out + orow * g.ldo + n) = v;
             } else {

@@ -79,6 +79,13 @@ def _ctc_case(dev, T, N, C, lens, in_lens, seed, blank=0, labels=None):
     ref_c, ref_g = octc.ctc_loss_c(acts, flat, ll, il, blank)
     a = torch.from_numpy(acts).to(dev)
     fl = torch.from_numpy(flat if len(flat) else np.zeros(1, np.int32)).to(dev)
+    from lstm_ctc_ocr_amd import _native as nat
+    for engine in (0, 1):          # the general one-wave kernel and the 4-wave LDS-resident kernel must both match
+        nat.call("ocr_set_ctc_engine", engine)
+        costs, grads = ops.ctc_loss(a, fl, torch.from_numpy(ll).to(dev), torch.from_numpy(il).to(dev), int(max(ll.max(), 1)), blank)
+        torch.cuda.synchronize()
+        assert np.allclose(costs.cpu().numpy(), ref_c, rtol=1e-4, atol=1e-4), (engine, costs.cpu().numpy(), ref_c)
+        assert np.abs(grads.cpu().numpy() - ref_g).max() < 5e-4, (engine, np.abs(grads.cpu().numpy() - ref_g).max())
     costs, grads = ops.ctc_loss(a, fl, torch.from_numpy(ll).to(dev), torch.from_numpy(il).to(dev), int(max(ll.max(), 1)), blank)
     torch.cuda.synchronize()
     c = costs.cpu().numpy(); g = grads.cpu().numpy()
