@@ -59,7 +59,8 @@ int ocr_ctc_beam_decode(const float* activations, const int* input_lengths, int 
 int ocr_gemm_nt_bf16(const void* P, long ldp, const void* Q, long ldq, void* out, long ldo, int M, int N, int K,
                      const float* bias, const void* mask, long ldmask, int flags, int splits, int row_group,
                      int row_skip, int swap_inner, int swap_outer, void* stream);
-/* engine selector for A/B measurements: 1 (default) = 256-row LDS-DMA tiles where the shape allows, 0 = 128x128 tiles */
+/* engine selector for A/B measurements: 1 (default) = tap-reuse halo conv + 256-row LDS-DMA GEMM tiles, 0 = 128x128 tiles,
+ * 2 / 3 = LDS-DMA tiles (two / three stage) without the halo kernel */
 int ocr_set_gemm_engine(int use_large_tile);
 /* 3x3 SAME stride-1 convolution, x bf16 [Nb,W,H,Cin], wpack bf16 [Cout][3][3][Cin], y [Nb,W,H,Cout]
  * (conv_single network.py:160-191; also its data gradient with flipped/transposed weights) */

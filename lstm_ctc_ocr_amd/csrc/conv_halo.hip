@@ -1,0 +1,223 @@
+// 3x3 SAME implicit-GEMM convolution with TAP REUSE for gfx950 (third generation; same contract as
+// ocr_conv3x3_bf16 — reference lib/networks/network.py:160-191 forward, and its data gradient).
+//
+// igemm.hip streams a fresh 256-pixel x 64-channel activation tile for every (tap, channel chunk): the same
+// activation rows cross L2 -> LDS nine times, and PMC shows the kernel limited by that on-chip traffic, not by
+// MFMA (46 % pipe utilisation at 1 PFLOP/s).  Here a workgroup stages, per 64-channel chunk, ONE halo tile: the
+// 256 output pixels are a contiguous run of the flat pixel index, and every tap of every one of them lies in the
+// contiguous run [m0 - H - 1, m0 + 256 + H + 1) — so 256 + 2H + 2 rows of 128 B are DMA'd once and the nine taps
+// are nine shifted views of that LDS image.  Per step (tap, chunk) only the 16 KiB weight tile is new:
+// 20 KiB of LDS-DMA per 32 MFMAs per wave instead of 48 KiB.
+// SAME-padding: whether a tap of an output pixel falls outside the image depends on (pixel, tap), so the halo
+// image cannot be pre-zeroed; instead every lane carries a 9-bit validity mask per pixel fragment and selects
+// zeros for the MFMA operand (4 v_cndmask per fragment).
+// Pipeline: weight tiles double-buffered (one step ahead), halo tiles double-buffered (one chunk ahead, issued at
+// tap 0 AFTER the weight DMA so the counted wait of tap 1 does not have to drain it), raw s_barrier per step.
+#include "common.h"
+
+enum { IGH_BIAS = 1, IGH_RELU = 2, IGH_MASK = 16 };
+
+struct HaloArgs {
+    const bf16_t* P; const bf16_t* Q;     // P [M pixels][C] ; Q [N][9*C]
+    int M, N, C;                          // C % 64 == 0
+    int cW, cH;
+    bf16_t* out; const float* bias; const bf16_t* mask; int flags;
+};
+
+__device__ u32x4 igh_zero_page[4];
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BN>
+__global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 64 */) {
+    constexpr int BM = 256;
+    constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N;
+    constexpr int WM = BM / WAVES_M, FM = WM / 16, FN = 4;
+    constexpr int QB = BN * 128, QI = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int PBYTES = NRpad * 128;
+    unsigned char* pbuf0 = smem;                       // 2 halo stages
+    unsigned char* qbuf0 = smem + 2 * PBYTES;          // 2 weight stages
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int H = g.cH, C = g.C;
+    const int NR = BM + 2 * H + 2;                     // halo rows actually needed
+    const int PI = NRpad / 64;                         // halo DMA instructions per wave (8 rows each, 8 waves)
+
+    const int mtiles = (g.M + BM - 1) / BM, ntiles = (g.N + BN - 1) / BN;
+    const int nblk = mtiles * ntiles;
+    int L = blockIdx.x;
+    if ((nblk & 7) == 0) L = (L & 7) * (nblk >> 3) + (L >> 3);
+    const int m0 = (L / ntiles) * BM, n0 = (L % ntiles) * BN;
+
+    const int rsub = lane >> 3;
+    const int csrc = ((lane & 7) ^ rsub) * 8;          // LDS position lane&7 of row r holds source chunk (lane&7)^(r&7)
+    const bf16_t* zero = (const bf16_t*)igh_zero_page;
+    const long mfirst = (long)m0 - H - 1;              // flat pixel of halo row 0
+
+    const bf16_t* qrow[QI];
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+        int n = n0 + (wave * QI + j) * 8 + rsub;
+        qrow[j] = (n < g.N) ? g.Q + (long)n * 9 * C + csrc : nullptr;
+    }
+    auto load_q = [&](int k0, int buf) {               // k0 = tap*C + chunk*64
+        unsigned char* sq = qbuf0 + buf * QB;
+#pragma unroll
+        for (int j = 0; j < QI; ++j) {
+            const bf16_t* src = qrow[j] ? qrow[j] + k0 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sq + (wave * QI + j) * 1024), 16, 0, 0);
+        }
+    };
+    auto load_p = [&](int chunk, int buf) {
+        unsigned char* sp = pbuf0 + buf * PBYTES;
+        for (int j = 0; j < PI; ++j) {
+            const int r = (wave * PI + j) * 8 + rsub;                // halo row (r & 7 == rsub)
+            const long m = mfirst + r;
+            const bf16_t* src = (r < NR && m >= 0 && m < g.M) ? g.P + m * C + chunk * 64 + csrc : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sp + (wave * PI + j) * 1024), 16, 0, 0);
+        }
+    };
+
+    // per pixel-fragment validity of the nine taps (bit t set <=> tap t of this lane's pixel is inside the image)
+    unsigned vmask[FM];
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+        const int m = m0 + wm * WM + b * 16 + (lane & 15);
+        unsigned bits = 0;
+        if (m < g.M) {
+            const int h = m % H, w = (m / H) % g.cW;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ww = w + t / 3 - 1, hh = h + t % 3 - 1;
+                if ((unsigned)ww < (unsigned)g.cW && (unsigned)hh < (unsigned)H) bits |= 1u << t;
+            }
+        }
+        vmask[b] = bits;
+    }
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
+    const int nchunks = C / 64;
+    const int nsteps = nchunks * 9;
+    // prologue: weights of step 0, then halo of chunk 0
+    load_q(0, 0);
+    load_p(0, 0);
+    int tap = 0, chunk = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        // Q(s) was issued one step ago; at tap 1 the halo of the NEXT chunk was issued right after it and may stay in flight
+        if (tap == 1 && chunk + 1 < nchunks) {
+            if (PI == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if (PI == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // issue next step's weights, and (at tap 0) the next chunk's halo AFTER them
+        {
+            int ntap = tap + 1, nchunk = chunk;
+            if (ntap == 9) { ntap = 0; ++nchunk; }
+            if (s + 1 < nsteps) load_q(ntap * C + nchunk * 64, (s + 1) & 1);
+            if (tap == 0 && chunk + 1 < nchunks) load_p(chunk + 1, (chunk + 1) & 1);
+        }
+        const unsigned char* ps = pbuf0 + (chunk & 1) * PBYTES;
+        const unsigned char* qs = qbuf0 + (s & 1) * QB;
+        const int shift = (H + 1) + (tap / 3 - 1) * H + (tap % 3 - 1);       // halo row of local pixel 0 for this tap
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int coffq = ((kk * 4 + fq) ^ fx) << 4;
+            bf16x8 af[FN], bfr[FM];
+#pragma unroll
+            for (int a = 0; a < FN; ++a) af[a] = *(const bf16x8*)(qs + (wn * 64 + a * 16 + frow) * 128 + coffq);
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+                const int rr = wm * WM + b * 16 + frow + shift;
+                bf16x8 v = *(const bf16x8*)(ps + rr * 128 + (((kk * 4 + fq) ^ (rr & 7)) << 4));
+                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                bfr[b] = ((vmask[b] >> tap) & 1u) ? v : z;
+            }
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int b = 0; b < FM; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (++tap == 9) { tap = 0; ++chunk; }
+    }
+
+    // ---- epilogue (m-block outer, n-fragment inner: the stores completing a 128-B run of a pixel row are adjacent)
+    const int flags = g.flags;
+    f32x4 bv[FN];
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+        const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+        bv[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if ((flags & IGH_BIAS) && n < g.N) bv[a] = *(const f32x4*)(g.bias + n);
+    }
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+        const int m = m0 + wm * WM + b * 16 + (lane & 15);
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+            if (n >= g.N) continue;
+            f32x4 v = acc[a][b] + bv[a];
+            if (flags & IGH_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            if (flags & IGH_MASK) {
+                u32x2 mk = *(const u32x2*)(g.mask + (long)m * g.N + n);
+                if (!(bf_lo(mk.x) > 0.f)) v.x = 0.f;
+                if (!(bf_hi(mk.x) > 0.f)) v.y = 0.f;
+                if (!(bf_lo(mk.y) > 0.f)) v.z = 0.f;
+                if (!(bf_hi(mk.y) > 0.f)) v.w = 0.f;
+            }
+            u32x2 pk;
+            pk.x = pack_bf2(v.x, v.y);
+            pk.y = pack_bf2(v.z, v.w);
+            *(u32x2*)(g.out + (long)m * g.N + n) = pk;
+        }
+    }
+}
+
+template <int BN>
+static int launch_halo(const HaloArgs& g, hipStream_t stream) {
+    const int NR = 256 + 2 * g.cH + 2;
+    const int NRpad = (NR + 63) / 64 * 64;
+    const int lds = 2 * NRpad * 128 + 2 * BN * 128;
+    static int lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return OCR_ERR_EXEC;
+        lds_set = lds;
+    }
+    int mt = (g.M + 255) / 256, nt = (g.N + BN - 1) / BN;
+    conv_halo_kernel<BN><<<mt * nt, 512, lds, stream>>>(g, NRpad);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+
+// -1 = shape not covered (caller falls back to igemm.hip / gemm.hip)
+int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
+                      const void* mask, int flags, hipStream_t stream) {
+    if ((Cin & 63) || (Cout & 3) || M < 1024 || H > 30) return -1;
+    if (flags & ~(IGH_BIAS | IGH_RELU | IGH_MASK)) return -1;
+    const int NRpad = (256 + 2 * H + 2 + 63) / 64 * 64;
+    if (NRpad / 64 != 5 && NRpad / 64 != 6) return -1;               // counted vmcnt literals exist for 5 and 6
+    HaloArgs g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags};
+    const int mt = (M + 255) / 256;
+    if (Cout >= 128 && (long)mt * ((Cout + 127) / 128) >= 200) return launch_halo<128>(g, stream);
+    if (Cout >= 128 && (long)mt * ((Cout + 63) / 64) < 256) return launch_halo<128>(g, stream);
+    return launch_halo<64>(g, stream);
+}
