@@ -80,6 +80,11 @@ int ocr_conv1_fwd(const float* x, const float* w, const float* bias, void* y, in
                   int relu, void* stream);
 int ocr_conv1_wgrad(const float* x, const void* dz, float* dw, float* db, int Nb, int W, int H, int Cout,
                     void* stream);
+/* conv1 + ReLU + 2x2 max-pool in one pass (LSTM_train.py:24-25); the backward recomputes the window instead of reading a
+ * stored 67 MB activation: p / dp are the POOLED map [Nb, W/2, H/2, Cout] */
+int ocr_conv1_pool_fwd(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout, void* stream);
+int ocr_conv1_pool_bwd(const float* x, const float* w, const float* bias, const void* dp, float* dw, float* db, int Nb,
+                       int W, int H, int Cout, void* stream);
 int ocr_maxpool_fwd(const void* x, void* y, int Nb, int W, int H, int C, int kw, int kh, void* stream);
 int ocr_maxpool_bwd(const void* x, const void* dy, void* dx, int Nb, int W, int H, int C, int kw, int kh,
                     int relu_mask, void* stream);

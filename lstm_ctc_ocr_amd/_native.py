@@ -33,6 +33,8 @@ _SIGS = {
     "ocr_conv3x3_wgrad_bf16": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "ocr_conv1_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "ocr_conv1_wgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "ocr_conv1_pool_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "ocr_conv1_pool_bwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "ocr_maxpool_fwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "ocr_maxpool_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "ocr_bn_train_fwd": ([_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P, _P], _I),

@@ -4,6 +4,11 @@
 // coalesced along the channel axis of the reference layout [N, W, H, C].
 #include "common.h"
 
+__device__ __forceinline__ void unpack8(u32x4 p, float* f) {
+    f[0] = bf_lo(p.x); f[1] = bf_hi(p.x); f[2] = bf_lo(p.y); f[3] = bf_hi(p.y);
+    f[4] = bf_lo(p.z); f[5] = bf_hi(p.z); f[6] = bf_lo(p.w); f[7] = bf_hi(p.w);
+}
+
 // ============================================================================================
 // conv1: x f32 [Nb, W, H] (single channel) -> y bf16 [Nb, W, H, Cout], 3x3 SAME, + bias, ReLU
 //   reference: conv_single(3,3,64,1,1,'conv1',c_i=1)  lib/networks/LSTM_train.py:24, network.py:160-191
@@ -118,13 +123,147 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
 }
 
 // ============================================================================================
+// conv1 + ReLU + 2x2 max-pool fused (forward) and its fused backward (pool routing + ReLU mask + conv1 weight gradient).
+// conv1's full-resolution output (N*W*H*64 bf16 = 67 MB at batch 64) is the largest tensor of the network and is only
+// ever consumed by pool1; with K = 9 it is cheaper to recompute than to store: the forward writes only the pooled map,
+// the backward recomputes the 2x2 window (identical fp32 arithmetic, hence identical arg-max and ReLU mask), routes the
+// pooled gradient to the first maximum (TF scan order: W outer, H inner) and accumulates dW / db in registers.
+//   reference: LSTM_train.py:24-25 (conv_single 3x3 c_i=1 -> max_pool 2,2), network.py:160-191, 343-350
+// ============================================================================================
+__device__ __forceinline__ void conv1_window(const float* __restrict__ xn, int W, int H, int w0, int h0,
+                                             const float (&wr)[9][8], const float (&br)[8], float (&o)[4][8], float (&patch)[4][4]) {
+    // 4x4 input patch around the 2x2 output window (rows w0-1..w0+2, cols h0-1..h0+2), zero outside the image
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ww = w0 - 1 + i, hh = h0 - 1 + j;
+            patch[i][j] = ((unsigned)ww < (unsigned)W && (unsigned)hh < (unsigned)H) ? xn[(long)ww * H + hh] : 0.f;
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int a = e >> 1, b = e & 1;               // window element (a over W, b over H) = TF scan order
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[e][c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[e][c] = fmaf(patch[a + t / 3][b + t % 3], wr[t][c], o[e][c]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[e][c] = fmaxf(o[e][c] + br[c], 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, bf16_t* __restrict__ p,
+                                                             int Nb, int W, int H, int Cout) {
+    const int groups = Cout >> 3, gq = threadIdx.x % groups, plane = threadIdx.x / groups, planes = 256 / groups;
+    float wr[9][8], br[8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) wr[t][c] = w[t * Cout + gq * 8 + c];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) br[c] = bias[gq * 8 + c];
+    const int Wo = W >> 1, Ho = H >> 1;
+    const long npix = (long)Nb * Wo * Ho;
+    for (long op = (long)blockIdx.x * planes + plane; op < npix; op += (long)gridDim.x * planes) {
+        const int ho = (int)(op % Ho);
+        const long q = op / Ho;
+        const int wo = (int)(q % Wo);
+        const long n = q / Wo;
+        float o[4][8], patch[4][4];
+        conv1_window(x + n * W * H, W, H, wo * 2, ho * 2, wr, br, o, patch);
+        float m[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) m[c] = fmaxf(fmaxf(o[0][c], o[1][c]), fmaxf(o[2][c], o[3][c]));   // rounding is monotone: max then round
+        u32x4 pk = {pack_bf2(m[0], m[1]), pack_bf2(m[2], m[3]), pack_bf2(m[4], m[5]), pack_bf2(m[6], m[7])};
+        *(u32x4*)(p + op * Cout + gq * 8) = pk;
+    }
+}
+
+__global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, const bf16_t* __restrict__ dp,
+                                                             float* __restrict__ dw, float* __restrict__ db, int Nb, int W,
+                                                             int H, int Cout, int pix_per_block) {
+    // Cout == 64: 8 channel groups x 32 pixel lanes
+    const int gq = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    float wr[9][8], br[8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) wr[t][c] = w[t * Cout + gq * 8 + c];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) br[c] = bias[gq * 8 + c];
+    const int Wo = W >> 1, Ho = H >> 1;
+    const long npix = (long)Nb * Wo * Ho;
+    const long p0 = (long)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
+    float acc[10][8];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[t][c] = 0.f;
+    for (long op = p0 + pl; op < p1; op += 32) {
+        const int ho = (int)(op % Ho);
+        const long q = op / Ho;
+        const int wo = (int)(q % Wo);
+        const long n = q / Wo;
+        float o[4][8], patch[4][4];
+        conv1_window(x + n * W * H, W, H, wo * 2, ho * 2, wr, br, o, patch);
+        float g[8];
+        unpack8(*(const u32x4*)(dp + op * Cout + gq * 8), g);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            // the forward stored bf16(max); compare on the same rounded values so ties resolve exactly like the unfused path
+            float r[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = bf_lo(pack_bf2(o[e][c], 0.f));
+            int best = 0; float bvv = r[0];
+#pragma unroll
+            for (int e = 1; e < 4; ++e) if (r[e] > bvv) { bvv = r[e]; best = e; }
+            const float gv = (bvv > 0.f) ? g[c] : 0.f;             // ReLU mask of the winning element
+            acc[9][c] += gv;
+            const int a = best >> 1, b = best & 1;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                // patch[a + t/3][b + t%3] with a run-time (a, b): select among the four window positions
+                const int i = t / 3, j = t % 3;
+                const float xv = (a == 0) ? ((b == 0) ? patch[i][j] : patch[i][j + 1]) : ((b == 0) ? patch[i + 1][j] : patch[i + 1][j + 1]);
+                acc[t][c] = fmaf(xv, gv, acc[t][c]);
+            }
+        }
+    }
+    __shared__ float red[4][10][64];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float v = acc[t][c];
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[t][c] = v;
+        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 8) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) red[wave][t][lane * 8 + c] = acc[t][c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 10 * 64; i += 256) {
+        int t = i / 64, c = i % 64;
+        float v = red[0][t][c] + red[1][t][c] + red[2][t][c] + red[3][t][c];
+        if (t < 9) atomicAdd(dw + t * Cout + c, v);
+        else atomicAdd(db + c, v);
+    }
+}
+
+// ============================================================================================
 // max-pool (VALID, window == stride, kw over axis W in {1,2}, kh over axis H in {1,2})
 //   reference: Network.max_pool  network.py:343-350 ; LSTM_train.py:25,27,30,33
 // ============================================================================================
-__device__ __forceinline__ void unpack8(u32x4 p, float* f) {
-    f[0] = bf_lo(p.x); f[1] = bf_hi(p.x); f[2] = bf_lo(p.y); f[3] = bf_hi(p.y);
-    f[4] = bf_lo(p.z); f[5] = bf_hi(p.z); f[6] = bf_lo(p.w); f[7] = bf_hi(p.w);
-}
 __device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) {
     // bf16 max is exact: keep the raw bits of the larger half (first operand wins ties)
     uint32_t lo = (bf_lo(b) > bf_lo(a)) ? (b & 0xffffu) : (a & 0xffffu);
@@ -565,6 +704,24 @@ extern "C" int ocr_conv1_wgrad(const float* x, const void* dz, float* dw, float*
     long npix = (long)Nb * W * H;
     int ppb = 1024;
     conv1_wgrad_kernel<<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, (const bf16_t*)dz, dw, db, Nb, W, H, Cout, ppb);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+extern "C" int ocr_conv1_pool_fwd(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout,
+                                  void* stream) {
+    if (!x || !w || !bias || !p || (Cout & 7) || Cout > 1024 || 256 % (Cout >> 3) || (W & 1) || (H & 1)) return OCR_ERR_INVALID;
+    long total = (long)Nb * (W / 2) * (H / 2) * (Cout >> 3);
+    conv1_pool_fwd_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+extern "C" int ocr_conv1_pool_bwd(const float* x, const float* w, const float* bias, const void* dp, float* dw, float* db,
+                                  int Nb, int W, int H, int Cout, void* stream) {
+    if (!x || !w || !bias || !dp || !dw || !db || Cout != 64 || (W & 1) || (H & 1)) return OCR_ERR_INVALID;
+    long npix = (long)Nb * (W / 2) * (H / 2);
+    int ppb = 256;
+    conv1_pool_bwd_kernel<<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, w, bias, (const bf16_t*)dp, dw, db, Nb, W, H,
+                                                                                Cout, ppb);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }

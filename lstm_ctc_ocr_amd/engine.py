@@ -121,10 +121,14 @@ class _ConvOp(_Op):
             return (N, W - self.kh + 1, 1, self.co)
         return (N, W, H, self.co)
 
+    fused_pool = None          # set by Engine._lower: conv1 + ReLU + 2x2 max-pool run as one kernel, no full-res activation
+
     def alloc(self, sp, s):
         o = self.out_shape(s)
         dev = self.eng.device
         sp.shape[self.key] = (s, o)
+        if self.fused_pool is not None:
+            return
         sp.buf[self.key + '/y'] = torch.empty(o, dtype=BF16, device=dev)
         sp.buf[self.key + '/dy'] = torch.empty(o, dtype=BF16, device=dev)
         if self.bn:
@@ -152,6 +156,9 @@ class _ConvOp(_Op):
         x = self.prev.y(sp)
         s, o = sp.shape[self.key]
         bias = e.param(self.name + '/biases')
+        if self.fused_pool is not None:
+            ops.conv1_pool_fwd(x, e.param(self.name + '/weights'), bias, out=self.fused_pool.y(sp))
+            return
         y = self.y(sp)
         if self.kind == 'c1':
             ops.conv1_fwd(x, e.param(self.name + '/weights'), bias, relu=self.relu, out=y)
@@ -174,6 +181,10 @@ class _ConvOp(_Op):
 
     def bwd(self, sp):
         e = self.eng
+        if self.fused_pool is not None:     # pool routing + ReLU mask + weight gradient in one recomputing pass
+            ops.conv1_pool_bwd(self.prev.y(sp), e.param(self.name + '/weights'), e.param(self.name + '/biases'),
+                               self.fused_pool.dy(sp), e.grad(self.name + '/weights'), e.grad(self.name + '/biases'))
+            return
         s, o = sp.shape[self.key]
         x = self.prev.y(sp)
         dy = self.dy(sp)                    # already ReLU-masked by the consumer unless this layer has BN
@@ -237,10 +248,15 @@ class _PoolOp(_Op):
         sp.buf[self.key + '/y'] = torch.empty(o, dtype=BF16, device=self.eng.device)
         sp.buf[self.key + '/dy'] = torch.empty(o, dtype=BF16, device=self.eng.device)
 
+    fused_into = None          # the conv1 op that computes this pool's output itself
+
     def fwd(self, sp):
-        ops.maxpool_fwd(self.prev.y(sp), self.kw_t, self.kh_f, out=self.y(sp))
+        if self.fused_into is None:
+            ops.maxpool_fwd(self.prev.y(sp), self.kw_t, self.kh_f, out=self.y(sp))
 
     def bwd(self, sp):
+        if self.fused_into is not None:
+            return
         pdy = self.prev.dy(sp)
         if pdy is not None:
             ops.maxpool_bwd(self.prev.y(sp), self.dy(sp), self.kw_t, self.kh_f, self.prev.mask_in_consumer, out=pdy)
@@ -411,7 +427,7 @@ class Engine(object):
     """Owns parameters, optimiser state and per-shape plans for one Network on one GPU."""
 
     def __init__(self, net, device='cuda:0', seed=None, max_label_len=31, use_graphs=True, group=None,
-                 persistent_lstm=True):
+                 persistent_lstm=True, fuse_conv1_pool=True):
         from .config import cfg
         if not torch.cuda.is_available():
             raise NativeError('Engine needs a ROCm GPU: the hot path has no CPU implementation')
@@ -423,6 +439,7 @@ class Engine(object):
         self.max_label_len = max_label_len
         self.use_graphs = use_graphs
         self.persistent_lstm = persistent_lstm
+        self.fuse_conv1_pool = fuse_conv1_pool
         self.group = group
         self.world = 1
         if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -567,6 +584,11 @@ class Engine(object):
             op.key = '%02d:%s' % (len(self.ops), nd.name)
             self.ops.append(op)
             prev = op
+        if self.fuse_conv1_pool:
+            for a, b in zip(self.ops[:-1], self.ops[1:]):
+                if (isinstance(a, _ConvOp) and a.kind == 'c1' and a.relu and isinstance(b, _PoolOp)
+                        and (b.kw_t, b.kh_f) == (2, 2)):
+                    a.fused_pool, b.fused_into = b, a
 
     def plan(self, N, W):
         key = (N, W)

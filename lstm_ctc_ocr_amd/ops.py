@@ -144,6 +144,20 @@ def conv1_wgrad(x, dz, dw, db):
     call("ocr_conv1_wgrad", ptr(_dev(x)), ptr(dz), ptr(dw), ptr(db), Nb, W, H, dz.shape[-1], _st())
 
 
+def conv1_pool_fwd(x, w, bias, out=None):
+    Nb, W, H = x.shape
+    Cout = w.shape[-1]
+    if out is None:
+        out = torch.empty((Nb, W // 2, H // 2, Cout), dtype=BF16, device=x.device)
+    call("ocr_conv1_pool_fwd", ptr(_dev(x)), ptr(w), ptr(bias), ptr(out), Nb, W, H, Cout, _st())
+    return out
+
+
+def conv1_pool_bwd(x, w, bias, dp, dw, db):
+    Nb, W, H = x.shape
+    call("ocr_conv1_pool_bwd", ptr(_dev(x)), ptr(w), ptr(bias), ptr(dp), ptr(dw), ptr(db), Nb, W, H, w.shape[-1], _st())
+
+
 def maxpool_fwd(x, kw, kh, out=None):
     Nb, W, H, C = x.shape
     if out is None:

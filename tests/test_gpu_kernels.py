@@ -275,6 +275,22 @@ def test_conv1(dev):
     assert relerr(dw.cpu(), wr.grad) < 1e-4 and relerr(db.cpu(), br.grad) < 1e-4
 
 
+def test_conv1_pool_fused_equals_unfused(dev):
+    Nb, W, H, Co = 5, 24, 32, 64
+    x = gen((Nb, W, H), 1).abs().to(dev); w = gen((3, 3, 1, Co), 2, 0.3).to(dev); b = gen((Co,), 3, 0.1).to(dev)
+    y = ops.conv1_fwd(x, w, b)
+    p_ref = ops.maxpool_fwd(y, 2, 2)
+    p = ops.conv1_pool_fwd(x, w, b)
+    assert maxerr(p.float().cpu(), p_ref.float().cpu()) == 0.0                     # bit-identical pooled map
+    dp = bf(gen(tuple(p.shape), 4)).to(dev).to(BF)
+    dz = ops.maxpool_bwd(y, dp, 2, 2, relu_mask=True)
+    dw_ref = torch.zeros_like(w); db_ref = torch.zeros(Co, device=dev)
+    ops.conv1_wgrad(x, dz, dw_ref, db_ref)
+    dw = torch.zeros_like(w); db = torch.zeros(Co, device=dev)
+    ops.conv1_pool_bwd(x, w, b, dp, dw, db)
+    assert relerr(dw.cpu(), dw_ref.cpu()) < 1e-5 and relerr(db.cpu(), db_ref.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("kw,kh", [(2, 2), (1, 2)])
 def test_maxpool(dev, kw, kh):
     Nb, W, H, C = 3, 8, 8, 64
