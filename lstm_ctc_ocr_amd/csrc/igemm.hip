@@ -248,7 +248,7 @@ int ig_try_dispatch(const void* P, long ldp, const void* Q, long ldq, void* out,
     int bn = 64;                                           // widest n-tile that still gives every CU a workgroup
     if (N >= 256 && (long)mt * ((N + 255) / 256) >= 256) bn = 256;
     else if (N >= 128 && (long)mt * ((N + 127) / 128) >= 256) bn = 128;
-    else if (N >= 128 && (long)mt * ((N + 63) / 64) < 256) bn = 128;   // chip cannot be filled anyway: fewer, fatter tiles
+    else if (N >= 128 && (long)mt * ((N + 63) / 64) < 96) bn = 128;    // tiny grid either way: fewer, fatter tiles
 #define IG_CASE(BNV)                                                                  \
     if (bn == BNV) return mode == 1 ? launch_ig<BNV, 1>(g, stream) : launch_ig<BNV, 0>(g, stream);
     IG_CASE(256) IG_CASE(128) IG_CASE(64)
