@@ -37,6 +37,12 @@ int ocr_ctc_workspace_size(int max_label_len, int max_time, int minibatch, size_
 int ocr_ctc_loss(const float* activations, float* gradients, const int* flat_labels, const int* label_lengths,
                  const int* input_lengths, int alphabet_size, int minibatch, int max_time, int max_label_len,
                  int blank_label, float* costs, void* workspace, void* stream);
+/* training form: one launch producing costs and scale * gradient as bf16 [minibatch][max_time][alphabet] (what the backward
+ * GEMMs read); label offsets computed in-kernel.  ocr_ctc_train_supported() == 0 -> use ocr_ctc_loss + ocr_tnc_to_ntc_bf16 */
+int ocr_ctc_train_supported(int alphabet_size, int max_time, int max_label_len);
+int ocr_ctc_loss_train(const float* activations, void* grad_ntc_bf16, float scale, const int* flat_labels,
+                       const int* label_lengths, const int* input_lengths, int alphabet_size, int minibatch, int max_time,
+                       int max_label_len, int blank_label, float* costs, void* stream);
 int ocr_set_ctc_engine(int fast);   /* 1 (default): 4-wave LDS-resident kernel where it fits; 0: one-wave general kernel */
 /* best-path decode (argmax, collapse repeats, drop blank): the greedy counterpart of
  * tf.nn.ctc_beam_search_decoder + sparse_tensor_to_dense(default 0) at network.py:656-657 / test.py:30-31.

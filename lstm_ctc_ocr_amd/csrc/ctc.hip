@@ -208,7 +208,9 @@ __global__ __launch_bounds__(64) void ctc_loss_grad_kernel(
 __global__ __launch_bounds__(256) void ctc_fast_kernel(
     const float* __restrict__ act, float* __restrict__ grad, const int* __restrict__ flat_labels,
     const int* __restrict__ label_off, const int* __restrict__ label_len, const int* __restrict__ input_len,
-    int T, int N, int C, int blank, float* __restrict__ costs, int SMAX) {
+    int T, int N, int C, int blank, float* __restrict__ costs, int SMAX,
+    bf16_t* __restrict__ grad_ntc /* optional: bf16 [N][T][C] = scale * gradient (the layout/dtype the backward GEMMs read) */,
+    float scale) {
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     float* lse = fsm;                          // [T]
@@ -218,18 +220,26 @@ __global__ __launch_bounds__(256) void ctc_fast_kernel(
     float* acc = beta + T * SMAX;              // [4][C]   per-wave posterior accumulators
     int* lab = (int*)(acc + 4 * C);            // [SMAX]
     __shared__ float s_logp;
-    __shared__ int s_repeats;
+    __shared__ int s_repeats, s_off;
 
     const int L = label_len[n];
     const int Tn = min(input_len[n], T);
     const int S = 2 * L + 1;
-    const int* labels = flat_labels + label_off[n];
     const size_t tstride = (size_t)N * C;
     const float* a_n = act + (size_t)n * C;
     float* g_n = grad ? grad + (size_t)n * C : nullptr;
+    bf16_t* gb_n = grad_ntc ? grad_ntc + (size_t)n * T * C : nullptr;
+    const bool want_grad = g_n || gb_n;
 
-    if (tid == 0) s_repeats = 0;
+    if (tid == 0) { s_repeats = 0; s_off = 0; }
     __syncthreads();
+    if (label_off == nullptr) {            // exclusive prefix sum of the label lengths, done here instead of a scan launch
+        int part = 0;
+        for (int i = tid; i < n; i += 256) part += label_len[i];
+        if (part) atomicAdd(&s_off, part);
+        __syncthreads();
+    }
+    const int* labels = flat_labels + (label_off ? label_off[n] : s_off);
     int rep = 0;
     for (int s = tid; s < S; s += 256) {
         lab[s] = (s & 1) ? labels[s >> 1] : blank;
@@ -238,10 +248,13 @@ __global__ __launch_bounds__(256) void ctc_fast_kernel(
     if (rep) atomicAdd(&s_repeats, rep);
     __syncthreads();
     const bool feasible = (Tn > 0) && (L + s_repeats <= Tn);
-    if (g_n) {          // frames this sample does not own (and everything when infeasible): zero gradient
+    if (want_grad) {    // frames this sample does not own (and everything when infeasible): zero gradient
         const int t0 = feasible ? Tn : 0;
         for (int t = t0 + wave; t < T; t += 4)
-            for (int k = lane; k < C; k += 64) g_n[t * tstride + k] = 0.f;
+            for (int k = lane; k < C; k += 64) {
+                if (g_n) g_n[t * tstride + k] = 0.f;
+                if (gb_n) gb_n[(size_t)t * C + k] = 0;
+            }
     }
     if (!feasible) { if (tid == 0) costs[n] = 0.f; return; }
 
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(256) void ctc_fast_kernel(
         float e1 = __shfl(a, S - 1, 64);
         float e2 = (S >= 2) ? __shfl(a, S - 2, 64) : NEG_INF;
         if (lane == 0) { s_logp = lse2(e1, e2); costs[n] = -s_logp; }
-    } else if (wave == 1 && g_n) {
+    } else if (wave == 1 && want_grad) {
         const int s = lane;
         const bool in = s < S;
         const int my = in ? lab[s] : blank;
@@ -301,7 +314,7 @@ __global__ __launch_bounds__(256) void ctc_fast_kernel(
         }
     }
     __syncthreads();
-    if (!g_n) return;
+    if (!want_grad) return;
     // phase 4
     const float logp = s_logp;
     float* wacc = acc + wave * C;
@@ -312,9 +325,12 @@ __global__ __launch_bounds__(256) void ctc_fast_kernel(
             if (al != NEG_INF && be != NEG_INF) atomicAdd(&wacc[lab[lane]], expf(al + be - logy[t * SMAX + lane] - logp));
         }
         const float* row = a_n + t * tstride;
-        float* grow = g_n + t * tstride;
         const float l = lse[t];
-        for (int k = lane; k < C; k += 64) grow[k] = expf(row[k] - l) - wacc[k];
+        for (int k = lane; k < C; k += 64) {
+            const float v = expf(row[k] - l) - wacc[k];
+            if (g_n) g_n[t * tstride + k] = v;
+            if (gb_n) gb_n[(size_t)t * C + k] = f2bf(v * scale);
+        }
     }
 }
 
@@ -412,7 +428,7 @@ extern "C" int ocr_ctc_loss(const float* activations, float* gradients, const in
         if (SMAX <= 64 && flds <= 64 * 1024 && g_ctc_fast) {
             ctc_fast_kernel<<<minibatch, 256, flds, stream>>>(activations, gradients, flat_labels, label_off, label_lengths,
                                                              input_lengths, max_time, minibatch, alphabet_size, blank_label, costs,
-                                                             SMAX);
+                                                             SMAX, nullptr, 1.0f);
             OCR_CHECK_LAUNCH();
             return OCR_OK;
         }
@@ -428,6 +444,34 @@ extern "C" int ocr_ctc_loss(const float* activations, float* gradients, const in
     else if (SMAX <= 128) LAUNCH_CTC(2);
     else LAUNCH_CTC(4);
 #undef LAUNCH_CTC
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+
+static size_t ctc_fast_lds(int SMAX, int max_time, int alphabet_size) {
+    size_t flds = ((size_t)max_time * (1 + 3 * SMAX) + 4 * (size_t)alphabet_size) * sizeof(float) + (size_t)SMAX * sizeof(int);
+    return (flds + 15) & ~(size_t)15;
+}
+// Training form: costs + the gradient ALREADY in the layout / dtype / scale the backward GEMMs consume
+// (bf16 [N][T][C], multiplied by `scale` = 1/(batch*world)); label offsets are computed in-kernel.  One launch instead of
+// scan + loss + transpose.  Covers S = 2L+1 <= 64 with the [T][S] tables in LDS; returns OCR_ERR_INVALID otherwise
+// (callers then use ocr_ctc_loss + ocr_tnc_to_ntc_bf16).
+extern "C" int ocr_ctc_train_supported(int alphabet_size, int max_time, int max_label_len) {
+    const int SMAX = smax_for(max_label_len);
+    return SMAX <= 64 && ctc_fast_lds(SMAX, max_time, alphabet_size) <= 64 * 1024;
+}
+extern "C" int ocr_ctc_loss_train(const float* activations, void* grad_ntc_bf16, float scale, const int* flat_labels,
+                                  const int* label_lengths, const int* input_lengths, int alphabet_size, int minibatch,
+                                  int max_time, int max_label_len, int blank_label, float* costs, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!activations || !grad_ntc_bf16 || !flat_labels || !label_lengths || !input_lengths || !costs) return OCR_ERR_INVALID;
+    if (alphabet_size <= 0 || minibatch <= 0 || max_time <= 0 || max_label_len < 0 || blank_label < 0 ||
+        blank_label >= alphabet_size || !ocr_ctc_train_supported(alphabet_size, max_time, max_label_len))
+        return OCR_ERR_INVALID;
+    const int SMAX = smax_for(max_label_len);
+    ctc_fast_kernel<<<minibatch, 256, ctc_fast_lds(SMAX, max_time, alphabet_size), stream>>>(
+        activations, nullptr, flat_labels, nullptr, label_lengths, input_lengths, max_time, minibatch, alphabet_size, blank_label,
+        costs, SMAX, (bf16_t*)grad_ntc_bf16, scale);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }

@@ -49,21 +49,21 @@ __device__ __forceinline__ bf16x8 tn2_frag(const unsigned char* a0) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int MODE /*0 plain, 1 conv3x3*/>
+template <int MODE /*0 plain, 1 conv3x3, 2 conv3x3 with Cin == 64: taps (2p, 2p+1) share one 128-channel A tile*/>
 __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
     constexpr int TILE = 64 * 256;                   // bytes of one operand tile: 64 rows x 128 channels bf16
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 stages x (A tile | B tile) = 64 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 1, wj = wave & 1;
-    const int itiles = g.I / 128;
-    const int tap = (MODE == 1) ? (int)(blockIdx.x / itiles) : 0;
-    const int i0 = (int)(blockIdx.x % itiles) * 128;
+    const int itiles = (MODE == 2) ? 1 : g.I / 128;
+    const int tap = (MODE == 1) ? (int)(blockIdx.x / itiles) : (MODE == 2 ? 2 * (int)blockIdx.x : 0);
+    const int i0 = (MODE == 2) ? 0 : (int)(blockIdx.x % itiles) * 128;
     const int j0 = blockIdx.y * 128;
     const int kbeg = blockIdx.z * g.k_per_split;
     const int kend = min(g.Mk, kbeg + g.k_per_split);
     const int dw = tap / 3 - 1, dh = tap % 3 - 1;
-    const bool do_cs = g.colsum != nullptr && i0 == 0 && (MODE == 0 || tap == 4);
+    const bool do_cs = g.colsum != nullptr && i0 == 0 && (MODE == 0 || tap == 4);     // (MODE 2: the pair (4, 5) block)
     const bf16_t* zero = (const bf16_t*)tn2_zero_page;
 
     // DMA geometry: instruction j of wave w covers tile rows (w*4 + j)*4 .. +3, lane -> (row lane>>4, 16-B position lane&15).
@@ -76,6 +76,8 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
     const bf16_t* pa[4];
     const bf16_t* pb[4];
     int pw[4], ph[4];
+    int ldw[4] = {0, 0, 0, 0}, ldh[4] = {0, 0, 0, 0};
+    bool ltap_ok[4] = {true, true, true, true};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = (wave * 4 + j) * 4 + rsub;
@@ -86,8 +88,14 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
         if (MODE == 0) {
             pa[j] = g.A + g.a_row_off + i0 + q * 8;          // row term added per step (row-group skip is not affine)
             pw[j] = ph[j] = 0;
-        } else {
+        } else if (MODE == 1) {
             pa[j] = g.A + (m + (long)dw * g.cH + dh) * g.cC + i0 + q * 8;
+            ph[j] = (int)(m % g.cH);
+            pw[j] = (int)((m / g.cH) % g.cW);
+        } else {                                             // this lane's chunk belongs to tap `tap` (q < 8) or `tap + 1`
+            const int tl = tap + (q >> 3);
+            ldw[j] = tl / 3 - 1; ldh[j] = tl % 3 - 1; ltap_ok[j] = tl < 9;
+            pa[j] = g.A + (m + (long)ldw[j] * g.cH + ldh[j]) * g.cC + (q & 7) * 8;
             ph[j] = (int)(m % g.cH);
             pw[j] = (int)((m / g.cH) % g.cW);
         }
@@ -107,13 +115,15 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
                 if (MODE == 0) {
                     long phys = (long)m + (g.grp > 0 ? (long)(m / g.grp) * g.skip : 0);
                     srca = pa[j] + phys * g.lda;
-                } else if ((unsigned)(pw[j] + dw) < (unsigned)g.cW && (unsigned)(ph[j] + dh) < (unsigned)g.cH) {
+                } else if (MODE == 1) {
+                    if ((unsigned)(pw[j] + dw) < (unsigned)g.cW && (unsigned)(ph[j] + dh) < (unsigned)g.cH) srca = pa[j] + koff * g.cC;
+                } else if (ltap_ok[j] && (unsigned)(pw[j] + ldw[j]) < (unsigned)g.cW && (unsigned)(ph[j] + ldh[j]) < (unsigned)g.cH) {
                     srca = pa[j] + koff * g.cC;
                 }
             }
             __builtin_amdgcn_global_load_lds((gptr_t)srca, (lptr_t)(sa + (wave * 4 + j) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)srcb, (lptr_t)(sb + (wave * 4 + j) * 1024), 16, 0, 0);
-            if (MODE == 1) {                                  // advance this row's pixel by 64 rows for the next step
+            if (MODE != 0) {                                  // advance this row's pixel by 64 rows for the next step
                 int h = ph[j] + step_h, w = pw[j] + step_w;
                 if (h >= g.cH) { h -= g.cH; ++w; }
                 while (w >= g.cW) w -= g.cW;
@@ -186,6 +196,10 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
     float* out = g.out;
     long ldo = g.ldo;
     if (MODE == 1) { out += (long)tap * g.cC * g.J; ldo = g.J; }
+    if (MODE == 2) {                                  // rows 0..63 -> tap `tap`, rows 64..127 -> tap + 1 (wave row wi selects)
+        if (tap + wi >= 9) return;
+        out += (long)(tap + wi) * 64 * g.J - (long)wi * 64 * g.J; ldo = g.J;
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -203,13 +217,14 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
 int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* out, long ldo, int Mk, int I, int J, int mode,
                      int grp, int skip, long a_row_off, int cW, int cH, int cC, float scale, int splits, float* colsum,
                      hipStream_t stream) {
-    if ((I & 127) || (J & 127) || Mk < 256) return -1;
+    const bool pair = (mode == 1 && I == 64);          // Cin == 64: two taps per A tile
+    if ((!pair && (I & 127)) || (J & 127) || Mk < 256) return -1;
     Tn2Args g = {};
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb; g.Mk = Mk; g.I = I; g.J = J;
     g.grp = grp; g.skip = skip; g.a_row_off = a_row_off; g.cW = cW; g.cH = cH; g.cC = cC;
     g.out = out; g.ldo = ldo; g.scale = scale; g.colsum = colsum;
-    const int taps = mode == 1 ? 9 : 1;
-    const long tiles = (long)taps * (I / 128) * (J / 128);
+    const int taps = pair ? 5 : (mode == 1 ? 9 : 1);
+    const long tiles = (long)taps * (pair ? 1 : I / 128) * (J / 128);
     if (splits <= 0) {                       // ~300 workgroups measured best (split sweep in tools/wgrad_probe.py): enough to
         splits = (int)((300 + tiles - 1) / tiles);   // fill 256 CUs, few enough that the fp32 atomic epilogue stays small
         int maxs = Mk / 256; if (maxs < 1) maxs = 1;
@@ -217,14 +232,16 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
         if (splits < 1) splits = 1;
     }
     g.k_per_split = ceil_div(ceil_div(Mk, splits), 64) * 64;
-    static bool attr_set[2] = {false, false};
-    const void* fn = mode == 1 ? (const void*)gemm_tn2_kernel<1> : (const void*)gemm_tn2_kernel<0>;
-    if (!attr_set[mode]) {
+    static bool attr_set[3] = {false, false, false};
+    const int km = pair ? 2 : mode;
+    const void* fn = km == 2 ? (const void*)gemm_tn2_kernel<2> : (km == 1 ? (const void*)gemm_tn2_kernel<1> : (const void*)gemm_tn2_kernel<0>);
+    if (!attr_set[km]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) return OCR_ERR_EXEC;
-        attr_set[mode] = true;
+        attr_set[km] = true;
     }
-    dim3 grid((I / 128) * taps, J / 128, ceil_div(Mk, g.k_per_split));
-    if (mode == 1) gemm_tn2_kernel<1><<<grid, 256, 65536, stream>>>(g);
+    dim3 grid(pair ? 5 : (I / 128) * taps, J / 128, ceil_div(Mk, g.k_per_split));
+    if (km == 2) gemm_tn2_kernel<2><<<grid, 256, 65536, stream>>>(g);
+    else if (km == 1) gemm_tn2_kernel<1><<<grid, 256, 65536, stream>>>(g);
     else gemm_tn2_kernel<0><<<grid, 256, 65536, stream>>>(g);
     OCR_CHECK_LAUNCH();
     return OCR_OK;

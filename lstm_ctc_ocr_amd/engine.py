@@ -616,10 +616,15 @@ class Engine(object):
 
     def _loss_and_backward(self, sp):
         logits = self.ops[-1].y(sp)
-        ops.ctc_loss(logits, sp.labels, sp.labels_len, sp.seq_len, self.max_label_len, blank=0, want_grad=True,
-                     workspace=sp.ctc_ws, costs=sp.costs, grads=sp.ctc_grad)
         # loss = mean over the GLOBAL batch -> d loss / d cost_n = 1 / (N * world)   (network.py:655)
-        ops.tnc_to_ntc_bf16(sp.ctc_grad, self.ops[-1].dy(sp), ocr_dist.loss_scale(sp.N, self.world))
+        scale = ocr_dist.loss_scale(sp.N, self.world)
+        if ops.ctc_train_supported(sp.C, sp.T, self.max_label_len):
+            ops.ctc_loss_train(logits, self.ops[-1].dy(sp), scale, sp.labels, sp.labels_len, sp.seq_len, self.max_label_len,
+                               sp.costs, blank=0)
+        else:
+            ops.ctc_loss(logits, sp.labels, sp.labels_len, sp.seq_len, self.max_label_len, blank=0, want_grad=True,
+                         workspace=sp.ctc_ws, costs=sp.costs, grads=sp.ctc_grad)
+            ops.tnc_to_ntc_bf16(sp.ctc_grad, self.ops[-1].dy(sp), scale)
         for op in reversed(self.ops):
             op.bwd(sp)
 

@@ -47,6 +47,18 @@ def ctc_loss(acts, flat_labels, label_lengths, input_lengths, max_label_len, bla
     return costs, (grads if want_grad else None)
 
 
+def ctc_train_supported(C, T, max_label_len):
+    return bool(nat.lib().ocr_ctc_train_supported(C, T, max_label_len))
+
+
+def ctc_loss_train(acts, grad_ntc_bf16, scale, flat_labels, label_lengths, input_lengths, max_label_len, costs, blank=0):
+    """costs + scale * d cost / d acts written as bf16 [N, T, C] in one launch."""
+    T, N, C = acts.shape
+    call("ocr_ctc_loss_train", ptr(_dev(acts)), ptr(grad_ntc_bf16), float(scale), ptr(flat_labels), ptr(label_lengths),
+         ptr(input_lengths), C, N, T, max_label_len, blank, ptr(costs), _st())
+    return costs
+
+
 def ctc_greedy_decode(acts, input_lengths, blank=0, pad_value=0):
     T, N, C = acts.shape
     out = torch.empty((N, T), dtype=torch.int32, device=acts.device)

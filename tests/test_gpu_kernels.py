@@ -91,6 +91,13 @@ def _ctc_case(dev, T, N, C, lens, in_lens, seed, blank=0, labels=None):
     c = costs.cpu().numpy(); g = grads.cpu().numpy()
     assert np.allclose(c, ref_c, rtol=1e-4, atol=1e-4), (c, ref_c)
     assert np.abs(g - ref_g).max() < 5e-4, np.abs(g - ref_g).max()   # fp32 log-space over T frames
+    if ops.ctc_train_supported(C, T, int(max(ll.max(), 1))):       # fused training form: bf16 [N,T,C] scaled gradient, in-kernel offsets
+        gb = torch.full((N, T, C), 7.0, dtype=BF, device=dev)
+        c3 = torch.empty(N, device=dev)
+        ops.ctc_loss_train(a, gb, 0.25, fl, torch.from_numpy(ll).to(dev), torch.from_numpy(il).to(dev), int(max(ll.max(), 1)), c3, blank)
+        assert np.allclose(c3.cpu().numpy(), ref_c, rtol=1e-4, atol=1e-4)
+        want = bf(torch.from_numpy(ref_g).permute(1, 0, 2) * 0.25)
+        assert maxerr(gb.float().cpu(), want) < 2e-3
     # score-only call must not touch gradients and give the same costs
     costs2, _ = ops.ctc_loss(a, fl, torch.from_numpy(ll).to(dev), torch.from_numpy(il).to(dev), int(max(ll.max(), 1)), blank,
                              want_grad=False)
