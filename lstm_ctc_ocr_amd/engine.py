@@ -40,6 +40,11 @@ class _Op(object):
     def __init__(self, eng, node, prev):
         self.eng, self.node, self.prev, self.name = eng, node, prev, node.name
         self.key = node.name          # buffer key; made unique by Engine._lower (the reference reuses layer names)
+        self.inputs = [prev]
+        self.consumers = 0            # how many ops read this op's output (residual graphs: > 1)
+
+    def grad_owner(self):             # the op whose dy buffer really receives gradients for this output (views forward it)
+        return self
 
     def out_shape(self, in_shape):
         raise NotImplementedError
@@ -71,6 +76,7 @@ class _InputOp(_Op):
     def __init__(self, eng):
         self.eng, self.name, self.prev, self.node = eng, 'data', None, None
         self.key = 'data'
+        self.inputs, self.consumers = [], 0
 
     def y(self, sp):
         return sp.x
@@ -97,6 +103,10 @@ class _ConvOp(_Op):
             if self.ci % 32 or self.co % 8:
                 raise NotImplementedError('%s: 3x3 conv needs C_in %% 32 == 0 and C_out %% 8 == 0' % self.name)
             self.kind = '3x3'
+        elif (self.kh, self.kw) == (1, 1):
+            if self.ci % 8 or self.co % 8:
+                raise NotImplementedError('%s: 1x1 conv needs C_in %% 8 == 0 and C_out %% 8 == 0' % self.name)
+            self.kind = '1x1'           # a plain GEMM over pixels
         elif self.padding == 'VALID':
             self.kind = 'full'          # kernel spans the whole feature axis -> plain GEMM over overlapping rows
         else:
@@ -167,6 +177,9 @@ class _ConvOp(_Op):
         relu_now = self.relu and not self.bn
         if self.kind == '3x3':
             ops.conv3x3(x, self.wpack.view(self.co, 3, 3, self.ci), out=tgt, bias=bias, relu=relu_now)
+        elif self.kind == '1x1':
+            Mx = s[0] * s[1] * s[2]
+            ops.gemm_nt(x.view(Mx, self.ci), self.wpack, out=tgt.view(Mx, self.co), bias=bias, relu=relu_now)
         else:
             N, W, H, C = s
             Wo = o[1]
@@ -202,12 +215,20 @@ class _ConvOp(_Op):
         if self.kind == 'c1':
             ops.conv1_wgrad(x, dz, dw, db)
             return
-        pdy = self.prev.dy(sp)
+        pdy, finish = e.grad_dst(sp, self.prev)
         pmask = self.prev.y(sp) if self.prev.mask_in_consumer else None
         if self.kind == '3x3':
             ops.conv3x3_wgrad(x, dz, dw, dbias=db)      # bias gradient rides on the weight-gradient pass
             if pdy is not None:
                 ops.conv3x3(dz, self.wdgrad.view(self.ci, 3, 3, self.co), out=pdy, mask=pmask)
+                finish()
+        elif self.kind == '1x1':
+            ops.gemm_tn(x.view(M, self.ci), dz.view(M, self.co), dw.view(self.ci, self.co), colsum=db)
+            if pdy is not None:
+                wsh = e.shadow(self.name + '/weights').view(self.ci, self.co)      # Q[n = ci][k = co]
+                ops.gemm_nt(dz.view(M, self.co), wsh, out=pdy.view(M, self.ci),
+                            mask=None if pmask is None else pmask.view(M, self.ci))
+                finish()
         else:
             N, W, H, C = s
             Wo = o[1]
@@ -222,6 +243,7 @@ class _ConvOp(_Op):
                 wsh = e.shadow(self.name + '/weights').view(K, self.co)      # [K][co] bf16, k = co contiguous
                 ops.gemm_nt(dz.view(M, self.co), wsh, out=col, M=M, N=K, K=self.co)
                 ops.conv5_col2im(col, pdy, N, W, H * C)
+                finish()
 
 
 class _PoolOp(_Op):
@@ -257,9 +279,10 @@ class _PoolOp(_Op):
     def bwd(self, sp):
         if self.fused_into is not None:
             return
-        pdy = self.prev.dy(sp)
+        pdy, finish = self.eng.grad_dst(sp, self.prev)
         if pdy is not None:
             ops.maxpool_bwd(self.prev.y(sp), self.dy(sp), self.kw_t, self.kh_f, self.prev.mask_in_consumer, out=pdy)
+            finish()
 
 
 class _ViewOp(_Op):
@@ -288,44 +311,107 @@ class _ViewOp(_Op):
         d = self.prev.dy(sp)
         return None if d is None else d.view(sp.shape[self.key][1])
 
+    def grad_owner(self):
+        return self.prev.grad_owner()
+
+
+class _AddOp(_Op):
+    """Network.add (network.py:461-463): element-wise sum of two feature maps (residual connections)."""
+
+    def dy_needed(self):
+        return True
+
+    def out_shape(self, s):
+        return s
+
+    def alloc(self, sp, s):
+        sp.shape[self.key] = (s, s)
+        sp.buf[self.key + '/y'] = torch.empty(s, dtype=BF16, device=self.eng.device)
+        sp.buf[self.key + '/dy'] = torch.empty(s, dtype=BF16, device=self.eng.device)
+
+    def fwd(self, sp):
+        ops.eltwise(0, self.inputs[0].y(sp), self.inputs[1].y(sp), self.y(sp))
+
+    def bwd(self, sp):
+        for p in self.inputs:
+            self.eng.deliver(sp, p, self.dy(sp))
+
+
+class _ReluOp(_Op):
+    """Network.relu (network.py:340-341) as a stand-alone layer (after a residual add)."""
+
+    def dy_needed(self):
+        return True
+
+    def out_shape(self, s):
+        return s
+
+    def alloc(self, sp, s):
+        sp.shape[self.key] = (s, s)
+        sp.buf[self.key + '/y'] = torch.empty(s, dtype=BF16, device=self.eng.device)
+        sp.buf[self.key + '/dy'] = torch.empty(s, dtype=BF16, device=self.eng.device)
+
+    def fwd(self, sp):
+        ops.eltwise(1, self.prev.y(sp), None, self.y(sp))
+
+    def bwd(self, sp):
+        self.eng.deliver(sp, self.prev, self.dy(sp), mask=self.y(sp))
+
 
 class _BiLstmOp(_Op):
     def __init__(self, eng, node, prev):
         super(_BiLstmOp, self).__init__(eng, node, prev)
         a = node.attrs
         self.U, self.C, self.D = a['num_hids'] // 2, a['nclasses'], a['din']
+        self.with_fc = a.get('with_fc', True)       # False: a hidden layer of a stacked BiLSTM, output = [N, T, 2U]
         if self.U % 32 or self.D % 32 or self.C % 8:
             raise NotImplementedError('%s: needs hidden %% 64 == 0, input features %% 32 == 0, classes %% 8 == 0' % self.name)
         dev, U, D, C = eng.device, self.U, self.D, self.C
         self.wxT = torch.empty((8 * U, D), dtype=BF16, device=dev)
         self.whT = torch.empty((2, 4 * U, U), dtype=BF16, device=dev)
         self.bias = torch.empty(8 * U, dtype=F32, device=dev)
-        self.wfcT = torch.empty((C, 2 * U), dtype=BF16, device=dev)
+        self.wfcT = torch.empty((C, 2 * U), dtype=BF16, device=dev) if self.with_fc else None
         self.wcat = torch.empty((D, 8 * U), dtype=BF16, device=dev)
+
+    def dy_needed(self):
+        return True
 
     def out_shape(self, s):
         N, T, D = s
-        return (T, N, self.C)
+        return (T, N, self.C) if self.with_fc else (N, T, 2 * self.U)
+
+    def y(self, sp):
+        if self.with_fc:
+            return sp.buf[self.key + '/y']
+        (N, T, _), _ = sp.shape[self.key]
+        return sp.buf[self.key + '/hout'].view(N, T, 2 * self.U)
+
+    def dy(self, sp):
+        if self.with_fc:
+            return sp.buf[self.key + '/dy']
+        (N, T, _), _ = sp.shape[self.key]
+        return sp.buf[self.key + '/dhout'].view(N, T, 2 * self.U)
 
     def alloc(self, sp, s):
         N, T, D = s
         U, C, dev = self.U, self.C, self.eng.device
         R = N * T
-        sp.shape[self.key] = (s, (T, N, C))
+        sp.shape[self.key] = (s, self.out_shape(s))
         b = sp.buf
         b[self.key + '/xproj'] = torch.empty((R, 8 * U), dtype=F32, device=dev)
         b[self.key + '/hout'] = torch.zeros((R, 2 * U), dtype=BF16, device=dev)
         b[self.key + '/gates'] = torch.zeros((2, R, 4 * U), dtype=F32, device=dev)
         b[self.key + '/cell'] = torch.zeros((2, R, U), dtype=F32, device=dev)
-        b[self.key + '/y'] = torch.empty((T, N, C), dtype=F32, device=dev)          # logits, time-major
-        b[self.key + '/dy'] = torch.empty((R, C), dtype=BF16, device=dev)           # d loss / d logits, [N,T,C]
+        if self.with_fc:
+            b[self.key + '/y'] = torch.empty((T, N, C), dtype=F32, device=dev)      # logits, time-major
+            b[self.key + '/dy'] = torch.empty((R, C), dtype=BF16, device=dev)       # d loss / d logits, [N,T,C]
         b[self.key + '/dhout'] = torch.empty((R, 2 * U), dtype=BF16, device=dev)
         b[self.key + '/dz'] = torch.zeros((R, 8 * U), dtype=BF16, device=dev)
         b[self.key + '/dc'] = torch.zeros((2, N, U), dtype=F32, device=dev)
         b[self.key + '/hprev'] = torch.empty((2, R, U), dtype=BF16, device=dev)
         b[self.key + '/sync_f'] = torch.zeros(ops.lstm_seq_sync_words(N), dtype=I32, device=dev)
         b[self.key + '/sync_b'] = torch.zeros(ops.lstm_seq_sync_words(N), dtype=I32, device=dev)
-        sp.lstm_sync = (b[self.key + '/sync_f'], b[self.key + '/sync_b'])
+        sp.lstm_sync = getattr(sp, 'lstm_sync', ()) + (b[self.key + '/sync_f'], b[self.key + '/sync_b'])
 
     def pack_jobs(self):
         e, U, D = self.eng, self.U, self.D
@@ -335,8 +421,9 @@ class _BiLstmOp(_Op):
             jobs.append(dict(type=0, R=D, Cc=4 * U, ldin=4 * U, lstm_units=U, src=w[:D], dst=self.wxT[d * 4 * U:(d + 1) * 4 * U]))
             jobs.append(dict(type=0, R=U, Cc=4 * U, ldin=4 * U, lstm_units=U, src=w[D:], dst=self.whT[d]))
             jobs.append(dict(type=2, R=D, Cc=4 * U, ldin=4 * U, ldout=8 * U, src=w, dst=self.wcat[:, d * 4 * U:]))
-        wf = e.param(self.name + '/weights')
-        jobs.append(dict(type=0, R=wf.shape[0], Cc=wf.shape[1], ldin=wf.shape[1], src=wf, dst=self.wfcT))
+        if self.with_fc:
+            wf = e.param(self.name + '/weights')
+            jobs.append(dict(type=0, R=wf.shape[0], Cc=wf.shape[1], ldin=wf.shape[1], src=wf, dst=self.wfcT))
         return jobs
 
     def refresh(self):
@@ -357,19 +444,21 @@ class _BiLstmOp(_Op):
             for s in range(T):
                 ops.lstm_fwd_step(b[self.key + '/xproj'], self.whT, sp.seq_len, b[self.key + '/hout'],
                                   b[self.key + '/gates'], b[self.key + '/cell'], N, T, U, s, 1.0)
-        ops.gemm_nt(b[self.key + '/hout'], self.wfcT, out=b[self.key + '/y'].view(R, C),
-                    bias=e.param(self.name + '/biases'), rowswap=(T, N))
+        if self.with_fc:
+            ops.gemm_nt(b[self.key + '/hout'], self.wfcT, out=b[self.key + '/y'].view(R, C),
+                        bias=e.param(self.name + '/biases'), rowswap=(T, N))
 
     def bwd(self, sp):
         e, U, C, D = self.eng, self.U, self.C, self.D
         (N, T, _), _ = sp.shape[self.key]
         R = N * T
         b = sp.buf
-        dl = b[self.key + '/dy']
         hout = b[self.key + '/hout']
-        # FC: dW += H^T dL, db += colsum dL, dH = dL Wfc^T
-        ops.gemm_tn(hout, dl, e.grad(self.name + '/weights'), colsum=e.grad(self.name + '/biases'))
-        ops.gemm_nt(dl, e.shadow(self.name + '/weights'), out=b[self.key + '/dhout'])
+        if self.with_fc:
+            dl = b[self.key + '/dy']
+            # FC: dW += H^T dL, db += colsum dL, dH = dL Wfc^T
+            ops.gemm_tn(hout, dl, e.grad(self.name + '/weights'), colsum=e.grad(self.name + '/biases'))
+            ops.gemm_nt(dl, e.shadow(self.name + '/weights'), out=b[self.key + '/dhout'])
         # BPTT, both directions per launch
         wsh = e.shadow(self.name + '/fw/weights')
         stride = e.offset(self.name + '/bw/weights') - e.offset(self.name + '/fw/weights')
@@ -390,10 +479,11 @@ class _BiLstmOp(_Op):
             ops.gemm_tn(x, dzd, dW[:D], Mk=R, I=D, J=4 * U, lda=D, ldb=8 * U, ldo=4 * U,
                         colsum=e.grad('%s/%s/biases' % (self.name, tag)))
             ops.gemm_tn(b[self.key + '/hprev'][d], dzd, dW[D:], Mk=R, I=U, J=4 * U, lda=U, ldb=8 * U, ldo=4 * U)
-        pdy = self.prev.dy(sp)
+        pdy, finish = e.grad_dst(sp, self.prev)
         if pdy is not None:
             pmask = self.prev.y(sp).view(R, D) if self.prev.mask_in_consumer else None
             ops.gemm_nt(dz, self.wcat, out=pdy.view(R, D), mask=pmask)
+            finish()
 
 
 # ====================================================================================================== plan per shape
@@ -408,11 +498,14 @@ class ShapePlan(object):
         self.labels = torch.zeros(N * eng.max_label_len, dtype=I32, device=dev)
         self.labels_len = torch.zeros(N, dtype=I32, device=dev)
         self.seq_len = torch.ones(N, dtype=I32, device=dev)
-        s = (N, W, eng.num_features)
+        self.oshape = {'data': (N, W, eng.num_features)}
+        self.scratch = {}
+        self.dy_done = set()
         for op in eng.ops:
+            s = self.oshape[op.prev.key]
             op.alloc(self, s)
-            s = op.out_shape(s)
-        self.T, _, self.C = s
+            self.oshape[op.key] = op.out_shape(s)
+        self.T, _, self.C = self.oshape[eng.ops[-1].key]
         self.costs = torch.zeros(N, dtype=F32, device=dev)
         self.ctc_grad = torch.empty((self.T, N, self.C), dtype=F32, device=dev)
         self.ctc_ws = torch.empty(ops.ctc_workspace_bytes(eng.max_label_len, self.T, N), dtype=torch.uint8, device=dev)
@@ -567,28 +660,87 @@ class Engine(object):
 
     # ------------------------------------------------------------------ lowering
     def _lower(self, net):
-        node = net.get_output('logits')
-        chain = []
-        while node.op != 'input':
-            chain.append(node)
-            node = node.inputs[0]
-        chain.reverse()
-        prev = _InputOp(self)
-        prev.dy_needed = lambda: False
+        """Topological lowering of the plan reachable from 'logits' (a chain for the shipped models, a DAG with residual
+        adds for deeper extractors).  Only data edges count: the second input of bi_lstm is the time_step_len slot."""
+        table = {'conv': _ConvOp, 'max_pool': _PoolOp, 'reshape_squeeze': _ViewOp, 'dropout': _ViewOp, 'bi_lstm': _BiLstmOp,
+                 'add': _AddOp, 'relu': _ReluOp}
+        data_op = _InputOp(self)
+        data_op.dy_needed = lambda: False
+        built = {}
         self.ops = []
-        table = {'conv': _ConvOp, 'max_pool': _PoolOp, 'reshape_squeeze': _ViewOp, 'dropout': _ViewOp, 'bi_lstm': _BiLstmOp}
-        for nd in chain:
+
+        def data_inputs(nd):
+            return nd.inputs if nd.op == 'add' else nd.inputs[:1]
+
+        def build(nd):
+            if nd.op == 'input':
+                return data_op
+            if id(nd) in built:
+                return built[id(nd)]
+            ins = [build(i) for i in data_inputs(nd)]
             if nd.op not in table:
                 raise NotImplementedError('layer %r (%s) has no gfx950 lowering yet' % (nd.op, nd.name))
-            op = table[nd.op](self, nd, prev)
+            op = table[nd.op](self, nd, ins[0])
+            op.inputs = ins
             op.key = '%02d:%s' % (len(self.ops), nd.name)
+            for i in ins:
+                i.grad_owner().consumers += 1
+            built[id(nd)] = op
             self.ops.append(op)
-            prev = op
+            return op
+
+        import sys
+        sys.setrecursionlimit(max(sys.getrecursionlimit(), 10000))
+        build(net.get_output('logits'))
         if self.fuse_conv1_pool:
             for a, b in zip(self.ops[:-1], self.ops[1:]):
-                if (isinstance(a, _ConvOp) and a.kind == 'c1' and a.relu and isinstance(b, _PoolOp)
-                        and (b.kw_t, b.kh_f) == (2, 2)):
+                if (isinstance(a, _ConvOp) and a.kind == 'c1' and a.relu and isinstance(b, _PoolOp) and b.prev is a
+                        and a.consumers == 1 and (b.kw_t, b.kh_f) == (2, 2)):
                     a.fused_pool, b.fused_into = b, a
+
+    # ------------------------------------------------------------------ gradient delivery (residual graphs)
+    def _scratch(self, sp, like):
+        key = (tuple(like.shape), like.dtype)
+        if key not in sp.scratch:
+            sp.scratch[key] = torch.empty_like(like)
+        return sp.scratch[key]
+
+    def grad_dst(self, sp, producer):
+        """Where a consumer's backward kernel should write d(loss)/d(producer output), plus a `finish` callback.
+        Single-consumer producers (every tensor of the shipped chain) get their dy buffer directly; for a tensor with
+        several consumers the first delivery writes it and later ones go through a scratch buffer + one add kernel."""
+        d = producer.dy(sp)
+        if d is None:
+            return None, (lambda: None)
+        owner = producer.grad_owner()
+        if owner.consumers <= 1 or owner.key not in sp.dy_done:
+            sp.dy_done.add(owner.key)
+            return d, (lambda: None)
+        tmp = self._scratch(sp, d)
+        return tmp, (lambda: ops.eltwise(0, d, tmp, d))
+
+    def deliver(self, sp, producer, grad, mask=None):
+        """Pass-through gradient (add / relu backward): dy(producer) (+)= mask > 0 ? grad : 0."""
+        d = producer.dy(sp)
+        if d is None:
+            return
+        g = grad.view(d.shape)
+        if mask is None and producer.mask_in_consumer:
+            mask = producer.y(sp)
+        owner = producer.grad_owner()
+        first = owner.consumers <= 1 or owner.key not in sp.dy_done
+        sp.dy_done.add(owner.key)
+        if first:
+            if mask is None:
+                d.copy_(g)
+            else:
+                ops.eltwise(2, g, mask.view(d.shape), d)
+        elif mask is None:
+            ops.eltwise(0, d, g, d)
+        else:
+            tmp = self._scratch(sp, d)
+            ops.eltwise(2, g, mask.view(d.shape), tmp)
+            ops.eltwise(0, d, tmp, d)
 
     def plan(self, N, W):
         key = (N, W)
@@ -615,6 +767,7 @@ class Engine(object):
             op.fwd(sp)
 
     def _loss_and_backward(self, sp):
+        sp.dy_done = set()
         logits = self.ops[-1].y(sp)
         # loss = mean over the GLOBAL batch -> d loss / d cost_n = 1 / (N * world)   (network.py:655)
         scale = ocr_dist.loss_scale(sp.N, self.world)

@@ -56,7 +56,58 @@ class LSTM_test(Network):
         _vgg_crnn(self)
 
 
-_NETWORKS = {'LSTM_train': LSTM_train, 'LSTM_test': LSTM_test}
+def _basic_block(net, src, c, name):
+    """ResNet BasicBlock through the reference DSL: conv-bn-relu, conv-bn, (+ 1x1 conv-bn projection when the width
+    changes), add, relu.  `src` is the name of the block input layer; returns the name of the block output."""
+    cin = net.layers[src].channels
+    (net.feed(src)
+        .conv_single(3, 3, c, 1, 1, name=name + '_a', bn=True)
+        .conv_single(3, 3, c, 1, 1, name=name + '_b', bn=True, relu=False))
+    skip = src
+    if cin != c:
+        net.feed(src).conv_single(1, 1, c, 1, 1, name=name + '_proj', bn=True, relu=False)
+        skip = name + '_proj'
+    net.feed(skip, name + '_b').add(name=name + '_add').relu(name=name + '_out')
+    return name + '_out'
+
+
+def _resnet_crnn(net, blocks=(3, 4, 6, 3), widths=(64, 128, 256, 512)):
+    """BASELINE configs[4]: ResNet-34-style extractor (BasicBlocks [3,4,6,3], stride-1 convs + the reference's pooling
+    schedule so that T = W/4 - 1) + 2 stacked BiLSTM(num_hid) + CTC — not in the reference, expressed in its DSL."""
+    (net.feed('data')
+        .conv_single(3, 3, widths[0], 1, 1, name='conv1', c_i=cfg.NCHANNELS)
+        .max_pool(2, 2, 2, 2, padding='VALID', name='pool1'))
+    cur = 'pool1'
+    pools = {0: (2, 2, 'pool2'), 1: (1, 2, 'pool3'), 2: (1, 2, 'pool4')}
+    for stage, (nb, c) in enumerate(zip(blocks, widths)):
+        for b in range(nb):
+            cur = _basic_block(net, cur, c, 'res%d_%d' % (stage + 1, b))
+        if stage in pools:
+            kh, kw, pname = pools[stage]
+            net.feed(cur).max_pool(kh, kw, kh, kw, padding='VALID', name=pname)
+            cur = pname
+    (net.feed(cur)
+        .conv_single(2, 2, widths[-1], 1, 1, padding='VALID', name='conv5', relu=False)
+        .reshape_squeeze_layer(d=widths[-1], name='reshaped_layer'))
+    (net.feed('reshaped_layer', 'time_step_len')
+        .bi_lstm(cfg.TRAIN.NUM_HID, cfg.TRAIN.NUM_LAYERS, name='logits', honour_num_layers=True))
+
+
+class RESNET_train(LSTM_train):
+    blocks, widths = (3, 4, 6, 3), (64, 128, 256, 512)
+
+    def setup(self):
+        _resnet_crnn(self, self.blocks, self.widths)
+
+
+class RESNET_test(LSTM_test):
+    blocks, widths = (3, 4, 6, 3), (64, 128, 256, 512)
+
+    def setup(self):
+        _resnet_crnn(self, self.blocks, self.widths)
+
+
+_NETWORKS = {'LSTM_train': LSTM_train, 'LSTM_test': LSTM_test, 'RESNET_train': RESNET_train, 'RESNET_test': RESNET_test}
 
 
 def get_network(name):
@@ -69,6 +120,8 @@ def get_network(name):
         elif len(parts) > 1 and parts[1] == 'test':
             return LSTM_test()
         raise KeyError('Unknown dataset: {}'.format(name))
+    if name in _NETWORKS:                 # configurations beyond the reference (deep CRNN)
+        return _NETWORKS[name]()
     return None
 
 

@@ -139,9 +139,23 @@ class Network(object):
 
     # ------------------------------------------------------------------------------------------ layers
     @layer
-    def bi_lstm(self, input, num_hids, num_layers, name, img_shape=None, trainable=True):
+    def bi_lstm(self, input, num_hids, num_layers, name, img_shape=None, trainable=True, honour_num_layers=False):
+        """honour_num_layers=False reproduces the reference (num_layers accepted and ignored, network.py:98,111-115).
+        With honour_num_layers=True (new configurations, e.g. BASELINE configs[4]) num_layers BiLSTMs are stacked: the
+        hidden layers feed their concatenated [N, T, num_hids] output forward, only the last one carries the FC."""
         from .config import cfg
         img, img_len = input[0], input[1]
+        if honour_num_layers:
+            for li in range(max(1, num_layers) - 1):
+                din_l = img.channels
+                u_l = num_hids // 2
+                hname = '%s/stack%d' % (name, li)
+                for d in ('fw', 'bw'):
+                    self.make_var('%s/%s/weights' % (hname, d), [din_l + u_l, 4 * u_l], 'glorot_uniform', trainable)
+                    self.make_var('%s/%s/biases' % (hname, d), [4 * u_l], 'zeros', trainable)
+                img = Node('bi_lstm', hname, [img, img_len], num_hids=num_hids, num_layers=1, nclasses=cfg.NCLASSES,
+                           din=din_l, with_fc=False, channels=num_hids)
+                self.layers[hname] = img
         din = img.channels
         u = num_hids // 2
         for d in ('fw', 'bw'):

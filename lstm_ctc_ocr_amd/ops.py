@@ -156,6 +156,12 @@ def conv1_wgrad(x, dz, dw, db):
     call("ocr_conv1_wgrad", ptr(_dev(x)), ptr(dz), ptr(dw), ptr(db), Nb, W, H, dz.shape[-1], _st())
 
 
+def eltwise(op, a, b, out):
+    """op 0: out = a + b ; 1: out = relu(a) ; 2: out = (b > 0) ? a : 0   (bf16, numel % 8 == 0)"""
+    call("ocr_eltwise_bf16", op, ptr(_dev(a)), ptr(b), ptr(out), a.numel(), _st())
+    return out
+
+
 def conv1_pool_fwd(x, w, bias, out=None):
     Nb, W, H = x.shape
     Cout = w.shape[-1]
