@@ -62,11 +62,12 @@ def conv_roofline(eng, device):
     """Every launch of the dominant kernel (gemm_nt_kernel<conv3x3>: 5 forward + 5 data-gradient convolutions per
     step) timed with events on the launch stream; achieved = sum(algorithmic flop) / sum(time)."""
     from lstm_ctc_ocr_amd import ops
+    RB = 64                      # always the headline configuration's layer shapes (batch 64, W = 256)
     shapes = [(128, 16, 64, 128), (64, 8, 128, 256), (64, 8, 256, 256), (64, 4, 256, 512), (64, 4, 512, 512)]
     tot_fl, tot_t, n_launch = 0.0, 0.0, 0
     for (W, H, Ci, Co) in shapes:
-        x = torch.randn(BATCH, W, H, Ci, device=device).to(torch.bfloat16)
-        y = torch.randn(BATCH, W, H, Co, device=device).to(torch.bfloat16)
+        x = torch.randn(RB, W, H, Ci, device=device).to(torch.bfloat16)
+        y = torch.randn(RB, W, H, Co, device=device).to(torch.bfloat16)
         wf = (torch.randn(Co, 3, 3, Ci, device=device) * 0.05).to(torch.bfloat16)
         wd = (torch.randn(Ci, 3, 3, Co, device=device) * 0.05).to(torch.bfloat16)
         b = torch.zeros(Co, device=device)
@@ -81,7 +82,7 @@ def conv_roofline(eng, device):
             e1.record()
             torch.cuda.synchronize()
             tot_t += e0.elapsed_time(e1) * 1e-3 / 10
-            tot_fl += 2.0 * BATCH * W * H * 9 * Ci * Co
+            tot_fl += 2.0 * RB * W * H * 9 * Ci * Co
             n_launch += 1
     ach = tot_fl / tot_t
     traffic = None
@@ -129,8 +130,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
-    ap.add_argument("--workload", choices=["fixed", "varwidth"], default="fixed",
-                    help="fixed = BASELINE configs[1] (the headline metric); varwidth = configs[3] (W in [80,320] padded per batch)")
+    ap.add_argument("--workload", choices=["fixed", "varwidth", "deep"], default="fixed",
+                    help="fixed = BASELINE configs[1] (the headline metric); varwidth = configs[3] (W in [80,320] padded per "
+                         "batch); deep = configs[4] (ResNet-34-style extractor + 2 x BiLSTM(512), 96 classes, bs=32/GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,7 +151,11 @@ def main():
     from lstm_ctc_ocr_amd.engine import Engine
     from lstm_ctc_ocr_amd.models import get_network
     cfg.TRAIN.SOLVER, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.WEIGHT_DECAY = 'Adam', 1e-4, 1e-5     # lstm/lstm.yml
-    eng = Engine(get_network('LSTM_train'), device=device, seed=cfg.RNG_SEED, use_graphs=not args.no_graphs)
+    global BATCH
+    net_name = 'LSTM_train'
+    if args.workload == 'deep':
+        cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, BATCH, net_name = 96, 2, 32, 'RESNET_train'
+    eng = Engine(get_network(net_name), device=device, seed=cfg.RNG_SEED, use_graphs=not args.no_graphs)
     eng.setup_optimizer()
     batches = (synth_batches if args.workload == 'fixed' else synth_batches_varwidth)(8, cfg.RNG_SEED + rank, device)
 
@@ -187,11 +193,16 @@ def main():
             "config": {"workload": ("VGG-7 + BiLSTM(256) + CTC train step, H=32 W=256, 10-char labels, C=64, bs=64/GPU "
                                     "(BASELINE.json configs[1]), Adam lr 1e-4 wd 1e-5 clip 10") if args.workload == "fixed" else
                                    ("VGG-7 + BiLSTM(256) + CTC train step, H=32, W in [80,320] padded per batch, masked CTC, "
-                                    "bs=64/GPU (BASELINE.json configs[3])"),
+                                    "bs=64/GPU (BASELINE.json configs[3])") if args.workload == "varwidth" else
+                                   ("ResNet-34-style extractor + 2 x BiLSTM(512) + CTC, 96 classes, H=32 W=256, bs=32/GPU "
+                                    "(BASELINE.json configs[4])"),
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world, "hipgraph": not args.no_graphs},
             "final_loss": loss,
             "model_tflops_per_gpu": value / world * TRAIN_GFLOP_PER_IMG * 1e9 / 1e12,
         }
+        if args.workload != "fixed":
+            line["metric"] = "captcha images/sec training (%s workload)" % args.workload
+            line.pop("model_tflops_per_gpu")
         line["roofline"] = conv_roofline(eng, device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
