@@ -37,6 +37,13 @@ __device__ __forceinline__ void group_arrive(unsigned* counter) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// same, but only the OLDEST stores have to be drained: `younger` later-issued stores may remain outstanding
+__device__ __forceinline__ void group_arrive_after(unsigned* counter, int younger) {
+    if (younger == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // wait until `counter` >= target; the exchanged rows are then read with sc1 (L1-bypassing) loads
 __device__ __forceinline__ void group_wait(unsigned* counter, unsigned target, int* err) {
     if (threadIdx.x == 0) {
@@ -133,13 +140,16 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
                     hn[r] = go[r] * tanhf_(c[r]);
                 }
                 u32x2 hp = {pack_bf2(hn[0], hn[1]), pack_bf2(hn[2], hn[3])};
-                store_wt8(hdst, hp);
+                store_wt8(hdst, hp);                       // the hand-off payload goes out FIRST ...
+                asm volatile("" ::: "memory");
                 float* gdst = a.gates + ((long)d * R + row) * (4L * U) + (long)ub * 64 + ul0;
                 *(f32x4*)(gdst + 0) = gi; *(f32x4*)(gdst + 16) = gj; *(f32x4*)(gdst + 32) = gf; *(f32x4*)(gdst + 48) = go;
                 *(f32x4*)(a.cell + ((long)d * R + row) * U + ub * 16 + ul0) = c;
             }
         }
-        if (s + 1 < T) group_arrive(counter);
+        // ... so the arrive only has to wait for IT: stores retire in issue order, the five 16-byte saves for the backward
+        // pass (gates, cell) may still be in flight when the counter is bumped
+        if (s + 1 < T) group_arrive_after(counter, 5);
         DBG_STAMP(3);
     }
 }

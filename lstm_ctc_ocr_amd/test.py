@@ -48,6 +48,9 @@ class SolverWrapper(object):
             img = Image.open(os.path.join(testDir, file))
             img = np.array(img.convert('L') if cfg.NCHANNELS == 1 else img.convert('RGB'))
             print(file, end=' ')
+            if img.shape[0] != cfg.NUM_FEATURES:        # the reference reshapes blindly (test.py:69) and raises for raw 160x60
+                from .utils.gen import _resize      # captchas; apply the training generator's resize (gen.py:47-52) instead
+                img = _resize(img, int(cfg.NUM_FEATURES / img.shape[0] * img.shape[1]), cfg.NUM_FEATURES)
             w = img.shape[1]
             width = int(math.ceil(w / cfg.POOL_SCALE) * cfg.POOL_SCALE)
             pad = [(0, 0), (0, width - w)] + [(0, 0)] * (img.ndim - 2)

@@ -1,0 +1,102 @@
+"""-m gpu: the reference-shaped drivers end to end on the device — train_net's loop (console protocol, snapshot naming,
+loss-triggered snapshot + validation), checkpoint save / restore / resume, test_net's directory protocol with batch-1
+inference (including the BN-always-training quirk at batch 1), on a small deterministic data stream."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from lstm_ctc_ocr_amd import checkpoint
+from lstm_ctc_ocr_amd.config import cfg, get_encode_decode_dict
+from lstm_ctc_ocr_amd.engine import Engine
+from lstm_ctc_ocr_amd.models import get_network
+from lstm_ctc_ocr_amd.utils import gen
+from oracle import decode as odec
+from oracle import graph as og
+
+
+def fixed_stream(batch_size, seed):
+    """A tiny, endlessly repeated captcha batch (so a few hundred steps are enough to over-fit it)."""
+    import random
+    random.seed(seed)
+    g = gen.generator(batch_size=batch_size)
+    batch = next(g)
+    while True:
+        yield batch
+
+
+def test_batch1_inference_matches_oracle_including_bn_quirk(dev):
+    eng = Engine(get_network('LSTM_test'), device='cuda:0', seed=3)
+    rng = np.random.RandomState(0)
+    x = rng.rand(1, 88, 32).astype(np.float32)
+    sl = np.array([88 // 4 - 1], np.int32)
+    logits = eng.forward(x, sl).float().cpu()
+    params = {k: torch.from_numpy(v) for k, v in eng.state_arrays().items()}
+    ref = og.forward(params, torch.from_numpy(x), sl.tolist(), sim_bf16=True)     # BN uses the statistics of this one image
+    assert float((logits - ref).abs().max()) < 5e-3
+    assert eng.decode(x, sl) == odec.reference_decode(logits.numpy(), sl)
+
+
+def test_train_net_loop_snapshots_and_resume(dev, tmp_path, capsys):
+    from lstm_ctc_ocr_amd import train as trainmod
+    from lstm_ctc_ocr_amd.edict import EasyDict as edict
+    old = (cfg.TRAIN.DISPLAY, cfg.TRAIN.SNAPSHOT_ITERS, cfg.VAL.VAL_STEP, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.WEIGHT_DECAY,
+           cfg.TRAIN.BATCH_SIZE, cfg.VAL.BATCH_SIZE, cfg.TRAIN.SOLVER)
+    cfg.TRAIN.DISPLAY, cfg.TRAIN.SNAPSHOT_ITERS, cfg.VAL.VAL_STEP = 10, 20, 20
+    cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.WEIGHT_DECAY, cfg.TRAIN.BATCH_SIZE, cfg.VAL.BATCH_SIZE, cfg.TRAIN.SOLVER = 1e-3, 1e-5, 8, 8, 'Adam'
+    try:
+        out_dir, log_dir = str(tmp_path / 'out'), str(tmp_path / 'log')
+        os.makedirs(out_dir); os.makedirs(log_dir)
+        net = get_network('LSTM_train')
+        eng = trainmod.make_engine(net)
+        sw = trainmod.SolverWrapper(eng, net, edict({'name': 'lstm_train'}), None, out_dir, log_dir)
+        sw.train_model(eng, 40, restore=False, train_gen=fixed_stream(8, 1), val_gen=fixed_stream(8, 1))
+        text = capsys.readouterr().out
+        assert re.search(r'iter: 10 / 40, total loss: \d+\.\d{7}, lr: 0\.0010000 speed: \d+\.\d{3}s / iter', text)
+        assert 'Wrote snapshot to: %s' % os.path.join(out_dir, 'lstm_ctc_iter_20.ckpt') in text       # (iter+1) % SNAPSHOT_ITERS == 0
+        assert re.search(r'accuracy: \d\.\d{5}', text)
+        losses = [float(l.split('\t')[1]) for l in open(os.path.join(log_dir, 'loss.tsv'))]
+        assert len(losses) == 39             # the reference loop starts at iteration 1 (train.py:93,111)
+        assert losses[-1] < 0.7 * losses[0]
+        assert os.path.basename(checkpoint.latest_checkpoint(out_dir)) == 'lstm_ctc_iter_40.ckpt'
+        # resume: a fresh engine restores weights + Adam slots and continues at the iteration in the file name
+        before = eng.state_arrays()
+        net2 = get_network('LSTM_train')
+        eng2 = trainmod.make_engine(net2)
+        sw2 = trainmod.SolverWrapper(eng2, net2, edict({'name': 'lstm_train'}), None, out_dir, log_dir)
+        sw2.train_model(eng2, 40, restore=True, train_gen=fixed_stream(8, 1), val_gen=fixed_stream(8, 1))   # range(40, 40): no step
+        after = eng2.state_arrays()
+        assert all(np.array_equal(before[k], after[k]) for k in before)
+        assert eng2.iteration == 40 and torch.equal(eng2.state1.cpu(), eng.state1.cpu())
+        assert 'Restoring from' in capsys.readouterr().out
+        with pytest.raises(Exception, match='Check your pretrained'):
+            trainmod.SolverWrapper(eng2, net2, edict({'name': 'x'}), None, str(tmp_path / 'empty'), log_dir).train_model(
+                eng2, 5, restore=True, train_gen=fixed_stream(8, 1), val_gen=fixed_stream(8, 1))
+    finally:
+        (cfg.TRAIN.DISPLAY, cfg.TRAIN.SNAPSHOT_ITERS, cfg.VAL.VAL_STEP, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.WEIGHT_DECAY,
+         cfg.TRAIN.BATCH_SIZE, cfg.VAL.BATCH_SIZE, cfg.TRAIN.SOLVER) = old
+
+
+def test_test_net_directory_protocol(dev, tmp_path, capsys):
+    from lstm_ctc_ocr_amd import test as testmod
+    from lstm_ctc_ocr_amd.edict import EasyDict as edict
+    from lstm_ctc_ocr_amd.utils import genImg
+    import random
+    random.seed(5)
+    val = str(tmp_path / 'val')
+    genImg.run(6, val)
+    files = sorted(os.listdir(val))
+    assert len(files) == 6 and re.match(r'\d{8}_[0-9a-zA-Z]{4,6}\.png$', files[0])
+    net = get_network('LSTM_test')
+    eng = Engine(net, device='cuda:0', seed=3)
+    out_dir = str(tmp_path / 'out'); os.makedirs(out_dir)
+    checkpoint.save(eng, os.path.join(out_dir, 'lstm_ctc_iter_2.ckpt'))
+    sw = testmod.SolverWrapper(eng, net, edict({'name': 'lstm_test'}), out_dir, logdir=str(tmp_path))
+    correct, total = sw.test_model(eng, testDir=val, restore=True)
+    text = capsys.readouterr().out
+    assert total == 6 and 0 <= correct <= 6
+    assert re.search(r'total acc:%d/6=\d\.\d{4}' % correct, text) and text.count('cost time:') == 6
