@@ -15,6 +15,8 @@
 //     that see every B row once (first i-tile, centre tap).
 // Requires I % 128 == 0 and J % 128 == 0 (256-byte tile rows); other shapes stay on gemm_tn.hip.
 #include "common.h"
+#include <stdlib.h>
+#include <stdio.h>
 
 struct Tn2Args {
     const bf16_t* A; const bf16_t* B;
@@ -23,6 +25,12 @@ struct Tn2Args {
     int grp, skip; long a_row_off;
     int cW, cH, cC;
     float* out; long ldo; float scale; float* colsum;
+    // workgroup -> (split, tap, i tile, j tile) map.  The dispatcher deals workgroups round-robin over the 8 XCDs (private
+    // L2 each), so XCD x = id & 7 is given the splits s = xs (mod XS), i tiles = xi (mod XI), j tiles = xj (mod XJ) with
+    // XS * XJ * XI = 8: an XCD then streams only 1/(XI*XS) of A and 1/(XJ*XS) of B through its L2 (every XCD used to
+    // stream both operands completely: TCC hit rate 2-66 %, 180-245 MB fetched per launch against 33-50 MB of operands).
+    int XS, XJ, XI, taps, itl, jtl;                // itl = i tiles per XCD, jtl = j tiles per XCD
+    int dbg_plain;                                 // diagnostic: plain stores instead of atomics (wrong sums, timing only)
     __device__ int cH_or1() const { return cH > 0 ? cH : 1; }
 };
 
@@ -56,12 +64,18 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 1, wj = wave & 1;
-    const int itiles = (MODE == 2) ? 1 : g.I / 128;
-    const int tap = (MODE == 1) ? (int)(blockIdx.x / itiles) : (MODE == 2 ? 2 * (int)blockIdx.x : 0);
-    const int i0 = (MODE == 2) ? 0 : (int)(blockIdx.x % itiles) * 128;
-    const int j0 = blockIdx.y * 128;
-    const int kbeg = blockIdx.z * g.k_per_split;
+    const int xcd = blockIdx.x & 7;
+    int q = blockIdx.x >> 3;
+    const int xs = xcd % g.XS, xj = (xcd / g.XS) % g.XJ, xi = xcd / (g.XS * g.XJ);
+    const int it_l = q % g.itl; q /= g.itl;
+    const int tapi = q % g.taps; q /= g.taps;
+    const int jt_l = q % g.jtl; q /= g.jtl;            // q is now the XCD-local split index
+    const int tap = (MODE == 1) ? tapi : (MODE == 2 ? 2 * tapi : 0);
+    const int i0 = (MODE == 2) ? 0 : (it_l * g.XI + xi) * 128;
+    const int j0 = (jt_l * g.XJ + xj) * 128;
+    const int kbeg = (q * g.XS + xs) * g.k_per_split;
     const int kend = min(g.Mk, kbeg + g.k_per_split);
+    if (kbeg >= kend) return;                          // rounding k_per_split up to 64 can leave trailing splits empty
     const int dw = tap / 3 - 1, dh = tap % 3 - 1;
     const bool do_cs = g.colsum != nullptr && i0 == 0 && (MODE == 0 || tap == 4);     // (MODE 2: the pair (4, 5) block)
     const bf16_t* zero = (const bf16_t*)tn2_zero_page;
@@ -208,7 +222,8 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = i0 + wi * 64 + a * 16 + (lane >> 4) * 4 + r;
-                atomicAdd(out + (long)i * ldo + j, acc[a][b][r] * g.scale);
+                if (g.dbg_plain) out[(long)i * ldo + j] = acc[a][b][r] * g.scale;
+                else atomicAdd(out + (long)i * ldo + j, acc[a][b][r] * g.scale);
             }
         }
 }
@@ -223,14 +238,45 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb; g.Mk = Mk; g.I = I; g.J = J;
     g.grp = grp; g.skip = skip; g.a_row_off = a_row_off; g.cW = cW; g.cH = cH; g.cC = cC;
     g.out = out; g.ldo = ldo; g.scale = scale; g.colsum = colsum;
+    { extern int g_tn2_dbg_plain; g.dbg_plain = g_tn2_dbg_plain; }
     const int taps = pair ? 5 : (mode == 1 ? 9 : 1);
-    const long tiles = (long)taps * (pair ? 1 : I / 128) * (J / 128);
-    if (splits <= 0) {                       // ~300 workgroups measured best (split sweep in tools/wgrad_probe.py): enough to
-        splits = (int)((300 + tiles - 1) / tiles);   // fill 256 CUs, few enough that the fp32 atomic epilogue stays small
-        int maxs = Mk / 256; if (maxs < 1) maxs = 1;
-        if (splits > maxs) splits = maxs;
-        if (splits < 1) splits = 1;
+    const int IT = pair ? 1 : I / 128, JT = J / 128;
+    const long tiles = (long)taps * IT * JT;
+    int maxs = Mk / 256; if (maxs < 1) maxs = 1;
+    // Workgroup count and XCD partition (sweep: tools/wgrad_part_sweep.py).  The K loop is latency-bound (two LDS stages, one
+    // 32 KiB tile in flight per workgroup), so the fastest grids keep both workgroup slots of every CU filled: 400-512
+    // workgroups.  Among the partitions (XS, XJ, XI) that reach that, take the least operand re-streaming plus atomic traffic
+    // bytes(A) * XJ + bytes(B) * XI + 2 * S * bytes(out)   (fp32 atomics cost ~0.8 us per MB, tools/atomic_probe.py).
+    const double ideal = 432.0 / (double)tiles;
+    const double bytesA = 2.0 * Mk * (pair ? 64 : I), bytesB = 2.0 * Mk * J, bytesO = 4.0 * taps * (pair ? 128 : I) * J;
+    double best = 1e300; int bXS = 1, bXJ = 1, bXI = 1, bS = 1;
+    for (int XS = 8; XS >= 1; XS >>= 1)
+        for (int XJ = 8 / XS; XJ >= 1; XJ >>= 1) {
+            const int XI = 8 / XS / XJ;
+            if (IT % XI || JT % XJ) continue;
+            int S;
+            if (splits > 0) { if (splits % XS) continue; S = splits; }      // an explicit split count is honoured exactly
+            else {
+                S = (int)(ideal / XS + 0.5) * XS;
+                if (S < XS) S = XS;
+                while (S > XS && ((long)S * tiles > 512 || S > maxs)) S -= XS;
+                if (S > maxs && XS > 1) continue;
+            }
+            const long wg = (long)S * tiles;
+            double cost = bytesA * XJ + bytesB * XI + 2.0 * S * bytesO;
+            if (splits <= 0 && wg < 400) cost += (400 - wg) * 40.0 * Mk;   // worth of a filled slot grows with the K loop
+            if (splits <= 0 && wg > 512) cost += (wg - 512) * 4.0e6;       // a third, ragged round of workgroups
+            if (cost < best) { best = cost; bXS = XS; bXJ = XJ; bXI = XI; bS = S; }
+        }
+    if (const char* e = getenv("OCR_TN2_PART")) {            // experiment knob: "XS,XJ,XI,S"
+        int xs, xj, xi, sp;
+        if (sscanf(e, "%d,%d,%d,%d", &xs, &xj, &xi, &sp) == 4 && xs * xj * xi == 8 && IT % xi == 0 && JT % xj == 0 && sp % xs == 0 && sp >= 1) {
+            bXS = xs; bXJ = xj; bXI = xi; bS = sp; best = 0;
+        }
     }
+    if (best == 1e300) return -1;
+    splits = bS;
+    g.XS = bXS; g.XJ = bXJ; g.XI = bXI; g.taps = taps; g.itl = IT / bXI; g.jtl = JT / bXJ;
     g.k_per_split = ceil_div(ceil_div(Mk, splits), 64) * 64;
     static bool attr_set[3] = {false, false, false};
     const int km = pair ? 2 : mode;
@@ -239,7 +285,7 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) return OCR_ERR_EXEC;
         attr_set[km] = true;
     }
-    dim3 grid(pair ? 5 : (I / 128) * taps, J / 128, ceil_div(Mk, g.k_per_split));
+    dim3 grid((unsigned)(tiles * splits));          // empty splits (kbeg >= Mk) only write zeros
     if (km == 2) gemm_tn2_kernel<2><<<grid, 256, 65536, stream>>>(g);
     else if (km == 1) gemm_tn2_kernel<1><<<grid, 256, 65536, stream>>>(g);
     else gemm_tn2_kernel<0><<<grid, 256, 65536, stream>>>(g);
