@@ -145,6 +145,8 @@ int ocr_optim_step(float* params, float* grads, float* state1, float* state2, lo
 /* ds_read_b64_tr_b16 lane-semantics probe: LDS holds shorts 0..8191 (value = element index); lane l reads at
  * byte offset addr[l]; out[l*4+j] = element j returned to lane l. */
 int ocr_probe_tr16(const int* addr /* 64 */, int* out /* 64*4 */, void* stream);
+/* out[id] = XCC_ID of workgroup id of a 1-D grid, out[nblocks + id] = its HW_ID register (evidence for id & 7 == XCD) */
+int ocr_probe_xcc(int* out /* 2*nblocks */, int nblocks, int threads, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,12 +7,15 @@
 //     into registers once (128 VGPRs at U = 256) and stays there for the whole sequence;
 //   * the cell state c (forward) / the cell gradient (backward) lives in registers;
 //   * the only cross-workgroup traffic per step is the 64 x 16-unit slice of h_t (forward) / of dz_t (backward)
-//     that the 16 workgroups of a (direction, batch-tile) group exchange.  Hand-off protocol (placement
-//     independent, MI355X guide G16/R1): write-through (sc1, agent-scope relaxed atomic) 8-byte payload stores ->
+//     that the 16 workgroups of a (direction, batch-tile) group exchange.  Three hand-off protocols are kept (A/B knob
+//     OCR_LSTM_PROTO): 2 (default) = data-as-flag inside one XCD's L2, 1 = data-as-flag through memory (sc1), both
+//     described further down, and 0 = counters (placement independent, MI355X guide G16/R1): write-through (sc1, agent-scope relaxed atomic) 8-byte payload stores ->
 //     every wave drains vmcnt -> __syncthreads -> one lane bumps a monotonic agent-scope counter; consumers:
 //     one lane polls the counter relaxed (bounded, s_sleep) -> __syncthreads -> 16-byte `buffer_load ... sc1`
 //     loads of the exchanged rows (write-through stores + L1-bypassing loads on both sides: no ~1.7 us
 //     buffer_inv acquire per step).  Every step writes fresh rows, so there is no write-after-read hazard.
+//     Measured at N = 64, T = 63 (us per launch, forward / backward): counters 166 / 187, data-as-flag sc1 151 / 203,
+//     XCD-local 143 / 170.  What remains per step (~2.2 us) is one L2 write plus one L2 read round trip and the gate math.
 //   * residency: the grid is (U/16) x 2 x ceil(N/16) one-wave workgroups (or ceil(N/64) four-wave ones), one per CU; the C entry point
 //     refuses grids above 256 workgroups (the caller then uses the per-step kernels).  Spins are bounded and
 //     report through an error word instead of hanging the device.
@@ -60,16 +63,66 @@ __device__ __forceinline__ bf16x8 load_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// ---- data-as-flag hand-off (PROTO 1) -------------------------------------------------------------------------------------
+// The exchanged tensor itself carries the "ready" information: it is pre-filled with the bf16 bit pattern 0xFFFF (a NaN
+// that sigma(.)*tanh(.) and the gate gradients never produce; a diverged run yields the canonical quiet NaN 0x7FC0/0xFFC0),
+// producers publish with write-through stores and move on WITHOUT draining them or bumping a counter, and consumers re-issue
+// their L1-bypassing operand loads until no element of the rows they need still holds the fill pattern.  Every 16-bit
+// element is checked (packed u16 max), so a partially landed row is simply polled again.  This removes the store drain
+// (~0.8 us) and the counter round trip from the per-step critical path of the counter protocol above.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned fold_fill(unsigned m, bf16x8 v) {      // running packed max over the 8 elements of v
+    u32x4 w = __builtin_bit_cast(u32x4, v);
+    return pk_max_u16(pk_max_u16(m, pk_max_u16(w.x, w.y)), pk_max_u16(w.z, w.w));
+}
+__device__ __forceinline__ bool holds_fill(unsigned m) { return (m & 0xFFFFu) == 0xFFFFu || (m >> 16) == 0xFFFFu; }
+__global__ void fill_words_kernel(unsigned* p, long n, unsigned v, unsigned* zero, int nzero) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero[i] = 0u;
+}
+
+// ---- XCD-local hand-off (PROTO 2) -------------------------------------------------------------------------------------
+// The 16 workgroups of a (direction, batch-tile) group are placed on ONE XCD (the dispatcher deals workgroup ids round-robin
+// over the 8 XCDs: id & 7), so their exchange can stay inside that XCD's L2: plain stores (L1 is write-through) and loads
+// that only skip the L1 — no write-through to memory, no memory-side read.  Still data-as-flag, so a placement that is not
+// what we assumed cannot produce wrong numbers: the consumer would keep seeing the fill pattern and report a timeout.
+// A failed poll costs a whole extra round trip (and its traffic), so each wave sleeps `presleep` x 64 clocks before its first
+// poll and adapts that to what it sees: a miss adds two units, eight first-try hits in a row remove one.
+#define POLL_ADAPT() do { if (spins > 0) { presleep += 2; streak = 0; } else if (++streak >= 8) { streak = 0; if (presleep > 0) --presleep; } } while (0)
+template <int PROTO> __device__ __forceinline__ void store_pub(void* p, u32x2 v) {
+    if (PROTO >= 2) *(u32x2*)p = v;
+    else store_wt8(p, v);
+}
+template <int PROTO> __device__ __forceinline__ bf16x8 load_pub(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    // `nt` loads are not kept in the L1 (every poll re-reads the XCD's L2) but, unlike sc1 loads, are served by that L2.
+    // Tried and rejected on gfx950: sc0 loads and `buffer_inv sc0` + plain loads both kept hitting the stale L1 line.
+    if (PROTO == 2) return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, /*nt*/ 2));
+    return load_sc1(rsrc, byte_off);
+}
+// workgroup -> (unit block, direction, batch tile); PROTO >= 2: 1-D grid, id = ((g >> 3) * 16 + ub) * 8 + (g & 7), g = zb * 2 + d
+template <int PROTO> __device__ __forceinline__ bool seq_decode(int ngroups, int& ub, int& d, int& zb) {
+    if (PROTO < 2) { ub = blockIdx.x; d = blockIdx.y; zb = blockIdx.z; return true; }
+    const int id = blockIdx.x, r = id >> 3;
+    const int g = (r >> 4) * 8 + (id & 7);
+    ub = r & 15; d = g & 1; zb = g >> 1;
+    return g < ngroups;
+}
+
 struct LstmSeqFwdArgs {
     const float* xproj; const bf16_t* whT; const int* seq_len; bf16_t* hout; float* gates; float* cell;
     unsigned* counters; int* err;
-    int Nb, T, U; float forget_bias; long long* dbg;
+    int Nb, T, U; float forget_bias; long long* dbg; int nosave; int presleep;
 };
 
-template <int KS /* U / 32 */, int WPB /* waves (16-row batch tiles) per workgroup */>
+template <int KS /* U / 32 */, int WPB /* waves (16-row batch tiles) per workgroup */, int PROTO /* 0 counters, 1 data-as-flag */>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_seq_kernel(LstmSeqFwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ub = blockIdx.x, d = blockIdx.y, zb = blockIdx.z;
+    int ub, d, zb;
+    const int nzb = (a.Nb + 16 * WPB - 1) / (16 * WPB);
+    if (!seq_decode<PROTO>(2 * nzb, ub, d, zb)) return;
     const int U = KS * 32, T = a.T;
     const int nl = lane & 15, q = lane >> 4;
     const int n = zb * (16 * WPB) + wave * 16 + nl;
@@ -78,8 +131,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int len = min(a.seq_len[nn], T);
     const long R = (long)a.Nb * T;
     const int ul0 = q * 4;
-    unsigned* counter = a.counters + (d * gridDim.z + zb) * CNT_STRIDE;   // one 256-B line per group counter
-    const unsigned group = gridDim.x;
+    unsigned* counter = a.counters + (d * nzb + zb) * CNT_STRIDE;   // one 256-B line per group counter
+    const unsigned group = U / 16;
 
     // W_h^T slice: 4 gate fragments x KS k-steps, resident for the whole sequence
     bf16x8 w[4][KS];
@@ -91,6 +144,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
             for (int kk = 0; kk < KS; ++kk) w[g][kk] = *(const bf16x8*)(wbase + (long)g * 16 * U + kk * 32);
     }
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    int presleep = a.presleep, streak = 0;
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.hout, 0, (int)(R * 2 * U * 2), 0x00020000);
     for (int s = 0; s < T; ++s) {
         const int dbgi = s;
@@ -108,12 +162,33 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
-            group_wait(counter, group * (unsigned)s, a.err);
-            DBG_STAMP(1);
             const unsigned hoff = (unsigned)((rowp * (2L * U) + (long)d * U + q * 8) * 2);
             bf16x8 b[KS];
+            if (PROTO == 0) {
+                group_wait(counter, group * (unsigned)s, a.err);
+                DBG_STAMP(1);
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) b[kk] = load_sc1(hrsrc, hoff + kk * 64);
+                for (int kk = 0; kk < KS; ++kk) b[kk] = load_sc1(hrsrc, hoff + kk * 64);
+            } else {
+                unsigned spins = 0;
+                for (int i = 0; i < presleep; ++i) __builtin_amdgcn_s_sleep(1);
+                while (true) {
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) b[kk] = load_pub<PROTO>(hrsrc, hoff + kk * 64);
+                    __builtin_amdgcn_sched_barrier(0);
+                    unsigned m = 0;
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) m = fold_fill(m, b[kk]);
+                    if (!__any(active && holds_fill(m))) break;       // rows past their length read a don't-care row
+                    if (++spins > (SPIN_LIMIT >> 4)) { if (lane == 0) atomicExch(a.err, 1); return; }
+                }
+                DBG_STAMP(1);
+                POLL_ADAPT();
+                if (!active) {
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) b[kk] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);      // keep ALL loads in flight before the first MFMA: one round trip, not KS
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk)
@@ -126,7 +201,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
             bf16_t* hdst = a.hout + row * (2L * U) + (long)d * U + ub * 16 + ul0;
             if (!active) {
                 u32x2 z = {0u, 0u};
-                store_wt8(hdst, z);
+                store_pub<PROTO>(hdst, z);
             } else {
                 f32x4 zi = xi + acc[0], zj = xj + acc[1], zf = xf + acc[2], zo = xo + acc[3];
                 f32x4 gi, gj, gf, go, hn;
@@ -140,16 +215,18 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
                     hn[r] = go[r] * tanhf_(c[r]);
                 }
                 u32x2 hp = {pack_bf2(hn[0], hn[1]), pack_bf2(hn[2], hn[3])};
-                store_wt8(hdst, hp);                       // the hand-off payload goes out FIRST ...
+                store_pub<PROTO>(hdst, hp);                // the hand-off payload goes out FIRST ...
                 asm volatile("" ::: "memory");
                 float* gdst = a.gates + ((long)d * R + row) * (4L * U) + (long)ub * 64 + ul0;
+                if (!a.nosave) {
                 *(f32x4*)(gdst + 0) = gi; *(f32x4*)(gdst + 16) = gj; *(f32x4*)(gdst + 32) = gf; *(f32x4*)(gdst + 48) = go;
                 *(f32x4*)(a.cell + ((long)d * R + row) * U + ub * 16 + ul0) = c;
+                }
             }
         }
         // ... so the arrive only has to wait for IT: stores retire in issue order, the five 16-byte saves for the backward
         // pass (gates, cell) may still be in flight when the counter is bumped
-        if (s + 1 < T) group_arrive_after(counter, 5);
+        if (PROTO == 0 && s + 1 < T) group_arrive_after(counter, 5);
         DBG_STAMP(3);
     }
 }
@@ -157,13 +234,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
 struct LstmSeqBwdArgs {
     const bf16_t* wh; long ldw; long w_dir_stride; const int* seq_len; const bf16_t* dhout; const float* gates;
     const float* cell; bf16_t* dz; unsigned* counters; int* err;
-    int Nb, T, U; long long* dbg;
+    int Nb, T, U; long long* dbg; int presleep;
 };
 
-template <int KS /* 4U / 32 */, int WPB>
+template <int KS /* 4U / 32 */, int WPB, int PROTO>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_seq_kernel(LstmSeqBwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ub = blockIdx.x, d = blockIdx.y, zb = blockIdx.z;
+    int ub, d, zb;
+    const int nzb = (a.Nb + 16 * WPB - 1) / (16 * WPB);
+    if (!seq_decode<PROTO>(2 * nzb, ub, d, zb)) return;
     const int U = KS * 8, T = a.T;
     const int nl = lane & 15, q = lane >> 4;
     const int n = zb * (16 * WPB) + wave * 16 + nl;
@@ -172,8 +251,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int len = min(a.seq_len[nn], T);
     const long R = (long)a.Nb * T;
     const int u0 = ub * 16 + q * 4;
-    unsigned* counter = a.counters + (d * gridDim.z + zb) * CNT_STRIDE;   // one 256-B line per group counter
-    const unsigned group = gridDim.x;
+    unsigned* counter = a.counters + (d * nzb + zb) * CNT_STRIDE;   // one 256-B line per group counter
+    const unsigned group = U / 16;
 
     bf16x8 w[KS];   // W_h rows (16 units of this workgroup) x K = 4U, resident
     {
@@ -182,6 +261,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
         for (int kk = 0; kk < KS; ++kk) w[kk] = *(const bf16x8*)(wbase + kk * 32);
     }
     f32x4 dcs = {0.f, 0.f, 0.f, 0.f};
+    int presleep = a.presleep, streak = 0;
     const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, (int)(R * 8 * U * 2), 0x00020000);
     for (int s = T - 1, it = 0; s >= 0; --s, ++it) {
         const int dbgi = it;
@@ -205,13 +285,34 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
         if (it > 0) {
-            group_wait(counter, group * (unsigned)it, a.err);
-            DBG_STAMP(1);
             const unsigned zoff = (unsigned)((rown * (8L * U) + (long)d * 4 * U + q * 8) * 2);
             // all K/32 operand loads in flight at once: one L2 round trip per step instead of four
             bf16x8 z[KS];
+            if (PROTO == 0) {
+                group_wait(counter, group * (unsigned)it, a.err);
+                DBG_STAMP(1);
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) z[kk] = load_sc1(zrsrc, zoff + kk * 64);
+                for (int kk = 0; kk < KS; ++kk) z[kk] = load_sc1(zrsrc, zoff + kk * 64);
+            } else {
+                unsigned spins = 0;
+                for (int i = 0; i < presleep; ++i) __builtin_amdgcn_s_sleep(1);
+                while (true) {
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) z[kk] = load_pub<PROTO>(zrsrc, zoff + kk * 64);
+                    __builtin_amdgcn_sched_barrier(0);
+                    unsigned m = 0;
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) m = fold_fill(m, z[kk]);
+                    if (!__any(has_next && holds_fill(m))) break;     // rows without a successor step read a don't-care row
+                    if (++spins > (SPIN_LIMIT >> 4)) { if (lane == 0) atomicExch(a.err, 1); return; }
+                }
+                DBG_STAMP(1);
+                POLL_ADAPT();
+                if (!has_next) {
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) z[kk] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);      // hipcc otherwise ping-pongs two registers: 16 serial sc1 round trips
 #pragma unroll
             for (int k0 = 0; k0 < KS; k0 += 4) {
@@ -227,7 +328,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
             if (!active) {
                 u32x2 z = {0u, 0u};
 #pragma unroll
-                for (int g = 0; g < 4; ++g) store_wt8(zdst + (long)g * U, z);
+                for (int g = 0; g < 4; ++g) store_pub<PROTO>(zdst + (long)g * U, z);
             } else {
                 f32x4 dh = (acc0 + acc1) + (acc2 + acc3);
                 if (!has_next) dh = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -244,13 +345,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
                     dcs[r] = dc * gf[r];
                 }
                 u32x2 p;
-                p.x = pack_bf2(di[0], di[1]); p.y = pack_bf2(di[2], di[3]); store_wt8(zdst + 0L * U, p);
-                p.x = pack_bf2(dj[0], dj[1]); p.y = pack_bf2(dj[2], dj[3]); store_wt8(zdst + 1L * U, p);
-                p.x = pack_bf2(df[0], df[1]); p.y = pack_bf2(df[2], df[3]); store_wt8(zdst + 2L * U, p);
-                p.x = pack_bf2(dov[0], dov[1]); p.y = pack_bf2(dov[2], dov[3]); store_wt8(zdst + 3L * U, p);
+                p.x = pack_bf2(di[0], di[1]); p.y = pack_bf2(di[2], di[3]); store_pub<PROTO>(zdst + 0L * U, p);
+                p.x = pack_bf2(dj[0], dj[1]); p.y = pack_bf2(dj[2], dj[3]); store_pub<PROTO>(zdst + 1L * U, p);
+                p.x = pack_bf2(df[0], df[1]); p.y = pack_bf2(df[2], df[3]); store_pub<PROTO>(zdst + 2L * U, p);
+                p.x = pack_bf2(dov[0], dov[1]); p.y = pack_bf2(dov[2], dov[3]); store_pub<PROTO>(zdst + 3L * U, p);
             }
         }
-        if (s > 0) group_arrive(counter);
+        if (PROTO == 0 && s > 0) group_arrive(counter);
         DBG_STAMP(3);
     }
 }
@@ -290,6 +391,11 @@ static int seq_rows_per_wg(int Nb, int U) {
     if (want) return seq_rows_per_wg_default(Nb, U);
     return 0;
 }
+static int seq_proto() {            // A/B knob: OCR_LSTM_PROTO = 0 counters (sc1), 1 data-as-flag (sc1), 2 data-as-flag inside one XCD (default)
+    const char* e = getenv("OCR_LSTM_PROTO");
+    int p = e ? atoi(e) : 2;
+    return p < 0 || p > 2 ? 2 : p;
+}
 extern "C" int ocr_lstm_seq_supported(int Nb, int U) { return U == 256 && seq_rows_per_wg(Nb, U) != 0; }
 // int32 words the caller must provide in `sync` (group counters + error word)
 extern "C" int ocr_lstm_seq_sync_words(int Nb) { return (2 * ceil_div(Nb, 16) + 1) * CNT_STRIDE; }
@@ -302,14 +408,21 @@ extern "C" int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, cons
     if (Nb <= 0 || T <= 0 || !ocr_lstm_seq_supported(Nb, U)) return OCR_ERR_INVALID;
     const int rows = seq_rows_per_wg(Nb, U);
     const int nz = ceil_div(Nb, rows), words = ocr_lstm_seq_sync_words(Nb);
-    zero_words_kernel<<<1, 256, 0, stream>>>((unsigned*)sync, words);
+    const int proto = seq_proto();
+    if (proto == 0) zero_words_kernel<<<1, 256, 0, stream>>>((unsigned*)sync, words);
+    else fill_words_kernel<<<256, 256, 0, stream>>>((unsigned*)hout, (long)Nb * T * 2 * U / 2, 0xFFFFFFFFu, (unsigned*)sync, words);
     OCR_CHECK_LAUNCH();
     LstmSeqFwdArgs a = {xproj, (const bf16_t*)whT_packed, seq_len, (bf16_t*)hout, gates, cell, (unsigned*)sync,
-                        (int*)sync + words - 1, Nb, T, U, forget_bias, g_lstm_dbg};
+                        (int*)sync + words - 1, Nb, T, U, forget_bias, g_lstm_dbg, getenv("OCR_LSTM_NOSAVE") ? 1 : 0, getenv("OCR_LSTM_PRESLEEP_F") ? atoi(getenv("OCR_LSTM_PRESLEEP_F")) : 0};
     dim3 grid(U / 16, 2, nz);
-    if (rows == 16) lstm_fwd_seq_kernel<8, 1><<<grid, 64, 0, stream>>>(a);
-    else if (rows == 32) lstm_fwd_seq_kernel<8, 2><<<grid, 128, 0, stream>>>(a);
-    else lstm_fwd_seq_kernel<8, 4><<<grid, 256, 0, stream>>>(a);
+    const dim3 g1(16 * 8 * ceil_div(2 * nz, 8));
+#define LAUNCH_FWD(P, G) do { if (rows == 16) lstm_fwd_seq_kernel<8, 1, P><<<G, 64, 0, stream>>>(a); \
+        else if (rows == 32) lstm_fwd_seq_kernel<8, 2, P><<<G, 128, 0, stream>>>(a); \
+        else lstm_fwd_seq_kernel<8, 4, P><<<G, 256, 0, stream>>>(a); } while (0)
+    if (proto == 0) LAUNCH_FWD(0, grid);
+    else if (proto == 1) LAUNCH_FWD(1, grid);
+    else LAUNCH_FWD(2, g1);
+#undef LAUNCH_FWD
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
@@ -322,14 +435,21 @@ extern "C" int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, con
     if (Nb <= 0 || T <= 0 || !ocr_lstm_seq_supported(Nb, U)) return OCR_ERR_INVALID;
     const int rows = seq_rows_per_wg(Nb, U);
     const int nz = ceil_div(Nb, rows), words = ocr_lstm_seq_sync_words(Nb);
-    zero_words_kernel<<<1, 256, 0, stream>>>((unsigned*)sync, words);
+    const int proto = seq_proto();
+    if (proto == 0) zero_words_kernel<<<1, 256, 0, stream>>>((unsigned*)sync, words);
+    else fill_words_kernel<<<256, 256, 0, stream>>>((unsigned*)dz, (long)Nb * T * 8 * U / 2, 0xFFFFFFFFu, (unsigned*)sync, words);
     OCR_CHECK_LAUNCH();
     LstmSeqBwdArgs a = {(const bf16_t*)wh, ldw, w_dir_stride, seq_len, (const bf16_t*)dhout, gates, cell, (bf16_t*)dz,
-                        (unsigned*)sync, (int*)sync + words - 1, Nb, T, U, g_lstm_dbg};
+                        (unsigned*)sync, (int*)sync + words - 1, Nb, T, U, g_lstm_dbg, getenv("OCR_LSTM_PRESLEEP") ? atoi(getenv("OCR_LSTM_PRESLEEP")) : 4};
     dim3 grid(U / 16, 2, nz);
-    if (rows == 16) lstm_bwd_seq_kernel<32, 1><<<grid, 64, 0, stream>>>(a);
-    else if (rows == 32) lstm_bwd_seq_kernel<32, 2><<<grid, 128, 0, stream>>>(a);
-    else lstm_bwd_seq_kernel<32, 4><<<grid, 256, 0, stream>>>(a);
+    const dim3 g1(16 * 8 * ceil_div(2 * nz, 8));
+#define LAUNCH_BWD(P, G) do { if (rows == 16) lstm_bwd_seq_kernel<32, 1, P><<<G, 64, 0, stream>>>(a); \
+        else if (rows == 32) lstm_bwd_seq_kernel<32, 2, P><<<G, 128, 0, stream>>>(a); \
+        else lstm_bwd_seq_kernel<32, 4, P><<<G, 256, 0, stream>>>(a); } while (0)
+    if (proto == 0) LAUNCH_BWD(0, grid);
+    else if (proto == 1) LAUNCH_BWD(1, grid);
+    else LAUNCH_BWD(2, g1);
+#undef LAUNCH_BWD
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }

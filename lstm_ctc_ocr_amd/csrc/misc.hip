@@ -21,6 +21,21 @@ extern "C" int ocr_probe_tr16(const int* addr, int* out, void* stream) {
     return OCR_OK;
 }
 
+// Which XCD does workgroup `id` of a 1-D grid land on?  out[id] = XCC_ID hardware register (id 20, bits 3:0), out[n + id] = CU id
+// (HW_ID register: id 4).  Evidence for the "workgroup id & 7 == XCD" placement the XCD-aware tile maps assume.
+__global__ void probe_xcc_kernel(int* __restrict__ out, int n) {
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = (int)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
+        out[n + blockIdx.x] = (int)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+    }
+}
+extern "C" int ocr_probe_xcc(int* out, int nblocks, int threads, void* stream) {
+    if (!out || nblocks <= 0 || threads <= 0 || threads > 1024) return OCR_ERR_INVALID;
+    probe_xcc_kernel<<<nblocks, threads, 0, (hipStream_t)stream>>>(out, nblocks);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+
 extern "C" const char* ocr_status_string(int status) {
     switch (status) {
         case OCR_OK: return "no error";
