@@ -97,6 +97,9 @@ int ocr_conv1_pool_bwd(const float* x, const float* w, const float* bias, const 
 int ocr_maxpool_fwd(const void* x, void* y, int Nb, int W, int H, int C, int kw, int kh, void* stream);
 int ocr_maxpool_bwd(const void* x, const void* dy, void* dx, int Nb, int W, int H, int C, int kw, int kh,
                     int relu_mask, void* stream);
+/* training-mode batch norm over rows of x[M][C] (network.py:176-178): batch statistics, biased variance.  `workspace` is
+ * ocr_bn_workspace_bytes(M, C) bytes of caller-owned scratch (per-block partial sums; neither zeroed nor kept) */
+size_t ocr_bn_workspace_bytes(long M, int C);
 int ocr_bn_train_fwd(const void* x, void* y, const float* gamma, const float* beta, float* save_mean,
                      float* save_rstd, long M, int C, float eps, int relu, void* workspace, void* stream);
 int ocr_bn_train_bwd(const void* x, const void* y, const void* dy, void* dx, const float* gamma,

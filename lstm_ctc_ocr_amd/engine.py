@@ -146,7 +146,7 @@ class _ConvOp(_Op):
             sp.buf[self.key + '/dz'] = torch.empty(o, dtype=BF16, device=dev)
             sp.buf[self.key + '/mean'] = torch.empty(self.co, dtype=F32, device=dev)
             sp.buf[self.key + '/rstd'] = torch.empty(self.co, dtype=F32, device=dev)
-            sp.buf[self.key + '/bnws'] = torch.empty(2 * self.co, dtype=torch.float64, device=dev)
+            sp.buf[self.key + '/bnws'] = ops.bn_workspace(o[0] * o[1] * o[2], self.co, dev)
         if self.kind == 'full':
             N, W, H, C = s
             sp.buf[self.key + '/col'] = torch.empty((N * o[1], self.kh * H * C), dtype=BF16, device=dev)

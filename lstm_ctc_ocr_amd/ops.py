@@ -192,6 +192,11 @@ def maxpool_bwd(x, dy, kw, kh, relu_mask, out=None):
     return out
 
 
+def bn_workspace(M, C, device):
+    """Scratch block for bn_train_fwd / bn_train_bwd on [M, C] (ocr_bn_workspace_bytes)."""
+    return torch.empty(int(nat.lib().ocr_bn_workspace_bytes(int(M), int(C))), dtype=torch.uint8, device=device)
+
+
 def bn_train_fwd(x2d, gamma, beta, eps, relu, workspace, out=None, save_mean=None, save_rstd=None):
     M, C = x2d.shape
     if out is None: out = torch.empty_like(x2d)

@@ -321,7 +321,7 @@ def test_batchnorm(dev, M, C):
     xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
     mu = xr.mean(0); var = xr.var(0, unbiased=False)
     yr = torch.relu((xr - mu) * torch.rsqrt(var + 1e-3) * gr + br)
-    ws = torch.empty(2 * C, dtype=torch.float64, device=dev)
+    ws = ops.bn_workspace(M, C, dev)
     xd = x.to(dev).to(BF)
     y, sm, sr = ops.bn_train_fwd(xd, gamma.to(dev), beta.to(dev), 1e-3, True, ws)
     assert relerr(sm.cpu(), mu.detach()) < 1e-4 and relerr(sr.cpu(), torch.rsqrt(var + 1e-3).detach()) < 1e-4

@@ -120,7 +120,7 @@ def main():
     dw1 = torch.zeros(3, 3, 1, 64, device=dev); db1 = torch.zeros(64, device=dev)
     rec("conv1.wgrad", timeit(lambda: ops.conv1_wgrad(x1, d1, dw1, db1)), bytes_=d1.numel() * 2)
     xb = torch.randn(Nb * 256, 512, device=dev).to(BF); g = torch.ones(512, device=dev); be = torch.zeros(512, device=dev)
-    wsb = torch.empty(1024, dtype=torch.float64, device=dev); yb = torch.empty_like(xb)
+    wsb = ops.bn_workspace(Nb * 256, 512, dev); yb = torch.empty_like(xb)
     sm = torch.empty(512, device=dev); sr = torch.empty(512, device=dev)
     rec("bn.fwd", timeit(lambda: ops.bn_train_fwd(xb, g, be, 1e-3, True, wsb, out=yb, save_mean=sm, save_rstd=sr)),
         bytes_=xb.numel() * 6)
