@@ -94,6 +94,9 @@ def lib():
             fn = getattr(_lib, name)
             fn.argtypes = argtypes
             fn.restype = restype
+        for env, setter in (("OCR_GEMM_ENGINE", "ocr_set_gemm_engine"), ("OCR_WGRAD_ENGINE", "ocr_set_wgrad_engine")):
+            if os.environ.get(env):                       # A/B knobs for experiments (see include/ocr_hip.h)
+                getattr(_lib, setter)(int(os.environ[env]))
     return _lib
 
 

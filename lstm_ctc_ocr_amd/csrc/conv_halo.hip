@@ -29,7 +29,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int BN>
-__global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 64 */) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 64 */) {
     constexpr int BM = 256;
     constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N;
     constexpr int WM = BM / WAVES_M, FM = WM / 16, FN = 4;
@@ -107,6 +107,18 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs g, int NRpad /*
     const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
     const int nchunks = C / 64;
     const int nsteps = nchunks * 9;
+    // Fragment addressing with as little per-step VALU work as possible (PMC: 2.4 VALU instructions per MFMA made the vector
+    // ALU as busy as the matrix pipe, and the two do not overlap while all waves move in lock step):
+    //   * SAME-padding: a lane whose pixel has no valid tap reads a 128-byte ROW OF ZEROS kept behind the tiles instead of
+    //     selecting zeros into the 4 loaded registers — one v_cndmask on the address instead of four on the data;
+    //   * the swizzle term ((kk*4 + fq) ^ (row & 7)) only depends on (lane, tap): row = wm*WM + b*16 + (lane&15) + shift,
+    //     so it is formed once per step, the second K-half is `^ 64`, and the fragment index b is an immediate offset.
+    unsigned char* zrow = qbuf0 + 2 * QB;              // 128 zero bytes (written below, fenced by the first barrier)
+    if (tid < 32) ((unsigned*)zrow)[tid] = 0u;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;          // LDS byte address of smem (0 for dynamic LDS, kept general)
+    const unsigned zoff = (unsigned)(zrow - smem);
+    const unsigned qfrag0 = (unsigned)(qbuf0 - smem) + (wn * 64 + frow) * 128 + ((fq ^ fx) << 4);   // + stage*QB, ^64 for kk = 1
+    const unsigned prow0 = (wm * WM + frow) * 128;                                                  // + shift*128 + swizzle
     // prologue: weights of step 0, then halo of chunk 0
     load_q(0, 0);
     load_p(0, 0);
@@ -129,27 +141,39 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs g, int NRpad /*
             if (s + 1 < nsteps) load_q(ntap * C + nchunk * 64, (s + 1) & 1);
             if (tap == 0 && chunk + 1 < nchunks) load_p(chunk + 1, (chunk + 1) & 1);
         }
-        const unsigned char* ps = pbuf0 + (chunk & 1) * PBYTES;
-        const unsigned char* qs = qbuf0 + (s & 1) * QB;
         const int shift = (H + 1) + (tap / 3 - 1) * H + (tap % 3 - 1);       // halo row of local pixel 0 for this tap
+        const unsigned qa = qfrag0 + (s & 1) * QB;
+        const unsigned pbase = (chunk & 1) * PBYTES + prow0 + shift * 128 + ((fq ^ ((frow + shift) & 7)) << 4);
+        unsigned pa[FM];
+#pragma unroll
+        for (int b = 0; b < FM; ++b) pa[b] = ((vmask[b] >> tap) & 1u) ? pbase + b * 2048 : zoff;
+        // All 16 fragment reads of the step are issued back to back as inline asm (the compiler does not count them, so it adds
+        // no waits of its own), then two hand-placed counted waits: lgkmcnt(8) before the first K-half's MFMAs — its eight
+        // fragments were issued first and LDS returns in order — and lgkmcnt(0) before the second.  hipcc's own schedule
+        // interleaved small read groups with the MFMAs and drained lgkmcnt(0) five times per step.
+        u32x4 afr[2][FN], bfr[2][FM];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const int coffq = ((kk * 4 + fq) ^ fx) << 4;
-            bf16x8 af[FN], bfr[FM];
+            const unsigned qk = qa ^ (kk * 64);
 #pragma unroll
-            for (int a = 0; a < FN; ++a) af[a] = *(const bf16x8*)(qs + (wn * 64 + a * 16 + frow) * 128 + coffq);
+            for (int a = 0; a < FN; ++a)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[kk][a]) : "v"(lds0 + qk), "n"(a * 2048));
 #pragma unroll
-            for (int b = 0; b < FM; ++b) {
-                const int rr = wm * WM + b * 16 + frow + shift;
-                bf16x8 v = *(const bf16x8*)(ps + rr * 128 + (((kk * 4 + fq) ^ (rr & 7)) << 4));
-                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                bfr[b] = ((vmask[b] >> tap) & 1u) ? v : z;
-            }
+            for (int b = 0; b < FM; ++b)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[kk][b]) : "v"(lds0 + (pa[b] ^ (kk * 64))));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < FN; ++a)
 #pragma unroll
                 for (int b = 0; b < FM; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[kk][a]),
+                                                                        __builtin_bit_cast(bf16x8, bfr[kk][b]), acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (++tap == 9) { tap = 0; ++chunk; }
@@ -195,7 +219,7 @@ template <int BN>
 static int launch_halo(const HaloArgs& g, hipStream_t stream) {
     const int NR = 256 + 2 * g.cH + 2;
     const int NRpad = (NR + 63) / 64 * 64;
-    const int lds = 2 * NRpad * 128 + 2 * BN * 128;
+    const int lds = 2 * NRpad * 128 + 2 * BN * 128 + 128;        // halo stages, weight stages, one row of zeros
     static int lds_set = 0;
     if (lds > lds_set) {
         if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
