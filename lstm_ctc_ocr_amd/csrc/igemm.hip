@@ -36,7 +36,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int BN, int MODE /*0 plain, 1 conv3x3*/, int STAGES /*2 or 3 LDS stages*/>
-__global__ __launch_bounds__(512) void igemm_kernel(IgArgs g) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_kernel(IgArgs g) {
     constexpr int BM = 256, BK = 64;
     constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N;
     constexpr int WM = BM / WAVES_M;               // 128 / 64 / 32
@@ -118,22 +118,36 @@ __global__ __launch_bounds__(512) void igemm_kernel(IgArgs g) {
     const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
     const int ntk = g.K / BK;
     constexpr int NI = 4 + QI;        // DMA instructions one wave issues per stage
+    // All fragment reads of a K tile are issued back to back as inline asm (the compiler neither counts nor waits for them),
+    // then one counted wait per K-half: the first half's FN + FM fragments were issued first and LDS returns in order.
+    // (hipcc's own schedule interleaved small read groups with the MFMAs and drained lgkmcnt(0) several times per tile.)
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned qoff = PB + (wn * 64 + frow) * 128 + ((fq ^ fx) << 4);     // ^ 64 for the second K-half; + a * 2048
+    const unsigned poff = (wm * WM + frow) * 128 + ((fq ^ fx) << 4);          // + b * 2048
     auto compute = [&](int buf) {
-        const unsigned char* ps = smem + buf * STAGE;
-        const unsigned char* qs = ps + PB;
+        const unsigned base = lds0 + buf * STAGE;
+        u32x4 af[2][FN], bfr[2][FM];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const int coff = ((kk * 4 + fq) ^ fx) << 4;
-            bf16x8 af[FN], bfr[FM];
 #pragma unroll
-            for (int a = 0; a < FN; ++a) af[a] = *(const bf16x8*)(qs + (wn * 64 + a * 16 + frow) * 128 + coff);
+            for (int a = 0; a < FN; ++a)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[kk][a]) : "v"(base + (qoff ^ (kk * 64))), "n"(a * 2048));
 #pragma unroll
-            for (int b = 0; b < FM; ++b) bfr[b] = *(const bf16x8*)(ps + (wm * WM + b * 16 + frow) * 128 + coff);
+            for (int b = 0; b < FM; ++b)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[kk][b]) : "v"(base + (poff ^ (kk * 64))), "n"(b * 2048));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FN + FM) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < FN; ++a)
 #pragma unroll
                 for (int b = 0; b < FM; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kk][a]),
+                                                                        __builtin_bit_cast(bf16x8, bfr[kk][b]), acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     if (STAGES == 2) {
