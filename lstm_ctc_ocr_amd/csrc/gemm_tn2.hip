@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
     int offa[4], offb[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) { offa[a] = tn2_frag_off(wi * 4 + a, lane); offb[a] = tn2_frag_off(wj * 4 + a, lane); }
@@ -166,18 +167,39 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
             if (k0 + 64 < kend) stage_load(k0 + 64, cur ^ 1);
             const unsigned char* ta = smem + cur * (2 * TILE);
             const unsigned char* tb = ta + TILE;
+            // The 32 transposing reads of the step are inline asm: hipcc put an s_waitcnt vmcnt(0) between the LDS-DMA of the
+            // NEXT stage (issued just above) and the builtin ds_read_tr of this one — it cannot prove that the DMA writes
+            // another stage — which serialised every step into "DMA round trip, then compute" (MFMA 12-19 % busy).  Asm reads
+            // are neither counted nor fenced by the compiler; the waits are placed by hand: 32 reads are outstanding and
+            // lgkmcnt holds at most 15, so lgkmcnt(15) (>= 17 retired, LDS returns in order) covers the first K-half.
+            const unsigned sbase = lds0 + cur * (2 * TILE);
+            s16x4 flo[2][8], fhi[2][8];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 af[4], bfr[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) af[a] = tn2_frag(ta + offa[a] + kk * (32 * 256));
+                for (int f = 0; f < 8; ++f) {
+                    const unsigned ad = sbase + (f < 4 ? offa[f] : TILE + offb[f - 4]);
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(flo[kk][f]) : "v"(ad), "n"(kk * 32 * 256));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fhi[kk][f]) : "v"(ad), "n"(kk * 32 * 256 + 16 * 256));
+                }
+            }
 #pragma unroll
-                for (int b = 0; b < 4; ++b) bfr[b] = tn2_frag(tb + offb[b] + kk * (32 * 256));
+            for (int kk = 0; kk < 2; ++kk) {
+                if (kk == 0) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 fr[8];
+#pragma unroll
+                for (int f = 0; f < 8; ++f) {
+                    s16x8 v = {flo[kk][f][0], flo[kk][f][1], flo[kk][f][2], flo[kk][f][3], fhi[kk][f][0], fhi[kk][f][1], fhi[kk][f][2], fhi[kk][f][3]};
+                    fr[f] = __builtin_bit_cast(bf16x8, v);
+                }
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[a], fr[4 + b], acc[a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (do_cs) {      // thread -> source chunk q = tid & 15 (8 columns), rows (tid >> 4) + 16 * i
                 const int q = tid & 15;
