@@ -57,10 +57,13 @@ __device__ __forceinline__ bf16x8 tn2_frag(const unsigned char* a0) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int MODE /*0 plain, 1 conv3x3, 2 conv3x3 with Cin == 64: taps (2p, 2p+1) share one 128-channel A tile*/>
+template <int MODE /*0 plain, 1 conv3x3, 2 conv3x3 with Cin == 64: taps (2p, 2p+1) share one 128-channel A tile*/,
+          int BKR /* rows of m per pipeline stage: 64 or 32 */, int NST /* LDS stages: 2..4 */>
 __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
-    constexpr int TILE = 64 * 256;                   // bytes of one operand tile: 64 rows x 128 channels bf16
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 stages x (A tile | B tile) = 64 KiB
+    constexpr int TILE = BKR * 256;                  // bytes of one operand tile: BKR rows x 128 channels bf16
+    constexpr int NJ = BKR / 16;                     // DMA instructions per wave, operand and stage
+    constexpr int NKK = BKR / 32;                    // 32-row MFMA K steps per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NST stages x (A tile | B tile)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 1, wj = wave & 1;
@@ -86,15 +89,16 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
     // instead of being re-derived with two integer divisions per DMA instruction (that version spent 8.5 VALU
     // instructions per MFMA and was VALU-bound).
     const int rsub = lane >> 4, pos = lane & 15;
-    int trow[4];
-    const bf16_t* pa[4];
-    const bf16_t* pb[4];
-    int pw[4], ph[4];
-    int ldw[4] = {0, 0, 0, 0}, ldh[4] = {0, 0, 0, 0};
-    bool ltap_ok[4] = {true, true, true, true};
+    int trow[NJ];
+    const bf16_t* pa[NJ];
+    const bf16_t* pb[NJ];
+    int pw[NJ], ph[NJ];
+    int ldw[NJ], ldh[NJ];
+    bool ltap_ok[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (wave * 4 + j) * 4 + rsub;
+    for (int j = 0; j < NJ; ++j) {
+        ldw[j] = 0; ldh[j] = 0; ltap_ok[j] = true;
+        const int r = (wave * NJ + j) * 4 + rsub;
         const int q = pos ^ ((r & 7) << 1);                 // source chunk held at LDS position `pos`
         trow[j] = r;
         const long m = (long)kbeg + r;
@@ -114,13 +118,13 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
             pw[j] = (int)((m / g.cH) % g.cW);
         }
     }
-    const int step_h = 64 % g.cH_or1(), step_w = 64 / g.cH_or1();
+    const int step_h = BKR % g.cH_or1(), step_w = BKR / g.cH_or1();
     auto stage_load = [&](int k0, int buf) {
         unsigned char* sa = smem + buf * (2 * TILE);
         unsigned char* sb = sa + TILE;
         const long koff = (long)(k0 - kbeg);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int m = k0 + trow[j];
             const bf16_t* srca = zero;
             const bf16_t* srcb = zero;
@@ -135,9 +139,9 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
                     srca = pa[j] + koff * g.cC;
                 }
             }
-            __builtin_amdgcn_global_load_lds((gptr_t)srca, (lptr_t)(sa + (wave * 4 + j) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)srcb, (lptr_t)(sb + (wave * 4 + j) * 1024), 16, 0, 0);
-            if (MODE != 0) {                                  // advance this row's pixel by 64 rows for the next step
+            __builtin_amdgcn_global_load_lds((gptr_t)srca, (lptr_t)(sa + (wave * NJ + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)srcb, (lptr_t)(sb + (wave * NJ + j) * 1024), 16, 0, 0);
+            if (MODE != 0) {                                  // advance this row's pixel by BKR rows for the next step
                 int h = ph[j] + step_h, w = pw[j] + step_w;
                 if (h >= g.cH) { h -= g.cH; ++w; }
                 while (w >= g.cW) w -= g.cW;
@@ -158,24 +162,35 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) { offa[a] = tn2_frag_off(wi * 4 + a, lane); offb[a] = tn2_frag_off(wj * 4 + a, lane); }
 
-    if (kbeg < kend) {
-        stage_load(kbeg, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int cur = 0;
-        for (int k0 = kbeg; k0 < kend; k0 += 64) {
-            if (k0 + 64 < kend) stage_load(k0 + 64, cur ^ 1);
-            const unsigned char* ta = smem + cur * (2 * TILE);
-            const unsigned char* tb = ta + TILE;
-            // The 32 transposing reads of the step are inline asm: hipcc put an s_waitcnt vmcnt(0) between the LDS-DMA of the
-            // NEXT stage (issued just above) and the builtin ds_read_tr of this one — it cannot prove that the DMA writes
-            // another stage — which serialised every step into "DMA round trip, then compute" (MFMA 12-19 % busy).  Asm reads
-            // are neither counted nor fenced by the compiler; the waits are placed by hand: 32 reads are outstanding and
-            // lgkmcnt holds at most 15, so lgkmcnt(15) (>= 17 retired, LDS returns in order) covers the first K-half.
-            const unsigned sbase = lds0 + cur * (2 * TILE);
-            s16x4 flo[2][8], fhi[2][8];
+    {
+        // NST stages, NST-1 steps in flight.  The counted wait at the top of step t retires stage t only (the 2*NJ DMA
+        // instructions of every younger stage stay outstanding); the raw s_barrier behind it makes that true for every wave's
+        // pieces and also orders "everyone finished reading stage t-1" (each wave ends a step with lgkmcnt(0)) before stage
+        // t+NST-1 is streamed into that buffer.  (__syncthreads() would drain the DMA queue: an LDS-DMA is a pending LDS
+        // write on the VM counter.)
+        // The transposing reads of a step are inline asm: hipcc puts an s_waitcnt vmcnt(0) between an LDS-DMA and a later
+        // builtin ds_read_tr — it cannot prove that the DMA writes another stage — which serialised every step into "DMA round
+        // trip, then compute" (MFMA 12-19 % busy).  Asm reads are neither counted nor fenced by the compiler; the waits are
+        // placed by hand.  With two K-halves per stage 32 reads are outstanding and lgkmcnt holds at most 15, so lgkmcnt(15)
+        // (>= 17 retired, LDS returns in order) covers the first half.
+        const int nst = (kend - kbeg + BKR - 1) / BKR;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+        for (int p = 0; p < NST - 1; ++p)
+            if (p < nst) stage_load(kbeg + p * BKR, p);
+        int cur = 0;
+        for (int t = 0; t < nst; ++t) {
+            const int younger = min(NST - 2, nst - 1 - t);           // stages that may stay in flight
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NJ) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + NST - 1 < nst) { int nb = cur + NST - 1; if (nb >= NST) nb -= NST; stage_load(kbeg + (t + NST - 1) * BKR, nb); }
+            const unsigned char* tb = smem + cur * (2 * TILE) + TILE;
+            const unsigned sbase = lds0 + cur * (2 * TILE);
+            s16x4 flo[NKK][8], fhi[NKK][8];
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
 #pragma unroll
                 for (int f = 0; f < 8; ++f) {
                     const unsigned ad = sbase + (f < 4 ? offa[f] : TILE + offb[f - 4]);
@@ -184,8 +199,8 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
                 }
             }
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                if (kk == 0) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+            for (int kk = 0; kk < NKK; ++kk) {
+                if (kk + 1 < NKK) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 bf16x8 fr[8];
@@ -204,17 +219,17 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
             if (do_cs) {      // thread -> source chunk q = tid & 15 (8 columns), rows (tid >> 4) + 16 * i
                 const int q = tid & 15;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < BKR / 16; ++i) {
                     const int r = (tid >> 4) + 16 * i;
                     u32x4 v = *(const u32x4*)(tb + r * 256 + ((q ^ ((r & 7) << 1)) << 4));
                     cs[0] += bf_lo(v.x); cs[1] += bf_hi(v.x); cs[2] += bf_lo(v.y); cs[3] += bf_hi(v.y);
                     cs[4] += bf_lo(v.z); cs[5] += bf_hi(v.z); cs[6] += bf_lo(v.w); cs[7] += bf_hi(v.w);
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            cur ^= 1;
+            cur = (cur + 1 == NST) ? 0 : cur + 1;
         }
+        __syncthreads();                                         // tiles are dead: the colsum reduction reuses the LDS
     }
 
     if (do_cs) {
@@ -300,17 +315,21 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
     splits = bS;
     g.XS = bXS; g.XJ = bXJ; g.XI = bXI; g.taps = taps; g.itl = IT / bXI; g.jtl = JT / bXJ;
     g.k_per_split = ceil_div(ceil_div(Mk, splits), 64) * 64;
-    static bool attr_set[3] = {false, false, false};
+    static int cfg = -1;                           // A/B knob OCR_TN2_PIPE: 0 = 64-row stages x 2 (default), 1 = 32 x 4, 2 = 32 x 3, 3 = 64 x 3
+    if (cfg < 0) { const char* e = getenv("OCR_TN2_PIPE"); cfg = e ? atoi(e) : 0; if (cfg < 0 || cfg > 3) cfg = 0; }
     const int km = pair ? 2 : mode;
-    const void* fn = km == 2 ? (const void*)gemm_tn2_kernel<2> : (km == 1 ? (const void*)gemm_tn2_kernel<1> : (const void*)gemm_tn2_kernel<0>);
-    if (!attr_set[km]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) return OCR_ERR_EXEC;
-        attr_set[km] = true;
-    }
-    dim3 grid((unsigned)(tiles * splits));          // empty splits (kbeg >= Mk) only write zeros
-    if (km == 2) gemm_tn2_kernel<2><<<grid, 256, 65536, stream>>>(g);
-    else if (km == 1) gemm_tn2_kernel<1><<<grid, 256, 65536, stream>>>(g);
-    else gemm_tn2_kernel<0><<<grid, 256, 65536, stream>>>(g);
+    dim3 grid((unsigned)(tiles * splits));          // empty splits (kbeg >= Mk) return at once
+#define TN2_LAUNCH(M_, BK_, NS_) do { \
+        static bool attr = false; const int lds = NS_ * 2 * BK_ * 256; \
+        if (!attr) { if (hipFuncSetAttribute((const void*)gemm_tn2_kernel<M_, BK_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC; attr = true; } \
+        gemm_tn2_kernel<M_, BK_, NS_><<<grid, 256, lds, stream>>>(g); } while (0)
+#define TN2_MODE(BK_, NS_) do { if (km == 2) TN2_LAUNCH(2, BK_, NS_); else if (km == 1) TN2_LAUNCH(1, BK_, NS_); else TN2_LAUNCH(0, BK_, NS_); } while (0)
+    if (cfg == 1) TN2_MODE(32, 4);
+    else if (cfg == 2) TN2_MODE(32, 3);
+    else if (cfg == 3) TN2_MODE(64, 3);
+    else TN2_MODE(64, 2);
+#undef TN2_MODE
+#undef TN2_LAUNCH
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
