@@ -138,7 +138,8 @@ int ocr_lstm_hprev(const void* hout, const int* seq_len, void* hprev, int Nb, in
 int ocr_lstm_pack_bias(const float* b_fw, const float* b_bw, float* out, int U, void* stream);
 
 /* ---- optimiser (train.py:73-85: clip_by_global_norm 10.0 + Adam / Momentum / RMSProp; L2 of network.py:630-637) */
-int ocr_optim_init(void* scalars /* 8 doubles */, double lr, void* stream);
+int ocr_optim_scalar_count(void);   /* doubles in the caller-owned `scalars` block: 8 of state + per-step partial-sum bins */
+int ocr_optim_init(void* scalars /* ocr_optim_scalar_count() doubles */, double lr, void* stream);
 int ocr_optim_set_lr(void* scalars, double lr, int multiply, void* stream);
 int ocr_optim_step(float* params, float* grads, float* state1, float* state2, long n, long n_reg,
                    float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,

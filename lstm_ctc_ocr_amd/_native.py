@@ -60,6 +60,7 @@ _SIGS = {
     "ocr_lstm_bwd_seq": ([_P, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
     "ocr_lstm_hprev": ([_P, _P, _P, _I, _I, _I, _P], _I),
     "ocr_lstm_pack_bias": ([_P, _P, _P, _I, _P], _I),
+    "ocr_optim_scalar_count": ([], _I),
     "ocr_optim_init": ([_P, _D, _P], _I),
     "ocr_optim_set_lr": ([_P, _D, _I, _P], _I),
     "ocr_optim_step": ([_P, _P, _P, _P, _L, _L, _F, _F, _I, _F, _F, _F, _P, _P], _I),

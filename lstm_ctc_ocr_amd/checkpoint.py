@@ -67,6 +67,8 @@ def restore(engine, path):
         engine.state1.copy_(torch.from_numpy(data['opt/state1']))
         if engine.state2 is not None and 'opt/state2' in data.files:
             engine.state2.copy_(torch.from_numpy(data['opt/state2']))
-        engine.scalars.copy_(torch.from_numpy(data['opt/scalars']))
+        sc = torch.from_numpy(data['opt/scalars'])          # the first 8 doubles are state, the rest per-step scratch
+        n = min(sc.numel(), engine.scalars.numel())
+        engine.scalars[:n].copy_(sc[:n])
     engine.iteration = int(data['meta/iteration']) if 'meta/iteration' in data.files else 0
     return engine

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int b = 0; b < FM; ++b) pa[b] = ((vmask[b] >> tap) & 1u) ? pbase + b * 2048 : zoff;
         // All 16 fragment reads of the step are issued back to back as inline asm (the compiler does not count them, so it adds
-        // no waits of its own), then two hand-placed counted waits: lgkmcnt(8) before the first K-half's MFMAs — its eight
+        // no waits of its own), then two hand-placed counted waits: lgkmcnt(FN + FM) before the first K-half's MFMAs — its
         // fragments were issued first and LDS returns in order — and lgkmcnt(0) before the second.  hipcc's own schedule
         // interleaved small read groups with the MFMAs and drained lgkmcnt(0) five times per step.
         u32x4 afr[2][FN], bfr[2][FM];
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            if (kk == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            if (kk == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FN + FM) : "memory");     // the second half's reads may stay in flight
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -21,6 +21,13 @@
 #define SC_B2T 5
 #define SC_STEP 6
 #define SC_GNORM 7
+// [8 .. 8+32) partial sums of g^2, [40 .. 40+32) partial sums of w^2: the norm pass adds each block's total into bin
+// (block & 31) — 32 addresses in different cache lines take the atomics in parallel, where ONE address serialised them
+// (~12 ns each: 384 blocks x 2 atomics were a 9 us tail on a 12 us pass) — and the update kernels add the bins up.
+#define SC_BINS 32
+#define SC_NORM_BINS 8
+#define SC_REG_BINS 40
+#define SC_TOTAL 72
 
 __global__ void optim_tick_kernel(double* sc, double beta1, double beta2) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -28,8 +35,22 @@ __global__ void optim_tick_kernel(double* sc, double beta1, double beta2) {
         sc[SC_B1T] = b1t; sc[SC_B2T] = b2t;
         sc[SC_STEP] += 1.0;
         sc[SC_LRT] = sc[SC_LR] * sqrt(1.0 - b2t) / (1.0 - b1t);
-        sc[SC_NORM2] = 0.0; sc[SC_REG2] = 0.0;
     }
+    if (blockIdx.x == 0 && threadIdx.x < 2 * SC_BINS) sc[SC_NORM_BINS + threadIdx.x] = 0.0;
+}
+// totals of the two bin arrays, computed by every block of an update kernel (64 cached loads); block 0 also publishes them
+__device__ __forceinline__ float optim_gnorm(double* sc) {
+    __shared__ double tot[2];
+    if (threadIdx.x < 64) {
+        double a = threadIdx.x < SC_BINS ? sc[SC_NORM_BINS + threadIdx.x] : 0.0;
+        double b = threadIdx.x < SC_BINS ? sc[SC_REG_BINS + threadIdx.x] : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+        if (threadIdx.x == 0) { tot[0] = a; tot[1] = b; }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc[SC_NORM2] = tot[0]; sc[SC_REG2] = tot[1]; sc[SC_GNORM] = sqrt(tot[0]); }
+    return (float)sqrt(tot[0]);
 }
 
 // pass 1: g += wd * w on the regularised prefix; accumulate sum g^2 (all) and sum w^2 (prefix)
@@ -54,8 +75,9 @@ __global__ __launch_bounds__(256) void optim_prep_kernel(const float* __restrict
     if (lane == 0) { red[0][wave] = s2; red[1][wave] = r2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&sc[SC_NORM2], (double)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
-        atomicAdd(&sc[SC_REG2], (double)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
+        const int bin = blockIdx.x & (SC_BINS - 1);
+        atomicAdd(&sc[SC_NORM_BINS + bin], (double)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+        atomicAdd(&sc[SC_REG_BINS + bin], (double)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
     }
 }
 
@@ -64,10 +86,9 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p,
                                                           float* __restrict__ m, float* __restrict__ v, long n,
                                                           float beta1, float beta2, float eps, float clip,
                                                           double* sc) {
-    const float gnorm = (float)sqrt(sc[SC_NORM2]);
+    const float gnorm = optim_gnorm(sc);
     const float scale = (clip > 0.f) ? clip / fmaxf(gnorm, clip) : 1.f;
     const float lrt = (float)sc[SC_LRT];
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc[SC_GNORM] = (double)gnorm;
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 256 * 4;
     for (; i < n; i += stride) {
@@ -84,10 +105,9 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p,
 __global__ __launch_bounds__(256) void momentum_update_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                               float* __restrict__ m, long n, float mom, float clip,
                                                               double* sc) {
-    const float gnorm = (float)sqrt(sc[SC_NORM2]);
+    const float gnorm = optim_gnorm(sc);
     const float scale = (clip > 0.f) ? clip / fmaxf(gnorm, clip) : 1.f;
     const float lr = (float)sc[SC_LR];
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc[SC_GNORM] = (double)gnorm;
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 256 * 4;
     for (; i < n; i += stride) {
@@ -101,10 +121,9 @@ __global__ __launch_bounds__(256) void momentum_update_kernel(float* __restrict_
 __global__ __launch_bounds__(256) void rmsprop_update_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                              float* __restrict__ ms, long n, float decay, float eps,
                                                              float clip, double* sc) {
-    const float gnorm = (float)sqrt(sc[SC_NORM2]);
+    const float gnorm = optim_gnorm(sc);
     const float scale = (clip > 0.f) ? clip / fmaxf(gnorm, clip) : 1.f;
     const float lr = (float)sc[SC_LR];
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc[SC_GNORM] = (double)gnorm;
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 256 * 4;
     for (; i < n; i += stride) {
@@ -121,6 +140,7 @@ __global__ void optim_init_kernel(double* sc, double lr) {
         sc[SC_NORM2] = 0; sc[SC_REG2] = 0; sc[SC_LR] = lr; sc[SC_LRT] = lr; sc[SC_B1T] = 1.0; sc[SC_B2T] = 1.0;
         sc[SC_STEP] = 0; sc[SC_GNORM] = 0;
     }
+    if (blockIdx.x == 0 && threadIdx.x < 2 * SC_BINS) sc[SC_NORM_BINS + threadIdx.x] = 0.0;
 }
 __global__ void optim_set_lr_kernel(double* sc, double lr) {
     if (threadIdx.x == 0 && blockIdx.x == 0) sc[SC_LR] = lr;
@@ -130,8 +150,9 @@ __global__ void optim_scale_lr_kernel(double* sc, double gamma) {
 }
 
 // ------------------------------------------------------------------------------------------
-// C ABI.  `scalars` is a caller-owned device block of 8 doubles (layout above).
+// C ABI.  `scalars` is a caller-owned device block of ocr_optim_scalar_count() = 72 doubles (layout above).
 // ------------------------------------------------------------------------------------------
+extern "C" int ocr_optim_scalar_count(void) { return SC_TOTAL; }
 extern "C" int ocr_optim_init(void* scalars, double lr, void* stream) {
     if (!scalars) return OCR_ERR_INVALID;
     optim_init_kernel<<<1, 64, 0, (hipStream_t)stream>>>((double*)scalars, lr);
@@ -158,9 +179,7 @@ extern "C" int ocr_optim_step(float* params, float* grads, float* state1, float*
     optim_tick_kernel<<<1, 64, 0, stream>>>(sc, (double)beta1, (double)beta2);
     OCR_CHECK_LAUNCH();
     int blocks = (int)((n / 4 + 255) / 256); if (blocks > 2048) blocks = 2048;
-    // the norm pass ends in two same-address double atomics per block (~12 ns each, serialised): 2048 blocks were 50 us
-    // of pure atomic tail; 384 blocks keep HBM busy and cost < 10 us of it
-    int pblocks = blocks > 384 ? 384 : blocks;
+    int pblocks = blocks > 1024 ? 1024 : blocks;       // the atomics at the end go to 32 bins, see SC_BINS
     optim_prep_kernel<<<pblocks, 256, 0, stream>>>(params, grads, n, weight_decay > 0.f ? n_reg : 0, weight_decay, sc);
     OCR_CHECK_LAUNCH();
     if (solver == 0) adam_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, state2, n, beta1, beta2, eps, clip_norm, sc);

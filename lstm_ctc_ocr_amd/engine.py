@@ -838,7 +838,7 @@ class Engine(object):
         self.lr = float(c.LEARNING_RATE if lr is None else lr)
         self.state1 = torch.zeros_like(self.params)
         self.state2 = torch.zeros_like(self.params) if self.solver == 0 else None
-        self.scalars = torch.zeros(8, dtype=torch.float64, device=self.device)
+        self.scalars = torch.zeros(ops.optim_scalar_count(), dtype=torch.float64, device=self.device)
         ops.optim_init(self.scalars, self.lr)
         self.opt_ready = True
 

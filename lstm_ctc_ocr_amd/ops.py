@@ -303,6 +303,10 @@ def lstm_pack_bias(b_fw, b_bw, out, U):
 SOLVERS = {"Adam": 0, "Momentum": 1, "RMS": 2}
 
 
+def optim_scalar_count():
+    return int(nat.lib().ocr_optim_scalar_count())
+
+
 def optim_init(scalars, lr):
     call("ocr_optim_init", ptr(_dev(scalars)), float(lr), _st())
 

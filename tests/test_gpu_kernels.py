@@ -454,7 +454,7 @@ def test_optimizer(dev, solver):
     n, n_reg = 4096 + 512, 4096
     p = gen((n,), 1); lr, wd, clip = 1e-2, 1e-3, 10.0
     pd = p.to(dev); s1 = torch.zeros(n, device=dev); s2 = torch.zeros(n, device=dev)
-    sc = torch.zeros(8, dtype=torch.float64, device=dev)
+    sc = torch.zeros(ops.optim_scalar_count(), dtype=torch.float64, device=dev)
     ops.optim_init(sc, lr)
     pr = p.double().clone(); m = torch.zeros(n, dtype=torch.float64); v = torch.zeros(n, dtype=torch.float64)
     for step in range(1, 4):
