@@ -14,6 +14,7 @@
 // Pipeline: weight tiles double-buffered (one step ahead), halo tiles double-buffered (one chunk ahead, issued at
 // tap 0 AFTER the weight DMA so the counted wait of tap 1 does not have to drain it), raw s_barrier per step.
 #include "common.h"
+#include <stdlib.h>
 
 enum { IGH_BIAS = 1, IGH_RELU = 2, IGH_MASK = 16 };
 
@@ -28,12 +29,12 @@ __device__ u32x4 igh_zero_page[4];
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BN>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 64 */) {
-    constexpr int BM = 256;
-    constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N;
+template <int BN, int NW /* waves per workgroup: 8 (256 pixels, one workgroup per CU) or 4 (128 pixels, two per CU) */>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 8 * NW */) {
+    constexpr int BM = 32 * NW;
+    constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
     constexpr int WM = BM / WAVES_M, FM = WM / 16, FN = 4;
-    constexpr int QB = BN * 128, QI = BN / 64;
+    constexpr int QB = BN * 128, QI = BN / (8 * NW);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int PBYTES = NRpad * 128;
     unsigned char* pbuf0 = smem;                       // 2 halo stages
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int H = g.cH, C = g.C;
     const int NR = BM + 2 * H + 2;                     // halo rows actually needed
-    const int PI = NRpad / 64;                         // halo DMA instructions per wave (8 rows each, 8 waves)
+    const int PI = NRpad / (8 * NW);                   // halo DMA instructions per wave (8 rows each)
 
     const int mtiles = (g.M + BM - 1) / BM, ntiles = (g.N + BN - 1) / BN;
     const int nblk = mtiles * ntiles;
@@ -113,10 +114,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     //     selecting zeros into the 4 loaded registers — one v_cndmask on the address instead of four on the data;
     //   * the swizzle term ((kk*4 + fq) ^ (row & 7)) only depends on (lane, tap): row = wm*WM + b*16 + (lane&15) + shift,
     //     so it is formed once per step, the second K-half is `^ 64`, and the fragment index b is an immediate offset.
-    unsigned char* zrow = qbuf0 + 2 * QB;              // 128 zero bytes (written below, fenced by the first barrier)
-    if (tid < 32) ((unsigned*)zrow)[tid] = 0u;
+    // (the zero row is row NR of the current halo stage: rows NR .. NRpad-1 exist only as padding of the DMA geometry and
+    //  are filled from the zero page with every halo tile; NRpad > NR always holds)
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;          // LDS byte address of smem (0 for dynamic LDS, kept general)
-    const unsigned zoff = (unsigned)(zrow - smem);
     const unsigned qfrag0 = (unsigned)(qbuf0 - smem) + (wn * 64 + frow) * 128 + ((fq ^ fx) << 4);   // + stage*QB, ^64 for kk = 1
     const unsigned prow0 = (wm * WM + frow) * 128;                                                  // + shift*128 + swizzle
     // prologue: weights of step 0, then halo of chunk 0
@@ -145,6 +145,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const unsigned qa = qfrag0 + (s & 1) * QB;
         const unsigned pbase = (chunk & 1) * PBYTES + prow0 + shift * 128 + ((fq ^ ((frow + shift) & 7)) << 4);
         unsigned pa[FM];
+        const unsigned zoff = (chunk & 1) * PBYTES + NR * 128;
 #pragma unroll
         for (int b = 0; b < FM; ++b) pa[b] = ((vmask[b] >> tap) & 1u) ? pbase + b * 2048 : zoff;
         // All 16 fragment reads of the step are issued back to back as inline asm (the compiler does not count them, so it adds
@@ -215,19 +216,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <int BN>
+template <int BN, int NW>
 static int launch_halo(const HaloArgs& g, hipStream_t stream) {
-    const int NR = 256 + 2 * g.cH + 2;
-    const int NRpad = (NR + 63) / 64 * 64;
-    const int lds = 2 * NRpad * 128 + 2 * BN * 128 + 128;        // halo stages, weight stages, one row of zeros
+    constexpr int BM = 32 * NW;
+    const int NR = BM + 2 * g.cH + 2;
+    const int NRpad = (NR + 8 * NW) / (8 * NW) * (8 * NW);       // strictly greater than NR: the spare rows are the zero rows
+    const int lds = 2 * NRpad * 128 + 2 * BN * 128;              // halo stages, weight stages
     static int lds_set = 0;
     if (lds > lds_set) {
-        if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return OCR_ERR_EXEC;
         lds_set = lds;
     }
-    int mt = (g.M + 255) / 256, nt = (g.N + BN - 1) / BN;
-    conv_halo_kernel<BN><<<mt * nt, 512, lds, stream>>>(g, NRpad);
+    int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
+    conv_halo_kernel<BN, NW><<<mt * nt, 64 * NW, lds, stream>>>(g, NRpad);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
@@ -237,11 +239,24 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
                       const void* mask, int flags, hipStream_t stream) {
     if ((Cin & 63) || (Cout & 3) || M < 1024 || H > 30) return -1;
     if (flags & ~(IGH_BIAS | IGH_RELU | IGH_MASK)) return -1;
-    const int NRpad = (256 + 2 * H + 2 + 63) / 64 * 64;
-    if (NRpad / 64 != 5 && NRpad / 64 != 6) return -1;               // counted vmcnt literals exist for 5 and 6
+    // Tile choice.  128-pixel workgroups of 4 waves leave room for TWO workgroups per CU (80 KiB of LDS each): they drift out
+    // of phase, so one's MFMA burst covers the other's barrier / DMA-issue / LDS-read phase (+5-7 % where the grid then still
+    // has two workgroups for every CU).  Otherwise 256-pixel workgroups of 8 waves, one per CU.
+    static int nw = -1;                                  // A/B knob OCR_HALO_NW: 8 / 4 force one kind, unset = by grid size
+    if (nw < 0) { const char* e = getenv("OCR_HALO_NW"); nw = e ? atoi(e) : 0; }
     HaloArgs g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags};
+    if (nw != 8) {
+        const int NR = 128 + 2 * H + 2, NRp = (NR + 32) / 32 * 32;
+        const long mt4 = (M + 127) / 128;
+        if (NRp / 32 == 5 || NRp / 32 == 6) {                                // counted vmcnt literals exist for 5 and 6
+            if (Cout >= 128 && mt4 * ((Cout + 127) / 128) >= 448) return launch_halo<128, 4>(g, stream);
+            if (mt4 * ((Cout + 63) / 64) >= 448 || nw == 4) return launch_halo<64, 4>(g, stream);
+        } else if (nw == 4) return -1;
+    }
+    const int NRpad = (256 + 2 * H + 2 + 64) / 64 * 64;
+    if (NRpad / 64 != 5 && NRpad / 64 != 6) return -1;               // counted vmcnt literals exist for 5 and 6
     const int mt = (M + 255) / 256;
-    if (Cout >= 128 && (long)mt * ((Cout + 127) / 128) >= 200) return launch_halo<128>(g, stream);
-    if (Cout >= 128 && (long)mt * ((Cout + 63) / 64) < 256) return launch_halo<128>(g, stream);
-    return launch_halo<64>(g, stream);
+    if (Cout >= 128 && (long)mt * ((Cout + 127) / 128) >= 200) return launch_halo<128, 8>(g, stream);
+    if (Cout >= 128 && (long)mt * ((Cout + 63) / 64) < 256) return launch_halo<128, 8>(g, stream);
+    return launch_halo<64, 8>(g, stream);
 }
