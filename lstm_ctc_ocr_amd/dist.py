@@ -15,9 +15,9 @@ def loss_scale(local_batch, world):
     return 1.0 / (float(local_batch) * float(world))
 
 
-def allreduce_sum_(flat, group=None):
+def allreduce_sum_(flat, group=None, force=False):
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 

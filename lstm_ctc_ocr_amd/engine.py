@@ -17,6 +17,8 @@ optimiser math.  oracle/graph.py(sim_bf16=True) rounds at the same points.
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -535,6 +537,7 @@ class Engine(object):
         self.fuse_conv1_pool = fuse_conv1_pool
         self.group = group
         self.world = 1
+        self.force_allreduce = bool(os.environ.get('OCR_FORCE_ALLREDUCE'))   # exercise the RCCL call on a 1-rank group (tests)
         if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(group)
         self._layout(net)
@@ -877,8 +880,8 @@ class Engine(object):
         """Data-parallel exchange: one all-reduce (sum) of the flat fp32 gradient buffer over RCCL/xGMI.  The 1/world
         factor is already folded into the CTC gradient hand-off, so the sum IS the global-batch mean gradient; the
         clip then sees the same global norm a single GPU would see at the global batch size."""
-        if self.world > 1:
-            ocr_dist.allreduce_sum_(self.grads, self.group)
+        if self.world > 1 or self.force_allreduce:
+            ocr_dist.allreduce_sum_(self.grads, self.group, force=self.force_allreduce)
 
     def train_step(self, data, labels, labels_len, seq_len, fetch_loss=True):
         """One optimisation step on a batch laid out as gen.py:41-67 produces it.  Returns the total loss

@@ -100,3 +100,31 @@ def test_test_net_directory_protocol(dev, tmp_path, capsys):
     text = capsys.readouterr().out
     assert total == 6 and 0 <= correct <= 6
     assert re.search(r'total acc:%d/6=\d\.\d{4}' % correct, text) and text.count('cost time:') == 6
+
+
+def test_rccl_call_path_on_a_one_rank_group(dev, monkeypatch):
+    """One GPU is all a test box has, so the exchange itself cannot be checked here (tests/test_dp_gloo.py does that with two
+    gloo ranks); this drives the REAL collective — RCCL all-reduce of the flat gradient buffer between the two hipGraphs —
+    on a 1-rank "nccl" group and requires the training trajectory to be the one of the plain single-GPU engine."""
+    import torch.distributed as dist
+    batch = next(fixed_stream(8, 3))
+    img, lab, ll, ts = (np.array(a) for a in batch)
+
+    def run(force):
+        if force:
+            monkeypatch.setenv('OCR_FORCE_ALLREDUCE', '1')
+        else:
+            monkeypatch.delenv('OCR_FORCE_ALLREDUCE', raising=False)
+        eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
+        eng.setup_optimizer('Adam', 1e-3)
+        return [eng.train_step(img, lab, ll, ts) for _ in range(5)], eng.state_arrays()
+
+    base_losses, base_state = run(False)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        losses, state = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert np.allclose(losses, base_losses, rtol=2e-3)
+    worst = max(float(np.abs(state[k] - base_state[k]).max()) for k in state)
+    assert worst < 2e-3, worst
