@@ -89,7 +89,7 @@ def conv_roofline(eng, device):
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")
     if os.path.exists(pmc):            # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-    return {"bound": "mfma", "kernel": "conv_halo_kernel (implicit-GEMM 3x3 SAME conv, forward + data gradient: 10 launches/step)",
+    return {"bound": "mfma", "kernel": "conv_halo_kernel<BN,NW> (implicit-GEMM 3x3 SAME conv, forward + data gradient: 10 launches/step)",
             "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK,
             "avg_launch_us": tot_t / n_launch * 1e6, "algorithmic_gflop_per_launch": tot_fl / n_launch / 1e9,
             "traffic": traffic, "traffic_note": "HBM bytes per launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), "
