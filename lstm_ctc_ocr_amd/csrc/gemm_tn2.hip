@@ -279,7 +279,8 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
     const int taps = pair ? 5 : (mode == 1 ? 9 : 1);
     const int IT = pair ? 1 : I / 128, JT = J / 128;
     const long tiles = (long)taps * IT * JT;
-    int maxs = Mk / 256; if (maxs < 1) maxs = 1;
+    int maxs = Mk / 768; if (maxs < 1) maxs = 1;      // at least 12 K steps per workgroup: shorter runs are all prologue + atomics
+                                                      // (Mk = 4032: 4-6 splits measured best, tools/tn_plain_probe.py)
     // Workgroup count and XCD partition (sweep: tools/wgrad_part_sweep.py).  The K loop is latency-bound (two LDS stages, one
     // 32 KiB tile in flight per workgroup), so the fastest grids keep both workgroup slots of every CU filled: 400-512
     // workgroups.  Among the partitions (XS, XJ, XI) that reach that, take the least operand re-streaming plus atomic traffic
