@@ -445,23 +445,29 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
-// pass 3: y = [relu](gamma * (x - mean) * rstd + beta)
+// pass 3: y = [relu](gamma * (x - mean) * rstd + beta).  A thread keeps ONE 8-channel group (its scale / shift live in
+// registers) and walks rows: the first version re-loaded 32 per-channel parameters for every 16 bytes of data.
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       long M, int C, int relu) {
+                                                       long M, int C, int relu, int rows_per_block) {
     const int groups = C >> 3;
-    const long total = M * groups;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        int gq = (int)(idx % groups);
-        long r = idx / groups;
-        float v[8];
+    const int rl = threadIdx.x / groups, gq = threadIdx.x % groups, rlanes = 256 / groups;
+    if (rl >= rlanes) return;
+    float mu[8], rs[8], gm[8], bt[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = gq * 8 + c;
+        mu[c] = mean[ch]; rs[c] = rstd[ch]; gm[c] = gamma[ch]; bt[c] = beta[ch];
+    }
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+#pragma unroll 4
+    for (long r = r0 + rl; r < r1; r += rlanes) {
+        float v[8], o[8];
         unpack8(*(const u32x4*)(x + r * C + gq * 8), v);
-        float o[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            int ch = gq * 8 + c;
-            float t = (v[c] - mean[ch]) * rstd[ch] * gamma[ch] + beta[ch];
+            float t = (v[c] - mu[c]) * rs[c] * gm[c] + bt[c];
             o[c] = relu ? fmaxf(t, 0.f) : t;
         }
         u32x4 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
@@ -508,19 +514,27 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
         dgamma[c] += (float)sx;
     }
 }
-// backward pass 2: dx = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat));  dgamma += sum dz*xhat, dbeta += sum dz
+// backward pass 2: dx = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat))   (per-thread channel group, as bn_apply_kernel)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
                                                            const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const double* __restrict__ sums,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           long M, int C, int relu) {
+                                                           long M, int C, int relu, int rows_per_block) {
     const int groups = C >> 3;
-    const long total = M * groups;
+    const int rl = threadIdx.x / groups, gq = threadIdx.x % groups, rlanes = 256 / groups;
+    if (rl >= rlanes) return;
     const double invM = 1.0 / (double)M;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        int gq = (int)(idx % groups);
-        long r = idx / groups;
+    float mu[8], rs[8], gr[8], mdz[8], mdzx[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = gq * 8 + c;
+        mu[c] = mean[ch]; rs[c] = rstd[ch]; gr[c] = gamma[ch] * rstd[ch];
+        mdz[c] = (float)(sums[ch] * invM); mdzx[c] = (float)(sums[C + ch] * invM);
+    }
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+#pragma unroll 2
+    for (long r = r0 + rl; r < r1; r += rlanes) {
         float xv[8], yv[8], g[8], o[8];
         unpack8(*(const u32x4*)(x + r * C + gq * 8), xv);
         unpack8(*(const u32x4*)(dy + r * C + gq * 8), g);
@@ -531,10 +545,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            int ch = gq * 8 + c;
-            float xh = (xv[c] - mean[ch]) * rstd[ch];
-            float mdz = (float)(sums[ch] * invM), mdzx = (float)(sums[C + ch] * invM);
-            o[c] = gamma[ch] * rstd[ch] * (g[c] - mdz - xh * mdzx);
+            float xh = (xv[c] - mu[c]) * rs[c];
+            o[c] = gr[c] * (g[c] - mdz[c] - xh * mdzx[c]);
         }
         u32x4 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
         *(u32x4*)(dx + r * C + gq * 8) = pk;
@@ -831,8 +843,9 @@ extern "C" int ocr_bn_train_fwd(const void* x, void* y, const float* gamma, cons
     OCR_CHECK_LAUNCH();
     bn_finalize_kernel<<<ceil_div(C, 16), 256, 0, stream>>>((const float*)workspace, nblk, save_mean, save_rstd, M, C, eps);
     OCR_CHECK_LAUNCH();
-    bn_apply_kernel<<<grid_for(M * (C >> 3), 8192), 256, 0, stream>>>((const bf16_t*)x, (bf16_t*)y, save_mean, save_rstd, gamma,
-                                                                       beta, M, C, relu);
+    const int arows = 4 * rlanes;                                   // rows per block of the apply pass: 4 per thread
+    bn_apply_kernel<<<ceil_div(M, (long)arows), 256, 0, stream>>>((const bf16_t*)x, (bf16_t*)y, save_mean, save_rstd, gamma,
+                                                                    beta, M, C, relu, arows);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
@@ -852,9 +865,10 @@ extern "C" int ocr_bn_train_bwd(const void* x, const void* y, const void* dy, vo
     OCR_CHECK_LAUNCH();
     bn_bwd_finalize_kernel<<<ceil_div(C, 16), 256, 0, stream>>>(part, nblk, sums, dgamma, dbeta, C);
     OCR_CHECK_LAUNCH();
-    bn_bwd_apply_kernel<<<grid_for(M * (C >> 3), 8192), 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy,
-                                                                           (bf16_t*)dx, save_mean, save_rstd, gamma,
-                                                                           sums, dgamma, dbeta, M, C, relu);
+    const int arows = 4 * (256 / (C >> 3));                         // rows per block of the apply pass: 4 per thread
+    bn_bwd_apply_kernel<<<ceil_div(M, (long)arows), 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy,
+                                                                        (bf16_t*)dx, save_mean, save_rstd, gamma,
+                                                                        sums, dgamma, dbeta, M, C, relu, arows);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
