@@ -701,13 +701,17 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
             }
         }
     } else if (jb.type == 1) {
-        const int Cin = jb.R, Cout = jb.Cc;
-        for (long idx = (long)b * 256 + threadIdx.x; idx < jb.n; idx += (long)jb.nblocks * 256) {
-            int co = (int)(idx % Cout);
-            long q = idx / Cout;
-            int ci = (int)(q % Cin);
-            int tap = (int)(q / Cin);
-            jb.dst[((long)ci * 9 + (8 - tap)) * Cout + co] = f2bf(jb.src[idx]);
+        const int Cin = jb.R, Cout = jb.Cc;            // Cout % 4 == 0: four output channels per thread and iteration
+        const int c4 = Cout >> 2;
+        const long total = jb.n >> 2;
+        for (long idx = (long)b * 256 + threadIdx.x; idx < total; idx += (long)jb.nblocks * 256) {
+            const int co = (int)(idx % c4) * 4;
+            const long q = idx / c4;
+            const int ci = (int)(q % Cin);
+            const int tap = (int)(q / Cin);
+            f32x4 v = *(const f32x4*)(jb.src + idx * 4);
+            u32x2 pk = {pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+            *(u32x2*)(jb.dst + ((long)ci * 9 + (8 - tap)) * Cout + co) = pk;
         }
     } else if (jb.type == 2) {
         const int c4 = jb.Cc >> 2;
