@@ -755,14 +755,19 @@ class Engine(object):
     def _bind(self, sp, data, seq_len, labels=None, labels_len=None):
         sp.x.copy_(torch.as_tensor(np.asarray(data, np.float32)) if not torch.is_tensor(data) else data, non_blocking=True)
         sl = torch.as_tensor(np.asarray(seq_len, np.int32)) if not torch.is_tensor(seq_len) else seq_len
-        sp.seq_len.copy_(sl, non_blocking=True)
+        dsts, srcs = [sp.seq_len], [sl]
         if labels is not None:
             lab = torch.as_tensor(np.asarray(labels, np.int32)) if not torch.is_tensor(labels) else labels
             ll = torch.as_tensor(np.asarray(labels_len, np.int32)) if not torch.is_tensor(labels_len) else labels_len
             if lab.numel() > sp.labels.numel():
                 raise ValueError('flat label vector longer than batch * max_label_len (%d)' % sp.labels.numel())
-            sp.labels[:lab.numel()].copy_(lab, non_blocking=True)
-            sp.labels_len.copy_(ll, non_blocking=True)
+            dsts += [sp.labels[:lab.numel()], sp.labels_len]
+            srcs += [lab, ll]
+        if all(t.is_cuda and t.dtype == torch.int32 for t in srcs):
+            torch._foreach_copy_(dsts, srcs)                  # device-resident batch: one multi-tensor copy kernel
+        else:
+            for d, t in zip(dsts, srcs):
+                d.copy_(t, non_blocking=True)
 
     # ------------------------------------------------------------------ forward / backward bodies (capturable)
     def _forward(self, sp):
