@@ -16,6 +16,7 @@
 //     the neighbouring m-tiles re-read the same activation rows out of that XCD's L2.
 // MFMA orientation and epilogue are unchanged: A := Q tile, B := P tile, each lane owns 4 consecutive n of one m.
 #include "common.h"
+#include <stdlib.h>
 
 enum { IG_BIAS = 1, IG_RELU = 2, IG_OUT_F32 = 4, IG_MASK = 16, IG_ROWSWAP = 32 };
 
@@ -35,14 +36,14 @@ __device__ u32x4 ig_zero_page[4];   // 64 B of zeros (device globals are zero-in
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BN, int MODE /*0 plain, 1 conv3x3*/, int STAGES /*2 or 3 LDS stages*/>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_kernel(IgArgs g) {
-    constexpr int BM = 256, BK = 64;
-    constexpr int WAVES_N = BN / 64, WAVES_M = 8 / WAVES_N;
+template <int BN, int MODE /*0 plain, 1 conv3x3*/, int STAGES /*2 or 3 LDS stages*/, int NW /*waves: 8 (256-row tiles) or 4 (128-row tiles, two workgroups per CU)*/>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_kernel(IgArgs g) {
+    constexpr int BM = 32 * NW, BK = 64;
+    constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
     constexpr int WM = BM / WAVES_M;               // 128 / 64 / 32
     constexpr int FM = WM / 16, FN = 4;
     constexpr int PB = BM * BK * 2, QB = BN * BK * 2, STAGE = PB + QB;
-    constexpr int QI = BN / 64;                    // Q DMA instructions per wave per stage
+    constexpr int QI = BN / (8 * NW);              // Q DMA instructions per wave per stage (P: always 4)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -227,24 +228,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 int g_ig_stages = 3;     // A/B knob (ocr_set_gemm_engine): 3 = three-stage counted-vmcnt pipeline where LDS allows, 2 = two-stage
 
-template <int BN, int MODE, int STAGES>
+template <int BN, int MODE, int STAGES, int NW>
 static int launch_ig2(const IgArgs& g, hipStream_t stream) {
-    constexpr int LDS = STAGES * (256 * 128 + BN * 128);
+    constexpr int BM = 32 * NW;
+    constexpr int LDS = STAGES * (BM * 128 + BN * 128);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kernel<BN, MODE, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)igemm_kernel<BN, MODE, STAGES, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return OCR_ERR_EXEC;
         attr_set = true;
     }
-    int mt = (g.M + 255) / 256, nt = (g.N + BN - 1) / BN;
-    igemm_kernel<BN, MODE, STAGES><<<mt * nt, 512, LDS, stream>>>(g);
+    int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
+    igemm_kernel<BN, MODE, STAGES, NW><<<mt * nt, 64 * NW, LDS, stream>>>(g);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
 template <int BN, int MODE>
 static int launch_ig(const IgArgs& g, hipStream_t stream) {
-    if (BN <= 128 && g_ig_stages == 3) return launch_ig2<(BN <= 128 ? BN : 128), MODE, 3>(g, stream);   // 3 x 48 KiB fits, 3 x 64 KiB does not
-    return launch_ig2<BN, MODE, 2>(g, stream);
+    if (BN <= 128 && g_ig_stages == 3) return launch_ig2<(BN <= 128 ? BN : 128), MODE, 3, 8>(g, stream);   // 3 x 48 KiB fits, 3 x 64 KiB does not
+    return launch_ig2<BN, MODE, 2, 8>(g, stream);
 }
 
 // Shared with gemm.hip's entry points: returns -1 when the shape is not covered (caller uses the small-tile kernel).
@@ -258,6 +260,18 @@ int ig_try_dispatch(const void* P, long ldp, const void* Q, long ldq, void* out,
     g.P = (const bf16_t*)P; g.Q = (const bf16_t*)Q; g.ldp = ldp; g.ldq = ldq; g.M = M; g.N = N; g.K = K;
     g.grp = grp; g.skip = skip; g.cW = cW; g.cH = cH; g.cC = cC; g.out = out; g.ldo = ldo; g.bias = bias;
     g.mask = (const bf16_t*)mask; g.ldmask = ldmask; g.flags = flags; g.swap_inner = swap_inner; g.swap_outer = swap_outer;
+    // 128-row tiles of 4 waves (72 KiB of LDS with three stages at BN = 64, 64 KiB with two at BN = 128: two workgroups per
+    // CU) when the 256-row grid cannot give every CU two waves' worth of work — the M = 4032 GEMMs of conv5 / LSTM / FC.
+    static int ig_nw = -1;                                 // A/B knob OCR_IG_NW: 8 / 4 force, unset = by grid size
+    if (ig_nw < 0) { const char* e = getenv("OCR_IG_NW"); ig_nw = e ? atoi(e) : 0; }
+    if (mode == 0 && ig_nw != 8) {
+        const long mt4 = (M + 127) / 128;
+        const long wg8 = (long)((M + 255) / 256) * ((N + 127) / 128);
+        if (ig_nw == 4 || wg8 < 400) {
+            if (N >= 128 && mt4 * ((N + 127) / 128) >= 448) return launch_ig2<128, 0, 2, 4>(g, stream);
+            return launch_ig2<64, 0, 3, 4>(g, stream);
+        }
+    }
     const int mt = (M + 255) / 256;
     int bn = 64;                                           // widest n-tile that still gives every CU a workgroup
     if (N >= 256 && (long)mt * ((N + 255) / 256) >= 256) bn = 256;
