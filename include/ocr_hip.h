@@ -134,6 +134,9 @@ int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, const int* seq_
                      float* cell, int Nb, int T, int U, float forget_bias, void* sync, void* stream);
 int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
                      const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync, void* stream);
+/* hand-off protocol of the persistent kernels: 2 (default) = data-as-flag inside one XCD's L2 — needs workgroups with equal
+ * (id & 7) on one XCD, see ocr_probe_xcc; 1 = data-as-flag through memory (sc1), 0 = counters (sc1): placement independent */
+int ocr_set_lstm_proto(int proto);
 int ocr_lstm_hprev(const void* hout, const int* seq_len, void* hprev, int Nb, int T, int U, void* stream);
 int ocr_lstm_pack_bias(const float* b_fw, const float* b_bw, float* out, int U, void* stream);
 

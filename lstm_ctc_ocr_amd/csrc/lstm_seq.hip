@@ -391,10 +391,20 @@ static int seq_rows_per_wg(int Nb, int U) {
     if (want) return seq_rows_per_wg_default(Nb, U);
     return 0;
 }
-static int seq_proto() {            // A/B knob: OCR_LSTM_PROTO = 0 counters (sc1), 1 data-as-flag (sc1), 2 data-as-flag inside one XCD (default)
-    const char* e = getenv("OCR_LSTM_PROTO");
-    int p = e ? atoi(e) : 2;
-    return p < 0 || p > 2 ? 2 : p;
+static int g_seq_proto = -1;
+// hand-off protocol: 0 counters (sc1), 1 data-as-flag (sc1), 2 data-as-flag inside one XCD (default).  Environment
+// OCR_LSTM_PROTO (A/B) wins over the setter, which the host uses to fall back to 1 when the device does not co-locate
+// workgroups with equal (id & 7) on one XCD (checked once with ocr_probe_xcc).
+extern "C" int ocr_set_lstm_proto(int proto) {
+    if (proto < 0 || proto > 2) return OCR_ERR_INVALID;
+    g_seq_proto = proto;
+    return OCR_OK;
+}
+static int seq_proto() {
+    static int env = -2;
+    if (env == -2) { const char* e = getenv("OCR_LSTM_PROTO"); env = e ? atoi(e) : -1; if (env < -1 || env > 2) env = -1; }
+    if (env >= 0) return env;
+    return g_seq_proto >= 0 ? g_seq_proto : 2;
 }
 extern "C" int ocr_lstm_seq_supported(int Nb, int U) { return U == 256 && seq_rows_per_wg(Nb, U) != 0; }
 // int32 words the caller must provide in `sync` (group counters + error word)

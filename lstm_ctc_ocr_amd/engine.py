@@ -25,6 +25,7 @@ import torch
 from . import dist as ocr_dist
 from . import ops
 from ._native import NativeError
+from ._native import call as nat_call
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 BN_EPS = 1e-3            # tf.contrib.layers.batch_norm default (reference network.py:176-178)
@@ -537,6 +538,7 @@ class Engine(object):
         self.fuse_conv1_pool = fuse_conv1_pool
         self.group = group
         self.world = 1
+        self._check_xcd_placement()
         self.force_allreduce = bool(os.environ.get('OCR_FORCE_ALLREDUCE'))   # exercise the RCCL call on a 1-rank group (tests)
         if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(group)
@@ -553,6 +555,23 @@ class Engine(object):
             self.load_arrays(staged)
 
     # ------------------------------------------------------------------ parameters
+    _xcd_checked = False
+
+    def _check_xcd_placement(self):
+        """The persistent LSTM's default hand-off keeps a workgroup group inside one XCD's L2 and relies on the dispatcher
+        placing workgroups with equal (id & 7) on the same XCD.  Verified once per process on the device itself; if it does
+        not hold (another partition mode, a future driver) the kernels are switched to the placement-independent protocol."""
+        if Engine._xcd_checked:
+            return
+        Engine._xcd_checked = True
+        n = 256
+        out = torch.zeros(2 * n, dtype=torch.int32, device=self.device)
+        nat_call('ocr_probe_xcc', out.data_ptr(), n, 64, torch.cuda.current_stream(self.device).cuda_stream)
+        xcc = out[:n].cpu().numpy()
+        colocated = all(len(set(xcc[r::8].tolist())) == 1 for r in range(8))
+        if not colocated:
+            nat_call('ocr_set_lstm_proto', 1)
+
     def _layout(self, net):
         specs = list(net.param_specs.values())
         order = [s for s in specs if s.regularized] + [s for s in specs if not s.regularized]
