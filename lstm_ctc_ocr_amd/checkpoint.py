@@ -21,10 +21,14 @@ def _index_path(output_dir):
 
 def save(engine, path):
     arrays = {'var/' + k: v for k, v in engine.state_arrays().items()}
-    if engine.opt_ready:
-        arrays['opt/state1'] = engine.state1.cpu().numpy()
-        if engine.state2 is not None:
-            arrays['opt/state2'] = engine.state2.cpu().numpy()
+    if engine.opt_ready:            # optimiser slots per variable, TF Saver style ("<var>/Adam", "<var>/Adam_1"): independent of
+        s1 = engine.state1.cpu().numpy()                # the engine's flat parameter layout
+        s2 = engine.state2.cpu().numpy() if engine.state2 is not None else None
+        for name, spec in engine.specs.items():
+            o, n = engine.offsets[name], int(np.prod(spec.shape))
+            arrays['slot1/' + name] = s1[o:o + n].reshape(spec.shape)
+            if s2 is not None:
+                arrays['slot2/' + name] = s2[o:o + n].reshape(spec.shape)
         arrays['opt/scalars'] = engine.scalars.cpu().numpy()
         arrays['opt/solver'] = np.int64(engine.solver)
     arrays['meta/iteration'] = np.int64(engine.iteration)
@@ -61,12 +65,20 @@ def restore(engine, path):
     import torch
     data = np.load(path)
     engine.load_arrays({k[4:]: data[k] for k in data.files if k.startswith('var/')})
-    if 'opt/state1' in data.files:
+    if 'opt/scalars' in data.files:
         if not engine.opt_ready:
             engine.setup_optimizer()
-        engine.state1.copy_(torch.from_numpy(data['opt/state1']))
-        if engine.state2 is not None and 'opt/state2' in data.files:
-            engine.state2.copy_(torch.from_numpy(data['opt/state2']))
+        s1 = np.zeros(engine.n_total, np.float32)
+        s2 = np.zeros(engine.n_total, np.float32)
+        for name, spec in engine.specs.items():
+            o, n = engine.offsets[name], int(np.prod(spec.shape))
+            if 'slot1/' + name in data.files:
+                s1[o:o + n] = data['slot1/' + name].reshape(-1)
+            if 'slot2/' + name in data.files:
+                s2[o:o + n] = data['slot2/' + name].reshape(-1)
+        engine.state1.copy_(torch.from_numpy(s1))
+        if engine.state2 is not None:
+            engine.state2.copy_(torch.from_numpy(s2))
         sc = torch.from_numpy(data['opt/scalars'])          # the first 8 doubles are state, the rest per-step scratch
         n = min(sc.numel(), engine.scalars.numel())
         engine.scalars[:n].copy_(sc[:n])

@@ -17,6 +17,10 @@ def loss_scale(local_batch, world):
 
 def allreduce_sum_(flat, group=None, force=False):
     import torch.distributed as dist
+    fake = os.environ.get('OCR_FAKE_WORLD')
+    if fake:                # single-GPU emulation of `fake` ranks holding identical data: the sum is a multiplication
+        flat.mul_(float(fake))      # (a real kernel on the current stream, so stream ordering is exercised like RCCL's)
+        return flat
     if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat

@@ -542,9 +542,20 @@ class Engine(object):
         self.force_allreduce = bool(os.environ.get('OCR_FORCE_ALLREDUCE'))   # exercise the RCCL call on a 1-rank group (tests)
         if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(group)
+        if os.environ.get('OCR_FAKE_WORLD'):            # single-GPU emulation of identical ranks (tests): see dist.allreduce_sum_
+            self.world = int(os.environ['OCR_FAKE_WORLD'])
+            self.force_allreduce = True
+        self.overlap_allreduce = os.environ.get('OCR_OVERLAP_ALLREDUCE', '1') != '0'
+        self.comm_stream = torch.cuda.Stream(device=self.device)
         self._layout(net)
         self._init_params(cfg.RNG_SEED if seed is None else seed)
         self._lower(net)
+        self.split_op = 0                                # first op of the late layers (backward part 1 = ops[split_op:])
+        if self.split_layer is not None:
+            for i, op in enumerate(self.ops):
+                if op.name == self.split_layer:
+                    self.split_op = i
+                    break
         self.plans = {}
         self.opt_ready = False
         self.graph_opt = None
@@ -573,19 +584,53 @@ class Engine(object):
             nat_call('ocr_set_lstm_proto', 1)
 
     def _layout(self, net):
+        """Flat parameter / gradient layout.  L2-regularised tensors form a prefix (the optimiser kernels take its length).
+        Within that constraint the tensors of the LATE layers — the last layers of the network holding >= 75 % of the
+        parameters, whose gradients are complete first in the backward pass — sit at the two ends and the early layers in
+        the middle:  [late regularised | early regularised | early rest | late rest].  Data parallelism then exchanges the
+        late gradients (two contiguous ranges) while the early layers' backward is still running (train_step)."""
         specs = list(net.param_specs.values())
-        order = [s for s in specs if s.regularized] + [s for s in specs if not s.regularized]
+        layer_of = lambda sp_: sp_.name.split('/')[0]
+        layers = []
+        for sp_ in specs:
+            if layer_of(sp_) not in layers:
+                layers.append(layer_of(sp_))
+        size = {l: 0 for l in layers}
+        for sp_ in specs:
+            size[layer_of(sp_)] += int(np.prod(sp_.shape))
+        total, acc, split = sum(size.values()), 0, 0
+        for i in range(len(layers) - 1, -1, -1):
+            acc += size[layers[i]]
+            split = i
+            if acc >= 0.75 * total:
+                break
+        late = set(layers[split:]) if split > 0 else set()
+        self.split_layer = layers[split] if split > 0 else None
+        is_late = lambda sp_: layer_of(sp_) in late
+        order = ([s_ for s_ in specs if s_.regularized and is_late(s_)] + [s_ for s_ in specs if s_.regularized and not is_late(s_)] +
+                 [s_ for s_ in specs if not s_.regularized and not is_late(s_)] + [s_ for s_ in specs if not s_.regularized and is_late(s_)])
         self.specs, self.offsets = {}, {}
         off = 0
-        for s in order:
-            if s.regularized is False and 'n_reg' not in self.__dict__:
+        self.n_reg = None
+        early0 = early1 = None
+        for s_ in order:
+            if not s_.regularized and self.n_reg is None:
                 self.n_reg = off
-            self.specs[s.name] = s
-            self.offsets[s.name] = off
-            off += _round_up(int(np.prod(s.shape)), ALIGN)
-        if 'n_reg' not in self.__dict__:
+            if not is_late(s_) and early0 is None:
+                early0 = off
+            if is_late(s_) and early0 is not None and early1 is None:
+                early1 = off
+            self.specs[s_.name] = s_
+            self.offsets[s_.name] = off
+            off += _round_up(int(np.prod(s_.shape)), ALIGN)
+        if self.n_reg is None:
             self.n_reg = off
         self.n_total = off
+        if early0 is None:
+            early0 = early1 = off                      # no early layers: everything is "late"
+        elif early1 is None:
+            early1 = off
+        self.early_range = (early0, early1)            # [early0, early1) = gradients finished last
         dev = self.device
         self.params = torch.zeros(self.n_total, dtype=F32, device=dev)
         self.grads = torch.zeros(self.n_total, dtype=F32, device=dev)
@@ -805,8 +850,49 @@ class Engine(object):
             ops.ctc_loss(logits, sp.labels, sp.labels_len, sp.seq_len, self.max_label_len, blank=0, want_grad=True,
                          workspace=sp.ctc_ws, costs=sp.costs, grads=sp.ctc_grad)
             ops.tnc_to_ntc_bf16(sp.ctc_grad, self.ops[-1].dy(sp), scale)
-        for op in reversed(self.ops):
+        for op in reversed(self.ops[self.split_op:]):
             op.bwd(sp)
+
+    def _backward_early(self, sp):
+        for op in reversed(self.ops[:self.split_op]):
+            op.bwd(sp)
+
+    def _capture(self, fn):
+        """hipGraph capture of fn() with Python's cyclic garbage collector paused: a collection that frees device tensors of
+        an unreferenced engine (engine <-> op cycles) in the middle of a capture aborts the process."""
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        was = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g):
+                fn()
+        finally:
+            if was:
+                gc.enable()
+        return g
+
+    def _run_split(self, sp):
+        """forward + loss + backward of the late layers as one graph, backward of the early layers as a second one (data-
+        parallel runs: the exchange of the late gradients is issued between the two)."""
+        def body1():
+            self.grads.zero_()
+            self._forward(sp)
+            self._loss_and_backward(sp)
+
+        def body2():
+            self._backward_early(sp)
+
+        if not self.use_graphs:
+            body1()
+            return body2
+        if getattr(sp, 'graph_fb1', None) is None:
+            body1(); body2()                                    # warm-up outside capture
+            sp.graph_fb1, sp.graph_fb2 = self._capture(body1), self._capture(body2)
+        sp.graph_fb1.replay()
+        return sp.graph_fb2.replay
 
     def _run(self, sp, which):
         """Run (or capture-then-replay) the forward(+backward) body for this shape."""
@@ -818,6 +904,7 @@ class Engine(object):
             self._forward(sp)
             if which == 'fb':
                 self._loss_and_backward(sp)
+                self._backward_early(sp)
 
         if not self.use_graphs:
             body()
@@ -825,10 +912,7 @@ class Engine(object):
         g = getattr(sp, attr)
         if g is None:
             body()                                   # warm-up outside capture (lazy module loads)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                body()
+            g = self._capture(body)
             setattr(sp, attr, g)
         g.replay()
 
@@ -893,27 +977,40 @@ class Engine(object):
             return
         if self.graph_opt is None:
             # capture WITHOUT a warm-up run: the optimiser mutates state, so the first real step is the capture's replay
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._optim_body()
-            self.graph_opt = g
+            self.graph_opt = self._capture(self._optim_body)
         self.graph_opt.replay()
 
-    def allreduce_grads(self):
-        """Data-parallel exchange: one all-reduce (sum) of the flat fp32 gradient buffer over RCCL/xGMI.  The 1/world
+    def allreduce_grads(self, lo=0, hi=None):
+        """Data-parallel exchange: all-reduce (sum) of a range of the flat fp32 gradient buffer over RCCL/xGMI.  The 1/world
         factor is already folded into the CTC gradient hand-off, so the sum IS the global-batch mean gradient; the
         clip then sees the same global norm a single GPU would see at the global batch size."""
         if self.world > 1 or self.force_allreduce:
-            ocr_dist.allreduce_sum_(self.grads, self.group, force=self.force_allreduce)
+            hi = self.n_total if hi is None else hi
+            if hi > lo:
+                ocr_dist.allreduce_sum_(self.grads[lo:hi], self.group, force=self.force_allreduce)
 
     def train_step(self, data, labels, labels_len, seq_len, fetch_loss=True):
         """One optimisation step on a batch laid out as gen.py:41-67 produces it.  Returns the total loss
-        (mean CTC cost of the local batch + L2 term) as a Python float when fetch_loss, else None."""
+        (mean CTC cost of the local batch + L2 term) as a Python float when fetch_loss, else None.
+        Data-parallel schedule: graph 1 (forward, CTC, backward of the late layers) -> the late gradients (~87 % of the
+        bytes for the CRNN) are all-reduced on a side stream WHILE graph 2 (backward of the early layers) runs -> the early
+        gradients are all-reduced -> join -> graph 3 (clip + optimiser + re-pack)."""
         sp = self.plan(data.shape[0], data.shape[1])
         self._bind(sp, data, seq_len, labels, labels_len)
-        self._run(sp, 'fb')
-        self.allreduce_grads()
+        if (self.world > 1 or self.force_allreduce) and self.overlap_allreduce and self.split_op > 0:
+            e0, e1 = self.early_range
+            main = torch.cuda.current_stream(self.device)
+            rest = self._run_split(sp)
+            self.comm_stream.wait_stream(main)
+            with torch.cuda.stream(self.comm_stream):
+                self.allreduce_grads(0, e0)
+                self.allreduce_grads(e1, self.n_total)
+            rest()                                       # backward of the early layers, concurrent with the exchange above
+            self.allreduce_grads(e0, e1)
+            main.wait_stream(self.comm_stream)
+        else:
+            self._run(sp, 'fb')
+            self.allreduce_grads()
         self.optimizer_step()
         self.iteration += 1
         self.last_plan = sp

