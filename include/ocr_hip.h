@@ -76,8 +76,7 @@ int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int Nb, int W, i
  * colsum (may be NULL): colsum[j] += scale * sum_m B[m][j] — the bias gradient, produced by the same pass */
 int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* out, long ldo, int Mk, int I, int J,
                      int row_group, int row_skip, long a_row_off, float scale, int splits, float* colsum, void* stream);
-int ocr_set_wgrad_engine(int use_dma_tiles);   /* A/B knob: 1 (default) = LDS-DMA BK=64 kernel where I,J % 128 == 0; 0 = register-staged
-                                                * kernel; 99 = timing diagnostic only (plain stores instead of atomics: WRONG sums) */
+int ocr_set_wgrad_engine(int use_dma_tiles);   /* A/B knob: 1 (default) = LDS-DMA kernel where I,J % 128 == 0; 0 = register-staged kernel */
 /* dw f32 [3][3][Cin][Cout] (TF HWIO) += conv weight gradient; dbias (may be NULL) += sum over pixels of dy */
 int ocr_conv3x3_wgrad_bf16(const void* x, const void* dy, float* dw, float* dbias, int Nb, int W, int H, int Cin,
                            int Cout, int splits, void* stream);

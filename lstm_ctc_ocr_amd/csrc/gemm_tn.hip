@@ -216,8 +216,7 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
                      int grp, int skip, long a_row_off, int cW, int cH, int cC, float scale, int splits, float* colsum,
                      hipStream_t stream);
 static int g_use_tn2 = 1;
-int g_tn2_dbg_plain = 0;
-extern "C" int ocr_set_wgrad_engine(int use_dma_tiles) { g_use_tn2 = use_dma_tiles != 0; g_tn2_dbg_plain = use_dma_tiles == 99; return OCR_OK; }
+extern "C" int ocr_set_wgrad_engine(int use_dma_tiles) { g_use_tn2 = use_dma_tiles != 0; return OCR_OK; }
 
 // out[I][ldo] += scale * A^T B   with A[Mk][lda] (row-group skip + fixed offset), B[Mk][ldb]
 extern "C" int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* out, long ldo,

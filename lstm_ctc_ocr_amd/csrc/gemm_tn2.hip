@@ -30,7 +30,6 @@ struct Tn2Args {
     // XS * XJ * XI = 8: an XCD then streams only 1/(XI*XS) of A and 1/(XJ*XS) of B through its L2 (every XCD used to
     // stream both operands completely: TCC hit rate 2-66 %, 180-245 MB fetched per launch against 33-50 MB of operands).
     int XS, XJ, XI, taps, itl, jtl;                // itl = i tiles per XCD, jtl = j tiles per XCD
-    int dbg_plain;                                 // diagnostic: plain stores instead of atomics (wrong sums, timing only)
     __device__ int cH_or1() const { return cH > 0 ? cH : 1; }
 };
 
@@ -259,8 +258,7 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = i0 + wi * 64 + a * 16 + (lane >> 4) * 4 + r;
-                if (g.dbg_plain) out[(long)i * ldo + j] = acc[a][b][r] * g.scale;
-                else atomicAdd(out + (long)i * ldo + j, acc[a][b][r] * g.scale);
+                atomicAdd(out + (long)i * ldo + j, acc[a][b][r] * g.scale);
             }
         }
 }
@@ -275,7 +273,6 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb; g.Mk = Mk; g.I = I; g.J = J;
     g.grp = grp; g.skip = skip; g.a_row_off = a_row_off; g.cW = cW; g.cH = cH; g.cC = cC;
     g.out = out; g.ldo = ldo; g.scale = scale; g.colsum = colsum;
-    { extern int g_tn2_dbg_plain; g.dbg_plain = g_tn2_dbg_plain; }
     const int taps = pair ? 5 : (mode == 1 ? 9 : 1);
     const int IT = pair ? 1 : I / 128, JT = J / 128;
     const long tiles = (long)taps * IT * JT;

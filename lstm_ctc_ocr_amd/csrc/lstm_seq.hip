@@ -114,7 +114,7 @@ template <int PROTO> __device__ __forceinline__ bool seq_decode(int ngroups, int
 struct LstmSeqFwdArgs {
     const float* xproj; const bf16_t* whT; const int* seq_len; bf16_t* hout; float* gates; float* cell;
     unsigned* counters; int* err;
-    int Nb, T, U; float forget_bias; long long* dbg; int nosave; int presleep;
+    int Nb, T, U; float forget_bias; long long* dbg; int presleep;
 };
 
 template <int KS /* U / 32 */, int WPB /* waves (16-row batch tiles) per workgroup */, int PROTO /* 0 counters, 1 data-as-flag */>
@@ -218,10 +218,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
                 store_pub<PROTO>(hdst, hp);                // the hand-off payload goes out FIRST ...
                 asm volatile("" ::: "memory");
                 float* gdst = a.gates + ((long)d * R + row) * (4L * U) + (long)ub * 64 + ul0;
-                if (!a.nosave) {
                 *(f32x4*)(gdst + 0) = gi; *(f32x4*)(gdst + 16) = gj; *(f32x4*)(gdst + 32) = gf; *(f32x4*)(gdst + 48) = go;
                 *(f32x4*)(a.cell + ((long)d * R + row) * U + ub * 16 + ul0) = c;
-                }
             }
         }
         // ... so the arrive only has to wait for IT: stores retire in issue order, the five 16-byte saves for the backward
@@ -423,7 +421,7 @@ extern "C" int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, cons
     else fill_words_kernel<<<256, 256, 0, stream>>>((unsigned*)hout, (long)Nb * T * 2 * U / 2, 0xFFFFFFFFu, (unsigned*)sync, words);
     OCR_CHECK_LAUNCH();
     LstmSeqFwdArgs a = {xproj, (const bf16_t*)whT_packed, seq_len, (bf16_t*)hout, gates, cell, (unsigned*)sync,
-                        (int*)sync + words - 1, Nb, T, U, forget_bias, g_lstm_dbg, getenv("OCR_LSTM_NOSAVE") ? 1 : 0, getenv("OCR_LSTM_PRESLEEP_F") ? atoi(getenv("OCR_LSTM_PRESLEEP_F")) : 0};
+                        (int*)sync + words - 1, Nb, T, U, forget_bias, g_lstm_dbg, getenv("OCR_LSTM_PRESLEEP_F") ? atoi(getenv("OCR_LSTM_PRESLEEP_F")) : 0};
     dim3 grid(U / 16, 2, nz);
     const dim3 g1(16 * 8 * ceil_div(2 * nz, 8));
 #define LAUNCH_FWD(P, G) do { if (rows == 16) lstm_fwd_seq_kernel<8, 1, P><<<G, 64, 0, stream>>>(a); \
