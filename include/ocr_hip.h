@@ -143,7 +143,7 @@ int ocr_lstm_pack_bias(const float* b_fw, const float* b_bw, float* out, int U, 
 int ocr_optim_scalar_count(void);   /* doubles in the caller-owned `scalars` block: 8 of state + per-step partial-sum bins */
 int ocr_optim_init(void* scalars /* ocr_optim_scalar_count() doubles */, double lr, void* stream);
 int ocr_optim_set_lr(void* scalars, double lr, int multiply, void* stream);
-int ocr_optim_step(float* params, float* grads, float* state1, float* state2, long n, long n_reg,
+int ocr_optim_step(float* params, float* grads, float* state1, float* state2, long n, long reg_begin, long reg_end,
                    float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
                    void* scalars, void* stream);
 

@@ -4,7 +4,7 @@
 // RMSProp / Momentum apply_gradients, with the L2 regulariser of lib/networks/network.py:630-637,660-662
 // (wd * ||w||^2 / 2 on conv + FC weights) folded in as g += wd * w.
 //
-// All parameters live in ONE flat fp32 buffer ordered [regularised tensors | the rest], so the whole
+// All parameters live in ONE flat fp32 buffer in which the L2-regularised tensors form one contiguous range, so the whole
 // step is two HBM-bound grid-stride kernels over that buffer (+ a 1-thread "tick" that advances the
 // Adam bias correction on the device, which keeps the step replayable from a hipGraph with no host
 // scalars baked in).  The same flat gradient buffer is what the data-parallel all-reduce sees.
@@ -53,15 +53,15 @@ __device__ __forceinline__ float optim_gnorm(double* sc) {
     return (float)sqrt(tot[0]);
 }
 
-// pass 1: g += wd * w on the regularised prefix; accumulate sum g^2 (all) and sum w^2 (prefix)
+// pass 1: g += wd * w on the regularised range [reg0, reg1); accumulate sum g^2 (all) and sum w^2 (that range)
 __global__ __launch_bounds__(256) void optim_prep_kernel(const float* __restrict__ p, float* __restrict__ g, long n,
-                                                         long n_reg, float wd, double* sc) {
+                                                         long reg0, long reg1, float wd, double* sc) {
     float s2 = 0.f, r2 = 0.f;
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 256 * 4;
-    for (; i < n; i += stride) {   // n % 4 == 0, n_reg % 4 == 0
+    for (; i < n; i += stride) {   // n, reg0, reg1 % 4 == 0
         f32x4 gv = *(const f32x4*)(g + i);
-        if (i < n_reg) {
+        if (i >= reg0 && i < reg1) {
             f32x4 pv = *(const f32x4*)(p + i);
             gv = gv + pv * wd;
             *(f32x4*)(g + i) = gv;
@@ -168,11 +168,12 @@ extern "C" int ocr_optim_set_lr(void* scalars, double lr, int multiply, void* st
 }
 // solver: 0 Adam (beta1, beta2, eps), 1 Momentum (beta1 = momentum), 2 RMSProp (beta1 = decay, eps)
 // state1/state2: Adam m, v ; Momentum accumulator (state2 unused) ; RMSProp mean-square (state2 unused)
-extern "C" int ocr_optim_step(float* params, float* grads, float* state1, float* state2, long n, long n_reg,
+extern "C" int ocr_optim_step(float* params, float* grads, float* state1, float* state2, long n, long reg_begin, long reg_end,
                               float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
                               void* scalars, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!params || !grads || !state1 || !scalars || n <= 0 || (n & 3) || (n_reg & 3) || n_reg < 0 || n_reg > n)
+    if (!params || !grads || !state1 || !scalars || n <= 0 || (n & 3) || (reg_begin & 3) || (reg_end & 3) || reg_begin < 0 ||
+        reg_end < reg_begin || reg_end > n)
         return OCR_ERR_INVALID;
     if (solver == 0 && !state2) return OCR_ERR_INVALID;
     double* sc = (double*)scalars;
@@ -180,7 +181,7 @@ extern "C" int ocr_optim_step(float* params, float* grads, float* state1, float*
     OCR_CHECK_LAUNCH();
     int blocks = (int)((n / 4 + 255) / 256); if (blocks > 2048) blocks = 2048;
     int pblocks = blocks > 1024 ? 1024 : blocks;       // the atomics at the end go to 32 bins, see SC_BINS
-    optim_prep_kernel<<<pblocks, 256, 0, stream>>>(params, grads, n, weight_decay > 0.f ? n_reg : 0, weight_decay, sc);
+    optim_prep_kernel<<<pblocks, 256, 0, stream>>>(params, grads, n, reg_begin, weight_decay > 0.f ? reg_end : reg_begin, weight_decay, sc);
     OCR_CHECK_LAUNCH();
     if (solver == 0) adam_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, state2, n, beta1, beta2, eps, clip_norm, sc);
     else if (solver == 1) momentum_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, n, beta1, clip_norm, sc);

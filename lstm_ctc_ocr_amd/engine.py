@@ -584,11 +584,11 @@ class Engine(object):
             nat_call('ocr_set_lstm_proto', 1)
 
     def _layout(self, net):
-        """Flat parameter / gradient layout.  L2-regularised tensors form a prefix (the optimiser kernels take its length).
-        Within that constraint the tensors of the LATE layers — the last layers of the network holding >= 75 % of the
-        parameters, whose gradients are complete first in the backward pass — sit at the two ends and the early layers in
-        the middle:  [late regularised | early regularised | early rest | late rest].  Data parallelism then exchanges the
-        late gradients (two contiguous ranges) while the early layers' backward is still running (train_step)."""
+        """Flat parameter / gradient layout: [early rest | early regularised | late regularised | late rest].
+        The L2-regularised tensors form ONE contiguous range in the middle (the optimiser kernels take its bounds); the
+        tensors of the LATE layers — the last layers of the network holding >= 75 % of the parameters, whose gradients are
+        complete first in the backward pass — form the upper part, so data parallelism exchanges them as one contiguous
+        all-reduce while the early layers' backward is still running (train_step)."""
         specs = list(net.param_specs.values())
         layer_of = lambda sp_: sp_.name.split('/')[0]
         layers = []
@@ -607,30 +607,20 @@ class Engine(object):
         late = set(layers[split:]) if split > 0 else set()
         self.split_layer = layers[split] if split > 0 else None
         is_late = lambda sp_: layer_of(sp_) in late
-        order = ([s_ for s_ in specs if s_.regularized and is_late(s_)] + [s_ for s_ in specs if s_.regularized and not is_late(s_)] +
-                 [s_ for s_ in specs if not s_.regularized and not is_late(s_)] + [s_ for s_ in specs if not s_.regularized and is_late(s_)])
+        groups = ([s_ for s_ in specs if not s_.regularized and not is_late(s_)], [s_ for s_ in specs if s_.regularized and not is_late(s_)],
+                  [s_ for s_ in specs if s_.regularized and is_late(s_)], [s_ for s_ in specs if not s_.regularized and is_late(s_)])
         self.specs, self.offsets = {}, {}
-        off = 0
-        self.n_reg = None
-        early0 = early1 = None
-        for s_ in order:
-            if not s_.regularized and self.n_reg is None:
-                self.n_reg = off
-            if not is_late(s_) and early0 is None:
-                early0 = off
-            if is_late(s_) and early0 is not None and early1 is None:
-                early1 = off
-            self.specs[s_.name] = s_
-            self.offsets[s_.name] = off
-            off += _round_up(int(np.prod(s_.shape)), ALIGN)
-        if self.n_reg is None:
-            self.n_reg = off
+        off, bounds = 0, []
+        for grp in groups:
+            bounds.append(off)
+            for s_ in grp:
+                self.specs[s_.name] = s_
+                self.offsets[s_.name] = off
+                off += _round_up(int(np.prod(s_.shape)), ALIGN)
+        bounds.append(off)
         self.n_total = off
-        if early0 is None:
-            early0 = early1 = off                      # no early layers: everything is "late"
-        elif early1 is None:
-            early1 = off
-        self.early_range = (early0, early1)            # [early0, early1) = gradients finished last
+        self.reg_range = (bounds[1], bounds[3])        # [early reg | late reg]
+        self.late_begin = bounds[2]                    # gradients of [late_begin, n_total) are complete after backward part 1
         dev = self.device
         self.params = torch.zeros(self.n_total, dtype=F32, device=dev)
         self.grads = torch.zeros(self.n_total, dtype=F32, device=dev)
@@ -965,7 +955,7 @@ class Engine(object):
             b1, b2, eps = float(c.MOMENTUM), 0.0, 0.0
         else:
             b1, b2, eps = 0.9, 0.0, 1e-10
-        ops.optim_step(self.params, self.grads, self.state1, self.state2, self.n_reg, float(c.WEIGHT_DECAY), 10.0,
+        ops.optim_step(self.params, self.grads, self.state1, self.state2, self.reg_range, float(c.WEIGHT_DECAY), 10.0,
                        self.solver, b1, b2, eps, self.scalars)
         self.refresh_weights()
 
@@ -992,21 +982,19 @@ class Engine(object):
     def train_step(self, data, labels, labels_len, seq_len, fetch_loss=True):
         """One optimisation step on a batch laid out as gen.py:41-67 produces it.  Returns the total loss
         (mean CTC cost of the local batch + L2 term) as a Python float when fetch_loss, else None.
-        Data-parallel schedule: graph 1 (forward, CTC, backward of the late layers) -> the late gradients (~87 % of the
-        bytes for the CRNN) are all-reduced on a side stream WHILE graph 2 (backward of the early layers) runs -> the early
+        Data-parallel schedule: graph 1 (forward, CTC, backward of the late layers) -> the late gradients (one contiguous
+        range, ~87 % of the bytes for the CRNN) are all-reduced on a side stream WHILE graph 2 (backward of the early layers) runs -> the early
         gradients are all-reduced -> join -> graph 3 (clip + optimiser + re-pack)."""
         sp = self.plan(data.shape[0], data.shape[1])
         self._bind(sp, data, seq_len, labels, labels_len)
         if (self.world > 1 or self.force_allreduce) and self.overlap_allreduce and self.split_op > 0:
-            e0, e1 = self.early_range
             main = torch.cuda.current_stream(self.device)
             rest = self._run_split(sp)
             self.comm_stream.wait_stream(main)
             with torch.cuda.stream(self.comm_stream):
-                self.allreduce_grads(0, e0)
-                self.allreduce_grads(e1, self.n_total)
+                self.allreduce_grads(self.late_begin, self.n_total)
             rest()                                       # backward of the early layers, concurrent with the exchange above
-            self.allreduce_grads(e0, e1)
+            self.allreduce_grads(0, self.late_begin)
             main.wait_stream(self.comm_stream)
         else:
             self._run(sp, 'fb')

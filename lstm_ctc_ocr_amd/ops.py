@@ -315,6 +315,7 @@ def optim_set_lr(scalars, lr, multiply=False):
     call("ocr_optim_set_lr", ptr(_dev(scalars)), float(lr), int(multiply), _st())
 
 
-def optim_step(params, grads, state1, state2, n_reg, weight_decay, clip_norm, solver, beta1, beta2, eps, scalars):
-    call("ocr_optim_step", ptr(_dev(params)), ptr(grads), ptr(state1), ptr(state2), params.numel(), n_reg,
+def optim_step(params, grads, state1, state2, reg_range, weight_decay, clip_norm, solver, beta1, beta2, eps, scalars):
+    """reg_range = (begin, end) of the L2-regularised tensors inside the flat buffer."""
+    call("ocr_optim_step", ptr(_dev(params)), ptr(grads), ptr(state1), ptr(state2), params.numel(), int(reg_range[0]), int(reg_range[1]),
          float(weight_decay), float(clip_norm), solver, float(beta1), float(beta2), float(eps), ptr(scalars), _st())

@@ -147,7 +147,7 @@ def test_data_parallel_schedule_on_emulated_ranks(dev, monkeypatch, overlap):
         else:
             monkeypatch.delenv('OCR_FAKE_WORLD', raising=False)
         eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
-        assert eng.split_layer == 'conv4_1' and 0 < eng.early_range[0] < eng.early_range[1] < eng.n_total
+        assert eng.split_layer == 'conv4_1' and 0 < eng.reg_range[0] < eng.late_begin < eng.reg_range[1] < eng.n_total
         eng.setup_optimizer('Adam', 0.0)                         # first step with lr = 0: the exchanged gradient itself
         eng.train_step(img, lab, ll, ts)
         grads = eng.grads.cpu().numpy().copy()

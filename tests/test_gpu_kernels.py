@@ -451,7 +451,7 @@ def test_lstm_fwd_bwd(dev, N, T, D, U, lens, persistent):
 # ------------------------------------------------------------------------------------------- optimiser
 @pytest.mark.parametrize("solver", ["Adam", "Momentum", "RMS"])
 def test_optimizer(dev, solver):
-    n, n_reg = 4096 + 512, 4096
+    n, r0, r1 = 4096 + 1024, 512, 4096 + 512              # regularised range in the middle of the flat buffer
     p = gen((n,), 1); lr, wd, clip = 1e-2, 1e-3, 10.0
     pd = p.to(dev); s1 = torch.zeros(n, device=dev); s2 = torch.zeros(n, device=dev)
     sc = torch.zeros(ops.optim_scalar_count(), dtype=torch.float64, device=dev)
@@ -461,8 +461,8 @@ def test_optimizer(dev, solver):
         g = gen((n,), 10 + step, 30.0 if step == 2 else 0.01)       # step 2 triggers the clip
         gd = g.to(dev).clone()
         b1, b2, eps = (0.9, 0.999, 1e-8) if solver == "Adam" else ((0.9, 0.0, 0.0) if solver == "Momentum" else (0.9, 0.0, 1e-10))
-        ops.optim_step(pd, gd, s1, s2, n_reg, wd, clip, ops.SOLVERS[solver], b1, b2, eps, sc)
-        gg = g.double().clone(); gg[:n_reg] += wd * pr[:n_reg]
+        ops.optim_step(pd, gd, s1, s2, (r0, r1), wd, clip, ops.SOLVERS[solver], b1, b2, eps, sc)
+        gg = g.double().clone(); gg[r0:r1] += wd * pr[r0:r1]
         norm = float(gg.norm()); gg *= clip / max(norm, clip)
         if solver == "Adam":
             m = 0.9 * m + 0.1 * gg; v = 0.999 * v + 0.001 * gg * gg

@@ -12,8 +12,7 @@ def grads(mutate):
     eng.setup_optimizer('Adam', 0.0)
     if mutate == 'skip_early':
         orig = eng.allreduce_grads
-        e0, e1 = eng.early_range
-        eng.allreduce_grads = lambda lo=0, hi=None: None if (lo, hi) == (e0, e1) else orig(lo, hi)
+        eng.allreduce_grads = lambda lo=0, hi=None: None if (lo, hi) == (0, eng.late_begin) else orig(lo, hi)
     if mutate == 'no_join':
         eng.comm_stream.wait_stream = lambda s: None
     eng.train_step(x, lab, ll, sl)
