@@ -170,3 +170,38 @@ def test_data_parallel_schedule_on_emulated_ranks(dev, monkeypatch, overlap):
     assert abs(gnorm - base_gnorm) < 2e-3 * base_gnorm
     diffs = np.concatenate([np.abs(state[k] - base_state[k]).ravel() for k in state])
     assert float(diffs.max()) < 7e-3 and float(diffs.mean()) < 2e-5, (diffs.max(), diffs.mean())   # Adam: <= lr per step on noise-level entries
+
+
+def test_data_parallel_schedule_on_a_residual_network(dev, monkeypatch):
+    """The two-graph backward and the bucket boundary on a residual DAG with stacked BiLSTMs (BASELINE configs[4] in miniature):
+    emulated two-rank gradients must equal the single-GPU ones."""
+    from lstm_ctc_ocr_amd import models
+    old = (cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS)
+    cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS = 96, 2
+    try:
+        class Tiny(models.RESNET_train):
+            blocks, widths = (1, 1, 1, 1), (64, 128, 128, 256)
+        rng = np.random.RandomState(3)
+        N, W = 16, 96
+        x = rng.rand(N, W, 32).astype(np.float32)
+        sl = np.full(N, W // 4 - 1, np.int32); ll = np.full(N, 3, np.int32)
+        lab = rng.randint(1, 95, N * 3).astype(np.int32)
+
+        def grads(fake):
+            if fake:
+                monkeypatch.setenv('OCR_FAKE_WORLD', '2')
+            else:
+                monkeypatch.delenv('OCR_FAKE_WORLD', raising=False)
+            eng = Engine(Tiny(), device='cuda:0', seed=5)
+            eng.setup_optimizer('Adam', 0.0)
+            eng.train_step(x, lab, ll, sl)
+            return eng, eng.grads.cpu().numpy().copy()
+
+        _, base = grads(False)
+        eng, g = grads(True)
+        assert eng.split_layer is not None and 0 < eng.split_op < len(eng.ops) and 0 < eng.late_begin < eng.n_total
+        # biases in front of batch norm have a mathematically zero gradient: what is stored there is summation-order noise
+        # (~1e-3 of the largest gradient in this net), so the bar is 5e-3; a missed or doubled exchange is off by ~0.5
+        assert float(np.abs(g - base).max()) < 5e-3 * float(np.abs(base).max())
+    finally:
+        cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS = old
