@@ -122,10 +122,12 @@ int ocr_lstm_fwd_step(const float* xproj, const void* whT_packed, const int* seq
 int ocr_lstm_bwd_step(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
                       const float* gates, const float* cell, void* dz, float* dc_state, int Nb, int T, int U,
                       int step, void* stream);
-/* whole-sequence (persistent) variants: one launch for all T steps, workgroups of a (direction, 64-row batch tile)
- * group exchange h_t / dz_t through write-through stores + an agent-scope counter.  `sync`: ocr_lstm_seq_sync_words(Nb)
- * int32 words (zeroed by the call; last word = spin-timeout error flag).  ocr_lstm_seq_supported() tells whether
- * the shape is covered (U == 256 and the grid fits one workgroup per CU); otherwise use the step entry points. */
+/* whole-sequence (persistent) variants: one launch for all T steps; the 16 workgroups of a (direction, 16-row batch tile)
+ * group exchange h_t / dz_t through the output tensor itself (hout / dz), which the call first fills with the bf16 pattern
+ * 0xFFFF ("not written yet") — see ocr_set_lstm_proto for the hand-off protocols.  `sync`: ocr_lstm_seq_sync_words(Nb) int32
+ * words of scratch (cleared by the call; last word = spin-timeout error flag, non-zero => results invalid).
+ * ocr_lstm_seq_supported() tells whether the shape is covered (U == 256 and the grid fits one workgroup per CU); otherwise
+ * use the step entry points. */
 int ocr_lstm_seq_supported(int Nb, int U);
 int ocr_lstm_seq_sync_words(int Nb);
 int ocr_lstm_seq_debug(void* dbg /* device int64[4*T] phase stamps of workgroup 0, NULL = off */);
