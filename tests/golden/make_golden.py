@@ -48,6 +48,19 @@ def main():
              labels=lab, label_lengths=lablen, loss_total=np.float64(total.item()), loss_ctc=np.float64(ctc.item()),
              weight_checksum=np.float64(sum(float(v.double().abs().sum()) for k, v in params.items() if k.endswith('weights'))),
              **{'p/' + k: v.numpy() for k, v in params.items() if not k.endswith('weights')})
+    # (3) BASELINE configs[1] at full size: N = 64, W = 256 (T = 63), 10-character labels, seeded parameters (same biases / BN
+    #     affine as above), bf16-rounded arithmetic.  Inputs and labels are regenerated from the seed by the tests.
+    r2 = np.random.RandomState(64256)
+    N, W, L = 64, 256, 10
+    x2 = r2.rand(N, W, 32).astype(np.float32)
+    lab2 = r2.randint(1, 63, N * L).astype(np.int32)
+    ll2 = np.full(N, L, np.int32)
+    sl2 = [W // 4 - 1] * N
+    lg = og.forward(params, torch.from_numpy(x2), sl2, sim_bf16=True)
+    costs2 = og._CTC.apply(lg, lab2, ll2, np.asarray(sl2, np.int32)).numpy()
+    np.savez_compressed(os.path.join(HERE, 'graph_c2.npz'), logits_bf16sim=lg.numpy().astype(np.float32), costs=costs2,
+                        greedy=odec.dense(odec.greedy_decode(lg.numpy(), np.asarray(sl2, np.int32))),
+                        x_checksum=np.float64(np.abs(x2.astype(np.float64)).sum()), seed=np.int64(64256))
     print('golden vectors written to', HERE)
 
 

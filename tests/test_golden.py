@@ -25,6 +25,26 @@ def load_graph_fixture():
     return d, params
 
 
+def c2_inputs():
+    """Inputs of the headline-configuration fixture (BASELINE configs[1]: N = 64, W = 256, T = 63, 10-character labels)."""
+    d = np.load(os.path.join(G, 'graph_c2.npz'))
+    r2 = np.random.RandomState(int(d['seed']))
+    N, W, L = 64, 256, 10
+    x = r2.rand(N, W, 32).astype(np.float32)
+    labels = r2.randint(1, 63, N * L).astype(np.int32)
+    assert abs(float(np.abs(x.astype(np.float64)).sum()) - float(d['x_checksum'])) < 1e-6 * float(d['x_checksum'])
+    return d, x, labels, np.full(N, L, np.int32), np.full(N, W // 4 - 1, np.int32)
+
+
+def test_oracle_reproduces_headline_fixture():
+    d, x, labels, ll, sl = c2_inputs()
+    _, params = load_graph_fixture()
+    lg = og.forward(params, torch.from_numpy(x), sl.tolist(), sim_bf16=True)
+    assert np.abs(lg.numpy() - d['logits_bf16sim']).max() < 1e-4
+    costs = og._CTC.apply(lg, labels, ll, sl).numpy()
+    assert np.allclose(costs, d['costs'], rtol=1e-5)
+
+
 def test_oracle_reproduces_ctc_fixture():
     d = np.load(os.path.join(G, 'ctc_small.npz'))
     costs, grads = octc.ctc_loss_c(d['acts'], d['flat_labels'], d['label_lengths'], d['input_lengths'])
@@ -80,3 +100,33 @@ def test_device_graph_matches_fixture(dev):
     eng.setup_optimizer('Adam', 1e-4)
     loss = eng.train_step(d['x'], d['labels'], d['label_lengths'], sl)
     assert abs(loss - float(d['loss_total'])) < 1e-3 * float(d['loss_total'])         # bar: CTC loss within 1e-3 relative
+
+
+@pytest.mark.gpu
+def test_device_matches_headline_fixture(dev):
+    """The device path at the full size of BASELINE configs[1] against the committed oracle output: logits, per-sample CTC costs
+    (bar 1e-3 relative) and the best-path strings of the device's own logits."""
+    from lstm_ctc_ocr_amd.config import cfg
+    from lstm_ctc_ocr_amd.engine import Engine
+    from lstm_ctc_ocr_amd.models import get_network
+    d, x, labels, ll, sl = c2_inputs()
+    _, params = load_graph_fixture()
+    eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=1)
+    eng.load_arrays({k: v.numpy() for k, v in params.items()})
+    logits = eng.forward(x, sl).float().cpu().numpy()
+    assert logits.shape == (63, 64, cfg.NCLASSES)
+    assert np.abs(logits - d['logits_bf16sim']).max() < 5e-3
+    sp = eng.plan(64, 256)
+    eng._bind(sp, x, sl, labels, ll)
+    eng._run(sp, 'fb')
+    torch.cuda.synchronize()
+    costs = sp.costs.cpu().numpy()
+    assert np.abs(costs - d['costs']).max() < 1e-3 * np.abs(d['costs']).max()
+    assert odec.dense(eng.decode(x, sl, method='greedy')).tolist() == odec.dense(odec.greedy_decode(logits, sl)).tolist()
+    margin = np.sort(d['logits_bf16sim'], axis=-1)
+    agree = [n for n in range(64) if float((margin[:, n, -1] - margin[:, n, -2]).min()) > 1e-2]
+    got = eng.decode(x, sl, method='greedy')
+    for n in agree:                                   # frames decided by more than the logit tolerance: identical strings
+        assert got[n] == [v for v in d['greedy'][n] if v != 0]
+    print('headline fixture: strings compared end-to-end: %d of 64' % len(agree))
+
