@@ -76,6 +76,10 @@ int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int Nb, int W, i
  * colsum (may be NULL): colsum[j] += scale * sum_m B[m][j] — the bias gradient, produced by the same pass */
 int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* out, long ldo, int Mk, int I, int J,
                      int row_group, int row_skip, long a_row_off, float scale, int splits, float* colsum, void* stream);
+/* nbatch products of one shape in one launch; problem b: A + b*strideA, B + b*strideB, out + b*strideOut, colsum + b*strideColsum */
+int ocr_gemm_tn_batched_bf16(const void* A, long lda, long strideA, const void* B, long ldb, long strideB, float* out, long ldo,
+                             long strideOut, int Mk, int I, int J, int nbatch, float scale, int splits, float* colsum,
+                             long strideColsum, void* stream);
 int ocr_set_wgrad_engine(int use_dma_tiles);   /* A/B knob: 1 (default) = LDS-DMA kernel where I,J % 128 == 0; 0 = register-staged kernel */
 /* dw f32 [3][3][Cin][Cout] (TF HWIO) += conv weight gradient; dbias (may be NULL) += sum over pixels of dy */
 int ocr_conv3x3_wgrad_bf16(const void* x, const void* dy, float* dw, float* dbias, int Nb, int W, int H, int Cin,
@@ -139,6 +143,8 @@ int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, const int* seq
  * (id & 7) on one XCD, see ocr_probe_xcc; 1 = data-as-flag through memory (sc1), 0 = counters (sc1): placement independent */
 int ocr_set_lstm_proto(int proto);
 int ocr_lstm_hprev(const void* hout, const int* seq_len, void* hprev, int Nb, int T, int U, void* stream);
+/* xh [2][Nb*T][D+U] = [x | h_{t-1} in direction order]: operand of the LSTMCell-matrix weight gradient (one GEMM per direction) */
+int ocr_lstm_xh(const void* x, const void* hout, const int* seq_len, void* xh, int Nb, int T, int D, int U, void* stream);
 int ocr_lstm_pack_bias(const float* b_fw, const float* b_bw, float* out, int U, void* stream);
 
 /* ---- optimiser (train.py:73-85: clip_by_global_norm 10.0 + Adam / Momentum / RMSProp; L2 of network.py:630-637) */

@@ -214,7 +214,7 @@ static int pick_splits(long tiles, int Mk) {
 // LDS-DMA generation (gemm_tn2.hip); -1 = shape not covered
 int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* out, long ldo, int Mk, int I, int J, int mode,
                      int grp, int skip, long a_row_off, int cW, int cH, int cC, float scale, int splits, float* colsum,
-                     hipStream_t stream);
+                     hipStream_t stream, int nbatch = 1, long sA = 0, long sB = 0, long sO = 0, long sC = 0);
 static int g_use_tn2 = 1;
 extern "C" int ocr_set_wgrad_engine(int use_dma_tiles) { g_use_tn2 = use_dma_tiles != 0; return OCR_OK; }
 
@@ -236,6 +236,25 @@ extern "C" int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb
     if (splits <= 0) splits = pick_splits(tiles, Mk);
     g.k_per_split = ceil_div(ceil_div(Mk, splits), 32) * 32;
     return big ? launch_tn<0, 4, 4>(g, 1, (hipStream_t)stream) : launch_tn<0, 2, 2>(g, 1, (hipStream_t)stream);
+}
+
+// `nbatch` independent products of one shape in ONE launch: problem b uses A + b*strideA, B + b*strideB, out + b*strideOut,
+// colsum + b*strideColsum (element strides).  Used for the two directions of the BiLSTM weight gradient (network.py:104-107).
+extern "C" int ocr_gemm_tn_batched_bf16(const void* A, long lda, long strideA, const void* B, long ldb, long strideB, float* out,
+                                        long ldo, long strideOut, int Mk, int I, int J, int nbatch, float scale, int splits,
+                                        float* colsum, long strideColsum, void* stream) {
+    if (!A || !B || !out || Mk <= 0 || I <= 0 || J <= 0 || (I & 7) || (J & 7) || nbatch <= 0) return OCR_ERR_INVALID;
+    if (g_use_tn2 && nbatch > 1) {
+        int rc = tn2_try_dispatch(A, lda, B, ldb, out, ldo, Mk, I, J, 0, 0, 0, 0, 0, 0, 0, scale, splits, colsum, (hipStream_t)stream,
+                                  nbatch, strideA, strideB, strideOut, strideColsum);
+        if (rc >= 0) return rc;
+    }
+    for (int b = 0; b < nbatch; ++b) {
+        int rc = ocr_gemm_tn_bf16((const bf16_t*)A + b * strideA, lda, (const bf16_t*)B + b * strideB, ldb, out + b * strideOut, ldo, Mk,
+                                  I, J, 0, 0, 0, scale, splits, colsum ? colsum + b * strideColsum : nullptr, stream);
+        if (rc != OCR_OK) return rc;
+    }
+    return OCR_OK;
 }
 
 // dW[3][3][Cin][Cout] (fp32, TF layout) += sum over pixels of x[shifted pixel][ci] * dy[pixel][co]

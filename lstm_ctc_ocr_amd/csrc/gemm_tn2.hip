@@ -30,6 +30,7 @@ struct Tn2Args {
     // XS * XJ * XI = 8: an XCD then streams only 1/(XI*XS) of A and 1/(XJ*XS) of B through its L2 (every XCD used to
     // stream both operands completely: TCC hit rate 2-66 %, 180-245 MB fetched per launch against 33-50 MB of operands).
     int XS, XJ, XI, taps, itl, jtl;                // itl = i tiles per XCD, jtl = j tiles per XCD
+    int nbatch; long sA, sB, sO, sC;               // batched plain mode: problem b uses A + b*sA, B + b*sB, out + b*sO, colsum + b*sC
     __device__ int cH_or1() const { return cH > 0 ? cH : 1; }
 };
 
@@ -71,7 +72,10 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
     const int xs = xcd % g.XS, xj = (xcd / g.XS) % g.XJ, xi = xcd / (g.XS * g.XJ);
     const int it_l = q % g.itl; q /= g.itl;
     const int tapi = q % g.taps; q /= g.taps;
-    const int jt_l = q % g.jtl; q /= g.jtl;            // q is now the XCD-local split index
+    const int jt_l = q % g.jtl; q /= g.jtl;
+    const int bi = q % g.nbatch; q /= g.nbatch;        // q is now the XCD-local split index
+    g.A += bi * g.sA; g.B += bi * g.sB; g.out += bi * g.sO;
+    if (g.colsum) g.colsum += bi * g.sC;
     const int tap = (MODE == 1) ? tapi : (MODE == 2 ? 2 * tapi : 0);
     const int i0 = (MODE == 2) ? 0 : (it_l * g.XI + xi) * 128;
     const int j0 = (jt_l * g.XJ + xj) * 128;
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
 // returns -1 if the shape is not covered
 int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* out, long ldo, int Mk, int I, int J, int mode,
                      int grp, int skip, long a_row_off, int cW, int cH, int cC, float scale, int splits, float* colsum,
-                     hipStream_t stream) {
+                     hipStream_t stream, int nbatch = 1, long sA = 0, long sB = 0, long sO = 0, long sC = 0) {
     const bool pair = (mode == 1 && I == 64);          // Cin == 64: two taps per A tile
     if ((!pair && (I & 127)) || (J & 127) || Mk < 256) return -1;
     Tn2Args g = {};
@@ -275,7 +279,8 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
     g.out = out; g.ldo = ldo; g.scale = scale; g.colsum = colsum;
     const int taps = pair ? 5 : (mode == 1 ? 9 : 1);
     const int IT = pair ? 1 : I / 128, JT = J / 128;
-    const long tiles = (long)taps * IT * JT;
+    const long tiles = (long)taps * IT * JT * nbatch;
+    g.nbatch = nbatch; g.sA = sA; g.sB = sB; g.sO = sO; g.sC = sC;
     int maxs = Mk / 768; if (maxs < 1) maxs = 1;      // at least 12 K steps per workgroup: shorter runs are all prologue + atomics
                                                       // (Mk = 4032: 4-6 splits measured best, tools/tn_plain_probe.py)
     // Workgroup count and XCD partition (sweep: tools/wgrad_part_sweep.py).  The K loop is latency-bound (two LDS stages, one
@@ -283,7 +288,7 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
     // workgroups.  Among the partitions (XS, XJ, XI) that reach that, take the least operand re-streaming plus atomic traffic
     // bytes(A) * XJ + bytes(B) * XI + 2 * S * bytes(out)   (fp32 atomics cost ~0.8 us per MB, tools/atomic_probe.py).
     const double ideal = 432.0 / (double)tiles;
-    const double bytesA = 2.0 * Mk * (pair ? 64 : I), bytesB = 2.0 * Mk * J, bytesO = 4.0 * taps * (pair ? 128 : I) * J;
+    const double bytesA = 2.0 * Mk * (pair ? 64 : I) * nbatch, bytesB = 2.0 * Mk * J * nbatch, bytesO = 4.0 * taps * (pair ? 128 : I) * J * nbatch;
     double best = 1e300; int bXS = 1, bXJ = 1, bXI = 1, bS = 1;
     for (int XS = 8; XS >= 1; XS >>= 1)
         for (int XJ = 8 / XS; XJ >= 1; XJ >>= 1) {

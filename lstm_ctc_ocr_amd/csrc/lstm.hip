@@ -236,6 +236,33 @@ __global__ void lstm_hprev_kernel(const bf16_t* __restrict__ hout, const int* __
     }
 }
 
+// xh[d][row(n,t)][D + U] = [x(n,t) | h at the step before (n,t) in direction d's own order]: the operand of ONE weight-gradient
+// GEMM per direction for the whole TF LSTMCell matrix [D + U, 4U] (concat([x_t, h_{t-1}]) of network.py:104-107)
+__global__ void lstm_xh_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ hout, const int* __restrict__ seq_len,
+                               bf16_t* __restrict__ xh, int Nb, int T, int D, int U) {
+    const int groups = (D + U) >> 3, dgroups = D >> 3;
+    const long R = (long)Nb * T;
+    const long total = 2L * R * groups;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int gq = (int)(idx % groups);
+        const long q = idx / groups;
+        const long row = q % R;
+        const int d = (int)(q / R);
+        u32x4 v = {0, 0, 0, 0};
+        if (gq < dgroups) {
+            v = *(const u32x4*)(x + row * D + gq * 8);
+        } else {
+            const int n = (int)(row / T), t = (int)(row % T);
+            const int len = min(seq_len[n], T);
+            if (t < len) {
+                const int tp = (d == 0) ? t - 1 : t + 1;
+                if (tp >= 0 && tp < len) v = *(const u32x4*)(hout + ((long)n * T + tp) * (2L * U) + (long)d * U + (gq - dgroups) * 8);
+            }
+        }
+        *(u32x4*)(xh + ((long)d * R + row) * (D + U) + gq * 8) = v;
+    }
+}
+
 // packed-column permutation used by the forward operands (see header)
 __global__ void lstm_pack_bias_kernel(const float* __restrict__ b_fw, const float* __restrict__ b_bw,
                                       float* __restrict__ out, int U) {
@@ -279,6 +306,14 @@ extern "C" int ocr_lstm_hprev(const void* hout, const int* seq_len, void* hprev,
     long total = 2L * Nb * T * (U >> 3);
     int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
     lstm_hprev_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)hout, seq_len, (bf16_t*)hprev, Nb, T, U);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+extern "C" int ocr_lstm_xh(const void* x, const void* hout, const int* seq_len, void* xh, int Nb, int T, int D, int U, void* stream) {
+    if (!x || !hout || !seq_len || !xh || (U & 7) || (D & 7)) return OCR_ERR_INVALID;
+    long total = 2L * Nb * T * ((D + U) >> 3);
+    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+    lstm_xh_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)hout, seq_len, (bf16_t*)xh, Nb, T, D, U);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }

@@ -412,6 +412,7 @@ class _BiLstmOp(_Op):
         b[self.key + '/dz'] = torch.zeros((R, 8 * U), dtype=BF16, device=dev)
         b[self.key + '/dc'] = torch.zeros((2, N, U), dtype=F32, device=dev)
         b[self.key + '/hprev'] = torch.empty((2, R, U), dtype=BF16, device=dev)
+        b[self.key + '/xh'] = torch.empty((2, R, self.D + U), dtype=BF16, device=dev)
         b[self.key + '/sync_f'] = torch.zeros(ops.lstm_seq_sync_words(N), dtype=I32, device=dev)
         b[self.key + '/sync_b'] = torch.zeros(ops.lstm_seq_sync_words(N), dtype=I32, device=dev)
         sp.lstm_sync = getattr(sp, 'lstm_sync', ()) + (b[self.key + '/sync_f'], b[self.key + '/sync_b'])
@@ -473,15 +474,24 @@ class _BiLstmOp(_Op):
             for s in range(T - 1, -1, -1):
                 ops.lstm_bwd_step(wsh[D:], 4 * U, stride, sp.seq_len, b[self.key + '/dhout'], b[self.key + '/gates'],
                                   b[self.key + '/cell'], b[self.key + '/dz'], b[self.key + '/dc'], N, T, U, s)
-        ops.lstm_hprev(hout, sp.seq_len, b[self.key + '/hprev'], N, T, U)
         dz = b[self.key + '/dz']
         x = self.prev.y(sp).view(R, D)
-        for d, tag in enumerate(('fw', 'bw')):
-            dW = e.grad('%s/%s/weights' % (self.name, tag))
-            dzd = dz[:, d * 4 * U:(d + 1) * 4 * U]
-            ops.gemm_tn(x, dzd, dW[:D], Mk=R, I=D, J=4 * U, lda=D, ldb=8 * U, ldo=4 * U,
-                        colsum=e.grad('%s/%s/biases' % (self.name, tag)))
-            ops.gemm_tn(b[self.key + '/hprev'][d], dzd, dW[D:], Mk=R, I=U, J=4 * U, lda=U, ldb=8 * U, ldo=4 * U)
+        gw = [e.grad('%s/%s/weights' % (self.name, tag)) for tag in ('fw', 'bw')]
+        gb = [e.grad('%s/%s/biases' % (self.name, tag)) for tag in ('fw', 'bw')]
+        if (D + U) % 128 == 0 and (4 * U) % 128 == 0:
+            # dW_d[D+U, 4U] = [x | h_prev,d]^T dz_d for both directions in ONE launch (the TF LSTMCell matrix is applied to
+            # concat([x_t, h_{t-1}]), network.py:104-107): 4 short-K weight-gradient launches become 1
+            xh = b[self.key + '/xh']
+            ops.lstm_xh(x, hout, sp.seq_len, xh, N, T, D, U)
+            ops.gemm_tn_batched(xh, D + U, R * (D + U), dz, 8 * U, 4 * U, gw[0], 4 * U, e.offset(self.name + '/bw/weights') -
+                                e.offset(self.name + '/fw/weights'), R, D + U, 4 * U, 2, colsum=gb[0],
+                                strideColsum=e.offset(self.name + '/bw/biases') - e.offset(self.name + '/fw/biases'))
+        else:
+            ops.lstm_hprev(hout, sp.seq_len, b[self.key + '/hprev'], N, T, U)
+            for d in range(2):
+                dzd = dz[:, d * 4 * U:(d + 1) * 4 * U]
+                ops.gemm_tn(x, dzd, gw[d][:D], Mk=R, I=D, J=4 * U, lda=D, ldb=8 * U, ldo=4 * U, colsum=gb[d])
+                ops.gemm_tn(b[self.key + '/hprev'][d], dzd, gw[d][D:], Mk=R, I=U, J=4 * U, lda=U, ldb=8 * U, ldo=4 * U)
         pdy, finish = e.grad_dst(sp, self.prev)
         if pdy is not None:
             pmask = self.prev.y(sp).view(R, D) if self.prev.mask_in_consumer else None

@@ -134,6 +134,19 @@ def gemm_tn(A, B, out, *, Mk=None, I=None, J=None, lda=None, ldb=None, ldo=None,
     return out
 
 
+def gemm_tn_batched(A, lda, strideA, B, ldb, strideB, out, ldo, strideOut, Mk, I, J, nbatch, colsum=None, strideColsum=0,
+                    scale=1.0, splits=0):
+    """nbatch independent out_b[I][J] += scale * A_b^T B_b in one launch (element strides between the problems)."""
+    call("ocr_gemm_tn_batched_bf16", ptr(_dev(A)), lda, strideA, ptr(B), ldb, strideB, ptr(out), ldo, strideOut, Mk, I, J, nbatch,
+         float(scale), splits, ptr(colsum), strideColsum, _st())
+    return out
+
+
+def lstm_xh(x2d, hout, seq_len, xh, Nb, T, D, U):
+    call("ocr_lstm_xh", ptr(_dev(x2d)), ptr(hout), ptr(seq_len), ptr(xh), Nb, T, D, U, _st())
+    return xh
+
+
 def conv3x3_wgrad(x, dy, dw, splits=0, dbias=None):
     Nb, W, H, Cin = x.shape
     Cout = dy.shape[-1]

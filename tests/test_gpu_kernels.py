@@ -258,6 +258,39 @@ def test_gemm_tn(dev, Mk, I, J):
     assert relerr(out.cpu(), 1.5 * (A.t() @ B)) < 1e-4
 
 
+def test_gemm_tn_batched_and_xh(dev):
+    """Two weight-gradient products in one launch (the BiLSTM directions) and the [x | h_prev] operand builder."""
+    Nb, T, D, U = 8, 21, 512, 256
+    R = Nb * T
+    rng = np.random.RandomState(4)
+    x = bf(torch.from_numpy(rng.randn(R, D).astype(np.float32)))
+    hout = bf(torch.from_numpy(rng.randn(R, 2 * U).astype(np.float32)))
+    lens = np.array([21, 5, 1, 21, 13, 7, 21, 2], np.int32)
+    xh = torch.empty(2, R, D + U, dtype=BF, device=dev)
+    ops.lstm_xh(x.to(dev).to(BF), hout.to(dev).to(BF), torch.from_numpy(lens).to(dev), xh, Nb, T, D, U)
+    ref = torch.zeros(2, R, D + U)
+    for d in range(2):
+        ref[d, :, :D] = x
+        for n in range(Nb):
+            for t in range(int(lens[n])):
+                tp = t - 1 if d == 0 else t + 1
+                if 0 <= tp < lens[n]:
+                    ref[d, n * T + t, D:] = hout[n * T + tp, d * U:(d + 1) * U]
+    assert torch.equal(xh.float().cpu(), ref)
+    dz = bf(torch.from_numpy((rng.randn(R, 8 * U) * 0.1).astype(np.float32)))
+    gap = 1024 + 64                                                   # the two outputs are not adjacent in the flat buffer
+    out = torch.zeros(2 * ((D + U) * 4 * U) + gap, device=dev)
+    cs = torch.zeros(2 * 4 * U + 128, device=dev)
+    so, sc = (D + U) * 4 * U + gap, 4 * U + 128
+    ops.gemm_tn_batched(xh, D + U, R * (D + U), dz.to(dev).to(BF), 8 * U, 4 * U, out, 4 * U, so, R, D + U, 4 * U, 2, colsum=cs, strideColsum=sc)
+    for d in range(2):
+        want = ref[d].double().t() @ dz[:, d * 4 * U:(d + 1) * 4 * U].double()
+        got = out[d * so:d * so + (D + U) * 4 * U].view(D + U, 4 * U).cpu().double()
+        assert relerr(got, want) < 1e-4
+        assert relerr(cs[d * sc:d * sc + 4 * U].cpu().double(), dz[:, d * 4 * U:(d + 1) * 4 * U].double().sum(0)) < 1e-4
+    assert float(out[(D + U) * 4 * U:(D + U) * 4 * U + gap].abs().max()) == 0.0
+
+
 def test_gemm_tn_conv5_rows(dev):
     Nb, W, HC, Co = 3, 9, 64, 128
     x = bf(gen((Nb, W, HC), 3)); dy = bf(gen((Nb * (W - 1), Co), 4))
