@@ -30,6 +30,19 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
     return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
 }
 
+// hardware exp2 / log2 forms (v_exp_f32, v_log_f32: ~1e-6 relative) for the T-sequential recursions of the fast kernel,
+// where the libm expf / logf sequences (about 40 instructions each, three per step) ARE the critical path
+__device__ __forceinline__ float lse2_fast(float a, float b) {
+    float m = fmaxf(a, b);
+    if (m == NEG_INF) return NEG_INF;
+    return m + __logf(__expf(a - m) + __expf(b - m));
+}
+__device__ __forceinline__ float lse3_fast(float a, float b, float c) {
+    float m = fmaxf(fmaxf(a, b), c);
+    if (m == NEG_INF) return NEG_INF;
+    return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+}
+
 // VT = extended-label slots per lane (S <= 64*VT).
 template <int VT>
 __global__ __launch_bounds__(64) void ctc_loss_grad_kernel(
@@ -288,7 +301,7 @@ __global__ __launch_bounds__(256) void ctc_fast_kernel(
             float p1 = __shfl_up(a, 1, 64), p2 = __shfl_up(a, 2, 64);
             if (lane < 1) p1 = NEG_INF;
             if (!skip) p2 = NEG_INF;
-            float v = lse3(a, p1, p2);
+            float v = lse3_fast(a, p1, p2);
             if (v != NEG_INF && in) v += logy[t * SMAX + s]; else if (!in) v = NEG_INF;
             a = v;
             if (in) alpha[t * SMAX + s] = a;
@@ -307,7 +320,7 @@ __global__ __launch_bounds__(256) void ctc_fast_kernel(
             float q1 = __shfl_down(b, 1, 64), q2 = __shfl_down(b, 2, 64);
             if (s + 1 >= S) q1 = NEG_INF;
             if (!skip) q2 = NEG_INF;
-            float v = lse3(b, q1, q2);
+            float v = lse3_fast(b, q1, q2);
             if (v != NEG_INF && in) v += logy[t * SMAX + s]; else if (!in) v = NEG_INF;
             b = v;
             if (in) beta[t * SMAX + s] = b;
