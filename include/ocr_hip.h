@@ -39,6 +39,8 @@ int ocr_ctc_loss(const float* activations, float* gradients, const int* flat_lab
                  int blank_label, float* costs, void* workspace, void* stream);
 /* training form: one launch producing costs and scale * gradient as bf16 [minibatch][max_time][alphabet] (what the backward
  * GEMMs read); label offsets computed in-kernel.  ocr_ctc_train_supported() == 0 -> use ocr_ctc_loss + ocr_tnc_to_ntc_bf16 */
+/* diagnostic: device int64[5] receiving 100 MHz wall-clock stamps at the phase boundaries of sample 0 of the fast kernel (NULL = off) */
+int ocr_ctc_debug(void* dbg);
 int ocr_ctc_train_supported(int alphabet_size, int max_time, int max_label_len);
 int ocr_ctc_loss_train(const float* activations, void* grad_ntc_bf16, float scale, const int* flat_labels,
                        const int* label_lengths, const int* input_lengths, int alphabet_size, int minibatch, int max_time,

@@ -22,6 +22,7 @@ _SIGS = {
     "ocr_ctc_workspace_size": ([_I, _I, _I, ctypes.POINTER(ctypes.c_size_t)], _I),
     "ocr_ctc_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P], _I),
     "ocr_set_ctc_engine": ([_I], _I),
+    "ocr_ctc_debug": ([_P], _I),
     "ocr_ctc_train_supported": ([_I, _I, _I], _I),
     "ocr_ctc_loss_train": ([_P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P], _I),
     "ocr_ctc_greedy_decode": ([_P, _P, _I, _I, _I, _I, _I, _P, _P, _P], _I),

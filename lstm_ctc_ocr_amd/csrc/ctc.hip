@@ -218,7 +218,10 @@ __global__ __launch_bounds__(64) void ctc_loss_grad_kernel(
 // The first version did all of this in one wave with a barrier and an L2 round trip per step: 3 x 63 serial steps,
 // ~0.8 us each (152 us at T = 63).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ctc_fast_kernel(
+__device__ long long* g_ctc_dbg = nullptr;
+constexpr int CTC_NW = 16;        // waves per sample: the frame-parallel phases (log-sum-exp rows, gradient rows) are latency chains per
+                                  // row (cross-lane reductions, LDS atomics): 16 waves x 4 rows instead of 4 x 16 rows
+__global__ __launch_bounds__(64 * CTC_NW) void ctc_fast_kernel(
     const float* __restrict__ act, float* __restrict__ grad, const int* __restrict__ flat_labels,
     const int* __restrict__ label_off, const int* __restrict__ label_len, const int* __restrict__ input_len,
     int T, int N, int C, int blank, float* __restrict__ costs, int SMAX,
@@ -230,8 +233,8 @@ __global__ __launch_bounds__(256) void ctc_fast_kernel(
     float* logy = lse + T;                     // [T][SMAX]
     float* alpha = logy + T * SMAX;            // [T][SMAX]
     float* beta = alpha + T * SMAX;            // [T][SMAX]
-    float* acc = beta + T * SMAX;              // [4][C]   per-wave posterior accumulators
-    int* lab = (int*)(acc + 4 * C);            // [SMAX]
+    float* acc = beta + T * SMAX;              // [CTC_NW][C]   per-wave posterior accumulators
+    int* lab = (int*)(acc + CTC_NW * C);       // [SMAX]
     __shared__ float s_logp;
     __shared__ int s_repeats, s_off;
 
@@ -248,13 +251,13 @@ __global__ __launch_bounds__(256) void ctc_fast_kernel(
     __syncthreads();
     if (label_off == nullptr) {            // exclusive prefix sum of the label lengths, done here instead of a scan launch
         int part = 0;
-        for (int i = tid; i < n; i += 256) part += label_len[i];
+        for (int i = tid; i < n; i += 64 * CTC_NW) part += label_len[i];
         if (part) atomicAdd(&s_off, part);
         __syncthreads();
     }
     const int* labels = flat_labels + (label_off ? label_off[n] : s_off);
     int rep = 0;
-    for (int s = tid; s < S; s += 256) {
+    for (int s = tid; s < S; s += 64 * CTC_NW) {
         lab[s] = (s & 1) ? labels[s >> 1] : blank;
         if ((s & 1) && s >= 3 && labels[s >> 1] == labels[(s >> 1) - 1]) rep++;
     }
@@ -263,16 +266,43 @@ __global__ __launch_bounds__(256) void ctc_fast_kernel(
     const bool feasible = (Tn > 0) && (L + s_repeats <= Tn);
     if (want_grad) {    // frames this sample does not own (and everything when infeasible): zero gradient
         const int t0 = feasible ? Tn : 0;
-        for (int t = t0 + wave; t < T; t += 4)
+        for (int t = t0 + wave; t < T; t += CTC_NW)
             for (int k = lane; k < C; k += 64) {
                 if (g_n) g_n[t * tstride + k] = 0.f;
                 if (gb_n) gb_n[(size_t)t * C + k] = 0;
             }
     }
     if (!feasible) { if (tid == 0) costs[n] = 0.f; return; }
+#define CSTAMP(k) do { if (g_ctc_dbg && n == 0 && tid == 0) g_ctc_dbg[k] = wall_clock64(); } while (0)
+    CSTAMP(0);
 
-    // phase 1
-    for (int t = wave; t < Tn; t += 4) {
+    // phase 1.  A wave owns frames wave, wave+16, ...; when they fit (T <= 64, C <= 128) ALL its activation rows are loaded
+    // first — independent loads, one memory round trip — and stay in registers for phase 4.  (Row after row, each frame paid
+    // a dependent global-load latency: 12 us of the 41 us kernel here, 7.5 more in phase 4.)
+    constexpr int MAXR = 4, MAXK = 2;
+    const bool cached = (T <= CTC_NW * MAXR) && (C <= 64 * MAXK);
+    float rowv[MAXR][MAXK];
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i)
+#pragma unroll
+            for (int j = 0; j < MAXK; ++j) {
+                const int t = wave + CTC_NW * i, k = lane + 64 * j;
+                rowv[i][j] = (t < Tn && k < C) ? a_n[t * tstride + k] : NEG_INF;
+            }
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int t = wave + CTC_NW * i;
+            float m = fmaxf(rowv[i][0], rowv[i][1]);
+            m = wave_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXK; ++j) sum += (rowv[i][j] == NEG_INF) ? 0.f : expf(rowv[i][j] - m);
+            sum = wave_sum(sum);
+            if (lane == 0 && t < Tn) lse[t] = m + logf(sum);
+        }
+    } else
+    for (int t = wave; t < Tn; t += CTC_NW) {
         const float* row = a_n + t * tstride;
         float m = NEG_INF;
         for (int k = lane; k < C; k += 64) m = fmaxf(m, row[k]);
@@ -283,12 +313,14 @@ __global__ __launch_bounds__(256) void ctc_fast_kernel(
         if (lane == 0) lse[t] = m + logf(sum);
     }
     __syncthreads();
+    CSTAMP(1);
     // phase 2
-    for (int i = tid; i < Tn * S; i += 256) {
+    for (int i = tid; i < Tn * S; i += 64 * CTC_NW) {
         const int t = i / S, s = i - t * S;
         logy[t * SMAX + s] = a_n[t * tstride + lab[s]] - lse[t];
     }
     __syncthreads();
+    CSTAMP(2);
     // phase 3
     if (wave == 0) {
         const int s = lane;
@@ -327,11 +359,34 @@ __global__ __launch_bounds__(256) void ctc_fast_kernel(
         }
     }
     __syncthreads();
+    CSTAMP(3);
     if (!want_grad) return;
     // phase 4
     const float logp = s_logp;
     float* wacc = acc + wave * C;
-    for (int t = wave; t < Tn; t += 4) {
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int t = wave + CTC_NW * i;
+            if (t >= Tn) break;                       // uniform per wave
+            for (int k = lane; k < C; k += 64) wacc[k] = 0.f;
+            if (lane < S) {
+                const float al = alpha[t * SMAX + lane], be = beta[t * SMAX + lane];
+                if (al != NEG_INF && be != NEG_INF) atomicAdd(&wacc[lab[lane]], expf(al + be - logy[t * SMAX + lane] - logp));
+            }
+            const float l = lse[t];
+#pragma unroll
+            for (int j = 0; j < MAXK; ++j) {
+                const int k = lane + 64 * j;
+                if (k < C) {
+                    const float v = expf(rowv[i][j] - l) - wacc[k];
+                    if (g_n) g_n[t * tstride + k] = v;
+                    if (gb_n) gb_n[(size_t)t * C + k] = f2bf(v * scale);
+                }
+            }
+        }
+    } else
+    for (int t = wave; t < Tn; t += CTC_NW) {
         for (int k = lane; k < C; k += 64) wacc[k] = 0.f;
         if (lane < S) {
             const float al = alpha[t * SMAX + lane], be = beta[t * SMAX + lane];
@@ -345,6 +400,7 @@ __global__ __launch_bounds__(256) void ctc_fast_kernel(
             if (gb_n) gb_n[(size_t)t * C + k] = f2bf(v * scale);
         }
     }
+    CSTAMP(4);
 }
 
 // Greedy (best-path) decode: per frame argmax (lowest index wins ties, like numpy.argmax),
@@ -436,10 +492,10 @@ extern "C" int ocr_ctc_loss(const float* activations, float* gradients, const in
     OCR_CHECK_LAUNCH();
     // fast path: S <= 64 and the three [T][S] tables fit in LDS
     {
-        size_t flds = ((size_t)max_time * (1 + 3 * SMAX) + 4 * (size_t)alphabet_size) * sizeof(float) + (size_t)SMAX * sizeof(int);
+        size_t flds = ((size_t)max_time * (1 + 3 * SMAX) + CTC_NW * (size_t)alphabet_size) * sizeof(float) + (size_t)SMAX * sizeof(int);
         flds = (flds + 15) & ~(size_t)15;
         if (SMAX <= 64 && flds <= 64 * 1024 && g_ctc_fast) {
-            ctc_fast_kernel<<<minibatch, 256, flds, stream>>>(activations, gradients, flat_labels, label_off, label_lengths,
+            ctc_fast_kernel<<<minibatch, 64 * CTC_NW, flds, stream>>>(activations, gradients, flat_labels, label_off, label_lengths,
                                                              input_lengths, max_time, minibatch, alphabet_size, blank_label, costs,
                                                              SMAX, nullptr, 1.0f);
             OCR_CHECK_LAUNCH();
@@ -462,13 +518,14 @@ extern "C" int ocr_ctc_loss(const float* activations, float* gradients, const in
 }
 
 static size_t ctc_fast_lds(int SMAX, int max_time, int alphabet_size) {
-    size_t flds = ((size_t)max_time * (1 + 3 * SMAX) + 4 * (size_t)alphabet_size) * sizeof(float) + (size_t)SMAX * sizeof(int);
+    size_t flds = ((size_t)max_time * (1 + 3 * SMAX) + CTC_NW * (size_t)alphabet_size) * sizeof(float) + (size_t)SMAX * sizeof(int);
     return (flds + 15) & ~(size_t)15;
 }
 // Training form: costs + the gradient ALREADY in the layout / dtype / scale the backward GEMMs consume
 // (bf16 [N][T][C], multiplied by `scale` = 1/(batch*world)); label offsets are computed in-kernel.  One launch instead of
 // scan + loss + transpose.  Covers S = 2L+1 <= 64 with the [T][S] tables in LDS; returns OCR_ERR_INVALID otherwise
 // (callers then use ocr_ctc_loss + ocr_tnc_to_ntc_bf16).
+extern "C" int ocr_ctc_debug(void* p) { long long* q = (long long*)p; return hipMemcpyToSymbol(HIP_SYMBOL(g_ctc_dbg), &q, sizeof(q)) == hipSuccess ? OCR_OK : OCR_ERR_MEMOPS; }
 extern "C" int ocr_ctc_train_supported(int alphabet_size, int max_time, int max_label_len) {
     const int SMAX = smax_for(max_label_len);
     return SMAX <= 64 && ctc_fast_lds(SMAX, max_time, alphabet_size) <= 64 * 1024;
@@ -482,7 +539,7 @@ extern "C" int ocr_ctc_loss_train(const float* activations, void* grad_ntc_bf16,
         blank_label >= alphabet_size || !ocr_ctc_train_supported(alphabet_size, max_time, max_label_len))
         return OCR_ERR_INVALID;
     const int SMAX = smax_for(max_label_len);
-    ctc_fast_kernel<<<minibatch, 256, ctc_fast_lds(SMAX, max_time, alphabet_size), stream>>>(
+    ctc_fast_kernel<<<minibatch, 64 * CTC_NW, ctc_fast_lds(SMAX, max_time, alphabet_size), stream>>>(
         activations, nullptr, flat_labels, nullptr, label_lengths, input_lengths, max_time, minibatch, alphabet_size, blank_label,
         costs, SMAX, (bf16_t*)grad_ntc_bf16, scale);
     OCR_CHECK_LAUNCH();
