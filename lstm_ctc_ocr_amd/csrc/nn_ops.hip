@@ -678,26 +678,45 @@ struct PackJob {            // 64 bytes, mirrored by lstm_ctc_ocr_amd/engine.py 
 };
 
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int njobs) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[64][65];
     int j = 0;
     while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block_start) ++j;
     const PackJob jb = jobs[j];
     const int b = blockIdx.x - jb.block_start;
-    if (jb.type == 0) {
-        const int ctiles = (jb.Cc + 31) / 32;
-        const int c0 = (b % ctiles) * 32, r0 = (b / ctiles) * 32;
-        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-        for (int i = ty; i < 32; i += 8) {
-            int r = r0 + i, c = c0 + tx;
-            tile[i][tx] = (r < jb.R && c < jb.Cc) ? jb.src[(long)r * jb.ldin + c] : 0.f;
+    if (jb.type == 0) {                                // fp32 [R][ldin] -> bf16 [Cc][R] (transposed), 64 x 64 tiles:
+        const int ctiles = (jb.Cc + 63) / 64;          // 16-byte loads along c, 8-byte stores along r
+        const int c0 = (b % ctiles) * 64, r0 = (b / ctiles) * 64;
+        {
+            const int ty = threadIdx.x >> 4, tx = (threadIdx.x & 15) * 4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int r = r0 + p * 16 + ty, c = c0 + tx;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (r < jb.R) {
+                    const float* src = jb.src + (long)r * jb.ldin + c;
+                    if (c + 3 < jb.Cc && (jb.ldin & 3) == 0) v = *(const f32x4*)src;
+                    else { if (c < jb.Cc) v.x = src[0]; if (c + 1 < jb.Cc) v.y = src[1]; if (c + 2 < jb.Cc) v.z = src[2]; if (c + 3 < jb.Cc) v.w = src[3]; }
+                }
+                float* trow = &tile[p * 16 + ty][tx];
+                trow[0] = v.x; trow[1] = v.y; trow[2] = v.z; trow[3] = v.w;
+            }
         }
         __syncthreads();
-        for (int i = ty; i < 32; i += 8) {
-            int c = c0 + i, r = r0 + tx;
-            if (c < jb.Cc && r < jb.R) {
+        {
+            const int cy = threadIdx.x >> 4, rq = (threadIdx.x & 15) * 4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int cl = p * 16 + cy, c = c0 + cl, r = r0 + rq;
+                if (c >= jb.Cc || r >= jb.R) continue;
                 int pc = c;
                 if (jb.lstm_units > 0) { int gidx = c / jb.lstm_units, u = c % jb.lstm_units; pc = (u >> 4) * 64 + gidx * 16 + (u & 15); }
-                jb.dst[(long)pc * jb.R + r] = f2bf(tile[tx][i]);
+                bf16_t* dst = jb.dst + (long)pc * jb.R + r;
+                if (r + 3 < jb.R && (jb.R & 3) == 0) {
+                    u32x2 pk = {pack_bf2(tile[rq][cl], tile[rq + 1][cl]), pack_bf2(tile[rq + 2][cl], tile[rq + 3][cl])};
+                    *(u32x2*)dst = pk;
+                } else {
+                    for (int k = 0; k < 4 && r + k < jb.R; ++k) dst[k] = f2bf(tile[rq + k][cl]);
+                }
             }
         }
     } else if (jb.type == 1) {

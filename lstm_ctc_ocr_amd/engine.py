@@ -704,7 +704,7 @@ class Engine(object):
         for i, j in enumerate(jobs):
             t = j['type']
             if t == 0:
-                nb = ((j['Cc'] + 31) // 32) * ((j['R'] + 31) // 32)
+                nb = ((j['Cc'] + 63) // 64) * ((j['R'] + 63) // 64)
             elif t == 1:
                 nb = min((j['n'] + 255) // 256, 512)
             elif t == 2:
