@@ -463,6 +463,15 @@ static inline int smax_for(int max_label_len) { return 2 * max_label_len + 1; }
 static int g_ctc_fast = 1;
 extern "C" int ocr_set_ctc_engine(int fast) { g_ctc_fast = fast; return OCR_OK; }   // A/B + test knob: 0 = one-wave reference kernel
 
+// the [T][S] tables of the fast kernel may need more than the 64 KiB of dynamic LDS a kernel gets by default (T = 79 of the
+// variable-width workload: 65 KiB); the limit is raised once
+constexpr size_t CTC_FAST_LDS_MAX = 128 * 1024;
+static bool ctc_fast_allow_lds() {
+    static int ok = -1;
+    if (ok < 0) ok = hipFuncSetAttribute((const void*)ctc_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CTC_FAST_LDS_MAX) == hipSuccess;
+    return ok == 1;
+}
+
 extern "C" int ocr_ctc_workspace_size(int max_label_len, int max_time, int minibatch,
                                       size_t* bytes) {
     if (!bytes || max_label_len < 0 || max_time <= 0 || minibatch <= 0) return OCR_ERR_INVALID;
@@ -494,7 +503,7 @@ extern "C" int ocr_ctc_loss(const float* activations, float* gradients, const in
     {
         size_t flds = ((size_t)max_time * (1 + 3 * SMAX) + CTC_NW * (size_t)alphabet_size) * sizeof(float) + (size_t)SMAX * sizeof(int);
         flds = (flds + 15) & ~(size_t)15;
-        if (SMAX <= 64 && flds <= 64 * 1024 && g_ctc_fast) {
+        if (SMAX <= 64 && flds <= CTC_FAST_LDS_MAX && g_ctc_fast && ctc_fast_allow_lds()) {
             ctc_fast_kernel<<<minibatch, 64 * CTC_NW, flds, stream>>>(activations, gradients, flat_labels, label_off, label_lengths,
                                                              input_lengths, max_time, minibatch, alphabet_size, blank_label, costs,
                                                              SMAX, nullptr, 1.0f);
@@ -528,7 +537,7 @@ static size_t ctc_fast_lds(int SMAX, int max_time, int alphabet_size) {
 extern "C" int ocr_ctc_debug(void* p) { long long* q = (long long*)p; return hipMemcpyToSymbol(HIP_SYMBOL(g_ctc_dbg), &q, sizeof(q)) == hipSuccess ? OCR_OK : OCR_ERR_MEMOPS; }
 extern "C" int ocr_ctc_train_supported(int alphabet_size, int max_time, int max_label_len) {
     const int SMAX = smax_for(max_label_len);
-    return SMAX <= 64 && ctc_fast_lds(SMAX, max_time, alphabet_size) <= 64 * 1024;
+    return SMAX <= 64 && ctc_fast_lds(SMAX, max_time, alphabet_size) <= CTC_FAST_LDS_MAX && ctc_fast_allow_lds();
 }
 extern "C" int ocr_ctc_loss_train(const float* activations, void* grad_ntc_bf16, float scale, const int* flat_labels,
                                   const int* label_lengths, const int* input_lengths, int alphabet_size, int minibatch,

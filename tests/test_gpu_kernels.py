@@ -129,6 +129,9 @@ def test_ctc_edge_cases(dev):
     # long labels: S = 2L+1 > 64 exercises two / four slots per lane; large alphabet exercises strided classes
     _ctc_case(dev, 90, 3, 96, [40, 33, 5], [90, 80, 90], 5)
     _ctc_case(dev, 200, 2, 200, [100, 70], [200, 199], 6)
+    # T = 79 (the longest plan of the variable-width workload): the fast kernel's tables need more than 64 KiB of LDS
+    assert ops.ctc_train_supported(64, 79, 10)
+    _ctc_case(dev, 79, 6, 64, [10, 4, 7, 10, 9, 5], [79, 60, 33, 79, 20, 12], 8)
     # non-zero blank
     _ctc_case(dev, 20, 4, 10, [3, 4, 5, 2], [20, 18, 15, 9], 7, blank=9,
               labels=[[1, 2, 3], [0, 0, 4, 8], [5, 6, 7, 8, 0], [2, 2]])
