@@ -126,8 +126,9 @@ def test_rccl_call_path_on_a_one_rank_group(dev, monkeypatch):
     finally:
         dist.destroy_process_group()
     assert np.allclose(losses, base_losses, rtol=2e-3)
-    worst = max(float(np.abs(state[k] - base_state[k]).max()) for k in state)
-    assert worst < 2e-3, worst
+    diffs = np.concatenate([np.abs(state[k] - base_state[k]).ravel() for k in state])
+    # Adam normalises the update, so entries whose gradient is summation-order noise may move by up to lr per step
+    assert float(diffs.max()) < 7e-3 and float(diffs.mean()) < 2e-5, (diffs.max(), diffs.mean())
 
 
 @pytest.mark.parametrize("overlap", ["1", "0"])
