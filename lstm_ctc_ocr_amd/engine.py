@@ -817,9 +817,9 @@ class Engine(object):
 
     # ------------------------------------------------------------------ input binding
     def _bind(self, sp, data, seq_len, labels=None, labels_len=None):
-        sp.x.copy_(torch.as_tensor(np.asarray(data, np.float32)) if not torch.is_tensor(data) else data, non_blocking=True)
+        x = torch.as_tensor(np.asarray(data, np.float32)) if not torch.is_tensor(data) else data
         sl = torch.as_tensor(np.asarray(seq_len, np.int32)) if not torch.is_tensor(seq_len) else seq_len
-        dsts, srcs = [sp.seq_len], [sl]
+        dsts, srcs = [sp.x, sp.seq_len], [x, sl]
         if labels is not None:
             lab = torch.as_tensor(np.asarray(labels, np.int32)) if not torch.is_tensor(labels) else labels
             ll = torch.as_tensor(np.asarray(labels_len, np.int32)) if not torch.is_tensor(labels_len) else labels_len
@@ -827,8 +827,10 @@ class Engine(object):
                 raise ValueError('flat label vector longer than batch * max_label_len (%d)' % sp.labels.numel())
             dsts += [sp.labels[:lab.numel()], sp.labels_len]
             srcs += [lab, ll]
-        if all(t.is_cuda and t.dtype == torch.int32 for t in srcs):
-            torch._foreach_copy_(dsts, srcs)                  # device-resident batch: one multi-tensor copy kernel
+        if all(t.is_cuda and t.dtype == d.dtype and t.shape == d.shape for t, d in zip(srcs, dsts)):
+            # device-resident batch: multi-tensor copy kernels instead of one blit (hipMemcpyAsync) per tensor — a blit is
+            # preceded by a queue barrier that left the GPU idle for ~9 us at the start of every step
+            torch._foreach_copy_(dsts, srcs)
         else:
             for d, t in zip(dsts, srcs):
                 d.copy_(t, non_blocking=True)
