@@ -896,6 +896,28 @@ class Engine(object):
         sp.graph_fb1.replay()
         return sp.graph_fb2.replay
 
+    def _run_step(self, sp):
+        """Whole training step of this shape as one hipGraph (no exchange between backward and optimiser on a single GPU: the
+        graph boundary cost ~8 us of idle GPU per step).  Only the forward/backward part is warmed up eagerly — the optimiser
+        mutates state, so its first execution is the first replay."""
+        if not self.opt_ready:
+            self.setup_optimizer()
+
+        def fb():
+            self.grads.zero_()
+            self._forward(sp)
+            self._loss_and_backward(sp)
+            self._backward_early(sp)
+
+        if getattr(sp, 'graph_step', None) is None:
+            fb()
+
+            def body():
+                fb()
+                self._optim_body()
+            sp.graph_step = self._capture(body)
+        sp.graph_step.replay()
+
     def _run(self, sp, which):
         """Run (or capture-then-replay) the forward(+backward) body for this shape."""
         attr = 'graph_fb' if which == 'fb' else 'graph_fwd'
@@ -954,6 +976,9 @@ class Engine(object):
         self.scalars = torch.zeros(ops.optim_scalar_count(), dtype=torch.float64, device=self.device)
         ops.optim_init(self.scalars, self.lr)
         self.opt_ready = True
+        self.graph_opt = None                            # captured optimiser graphs hold the old slot tensors
+        for sp in getattr(self, 'plans', {}).values():
+            sp.graph_step = None
 
     def scale_lr(self, gamma):
         ops.optim_set_lr(self.scalars, gamma, multiply=True)
@@ -1008,10 +1033,13 @@ class Engine(object):
             rest()                                       # backward of the early layers, concurrent with the exchange above
             self.allreduce_grads(0, self.late_begin)
             main.wait_stream(self.comm_stream)
+            self.optimizer_step()
+        elif self.world == 1 and not self.force_allreduce and self.use_graphs:
+            self._run_step(sp)                            # single GPU: forward, backward and optimiser as ONE graph
         else:
             self._run(sp, 'fb')
             self.allreduce_grads()
-        self.optimizer_step()
+            self.optimizer_step()
         self.iteration += 1
         self.last_plan = sp
         if fetch_loss:
