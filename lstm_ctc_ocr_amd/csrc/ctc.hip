@@ -43,6 +43,15 @@ __device__ __forceinline__ float lse3_fast(float a, float b, float c) {
     return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
 }
 
+// whole-wave shifts by one lane as DPP moves (wave_shr:1 / wave_shl:1, one VALU instruction; the lane shifted in takes `fill`)
+// instead of ds_bpermute round trips through the LDS crossbar: they sit on the T-sequential critical path of the recursions
+__device__ __forceinline__ float wave_shr1(float v, float fill) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float v, float fill) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
 // VT = extended-label slots per lane (S <= 64*VT).
 template <int VT>
 __global__ __launch_bounds__(64) void ctc_loss_grad_kernel(
@@ -330,8 +339,7 @@ __global__ __launch_bounds__(64 * CTC_NW) void ctc_fast_kernel(
         float a = (in && s < 2) ? logy[s] : NEG_INF;
         if (in) alpha[s] = a;
         for (int t = 1; t < Tn; ++t) {
-            float p1 = __shfl_up(a, 1, 64), p2 = __shfl_up(a, 2, 64);
-            if (lane < 1) p1 = NEG_INF;
+            float p1 = wave_shr1(a, NEG_INF), p2 = wave_shr1(p1, NEG_INF);
             if (!skip) p2 = NEG_INF;
             float v = lse3_fast(a, p1, p2);
             if (v != NEG_INF && in) v += logy[t * SMAX + s]; else if (!in) v = NEG_INF;
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(64 * CTC_NW) void ctc_fast_kernel(
         float b = (in && s >= S - 2) ? logy[(Tn - 1) * SMAX + s] : NEG_INF;
         if (in) beta[(Tn - 1) * SMAX + s] = b;
         for (int t = Tn - 2; t >= 0; --t) {
-            float q1 = __shfl_down(b, 1, 64), q2 = __shfl_down(b, 2, 64);
+            float q1 = wave_shl1(b, NEG_INF), q2 = wave_shl1(q1, NEG_INF);
             if (s + 1 >= S) q1 = NEG_INF;
             if (!skip) q2 = NEG_INF;
             float v = lse3_fast(b, q1, q2);
