@@ -25,6 +25,7 @@ import torch
 from . import dist as ocr_dist
 from . import ops
 from ._native import NativeError
+from .layout import FlatLayout
 from ._native import call as nat_call
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
@@ -594,43 +595,10 @@ class Engine(object):
             nat_call('ocr_set_lstm_proto', 1)
 
     def _layout(self, net):
-        """Flat parameter / gradient layout: [early rest | early regularised | late regularised | late rest].
-        The L2-regularised tensors form ONE contiguous range in the middle (the optimiser kernels take its bounds); the
-        tensors of the LATE layers — the last layers of the network holding >= 75 % of the parameters, whose gradients are
-        complete first in the backward pass — form the upper part, so data parallelism exchanges them as one contiguous
-        all-reduce while the early layers' backward is still running (train_step)."""
-        specs = list(net.param_specs.values())
-        layer_of = lambda sp_: sp_.name.split('/')[0]
-        layers = []
-        for sp_ in specs:
-            if layer_of(sp_) not in layers:
-                layers.append(layer_of(sp_))
-        size = {l: 0 for l in layers}
-        for sp_ in specs:
-            size[layer_of(sp_)] += int(np.prod(sp_.shape))
-        total, acc, split = sum(size.values()), 0, 0
-        for i in range(len(layers) - 1, -1, -1):
-            acc += size[layers[i]]
-            split = i
-            if acc >= 0.75 * total:
-                break
-        late = set(layers[split:]) if split > 0 else set()
-        self.split_layer = layers[split] if split > 0 else None
-        is_late = lambda sp_: layer_of(sp_) in late
-        groups = ([s_ for s_ in specs if not s_.regularized and not is_late(s_)], [s_ for s_ in specs if s_.regularized and not is_late(s_)],
-                  [s_ for s_ in specs if s_.regularized and is_late(s_)], [s_ for s_ in specs if not s_.regularized and is_late(s_)])
-        self.specs, self.offsets = {}, {}
-        off, bounds = 0, []
-        for grp in groups:
-            bounds.append(off)
-            for s_ in grp:
-                self.specs[s_.name] = s_
-                self.offsets[s_.name] = off
-                off += _round_up(int(np.prod(s_.shape)), ALIGN)
-        bounds.append(off)
-        self.n_total = off
-        self.reg_range = (bounds[1], bounds[3])        # [early reg | late reg]
-        self.late_begin = bounds[2]                    # gradients of [late_begin, n_total) are complete after backward part 1
+        """Flat parameter / gradient layout [early rest | early regularised | late regularised | late rest] — layout.py."""
+        lay = FlatLayout(net.param_specs.values(), ALIGN)
+        self.specs, self.offsets, self.n_total = lay.specs, lay.offsets, lay.n_total
+        self.split_layer, self.reg_range, self.late_begin = lay.split_layer, lay.reg_range, lay.late_begin
         dev = self.device
         self.params = torch.zeros(self.n_total, dtype=F32, device=dev)
         self.grads = torch.zeros(self.n_total, dtype=F32, device=dev)

@@ -109,3 +109,29 @@ def test_reference_cli_script_runs_against_this_lib(monkeypatch, tmp_path, capsy
     assert called['kw']['max_iters'] == 5 and called['kw']['restore'] is False and called['db'].name == 'lstm_train'
     assert type(called['net']).__name__ == 'LSTM_train'
     assert os.path.isdir(os.path.join(str(tmp_path), 'output', 'lstm_ctc'))
+
+
+def test_flat_layout_buckets():
+    """Flat parameter layout of the engine: one contiguous regularised range, late layers (>= 75 % of the parameters) on top."""
+    from lstm_ctc_ocr_amd.layout import FlatLayout
+    from lstm_ctc_ocr_amd.models import get_network
+    net = get_network('LSTM_train')
+    specs = list(net.param_specs.values())
+    lay = FlatLayout(specs, 64)
+    assert lay.split_layer == 'conv4_1'
+    n = {s.name: int(np.prod(s.shape)) for s in specs}
+    assert sum(n.values()) == 7158592 and lay.n_total >= 7158592 and lay.n_total % 64 == 0
+    r0, r1 = lay.reg_range
+    for s in specs:
+        o = lay.offsets[s.name]
+        assert o % 64 == 0
+        assert (r0 <= o < r1) == bool(s.regularized), s.name                       # regularised <=> inside the range
+        late = s.name.split('/')[0] in ('conv4_1', 'conv4_2', 'conv5', 'logits')
+        assert (o >= lay.late_begin) == late, s.name                               # late <=> upper bucket
+    spans = sorted((lay.offsets[k], lay.offsets[k] + n[k]) for k in n)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))                     # no overlap
+    late_params = sum(v for k, v in n.items() if lay.offsets[k] >= lay.late_begin)
+    assert late_params >= 0.75 * 7158592 and 0 < r0 < lay.late_begin < r1 < lay.n_total
+    # a one-layer net has nothing to split
+    one = FlatLayout([s for s in specs if s.name.startswith('conv1/')], 64)
+    assert one.split_layer is None and one.late_begin == one.n_total
