@@ -1,11 +1,15 @@
-"""Global configuration — same keys, defaults, merge rules and helpers as /root/reference/lib/lstm/config.py
-(cfg :10-72, get_encode_decode_dict :73-81, get_output_dir :84-90, get_log_dir :92-97, _merge_a_into_b
-:99-126, cfg_from_file :128-134, cfg_from_list :136-156).  Differences, all forced by this environment and
-listed in INTEGRATION.md: yaml.safe_load (PyYAML >= 6 rejects yaml.load without a Loader), an in-tree
-EasyDict, and ROOT_DIR overridable with $OCR_ROOT_DIR so outputs need not land inside the package."""
+"""Global configuration of the OCR path.
+
+Contract taken from the reference's lib/lstm/config.py (keys and defaults :10-72, label maps :73-81, output / log directory
+helpers :84-97, merge rules :99-126, file and list overrides :128-156): the same key tree, the same default values, the same
+exceptions for bad overrides — user scripts and lstm/lstm.yml written for the reference keep working.  The implementation is
+independent: the defaults are ONE nested table, and a single walker does both kinds of override.  Differences forced by this
+environment: yaml.safe_load (PyYAML >= 6 rejects a bare yaml.load), an in-tree EasyDict when the PyPI one is
+absent, ROOT_DIR overridable with $OCR_ROOT_DIR so outputs need not land inside the package.
+"""
+import ast
 import os
-import os.path as osp
-from time import localtime, strftime
+import time
 
 import numpy as np
 
@@ -14,136 +18,119 @@ try:                                    # the real package if the host has it, e
 except ImportError:                     # pragma: no cover - depends on the host
     from .edict import EasyDict as edict
 
-__C = edict()
-cfg = __C
+_ALPHABET = '0123456789' + 'abcdefghijklmnopqrstuvwxyz' + 'ABCDEFGHIJKLMNOPQRSTUVWXYZ'
+_HEIGHT, _PLANES = 32, 1
 
-__C.GPU_ID = 1
-__C.GPU_USAGE = 0.9
-__C.OFFSET_TIME_STEP = -1
-__C.POOL_SCALE = 4
-__C.IMG_SHAPE = [32, 100]
-__C.IMG_HEIGHT = 32
-__C.MAX_CHAR_LEN = 6
-__C.BLANK_TOKEN = 0
-__C.CHARSET = '0123456789abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ'
-__C.NCLASSES = len(__C.CHARSET) + 2
-__C.MIN_LEN = 4
-__C.MAX_LEN = 6
-__C.FONT = 'fonts/Ubuntu-M.ttf'
-__C.NCHANNELS = 1
-__C.NUM_FEATURES = __C.IMG_HEIGHT * __C.NCHANNELS
-
-__C.NET_NAME = 'lstm'
-__C.TRAIN = edict()
-__C.TRAIN.SOLVER = 'Adam'              # Adam | Momentum | RMS
-__C.TRAIN.TXT = 'annotation_train.txt'
-__C.TRAIN.WEIGHT_DECAY = 0.0005
-__C.TRAIN.LEARNING_RATE = 0.01
-__C.TRAIN.MOMENTUM = 0.9
-__C.TRAIN.GAMMA = 0.1
-__C.TRAIN.STEPSIZE = 50000
-__C.TRAIN.DISPLAY = 10
-__C.TRAIN.LOG_IMAGE_ITERS = 100
-__C.TRAIN.NUM_EPOCHS = 2000
-__C.TRAIN.NUM_HID = 512
-__C.TRAIN.NUM_LAYERS = 2
-__C.TRAIN.BATCH_SIZE = 64
-__C.TRAIN.SNAPSHOT_ITERS = 5000
-__C.TRAIN.SNAPSHOT_PREFIX = 'lstm'
-__C.TRAIN.SNAPSHOT_INFIX = ''
-
-__C.VAL = edict()
-__C.VAL.TXT = 'annotation_val.txt'
-__C.VAL.VAL_STEP = 1000
-__C.VAL.NUM_EPOCHS = 1000
-__C.VAL.BATCH_SIZE = 128
-__C.VAL.PRINT_NUM = 5
-
-__C.RNG_SEED = 3
-__C.ROOT_DIR = os.environ.get('OCR_ROOT_DIR', osp.abspath(osp.join(osp.dirname(__file__), '..')))
-__C.TEST = edict()
-__C.EXP_DIR = 'default'
-__C.LOG_DIR = 'default'
-__C.SPACE_INDEX = 0
-__C.SPACE_TOKEN = ''
+_DEFAULTS = {
+    # device / data geometry
+    'GPU_ID': 1, 'GPU_USAGE': 0.9,
+    'IMG_SHAPE': [32, 100], 'IMG_HEIGHT': _HEIGHT, 'NCHANNELS': _PLANES, 'NUM_FEATURES': _HEIGHT * _PLANES,
+    'POOL_SCALE': 4,                    # two 2x2 pools along the width
+    'OFFSET_TIME_STEP': -1,             # the 2x2 VALID conv5 eats one more step: T = W // POOL_SCALE + OFFSET_TIME_STEP
+    # label alphabet: classes 1..62 are characters, 0 is blank / padding, 63 is the TF decoder's blank
+    'CHARSET': _ALPHABET, 'NCLASSES': len(_ALPHABET) + 2, 'BLANK_TOKEN': 0, 'SPACE_INDEX': 0, 'SPACE_TOKEN': '',
+    'MAX_CHAR_LEN': 6, 'MIN_LEN': 4, 'MAX_LEN': 6, 'FONT': 'fonts/Ubuntu-M.ttf',
+    # bookkeeping
+    'NET_NAME': 'lstm', 'RNG_SEED': 3, 'EXP_DIR': 'default', 'LOG_DIR': 'default',
+    'ROOT_DIR': os.environ.get('OCR_ROOT_DIR', os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))),
+    'TRAIN': {
+        'SOLVER': 'Adam',               # Adam | Momentum | RMS
+        'LEARNING_RATE': 0.01, 'MOMENTUM': 0.9, 'WEIGHT_DECAY': 0.0005, 'GAMMA': 0.1, 'STEPSIZE': 50000,
+        'BATCH_SIZE': 64, 'NUM_EPOCHS': 2000, 'NUM_HID': 512, 'NUM_LAYERS': 2,
+        'DISPLAY': 10, 'LOG_IMAGE_ITERS': 100,
+        'SNAPSHOT_ITERS': 5000, 'SNAPSHOT_PREFIX': 'lstm', 'SNAPSHOT_INFIX': '',
+        'TXT': 'annotation_train.txt',
+    },
+    'VAL': {'BATCH_SIZE': 128, 'VAL_STEP': 1000, 'NUM_EPOCHS': 1000, 'PRINT_NUM': 5, 'TXT': 'annotation_val.txt'},
+    'TEST': {},
+}
 
 
+def _tree(table):
+    node = edict()
+    for key, value in table.items():
+        node[key] = _tree(value) if isinstance(value, dict) else value
+    return node
+
+
+cfg = _tree(_DEFAULTS)
+__C = cfg                               # the reference's private alias, kept for code that imports it
+
+
+# ------------------------------------------------------------------------------------------------ label maps
 def get_encode_decode_dict():
-    """char -> 1..len(CHARSET) by CHARSET position; '' <-> 0 (the CTC blank / padding value)."""
-    encode_maps, decode_maps = {}, {}
-    for i, char in enumerate(__C.CHARSET, 1):
-        encode_maps[char] = i
-        decode_maps[i] = char
-    encode_maps[__C.SPACE_TOKEN] = __C.SPACE_INDEX
-    decode_maps[__C.SPACE_INDEX] = __C.SPACE_TOKEN
-    return encode_maps, decode_maps
+    """(char -> class, class -> char): characters are numbered from 1 in CHARSET order; '' <-> 0 is blank / padding."""
+    chars = list(cfg.CHARSET)
+    encode = dict(zip(chars, range(1, len(chars) + 1)))
+    decode = {index: char for char, index in encode.items()}
+    encode[cfg.SPACE_TOKEN] = cfg.SPACE_INDEX
+    decode[cfg.SPACE_INDEX] = cfg.SPACE_TOKEN
+    return encode, decode
 
 
-def _ensure_dir(path):
-    if not os.path.exists(path):
-        os.makedirs(path)
+# ------------------------------------------------------------------------------------------------ directories
+def _made(path):
+    os.makedirs(path, exist_ok=True)
     return path
 
 
 def get_output_dir(imdb, weights_filename):
-    outdir = osp.abspath(osp.join(__C.ROOT_DIR, 'output', __C.EXP_DIR))
-    if weights_filename is not None:
-        outdir = osp.join(outdir, weights_filename)
-    return _ensure_dir(outdir)
+    """<ROOT_DIR>/output/<EXP_DIR>[/<weights_filename>], created on demand (snapshots go here)."""
+    parts = [cfg.ROOT_DIR, 'output', cfg.EXP_DIR] + ([weights_filename] if weights_filename is not None else [])
+    return _made(os.path.abspath(os.path.join(*parts)))
 
 
 def get_log_dir(imdb):
-    stamp = strftime("%Y-%m-%d-%H-%M-%S", localtime())
-    return _ensure_dir(osp.abspath(osp.join(__C.ROOT_DIR, 'logs', __C.LOG_DIR, imdb.name, stamp)))
+    """<ROOT_DIR>/logs/<LOG_DIR>/<imdb.name>/<timestamp>, created on demand."""
+    stamp = time.strftime('%Y-%m-%d-%H-%M-%S', time.localtime())
+    return _made(os.path.abspath(os.path.join(cfg.ROOT_DIR, 'logs', cfg.LOG_DIR, imdb.name, stamp)))
 
 
+# ------------------------------------------------------------------------------------------------ overrides
 def _merge_a_into_b(a, b):
-    """Strict recursive merge: unknown key -> KeyError, type mismatch -> ValueError (numpy arrays are cast)."""
+    """Overlay tree `a` on the configuration tree `b`.  Only existing keys may be set (KeyError otherwise) and a value must
+    keep the type of the default (ValueError otherwise; array defaults adopt lists through their dtype)."""
     if type(a) is not edict:
         return
-    for k, v in a.items():
-        if k not in b:
-            raise KeyError('{} is not a valid config key'.format(k))
-        old_type = type(b[k])
-        if old_type is not type(v):
-            if isinstance(b[k], np.ndarray):
-                v = np.array(v, dtype=b[k].dtype)
-            else:
-                raise ValueError(('Type mismatch ({} vs. {}) for config key: {}').format(type(b[k]), type(v), k))
-        if type(v) is edict:
-            try:
-                _merge_a_into_b(a[k], b[k])
-            except Exception:
-                print('Error under config key: {}'.format(k))
-                raise
-        else:
-            b[k] = v
+    for key in a:
+        if key not in b:
+            raise KeyError('{} is not a valid config key'.format(key))
+        new, old = a[key], b[key]
+        if type(new) is not type(old):
+            if not isinstance(old, np.ndarray):
+                raise ValueError('Type mismatch ({} vs. {}) for config key: {}'.format(type(old), type(new), key))
+            new = np.array(new, dtype=old.dtype)
+        if type(new) is not edict:
+            b[key] = new
+            continue
+        try:
+            _merge_a_into_b(new, old)
+        except Exception:
+            print('Error under config key: {}'.format(key))
+            raise
 
 
 def cfg_from_file(filename):
-    """Load a YAML config file and merge it into the defaults."""
+    """Overlay a YAML file (e.g. lstm/lstm.yml) on the defaults."""
     import yaml
-    with open(filename, 'r') as f:
-        yaml_cfg = edict(yaml.safe_load(f))
-    _merge_a_into_b(yaml_cfg, __C)
+    with open(filename) as stream:
+        _merge_a_into_b(edict(yaml.safe_load(stream)), cfg)
 
 
 def cfg_from_list(cfg_list):
-    """Set config keys from a flat [key, value, key, value, ...] list (the CLI's --set)."""
-    from ast import literal_eval
-    assert len(cfg_list) % 2 == 0
-    for k, v in zip(cfg_list[0::2], cfg_list[1::2]):
-        key_list = k.split('.')
-        d = __C
-        for subkey in key_list[:-1]:
-            assert subkey in d
-            d = d[subkey]
-        subkey = key_list[-1]
-        assert subkey in d
+    """Overlay `KEY.SUBKEY value` pairs given as a flat list (the command line's --set)."""
+    if len(cfg_list) % 2:
+        raise AssertionError('--set takes KEY VALUE pairs')
+    for dotted, text in zip(cfg_list[::2], cfg_list[1::2]):
+        *path, leaf = dotted.split('.')
+        node = cfg
+        for part in path:
+            assert part in node, dotted
+            node = node[part]
+        assert leaf in node, dotted
         try:
-            value = literal_eval(v)
-        except Exception:
-            value = v                   # plain string
-        assert type(value) == type(d[subkey]), \
-            'type {} does not match original type {}'.format(type(value), type(d[subkey]))
-        d[subkey] = value
+            value = ast.literal_eval(text)
+        except Exception:               # not a Python literal: a plain string
+            value = text
+        assert type(value) == type(node[leaf]), 'type {} does not match original type {}'.format(type(value), type(node[leaf]))
+        node[leaf] = value

@@ -14,102 +14,111 @@ from .utils.timer import Timer
 from .utils.training import accuracy_calculation
 
 
+LOSS_SNAPSHOT_BAR = 0.015          # a loss below the best seen so far (starting here) triggers a snapshot + validation (train.py:109,139)
+
+
 class SolverWrapper(object):
+    """The reference's training-loop object (lib/lstm/train.py:10-162) over an Engine instead of a tf.Session.
+
+    Kept from the reference because users and tests see it: constructor arguments, snapshot(sess, iter) and its file naming,
+    restoreLabel / mergeLabel, train_model(sess, max_iters, restore), every console line, and the iteration-numbering quirks
+    (the loop starts at 1; a resumed run starts at the number in the snapshot's name; a loss-triggered snapshot is always
+    written as ..._iter_2.ckpt — SURVEY Q6/Q7).  The loop body is organised as three policies: schedule, snapshot, validation."""
+
     def __init__(self, sess, network, imgdb, pre_train, output_dir, logdir):
-        """`sess` is the Engine (the role tf.Session plays in the reference)."""
-        self.net = network
-        self.imgdb = imgdb
-        self.pre_train = pre_train
-        self.output_dir = output_dir
-        self.logdir = logdir
-        self.engine = sess
+        self.engine, self.net, self.imgdb, self.pre_train = sess, network, imgdb, pre_train
+        self.output_dir, self.logdir = output_dir, logdir
         self.loss_log = open(os.path.join(logdir, 'loss.tsv'), 'a') if logdir and os.path.isdir(logdir) else None
+        self._val_batch = None
         print('done')
 
+    # ---------------------------------------------------------------------------------------- snapshots
+    def snapshot_path(self, iter):
+        infix = '_' + cfg.TRAIN.SNAPSHOT_INFIX if cfg.TRAIN.SNAPSHOT_INFIX != '' else ''
+        return os.path.join(self.output_dir, '%s_ctc%s_iter_%d.ckpt' % (cfg.TRAIN.SNAPSHOT_PREFIX, infix, iter + 1))
+
     def snapshot(self, sess, iter):
-        if not os.path.exists(self.output_dir):
-            os.makedirs(self.output_dir)
-        infix = ('_' + cfg.TRAIN.SNAPSHOT_INFIX if cfg.TRAIN.SNAPSHOT_INFIX != '' else '')
-        filename = (cfg.TRAIN.SNAPSHOT_PREFIX + '_ctc' + infix + '_iter_{:d}'.format(iter + 1) + '.ckpt')
-        filename = os.path.join(self.output_dir, filename)
+        os.makedirs(self.output_dir, exist_ok=True)
+        filename = self.snapshot_path(iter)
         checkpoint.save(sess, filename)
         print('Wrote snapshot to: {:s}'.format(filename))
 
+    def _resume(self, eng):
+        """Load the newest snapshot of output_dir; the iteration to continue from is the number in its file name."""
+        ckpt = None
+        try:
+            ckpt = checkpoint.latest_checkpoint(self.output_dir)
+            print('Restoring from {}...'.format(ckpt), end=' ')
+            checkpoint.restore(eng, ckpt)
+            start = int(os.path.splitext(os.path.basename(ckpt))[0].split('_')[-1])
+            eng.iteration = start
+            print('done')
+            return start
+        except Exception:
+            raise Exception('Check your pretrained {}'.format(ckpt))
+
+    # ---------------------------------------------------------------------------------------- labels
     def restoreLabel(self, label_vec, label_len):
-        labels = []
-        for l_len in label_len:
-            labels.append(label_vec[:l_len])
-            label_vec = label_vec[l_len:]
-        return labels
+        """Flat label vector -> one list per sample."""
+        out, pos = [], 0
+        for n in label_len:
+            out.append(label_vec[pos:pos + n])
+            pos += n
+        return out
 
     def mergeLabel(self, labels, ignore=0):
-        label_lst = []
-        for l in labels:
-            while l[-1] == ignore:
-                l = l[:-1]
-            label_lst.extend(l)
-        return np.array(label_lst)
+        """Per-sample label lists (right-padded with `ignore`) -> flat vector."""
+        flat = []
+        for seq in labels:
+            seq = list(seq)
+            while seq and seq[-1] == ignore:
+                seq.pop()
+            flat.extend(seq)
+        return np.array(flat)
 
+    # ---------------------------------------------------------------------------------------- validation
+    def _validate(self, eng, val_gen):
+        """Sequence accuracy on ONE validation batch, drawn once and reused (train.py:146-162)."""
+        if self._val_batch is None:
+            images, labels, label_lens, steps = next(val_gen)
+            self._val_batch = (np.array(images), np.array(steps), self.restoreLabel(labels, label_lens))
+        images, steps, truth = self._val_batch
+        return accuracy_calculation(truth, eng.decode(images, steps), ignore_value=0)
+
+    # ---------------------------------------------------------------------------------------- the loop
     def train_model(self, sess, max_iters, restore=False, train_gen=None, val_gen=None):
         eng = sess
-        rank = getattr(eng, 'rank', 0)
-        if train_gen is None:
-            train_gen = get_batch(num_workers=12, batch_size=cfg.TRAIN.BATCH_SIZE, vis=False)
-        if val_gen is None:
-            val_gen = get_batch(num_workers=1, batch_size=cfg.VAL.BATCH_SIZE, vis=False)
-
-        loss_node, dense_decoded = self.net.build_loss()
+        chief = getattr(eng, 'rank', 0) == 0            # data parallel: every rank trains, rank 0 prints / snapshots / validates
+        train_gen = train_gen or get_batch(num_workers=12, batch_size=cfg.TRAIN.BATCH_SIZE, vis=False)
+        val_gen = val_gen or get_batch(num_workers=1, batch_size=cfg.VAL.BATCH_SIZE, vis=False)
+        self.net.build_loss()
         eng.setup_optimizer(cfg.TRAIN.SOLVER, cfg.TRAIN.LEARNING_RATE)
-        restore_iter = 1
+        first = self._resume(eng) if restore else 1
 
-        if restore:                                     # resuming a trainer (train.py:96-106)
-            ckpt = None
-            try:
-                ckpt = checkpoint.latest_checkpoint(self.output_dir)
-                print('Restoring from {}...'.format(ckpt), end=' ')
-                checkpoint.restore(eng, ckpt)
-                stem = os.path.splitext(os.path.basename(ckpt))[0]
-                restore_iter = int(stem.split('_')[-1])
-                eng.iteration = restore_iter
-                print('done')
-            except Exception:
-                raise Exception('Check your pretrained {}'.format(ckpt))
-
-        timer = Timer()
-        loss_min = 0.015
-        first_val = True
-        for iter in range(restore_iter, max_iters):
+        timer, best = Timer(), LOSS_SNAPSHOT_BAR
+        for iter in range(first, max_iters):
             timer.tic()
-            if iter != 0 and iter % cfg.TRAIN.STEPSIZE == 0:            # step LR decay (train.py:114-115)
+            if iter != 0 and iter % cfg.TRAIN.STEPSIZE == 0:            # step decay of the learning rate
                 eng.scale_lr(cfg.TRAIN.GAMMA)
-
-            img_Batch, label_Batch, label_len_Batch, time_step_Batch = next(train_gen)
-            ctc_loss = eng.train_step(np.array(img_Batch), np.array(label_Batch), np.array(label_len_Batch),
-                                      np.array(time_step_Batch))
-            if self.loss_log is not None and rank == 0:
-                self.loss_log.write('%d\t%.7f\n' % (iter, ctc_loss))
-            _diff_time = timer.toc(average=False)
-
-            if rank != 0:
+            images, labels, label_lens, steps = next(train_gen)
+            loss = eng.train_step(np.array(images), np.array(labels), np.array(label_lens), np.array(steps))
+            elapsed = timer.toc(average=False)
+            if not chief:
                 continue
+            if self.loss_log is not None:
+                self.loss_log.write('%d\t%.7f\n' % (iter, loss))
             if iter % cfg.TRAIN.DISPLAY == 0:
-                print('iter: %d / %d, total loss: %.7f, lr: %.7f' % (iter, max_iters, ctc_loss, eng.lr), end=' ')
-                print('speed: {:.3f}s / iter'.format(_diff_time))
-            if (iter + 1) % cfg.TRAIN.SNAPSHOT_ITERS == 0 or ctc_loss < loss_min:
-                if ctc_loss < loss_min:
-                    print('loss: ', ctc_loss, end=' ')
-                    self.snapshot(eng, 1)
-                    loss_min = ctc_loss
-                else:
-                    self.snapshot(eng, iter)
-            if (iter + 1) % cfg.VAL.VAL_STEP == 0 or loss_min == ctc_loss:
-                if first_val:
-                    val_img_Batch, val_label_Batch, val_label_len_Batch, val_time_step_Batch = next(val_gen)
-                    org = self.restoreLabel(val_label_Batch, val_label_len_Batch)
-                    first_val = False
-                res = eng.decode(np.array(val_img_Batch), np.array(val_time_step_Batch))
-                acc = accuracy_calculation(org, res, ignore_value=0)
-                print('accuracy: {:.5f}'.format(acc))
+                print('iter: %d / %d, total loss: %.7f, lr: %.7f' % (iter, max_iters, loss, eng.lr), end=' ')
+                print('speed: {:.3f}s / iter'.format(elapsed))
+            new_best = loss < best
+            if new_best:
+                print('loss: ', loss, end=' ')
+                self.snapshot(eng, 1)
+                best = loss
+            elif (iter + 1) % cfg.TRAIN.SNAPSHOT_ITERS == 0:
+                self.snapshot(eng, iter)
+            if new_best or (iter + 1) % cfg.VAL.VAL_STEP == 0:
+                print('accuracy: {:.5f}'.format(self._validate(eng, val_gen)))
         if self.loss_log is not None:
             self.loss_log.flush()
 

@@ -135,3 +135,41 @@ def test_flat_layout_buckets():
     # a one-layer net has nothing to split
     one = FlatLayout([s for s in specs if s.name.startswith('conv1/')], 64)
     assert one.split_layer is None and one.late_begin == one.n_total
+
+
+def test_own_cli_drivers_parse_and_open_a_session(monkeypatch, tmp_path, capsys):
+    """This repository's lstm/train_net.py and lstm/test_net.py: the reference's flag set, config overlay from lstm.yml and
+    --set, directory creation, network construction; the final train_net / test_net call is intercepted (it needs a GPU)."""
+    import importlib
+    lstm_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'lstm')
+    monkeypatch.syspath_prepend(lstm_dir)
+    monkeypatch.setenv('OCR_ROOT_DIR', str(tmp_path))
+    from lstm_ctc_ocr_amd.config import cfg
+    monkeypatch.setattr(cfg, 'ROOT_DIR', str(tmp_path))
+    import copy
+    saved = copy.deepcopy({k: dict(v) if isinstance(v, dict) else v for k, v in cfg.items()})
+    import lib.lstm.test as lt_test
+    import lib.lstm.train as lt_train
+    seen = {}
+    monkeypatch.setattr(lt_train, 'train_net', lambda network, imgdb, **kw: seen.update(train=(network, imgdb, kw)))
+    monkeypatch.setattr(lt_test, 'test_net', lambda network, imgdb, **kw: seen.update(test=(network, imgdb, kw)))
+    try:
+        train_cli = importlib.import_module('train_net')
+        train_cli.main(['--network=LSTM_train', '--cfg=' + os.path.join(lstm_dir, 'lstm.yml'), '--restore=1', '--iters', '7',
+                        '--set', 'TRAIN.DISPLAY', '3'])
+        net, db, kw = seen['train']
+        assert type(net).__name__ == 'LSTM_train' and db.name == 'lstm_train' and kw['max_iters'] == 7 and kw['restore'] is True
+        assert cfg.TRAIN.DISPLAY == 3 and cfg.TRAIN.LEARNING_RATE == 1e-4            # --set and lstm.yml both applied
+        assert os.path.isdir(kw['output_dir']) and os.path.isdir(kw['log_dir']) and str(tmp_path) in kw['output_dir']
+        test_cli = importlib.import_module('test_net')
+        test_cli.main(['--network=LSTM_test', '--cfg=' + os.path.join(lstm_dir, 'lstm.yml')])
+        net, db, kw = seen['test']
+        assert type(net).__name__ == 'LSTM_test' and kw['restore'] is True and kw['testDir'] == './data/val/'
+        out = capsys.readouterr().out
+        assert 'Called with args:' in out and 'Using config:' in out and 'Use network `LSTM_test` in training' in out
+    finally:
+        for k, v in saved.items():                      # the drivers overlay lstm.yml on the global configuration
+            if isinstance(v, dict):
+                cfg[k].update(v)
+            else:
+                cfg[k] = v
