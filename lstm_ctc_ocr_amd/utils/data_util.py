@@ -1,8 +1,13 @@
-"""Background batch producer with the interface of /root/reference/lib/utils/data_util.py:15-129
-(GeneratorEnqueuer: start(workers, max_queue_size) / is_running() / stop() / .queue), re-implemented on
-multiprocessing with deterministic per-worker seeding (the reference reseeds workers from the OS)."""
+"""Background batch producer.
+
+Interface of the reference's lib/utils/data_util.py:15-129 — GeneratorEnqueuer(generator, use_multiprocessing, wait_time,
+random_seed) with start(workers, max_queue_size), is_running(), stop(timeout) and a public `.queue` — because get_batch() and
+user code poll `enqueuer.queue` directly.  Own implementation: one `_Backend` (threads or forked processes) supplies the
+queue, the stop flag and the worker factory, every worker is seeded `random_seed + worker index` (the reference reseeds its
+processes from the OS, so its data stream is not reproducible — SURVEY Q9), and a bounded queue does the back-pressure.
+"""
 import multiprocessing
-import queue as pyqueue
+import queue
 import random
 import threading
 import time
@@ -10,64 +15,84 @@ import time
 import numpy as np
 
 
+class _Backend(object):
+    """Queue / event / worker constructors for one of the two execution modes."""
+
+    def __init__(self, processes, capacity):
+        self.processes = processes
+        if processes:
+            ctx = multiprocessing.get_context('fork')       # the generator object is inherited, not pickled
+            self.queue, self.halt = ctx.Queue(maxsize=capacity), ctx.Event()
+            self._spawn = lambda fn, i: ctx.Process(target=fn, args=(i,), daemon=True)
+        else:
+            self.queue, self.halt = queue.Queue(maxsize=capacity), threading.Event()
+            self._spawn = lambda fn, i: threading.Thread(target=fn, args=(i,), daemon=True)
+
+    def launch(self, fn, count):
+        workers = [self._spawn(fn, i) for i in range(count)]
+        for w in workers:
+            w.start()
+        return workers
+
+    def retire(self, worker, timeout):
+        if not worker.is_alive():
+            return
+        if self.processes:
+            worker.terminate()
+        else:
+            worker.join(timeout)
+
+
 class GeneratorEnqueuer(object):
     def __init__(self, generator, use_multiprocessing=False, wait_time=0.05, random_seed=None):
-        self.wait_time = wait_time
         self._generator = generator
         self._use_multiprocessing = use_multiprocessing
-        self._threads = []
-        self._stop_event = None
-        self.queue = None
+        self.wait_time = wait_time
         self.random_seed = random_seed
+        self._backend, self._workers = None, []
+        self.queue = None
 
-    def _worker(self, idx):
+    # -- worker side -----------------------------------------------------------------------------------------------------
+    def _produce(self, index):
+        backend = self._backend
         if self.random_seed is not None:
-            np.random.seed(self.random_seed + idx)
-            random.seed(self.random_seed + idx)
-        while not self._stop_event.is_set():
-            try:
-                if self._use_multiprocessing or self.queue.qsize() < self._max_queue_size:
-                    self.queue.put(next(self._generator))
-                else:
-                    time.sleep(self.wait_time)
-            except Exception:
-                self._stop_event.set()
-                raise
-
-    def start(self, workers=1, max_queue_size=10):
-        self._max_queue_size = max_queue_size
+            random.seed(self.random_seed + index)
+            np.random.seed(self.random_seed + index)
         try:
-            if self._use_multiprocessing:
-                ctx = multiprocessing.get_context('fork')
-                self.queue = ctx.Queue(maxsize=max_queue_size)
-                self._stop_event = ctx.Event()
-                mk = lambda i: ctx.Process(target=self._worker, args=(i,), daemon=True)
-            else:
-                self.queue = pyqueue.Queue()
-                self._stop_event = threading.Event()
-                mk = lambda i: threading.Thread(target=self._worker, args=(i,), daemon=True)
-            for i in range(workers):
-                t = mk(i)
-                self._threads.append(t)
-                t.start()
+            while not backend.halt.is_set():
+                item = next(self._generator)
+                while not backend.halt.is_set():            # bounded queue: wait for room, stay responsive to stop()
+                    try:
+                        backend.queue.put(item, timeout=self.wait_time)
+                        break
+                    except queue.Full:
+                        continue
+        except StopIteration:
+            backend.halt.set()
+        except Exception:
+            backend.halt.set()
+            raise
+
+    # -- owner side ------------------------------------------------------------------------------------------------------
+    def start(self, workers=1, max_queue_size=10):
+        self._backend = _Backend(self._use_multiprocessing, max_queue_size)
+        self.queue = self._backend.queue
+        try:
+            self._workers = self._backend.launch(self._produce, workers)
         except Exception:
             self.stop()
             raise
 
     def is_running(self):
-        return self._stop_event is not None and not self._stop_event.is_set()
+        return self._backend is not None and not self._backend.halt.is_set()
 
     def stop(self, timeout=None):
-        if self.is_running():
-            self._stop_event.set()
-        for t in self._threads:
-            if t.is_alive():
-                if self._use_multiprocessing:
-                    t.terminate()
-                else:
-                    t.join(timeout)
-        if self._use_multiprocessing and self.queue is not None:
-            self.queue.close()
-        self._threads = []
-        self._stop_event = None
-        self.queue = None
+        backend = self._backend
+        if backend is None:
+            return
+        backend.halt.set()
+        for w in self._workers:
+            backend.retire(w, timeout)
+        if backend.processes:
+            backend.queue.close()
+        self._backend, self._workers, self.queue = None, [], None
