@@ -6,7 +6,7 @@ VGG-7 + BiLSTM(256) + CTC CRNN at H=32, W=256, 10-char labels, batch 64 per GPU 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-One JSON line on rank 0.  `roofline` is the dominant kernel (implicit-GEMM 3x3 convolution, MFMA-bound), timed
+One JSON line on rank 0.  `roofline` is the dominant kernel (conv_halo_kernel: implicit-GEMM 3x3 convolution, MFMA-bound), timed
 live with HIP events on the launch stream; `cpu_baseline` is the CPU oracle (a torch-CPU restatement of the
 reference TF1 graph — the TF reference itself cannot run here) on a bounded sample of the same workload.
 """
@@ -59,8 +59,8 @@ def synth_batches(n_batches, seed, device):
 
 
 def conv_roofline(eng, device):
-    """Every launch of the dominant kernel (gemm_nt_kernel<conv3x3>: 5 forward + 5 data-gradient convolutions per
-    step) timed with events on the launch stream; achieved = sum(algorithmic flop) / sum(time)."""
+    """Every launch of the dominant kernel (conv_halo_kernel: 5 forward + 5 data-gradient 3x3 convolutions per step) timed
+    with HIP events on the launch stream; achieved = sum(algorithmic flop) / sum(time)."""
     from lstm_ctc_ocr_amd import ops
     RB = 64                      # always the headline configuration's layer shapes (batch 64, W = 256)
     shapes = [(128, 16, 64, 128), (64, 8, 128, 256), (64, 8, 256, 256), (64, 4, 256, 512), (64, 4, 512, 512)]
