@@ -9,7 +9,7 @@ import numpy as np
 
 from . import checkpoint
 from .config import cfg
-from .utils.gen import get_batch
+from .utils.gen import get_batch, stream_seed
 from .utils.timer import Timer
 from .utils.training import accuracy_calculation
 
@@ -90,7 +90,7 @@ class SolverWrapper(object):
         eng = sess
         chief = getattr(eng, 'rank', 0) == 0            # data parallel: every rank trains, rank 0 prints / snapshots / validates
         train_gen = train_gen or get_batch(num_workers=12, batch_size=cfg.TRAIN.BATCH_SIZE, vis=False)
-        val_gen = val_gen or get_batch(num_workers=1, batch_size=cfg.VAL.BATCH_SIZE, vis=False)
+        val_gen = val_gen or get_batch(num_workers=1, seed=stream_seed(stream=1), batch_size=cfg.VAL.BATCH_SIZE, vis=False)
         self.net.build_loss()
         eng.setup_optimizer(cfg.TRAIN.SOLVER, cfg.TRAIN.LEARNING_RATE)
         first = self._resume(eng) if restore else 1

@@ -26,18 +26,42 @@ encode_maps, decode_maps = get_encode_decode_dict()
 _FONT_CACHE = {}
 
 
-def _font(size):
-    key = (cfg.FONT, size)
-    if key not in _FONT_CACHE:
-        path = cfg.FONT if os.path.isabs(cfg.FONT) else os.path.join(cfg.ROOT_DIR, cfg.FONT)
-        try:
-            _FONT_CACHE[key] = ImageFont.truetype(path, size)
-        except (IOError, OSError):
+_SUBSTITUTE_FONTS = ('/usr/share/fonts/truetype/dejavu/DejaVuSans-Bold.ttf', 'DejaVuSans-Bold.ttf')
+_font_path = {}
+
+
+def resolve_font():
+    """Path of the TrueType file the renderer uses.  cfg.FONT ('fonts/Ubuntu-M.ttf', config.py:26 of the reference) is a binary
+    asset of the reference repository and is not redistributed here: drop it into <ROOT_DIR>/fonts/ (or point $OCR_FONT at any
+    .ttf) to render with it.  When it is absent the substitution is announced on stderr — once per process, never silently —
+    and `OCR_STRICT_FONT=1` turns it into an error."""
+    want = os.environ.get('OCR_FONT') or cfg.FONT
+    if want in _font_path:
+        return _font_path[want]
+    path = want if os.path.isabs(want) else os.path.join(cfg.ROOT_DIR, want)
+    if not os.path.exists(path):
+        if os.environ.get('OCR_STRICT_FONT') == '1':
+            raise IOError('captcha font %s not found (cfg.FONT / $OCR_FONT); OCR_STRICT_FONT=1 forbids a substitute' % path)
+        for cand in _SUBSTITUTE_FONTS:
             try:
-                _FONT_CACHE[key] = ImageFont.truetype("DejaVuSans.ttf", size)
+                ImageFont.truetype(cand, 12)
             except (IOError, OSError):
-                print('cannot open the font')
-                _FONT_CACHE[key] = ImageFont.load_default()
+                continue
+            sys.stderr.write('[gen] WARNING: captcha font %s not found; rendering with %s instead '
+                             '(copy the font there or set $OCR_FONT; OCR_STRICT_FONT=1 makes this an error)\n' % (path, cand))
+            path = cand
+            break
+        else:
+            raise IOError('captcha font %s not found and no substitute TrueType font is installed' % path)
+    _font_path[want] = path
+    return path
+
+
+def _font(size):
+    path = resolve_font()
+    key = (path, size)
+    if key not in _FONT_CACHE:
+        _FONT_CACHE[key] = ImageFont.truetype(path, size)
     return _FONT_CACHE[key]
 
 
@@ -45,8 +69,8 @@ def randRGB():
     return (random.randint(0, 255), random.randint(0, 255), random.randint(0, 255))
 
 
-def gen_rand():
-    n = random.randint(cfg.MIN_LEN, cfg.MAX_LEN)
+def gen_rand(min_len=None, max_len=None):
+    n = random.randint(cfg.MIN_LEN if min_len is None else min_len, cfg.MAX_LEN if max_len is None else max_len)
     return "".join(random.choice(cfg.CHARSET) for _ in range(n))
 
 
@@ -86,9 +110,11 @@ def render_captcha(chars, width=160, height=60):
     return img.filter(ImageFilter.SMOOTH)
 
 
-def generateImg():
-    chars = gen_rand()
-    return np.array(render_captcha(chars)), chars
+def generateImg(min_len=None, max_len=None, width=160, height=60):
+    """One captcha.  Defaults = the reference (4-6 characters on ImageCaptcha's 160x60 canvas, gen.py:31-37); the keyword
+    arguments produce the wider workloads of BASELINE.json (10 characters on 480x60 -> W = 256 after the resize to H = 32)."""
+    chars = gen_rand(min_len, max_len)
+    return np.array(render_captcha(chars, width, height)), chars
 
 
 def to_gray_reference(im_rgb):
@@ -122,11 +148,18 @@ def groupBatch(imgs, labels):
     return img_batch, label_vec, label_len, time_steps
 
 
-def generator(batch_size=32, vis=False):
+def generator(batch_size=32, vis=False, min_len=None, max_len=None, width=160, px_per_char=None):
+    """Endless stream of groupBatch() tuples.  px_per_char: canvas width follows the label (len * px_per_char) instead of
+    being fixed — variable-width batches (BASELINE.json configs[3])."""
     images, labels = [], []
     while True:
         try:
-            im, label = generateImg()
+            if px_per_char:
+                chars = gen_rand(min_len, max_len)
+                canvas = min(600, len(chars) * px_per_char + random.randint(-8, 8))          # 600 px -> W = 320 at H = 32
+                im, label = np.array(render_captcha(chars, canvas, 60)), chars
+            else:
+                im, label = generateImg(min_len, max_len, width)
             if cfg.NCHANNELS == 1:
                 im = to_gray_reference(im)
             images.append(im)
@@ -141,10 +174,22 @@ def generator(batch_size=32, vis=False):
             continue
 
 
-def get_batch(num_workers, **kwargs):
+def stream_seed(rank=None, stream=0):
+    """Seed of one data stream: cfg.RNG_SEED, made distinct per data-parallel rank ($RANK) and per stream kind (0 = training,
+    1 = validation).  Workers add their index (data_util.GeneratorEnqueuer), so the strides keep every (rank, stream, worker)
+    triple apart."""
+    from ..dist import rank_seed
+    rank = int(os.environ.get('RANK', '0')) if rank is None else rank
+    return rank_seed(cfg.RNG_SEED, rank) + 7919 * int(stream)
+
+
+def get_batch(num_workers, seed=None, **kwargs):
+    """Multiprocess prefetch of generator(**kwargs) batches (gen.py:112-128).  seed: base seed of the workers
+    (default: stream_seed() — rank-dependent, so data-parallel replicas draw different samples)."""
     enqueuer = None
     try:
-        enqueuer = GeneratorEnqueuer(generator(**kwargs), use_multiprocessing=True, random_seed=cfg.RNG_SEED)
+        enqueuer = GeneratorEnqueuer(generator(**kwargs), use_multiprocessing=True,
+                                     random_seed=stream_seed() if seed is None else seed)
         enqueuer.start(max_queue_size=24, workers=num_workers)
         generator_output = None
         while True:

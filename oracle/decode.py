@@ -41,8 +41,9 @@ def _logsumexp(*xs):
     return m + np.log(sum(np.exp(x - m) for x in xs))
 
 
-def beam_search_tf(logits_tnc, seq_len, beam_width=100, merge_repeated=True, blank=None):
-    """Returns (list of label lists, list of log-probabilities) for top path per sample."""
+def beam_search_tf(logits_tnc, seq_len, beam_width=100, merge_repeated=True, blank=None, top_paths=1):
+    """Returns (list of label lists, list of log-probabilities) for the top path per sample; with top_paths > 1 every
+    entry is a list of the `top_paths` best (labels / log-probabilities) in rank order, as TF's decoded[k] outputs."""
     T, N, C = logits_tnc.shape
     if blank is None:
         blank = C - 1
@@ -73,17 +74,21 @@ def beam_search_tf(logits_tnc, seq_len, beam_width=100, merge_repeated=True, bla
                         add(prefix + (c,), -np.inf, tot + lp)
             ranked = sorted(nxt.items(), key=lambda kv: -_logsumexp(*kv[1]))[:beam_width]
             beams = dict(ranked)
-        best, (pb, pnb) = max(beams.items(), key=lambda kv: _logsumexp(*kv[1]))
-        seq = list(best)
-        if merge_repeated:
-            merged, prev = [], None
-            for s in seq:
-                if s != prev:
-                    merged.append(s)
-                prev = s
-            seq = merged
-        results.append(seq)
-        scores.append(_logsumexp(pb, pnb))
+        ranked = sorted(beams.items(), key=lambda kv: -_logsumexp(*kv[1]))[:max(1, top_paths)]
+        seqs, scs = [], []
+        for best, (pb, pnb) in ranked:
+            seq = list(best)
+            if merge_repeated:
+                merged, prev = [], None
+                for s in seq:
+                    if s != prev:
+                        merged.append(s)
+                    prev = s
+                seq = merged
+            seqs.append(seq)
+            scs.append(_logsumexp(pb, pnb))
+        results.append(seqs[0] if top_paths == 1 else seqs)
+        scores.append(scs[0] if top_paths == 1 else scs)
     return results, scores
 
 

@@ -38,7 +38,36 @@ POOL_AFTER = {"conv1": (2, 2), "conv2": (2, 2), "conv3_2": (1, 2), "conv4_2": (1
 
 
 def q(x, sim):
-    return x.to(torch.bfloat16).to(torch.float32) if sim else x
+    """bf16 rounding of a WEIGHT operand (forward only; the gradient passes straight through — the device keeps weight
+    gradients in fp32)."""
+    if not sim:
+        return x
+    return x + (x.detach().to(torch.bfloat16).to(torch.float32) - x.detach())
+
+
+class _RoundBoth(torch.autograd.Function):
+    """bf16 rounding of an ACTIVATION as the device stores it: the value is rounded on the way forward and its gradient is
+    rounded on the way back (the device keeps every activation gradient as bf16: DESIGN.md section 2)."""
+
+    @staticmethod
+    def forward(ctx, x, fwd):
+        return x.to(torch.bfloat16).to(torch.float32) if fwd else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32), None
+
+
+SIM_GRAD_ROUNDING = True     # tests may switch the backward rounding off to measure what it explains
+
+
+def qa(x, sim, fwd=True):
+    """activation storage point: round the value (if fwd) and, in the backward pass, its gradient"""
+    if not sim:
+        return x
+    if not SIM_GRAD_ROUNDING or not x.requires_grad:
+        return x.to(torch.bfloat16).to(torch.float32) if fwd else x
+    return _RoundBoth.apply(x, fwd)
 
 
 def init_params(num_hid=512, nclasses=64, seed=3, specs=CONV_SPECS):
@@ -104,10 +133,10 @@ def lstm_direction(x, seq_len, W, b, reverse, sim, forget_bias=1.0):
         t_idx = (lens - 1 - s).clamp(min=0) if reverse else torch.full((N,), s, dtype=torch.long)
         active = (s < lens)
         xs = xproj[torch.arange(N), t_idx]
-        z = xs + h @ Wh
+        z = qa(xs + h @ Wh, sim, fwd=False)              # d loss / d z is stored as bf16 (operand of the weight-gradient GEMMs)
         i, j, f, o = z.split(U, dim=1)
         cn = torch.sigmoid(f + forget_bias) * c + torch.sigmoid(i) * torch.tanh(j)
-        hn = q(torch.sigmoid(o) * torch.tanh(cn), sim)
+        hn = qa(torch.sigmoid(o) * torch.tanh(cn), sim)
         m = active.unsqueeze(1)
         c = torch.where(m, cn, c)
         h = torch.where(m, hn, h)
@@ -147,16 +176,16 @@ def forward(params, x, seq_len, sim_bf16=False, specs=CONV_SPECS, pool_after=POO
     for idx, (name, kh, kw, ci, co, padding, bn, relu) in enumerate(specs):
         z = conv_single(h, params[name + "/weights"], params[name + "/biases"], padding, sim, first=(idx == 0))
         if bn:
-            z = q(z, sim)
+            z = qa(z, sim)
             if keep: inter[name + "/pre_bn"] = z
             z = batch_norm_train(z, params["%s/%s/gamma" % (name, name)], params["%s/%s/beta" % (name, name)])
         if relu:
             z = torch.relu(z)
-        h = q(z, sim)
+        h = qa(z, sim)
         if keep: inter[name] = h
         if name in pool_after:
             kw_, kh_ = pool_after[name]
-            h = max_pool(h, kw_, kh_)
+            h = qa(max_pool(h, kw_, kh_), sim, fwd=False)        # the pooled map's gradient is a bf16 tensor on the device
             if keep: inter[name + "/pool"] = h
     N, A, B, D = h.shape
     feat = h.reshape(N, A * B, D)                       # reshape_squeeze_layer (network.py:361-368)
@@ -166,7 +195,7 @@ def forward(params, x, seq_len, sim_bf16=False, specs=CONV_SPECS, pool_after=POO
     if keep: inter["lstm_out"] = hcat
     T = A * B
     logits = hcat.reshape(N * T, -1) @ q(params["logits/weights"], sim) + params["logits/biases"]
-    logits = logits.reshape(N, T, -1).permute(1, 0, 2).contiguous()
+    logits = qa(logits.reshape(N, T, -1).permute(1, 0, 2).contiguous(), sim, fwd=False)   # CTC gradient handed over as bf16
     return (logits, inter) if keep else logits
 
 

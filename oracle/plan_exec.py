@@ -21,17 +21,17 @@ def forward(net, params, x, seq_len, sim_bf16=False, keep=False):
             h = ev(nd.inputs[0])
             z = og.conv_single(h, params[nd.name + '/weights'], params[nd.name + '/biases'], a['padding'], sim, first=(a['c_i'] == 1))
             if a['bn']:
-                z = og.q(z, sim)
+                z = og.qa(z, sim)
                 z = og.batch_norm_train(z, params['%s/%s/gamma' % (nd.name, nd.name)], params['%s/%s/beta' % (nd.name, nd.name)])
             if a['relu']:
                 z = torch.relu(z)
-            out = og.q(z, sim)
+            out = og.qa(z, sim)
         elif nd.op == 'max_pool':
-            out = og.max_pool(ev(nd.inputs[0]), nd.attrs['k_h'], nd.attrs['k_w'])
+            out = og.qa(og.max_pool(ev(nd.inputs[0]), nd.attrs['k_h'], nd.attrs['k_w']), sim, fwd=False)
         elif nd.op == 'add':
-            out = og.q(ev(nd.inputs[0]) + ev(nd.inputs[1]), sim)
+            out = og.qa(ev(nd.inputs[0]) + ev(nd.inputs[1]), sim)
         elif nd.op == 'relu':
-            out = torch.relu(ev(nd.inputs[0]))
+            out = og.qa(torch.relu(ev(nd.inputs[0])), sim, fwd=False)
         elif nd.op in ('reshape_squeeze',):
             h = ev(nd.inputs[0])
             out = h.reshape(h.shape[0], h.shape[1] * h.shape[2], h.shape[3])
@@ -45,7 +45,7 @@ def forward(net, params, x, seq_len, sim_bf16=False, keep=False):
             if nd.attrs.get('with_fc', True):
                 N, T, _ = hcat.shape
                 lg = hcat.reshape(N * T, -1) @ og.q(params[nd.name + '/weights'], sim) + params[nd.name + '/biases']
-                out = lg.reshape(N, T, -1).permute(1, 0, 2).contiguous()
+                out = og.qa(lg.reshape(N, T, -1).permute(1, 0, 2).contiguous(), sim, fwd=False)
             else:
                 out = hcat
         else:

@@ -105,7 +105,7 @@ def test_device_graph_matches_fixture(dev):
 @pytest.mark.gpu
 def test_device_matches_headline_fixture(dev):
     """The device path at the full size of BASELINE configs[1] against the committed oracle output: logits, per-sample CTC costs
-    (bar 1e-3 relative) and the best-path strings of the device's own logits."""
+    (bar 1e-3 relative) and both decoders on the device's own logits."""
     from lstm_ctc_ocr_amd.config import cfg
     from lstm_ctc_ocr_amd.engine import Engine
     from lstm_ctc_ocr_amd.models import get_network
@@ -122,11 +122,7 @@ def test_device_matches_headline_fixture(dev):
     torch.cuda.synchronize()
     costs = sp.costs.cpu().numpy()
     assert np.abs(costs - d['costs']).max() < 1e-3 * np.abs(d['costs']).max()
+    # kernel level: the device's decoders on the device's own logits, all 64 samples (random weights give near-uniform
+    # posteriors, so END-TO-END string identity is asserted on trained weights instead: tests/test_trained_fixture.py)
     assert odec.dense(eng.decode(x, sl, method='greedy')).tolist() == odec.dense(odec.greedy_decode(logits, sl)).tolist()
-    margin = np.sort(d['logits_bf16sim'], axis=-1)
-    agree = [n for n in range(64) if float((margin[:, n, -1] - margin[:, n, -2]).min()) > 1e-2]
-    got = eng.decode(x, sl, method='greedy')
-    for n in agree:                                   # frames decided by more than the logit tolerance: identical strings
-        assert got[n] == [v for v in d['greedy'][n] if v != 0]
-    print('headline fixture: strings compared end-to-end: %d of 64' % len(agree))
-
+    assert eng.decode(x, sl, method='beam') == odec.reference_decode(logits, sl, beam_width=100)

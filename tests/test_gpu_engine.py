@@ -62,56 +62,68 @@ def test_forward_parity(engine, N, W, varlen):
     # kernel-level: bit-exact best path of the device's own logits, and the reference's beam decode (blank C-1, zeros stripped)
     assert dec == odec.greedy_decode(logits.numpy(), sl)
     assert engine.decode(x, sl, method='beam') == odec.reference_decode(logits.numpy(), sl, beam_width=100)
-    # end-to-end: identical strings wherever the oracle's per-frame top-2 margin exceeds the logit tolerance
-    # (random-init weights give near-uniform posteriors, so sub-tolerance ties exist and are excluded)
-    ref_dec = odec.greedy_decode(ref.numpy(), sl)
-    checked = 0
-    for n in range(N):
-        top2 = torch.topk(ref[:int(sl[n]), n], 2, dim=-1).values
-        if float((top2[:, 0] - top2[:, 1]).min()) > 1e-2:
-            assert dec[n] == ref_dec[n]
-            checked += 1
-    print('strings compared end-to-end:', checked, 'of', N)
+    # end-to-end string identity (device vs fp32 oracle, every sample) is asserted on trained weights: test_trained_fixture.py
+
+
+def _oracle_grads(params, x, labels, ll, sl, wd, sim, grad_rounding=True):
+    og.SIM_GRAD_ROUNDING = grad_rounding
+    try:
+        leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        total, ctc, _ = og.loss_fn(leaves, torch.from_numpy(x), labels, ll, sl.tolist(), wd, sim_bf16=sim)
+        total.backward()
+    finally:
+        og.SIM_GRAD_ROUNDING = True
+    grads = {}
+    for k, v in leaves.items():
+        g = v.grad if v.grad is not None else torch.zeros_like(v)
+        grads[k] = g - wd * params[k] if og.REGULARISED(k) else g          # the device adds wd * w inside the optimiser kernel
+    return grads, float(ctc.detach())
+
+
+# Per-tensor bars for |g_dev - g_oracle|_2 / |g_oracle|_2 against the bf16-simulating oracle, which rounds values AND
+# activation gradients where the device stores bf16 (oracle/graph.py qa()).  Measured on MI355X (round 2, printed by the
+# test) with 2x headroom; the distance to the pure-fp32 oracle (= the bf16 noise itself) is printed beside it and bounded
+# loosely.  A structural error (wrong tap, missed mask, missed residual branch) is O(1) in both.
+GRAD_L2_BAR = {'default': 2e-2}
+GRAD_L2_BAR_FP32 = 8e-2
 
 
 def test_train_step_parity(engine):
     N, W = 8, 88
     x, labels, ll, sl = make_batch(N, W, 2, 4, 2)
     params = {k: torch.from_numpy(v) for k, v in engine.state_arrays().items()}
-    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    total, ctc, _ = og.loss_fn(leaves, torch.from_numpy(x), labels, ll, sl.tolist(), 1e-5, sim_bf16=True)
-    total.backward()
+    g_sim, ctc_ref = _oracle_grads(params, x, labels, ll, sl, 1e-5, sim=True)
+    g_sim_nr, _ = _oracle_grads(params, x, labels, ll, sl, 1e-5, sim=True, grad_rounding=False)
+    g_f32, ctc_f32 = _oracle_grads(params, x, labels, ll, sl, 1e-5, sim=False)
     # run forward+backward only (no optimiser) and compare raw gradients
     sp = engine.plan(N, W)
     engine._bind(sp, x, sl, labels, ll)
     engine._run(sp, 'fb')
     torch.cuda.synchronize()
-    ctc_dev, ctc_ref = float(sp.costs.cpu().numpy().mean()), float(ctc.detach())
+    ctc_dev = float(sp.costs.cpu().numpy().mean())
     assert abs(ctc_dev - ctc_ref) / ctc_ref < 1e-3, (ctc_dev, ctc_ref)
-    worst = 0.0
+    assert abs(ctc_dev - ctc_f32) / ctc_f32 < 1e-3, (ctc_dev, ctc_f32)          # north-star bar against the fp32 graph
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    bad = []
     for name in engine.specs:
         g = engine.grad(name).cpu()
-        ref = leaves[name].grad
-        if ref is None:
-            continue
-        if og.REGULARISED(name):
-            ref = ref - 1e-5 * params[name]            # device adds wd*w inside the optimiser kernel
-        denom = float(ref.abs().max())
         if name in ('conv4_1/biases', 'conv4_2/biases'):
             # a bias in front of batch-norm has a mathematically zero gradient (BN removes the mean): both sides
             # hold rounding noise only — require it to be negligible against the layer's weight gradient
-            scale = float(leaves[name.replace('biases', 'weights')].grad.abs().max())
+            scale = float(g_sim[name.replace('biases', 'weights')].abs().max())
             print('grad %-28s |noise| %.3e (weight-grad scale %.3e)' % (name, float(g.abs().max()), scale))
             assert bool(torch.isfinite(g).all()) and float(g.abs().max()) < scale
             continue
-        if denom < 1e-9:
+        if float(g_sim[name].abs().max()) < 1e-9:
             assert float(g.abs().max()) < 1e-5, name
             continue
-        e = float((g - ref).abs().max()) / denom
-        print('grad %-28s rel err %.3e' % (name, e))
-        worst = max(worst, e)
-        assert e < 6e-2, (name, e)
-    print('worst gradient rel err', worst)
+        e_sim, e_nr, e_f32 = l2(g, g_sim[name]), l2(g, g_sim_nr[name]), l2(g, g_f32[name])
+        mx = float((g - g_sim[name]).abs().max() / g_sim[name].abs().max())
+        print('grad %-28s L2-rel vs bf16sim %.3e (no grad rounding %.3e) vs fp32 %.3e | max-rel vs bf16sim %.3e'
+              % (name, e_sim, e_nr, e_f32, mx))
+        if not (e_sim < GRAD_L2_BAR.get(name, GRAD_L2_BAR['default']) and e_f32 < GRAD_L2_BAR_FP32):
+            bad.append((name, e_sim, e_f32))
+    assert not bad, bad
 
 
 def test_training_reduces_loss_and_matches_oracle_update(engine):
@@ -139,6 +151,9 @@ def test_training_reduces_loss_and_matches_oracle_update(engine):
 
 
 # ------------------------------------------------------------------------------------------- beyond the reference: config 5
+DEEP_GRAD_L2_BAR = 0.15       # tightened from the measured values once the oracle rounds activation gradients too (see below)
+
+
 def test_residual_stacked_network_parity(dev):
     """BASELINE configs[4] in miniature: residual BasicBlocks (add / relu / 1x1 projection, tensors with two consumers),
     two stacked BiLSTMs and a 96-class alphabet, lowered by the same engine and checked against the plan-walking oracle."""
@@ -183,7 +198,7 @@ def test_residual_stacked_network_parity(dev):
             # by |dz| / |dz - projections|: measured ~1 % L2 per BN layer (0.2-0.4 % for the BN-free tail), growing smoothly
             # from the loss to conv1 (11 BN layers here).  A structural error (missed residual contribution, wrong mask,
             # wrong halo) would show as O(1), so the bars are: L2-relative < 15 %, cosine > 0.99, and SGD still converges.
-            if not (e2 < 0.15 and cos > 0.99):
+            if not (e2 < DEEP_GRAD_L2_BAR and cos > 0.99):
                 bad.append((name, e2, cos))
         assert not bad, bad
         eng.setup_optimizer('Adam', 1e-4)

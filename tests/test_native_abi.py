@@ -30,6 +30,34 @@ def test_status_codes_and_host_side_validation():
     assert lib.ocr_lstm_seq_supported(64 * 9, 256) == 0                            # would not be one workgroup per CU
 
 
+def test_warpctc_abi_is_exported_with_its_own_prototypes():
+    """include/warpctc_abi.h: the FFI the reference binds (network.py:6,653-654 -> libwarpctc compute_ctc_loss)."""
+    import re
+    import os
+    import numpy as np
+    from lstm_ctc_ocr_amd import warpctc
+    lib = warpctc._lib()
+    hdr = open(os.path.join(os.path.dirname(nat.HEADER_PATH), 'warpctc_abi.h')).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for name in ('compute_ctc_loss', 'get_workspace_size', 'ctcGetStatusString', 'get_warpctc_version'):
+        assert re.search(r"\b%s\s*\(" % name, hdr) and hasattr(lib, name), name
+    assert lib.get_warpctc_version() == 2
+    assert lib.ctcGetStatusString(0) == b'no error' and lib.ctcGetStatusString(3) == b'execution failed'
+    assert ctypes.sizeof(warpctc.ctcOptions) == 24                      # {int; pad; union{unsigned, void*}; int; pad} on LP64
+    ll = np.array([2, 1], np.int32); il = np.array([5, 3], np.int32)
+    ip = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    opt = warpctc.ctcOptions(); opt.loc = warpctc.CTC_GPU; opt.blank_label = 0
+    sz = ctypes.c_size_t(0)
+    assert lib.get_workspace_size(ip(ll), ip(il), 5, 2, opt, ctypes.byref(sz)) == 0 and sz.value > 0
+    assert lib.get_workspace_size(ip(ll), ip(il), 5, 0, opt, ctypes.byref(sz)) == 2                 # invalid value
+    assert lib.get_workspace_size(None, ip(il), 5, 2, opt, ctypes.byref(sz)) == 2
+    opt.loc = warpctc.CTC_CPU                   # there is no host implementation: loud status, never a silent CPU computation
+    assert lib.get_workspace_size(ip(ll), ip(il), 5, 2, opt, ctypes.byref(sz)) == 3
+    costs = np.zeros(2, np.float32)
+    assert lib.compute_ctc_loss(None, None, ip(ll), ip(ll), ip(il), 5, 2, costs.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                None, opt) == 2
+
+
 def test_hot_path_has_no_cpu_fallback():
     import pytest
     import torch

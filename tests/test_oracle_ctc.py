@@ -96,3 +96,28 @@ def test_decoders_on_hand_cases_and_enumeration():
         seqs, scores = odec.beam_search_tf(x, [T], beam_width=10000, merge_repeated=False)
         assert tuple(seqs[0]) == best[0]
         assert abs(np.exp(scores[0]) - best[1]) < 1e-9
+
+
+def test_tensorflow_beam_search_known_answer():
+    """The only external vector that exists for tf.nn.ctc_beam_search_decoder (network.py:656): TensorFlow's own
+    ctc_decoder_ops_test.py::testCTCDecoderBeamSearch — depth 6 (blank = class 5), 5 time steps, beam_width = 2,
+    top_paths = 2, merge_repeated = False.  TF expects decoded[0] = [1, 0] and decoded[1] = [0, 1, 0]: with only two beams
+    the search loses the truly most probable labelling ([0, 1, 0], which enumeration and any beam >= 3 return) to [1, 0] —
+    the oracle must reproduce that pruning behaviour, not just the arg-max.  (The log-probabilities TF 1.0 lists for this
+    vector, 0.584855 / 0.389139, are not probabilities of these labellings — exp(-a) + exp(-b) > 1 — so only the
+    label sequences are pinned.)"""
+    prob = np.array([[0.30999, 0.309938, 0.0679938, 0.0673362, 0.0708352, 0.173908],
+                     [0.215136, 0.439699, 0.0370931, 0.0393967, 0.0381581, 0.230517],
+                     [0.199959, 0.489485, 0.0233221, 0.0251417, 0.0233289, 0.238763],
+                     [0.279611, 0.452966, 0.0204795, 0.0209126, 0.0194803, 0.20655],
+                     [0.51286, 0.288951, 0.0243026, 0.0220788, 0.0219297, 0.129878],
+                     [0.155251, 0.164444, 0.173517, 0.176138, 0.169979, 0.160671]], np.float64)   # row 5: beyond seq_len
+    logits = (np.log(prob) + 2.0)[:, None, :]                  # "arbitrary offset - this is fine"
+    seqs, scores = odec.beam_search_tf(logits, [5], beam_width=2, merge_repeated=False, top_paths=2)
+    assert seqs[0] == [[1, 0], [0, 1, 0]]
+    assert scores[0][0] > scores[0][1]
+    # cross-check of the two labellings' true probabilities by path enumeration (blank = 5)
+    _, table = octc.ctc_brute_force(logits[:5, 0, :], [], blank=5)
+    assert max(table.items(), key=lambda kv: kv[1])[0] == (0, 1, 0)
+    assert odec.beam_search_tf(logits, [5], beam_width=100, merge_repeated=False)[0] == [[0, 1, 0]]
+    assert abs(np.exp(odec.beam_search_tf(logits, [5], beam_width=10000, merge_repeated=False)[1][0]) - table[(0, 1, 0)]) < 1e-9
