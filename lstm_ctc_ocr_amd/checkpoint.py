@@ -61,11 +61,13 @@ def latest_checkpoint(output_dir):
     return os.path.join(output_dir, kept[-1]) if kept else None
 
 
-def restore(engine, path):
+def restore(engine, path, with_optimizer=True):
+    """Load a snapshot.  with_optimizer=False (inference, test.py) restores the variables only: no optimiser slots are
+    allocated for a network that will never take a step."""
     import torch
     data = np.load(path)
     engine.load_arrays({k[4:]: data[k] for k in data.files if k.startswith('var/')})
-    if 'opt/scalars' in data.files:
+    if with_optimizer and 'opt/scalars' in data.files:
         if not engine.opt_ready:
             engine.setup_optimizer()
         s1 = np.zeros(engine.n_total, np.float32)
@@ -82,5 +84,6 @@ def restore(engine, path):
         sc = torch.from_numpy(data['opt/scalars'])          # the first 8 doubles are state, the rest per-step scratch
         n = min(sc.numel(), engine.scalars.numel())
         engine.scalars[:n].copy_(sc[:n])
+        engine.lr = float(data['opt/scalars'][2])           # host mirror of the device learning rate (console line, scale_lr)
     engine.iteration = int(data['meta/iteration']) if 'meta/iteration' in data.files else 0
     return engine

@@ -25,7 +25,7 @@ import torch
 from . import dist as ocr_dist
 from . import ops
 from ._native import NativeError
-from .layout import FlatLayout
+from .layout import FlatLayout, execution_order
 from ._native import call as nat_call
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
@@ -558,15 +558,21 @@ class Engine(object):
             self.force_allreduce = True
         self.overlap_allreduce = os.environ.get('OCR_OVERLAP_ALLREDUCE', '1') != '0'
         self.comm_stream = torch.cuda.Stream(device=self.device)
+        self._lower(net)                                 # operators first: the parameter layout follows their EXECUTION order
         self._layout(net)
         self._init_params(cfg.RNG_SEED if seed is None else seed)
-        self._lower(net)
         self.split_op = 0                                # first op of the late layers (backward part 1 = ops[split_op:])
         if self.split_layer is not None:
             for i, op in enumerate(self.ops):
                 if op.name == self.split_layer:
                     self.split_op = i
                     break
+            # the exchange of [late_begin, n_total) starts after backward part 1 = ops[split_op:]: no operator of part 2 may own
+            # a variable in that range (it would be written while RCCL reads it), none of part 1 a variable below it
+            for i, op in enumerate(self.ops):
+                for name, owner in self._owner.items():
+                    if owner == op.name:
+                        assert (self.offsets[name] >= self.late_begin) == (i >= self.split_op), (op.name, name)
         self.plans = {}
         self.opt_ready = False
         self.graph_opt = None
@@ -596,7 +602,8 @@ class Engine(object):
 
     def _layout(self, net):
         """Flat parameter / gradient layout [early rest | early regularised | late regularised | late rest] — layout.py."""
-        lay = FlatLayout(net.param_specs.values(), ALIGN)
+        lay = FlatLayout(net.param_specs.values(), ALIGN, order=[op.name for op in self.ops])
+        self._owner = lay.owner
         self.specs, self.offsets, self.n_total = lay.specs, lay.offsets, lay.n_total
         self.split_layer, self.reg_range, self.late_begin = lay.split_layer, lay.reg_range, lay.late_begin
         dev = self.device
@@ -703,18 +710,10 @@ class Engine(object):
         data_op.dy_needed = lambda: False
         built = {}
         self.ops = []
-
-        def data_inputs(nd):
-            return nd.inputs if nd.op == 'add' else nd.inputs[:1]
-
-        def build(nd):
-            if nd.op == 'input':
-                return data_op
-            if id(nd) in built:
-                return built[id(nd)]
-            ins = [build(i) for i in data_inputs(nd)]
+        for nd in execution_order(net.get_output('logits')):
             if nd.op not in table:
                 raise NotImplementedError('layer %r (%s) has no gfx950 lowering yet' % (nd.op, nd.name))
+            ins = [data_op if i.op == 'input' else built[id(i)] for i in (nd.inputs if nd.op == 'add' else nd.inputs[:1])]
             op = table[nd.op](self, nd, ins[0])
             op.inputs = ins
             op.key = '%02d:%s' % (len(self.ops), nd.name)
@@ -722,11 +721,6 @@ class Engine(object):
                 i.grad_owner().consumers += 1
             built[id(nd)] = op
             self.ops.append(op)
-            return op
-
-        import sys
-        sys.setrecursionlimit(max(sys.getrecursionlimit(), 10000))
-        build(net.get_output('logits'))
         if self.fuse_conv1_pool:
             for a, b in zip(self.ops[:-1], self.ops[1:]):
                 if (isinstance(a, _ConvOp) and a.kind == 'c1' and a.relu and isinstance(b, _PoolOp) and b.prev is a
@@ -939,7 +933,9 @@ class Engine(object):
         c = self.cfg.TRAIN
         self.solver = ops.SOLVERS.get(solver or c.SOLVER, 1)       # reference: anything else -> Momentum (train.py:76)
         self.lr = float(c.LEARNING_RATE if lr is None else lr)
-        self.state1 = torch.zeros_like(self.params)
+        # slot initial values as TensorFlow creates them: Adam m = v = 0, Momentum accumulator 0, RMSProp "rms" slot = ONES
+        # (tf.train.RMSPropOptimizer: the first steps are ~ lr * g / sqrt(0.9 + 0.1 g^2), not lr * sign(g) / sqrt(0.1))
+        self.state1 = torch.ones_like(self.params) if self.solver == 2 else torch.zeros_like(self.params)
         self.state2 = torch.zeros_like(self.params) if self.solver == 0 else None
         self.scalars = torch.zeros(ops.optim_scalar_count(), dtype=torch.float64, device=self.device)
         ops.optim_init(self.scalars, self.lr)

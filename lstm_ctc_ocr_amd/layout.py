@@ -4,33 +4,76 @@
 
 * the L2-regularised tensors (conv + FC weights, network.py:170-171,123-124) form ONE contiguous range, whose bounds the
   optimiser kernels take (`ocr_optim_step(..., reg_begin, reg_end, ...)`);
-* the tensors of the LATE layers — the last layers of the network (in definition order) that together hold at least
-  `late_fraction` of the parameters — form the upper part of the buffer.  Their gradients are complete first in the backward
+* the tensors of the LATE layers — the last layers of the network in EXECUTION order (`order`: the names of the lowered
+  operators as the engine runs them; definition order when not given — the two differ on residual graphs, where a block's
+  1x1 projection is defined after its convolutions but lowered before them) that together hold at least `late_fraction` of
+  the parameters — form the upper part of the buffer.  Their gradients are complete first in the backward
   pass, so data parallelism all-reduces [late_begin, n_total) as one contiguous bucket while the early layers' backward is
   still running, and [0, late_begin) afterwards (Engine.train_step).
 """
 import numpy as np
 
 
+def execution_order(output_node):
+    """Plan nodes reachable from `output_node` in the order the engine executes them: depth-first post-order over DATA edges
+    (only `add` has two; the second input of bi_lstm is the time_step_len slot).  Input slots are not listed."""
+    import sys
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 10000))
+    seen, order = set(), []
+
+    def visit(nd):
+        if nd.op == 'input' or id(nd) in seen:
+            return
+        seen.add(id(nd))
+        for i in (nd.inputs if nd.op == 'add' else nd.inputs[:1]):
+            visit(i)
+        order.append(nd)
+
+    visit(output_node)
+    return order
+
+
 def round_up(x, m):
     return (int(x) + m - 1) // m * m
 
 
-def layer_of(name):
+def layer_of(name, layers=None):
+    """Owning layer of a variable: the longest layer name that prefixes it ('logits/stack0/fw/weights' -> 'logits/stack0',
+    'conv4_1/conv4_1/gamma' -> 'conv4_1'); without a layer list, the first path component."""
+    if layers:
+        best = None
+        for l in layers:
+            if name.startswith(l + '/') and (best is None or len(l) > len(best)):
+                best = l
+        if best is not None:
+            return best
     return name.split('/')[0]
 
 
 class FlatLayout(object):
-    def __init__(self, specs, align, late_fraction=0.75):
-        """specs: iterable of objects with .name, .shape, .regularized in definition (= forward) order."""
+    def __init__(self, specs, align, late_fraction=0.75, order=None):
+        """specs: iterable of objects with .name, .shape, .regularized in definition (= forward) order.
+        order: layer names in execution order (only those owning variables matter); every variable must belong to one."""
         specs = list(specs)
-        layers = []
-        for s in specs:
-            if layer_of(s.name) not in layers:
-                layers.append(layer_of(s.name))
+        known = list(order) if order is not None else None
+        if known is not None:
+            layers = []
+            for l in known:
+                if l not in layers and any(layer_of(s.name, known) == l for s in specs):
+                    layers.append(l)
+            orphans = [s.name for s in specs if layer_of(s.name, known) not in layers]
+            if orphans:
+                raise ValueError('variables without a lowered operator: %s' % orphans)
+        else:
+            layers = []
+            for s in specs:
+                if layer_of(s.name) not in layers:
+                    layers.append(layer_of(s.name))
+        owner = {s.name: layer_of(s.name, known) for s in specs}
+        self.owner = owner
         size = {l: 0 for l in layers}
         for s in specs:
-            size[layer_of(s.name)] += int(np.prod(s.shape))
+            size[owner[s.name]] += int(np.prod(s.shape))
         total, acc, split = sum(size.values()), 0, 0
         for i in range(len(layers) - 1, -1, -1):
             acc += size[layers[i]]
@@ -39,7 +82,8 @@ class FlatLayout(object):
                 break
         late = set(layers[split:]) if split > 0 else set()
         self.split_layer = layers[split] if split > 0 else None     # first late layer; None: no split (everything "early")
-        is_late = lambda s: layer_of(s.name) in late
+        is_late = lambda s: owner[s.name] in late
+        self.late_layers = late
         groups = ([s for s in specs if not s.regularized and not is_late(s)], [s for s in specs if s.regularized and not is_late(s)],
                   [s for s in specs if s.regularized and is_late(s)], [s for s in specs if not s.regularized and is_late(s)])
         self.specs, self.offsets = {}, {}

@@ -34,7 +34,7 @@ class SolverWrapper(object):
             try:
                 ckpt = checkpoint.latest_checkpoint(self.output_dir)
                 print('Restoring from {}...'.format(ckpt), end=' ')
-                checkpoint.restore(eng, ckpt)
+                checkpoint.restore(eng, ckpt, with_optimizer=False)
                 print('done')
             except Exception:
                 raise Exception('Check your pretrained {}'.format(ckpt))

@@ -137,6 +137,42 @@ def test_flat_layout_buckets():
     assert one.split_layer is None and one.late_begin == one.n_total
 
 
+def test_flat_layout_follows_execution_order_on_residual_graphs():
+    """A residual block's 1x1 projection is DEFINED after its two convolutions but EXECUTED before them (it is the first
+    input of the add).  The late bucket must be a suffix of the execution order, otherwise the early backward graph would
+    write a gradient that the concurrent all-reduce of the late bucket is reading (round-1 advisor finding)."""
+    from lstm_ctc_ocr_amd.config import cfg
+    from lstm_ctc_ocr_amd.layout import FlatLayout, execution_order, layer_of
+    from lstm_ctc_ocr_amd.models import get_network
+    old = (cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, cfg.TRAIN.NUM_HID)
+    try:
+        for hid in (512, 1024, 2048):
+            cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, cfg.TRAIN.NUM_HID = 96, 2, hid
+            net = get_network('RESNET_train')
+            order = [nd.name for nd in execution_order(net.get_output('logits'))]
+            i_proj, i_a = order.index('res4_0_proj'), order.index('res4_0_a')
+            assert i_proj < i_a                                                   # the premise
+            specs = list(net.param_specs.values())
+            lay = FlatLayout(specs, 64, order=order)
+            assert lay.split_layer is not None
+            split = order.index(lay.split_layer)
+            for s in specs:
+                own = layer_of(s.name, order)
+                assert own == lay.owner[s.name]
+                assert (lay.offsets[s.name] >= lay.late_begin) == (order.index(own) >= split), s.name
+            n_late = sum(int(np.prod(s.shape)) for s in specs if lay.offsets[s.name] >= lay.late_begin)
+            assert n_late >= 0.75 * sum(int(np.prod(s.shape)) for s in specs)
+            # stacked BiLSTM variables belong to their own operator, not to the final 'logits' one
+            assert lay.owner['logits/stack0/fw/weights'] == 'logits/stack0' and lay.owner['logits/fw/weights'] == 'logits'
+    finally:
+        cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, cfg.TRAIN.NUM_HID = old
+    # the shipped chain: execution order == definition order, same layout as before
+    net = get_network('LSTM_train')
+    a = FlatLayout(list(net.param_specs.values()), 64)
+    b = FlatLayout(list(net.param_specs.values()), 64, order=[nd.name for nd in execution_order(net.get_output('logits'))])
+    assert a.offsets == b.offsets and a.late_begin == b.late_begin and a.split_layer == b.split_layer == 'conv4_1'
+
+
 def test_own_cli_drivers_parse_and_open_a_session(monkeypatch, tmp_path, capsys):
     """This repository's lstm/train_net.py and lstm/test_net.py: the reference's flag set, config overlay from lstm.yml and
     --set, directory creation, network construction; the final train_net / test_net call is intercepted (it needs a GPU)."""

@@ -38,3 +38,28 @@ def test_enqueuer_threads():
     assert e.is_running() and got == [0, 1, 2]
     e.stop()
     assert not e.is_running()
+
+
+def test_data_streams_differ_per_rank_and_per_stream(monkeypatch):
+    """Round-1 finding: every data-parallel rank drew the SAME samples (and the validation batch replayed the first training
+    batch).  Seeds now depend on $RANK and on the stream kind; two ranks' first batches and train/val batches differ."""
+    from lstm_ctc_ocr_amd.utils import gen
+    from lstm_ctc_ocr_amd.utils.data_util import GeneratorEnqueuer
+
+    def first_labels(seed):
+        e = GeneratorEnqueuer(gen.generator(batch_size=4), use_multiprocessing=False, random_seed=seed)
+        e.start(workers=1, max_queue_size=2)
+        try:
+            return e.queue.get(timeout=60)[1]
+        finally:
+            e.stop(timeout=5)
+
+    monkeypatch.setenv('RANK', '0')
+    s0, v0 = gen.stream_seed(), gen.stream_seed(stream=1)
+    monkeypatch.setenv('RANK', '1')
+    s1 = gen.stream_seed()
+    assert len({s0, s1, v0}) == 3
+    assert all(abs(a - b) > 64 for a, b in ((s0, s1), (s0, v0), (s1, v0)))     # workers add their index (< 64) to the seed
+    l0, l1, lv = first_labels(s0), first_labels(s1), first_labels(v0)
+    assert l0 != l1 and l0 != lv
+    assert first_labels(s0) == l0                                               # and each stream is reproducible

@@ -173,12 +173,14 @@ def test_data_parallel_schedule_on_emulated_ranks(dev, monkeypatch, overlap):
     assert float(diffs.max()) < 7e-3 and float(diffs.mean()) < 2e-5, (diffs.max(), diffs.mean())   # Adam: <= lr per step on noise-level entries
 
 
-def test_data_parallel_schedule_on_a_residual_network(dev, monkeypatch):
+@pytest.mark.parametrize('hid', [512, 64])
+def test_data_parallel_schedule_on_a_residual_network(dev, monkeypatch, hid):
     """The two-graph backward and the bucket boundary on a residual DAG with stacked BiLSTMs (BASELINE configs[4] in miniature):
-    emulated two-rank gradients must equal the single-GPU ones."""
+    emulated two-rank gradients must equal the single-GPU ones.  hid = 64 shrinks the LSTMs so that the late bucket begins
+    INSIDE a residual block with a projection (whose definition order differs from its execution order)."""
     from lstm_ctc_ocr_amd import models
-    old = (cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS)
-    cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS = 96, 2
+    old = (cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, cfg.TRAIN.NUM_HID)
+    cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, cfg.TRAIN.NUM_HID = 96, 2, hid
     try:
         class Tiny(models.RESNET_train):
             blocks, widths = (1, 1, 1, 1), (64, 128, 128, 256)
@@ -204,5 +206,31 @@ def test_data_parallel_schedule_on_a_residual_network(dev, monkeypatch):
         # biases in front of batch norm have a mathematically zero gradient: what is stored there is summation-order noise
         # (~1e-3 of the largest gradient in this net), so the bar is 5e-3; a missed or doubled exchange is off by ~0.5
         assert float(np.abs(g - base).max()) < 5e-3 * float(np.abs(base).max())
+        print('hid', hid, 'late bucket starts at', eng.split_layer, 'op', eng.split_op, 'of', len(eng.ops))
     finally:
-        cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS = old
+        cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, cfg.TRAIN.NUM_HID = old
+
+
+def test_rmsprop_slot_starts_at_one_and_restore_keeps_the_learning_rate(dev, tmp_path):
+    """tf.train.RMSPropOptimizer creates its 'rms' slot filled with ONES (the reference's TRAIN.SOLVER = 'RMS', train.py:75);
+    a restored run must show and keep decaying the learning rate it was saved with (train.py:96-106,114-115)."""
+    old = cfg.TRAIN.SOLVER
+    try:
+        eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
+        eng.setup_optimizer('RMS', 1e-3)
+        assert float(eng.state1.min()) == 1.0 and float(eng.state1.max()) == 1.0
+        eng.setup_optimizer('Adam', 1e-3)
+        assert float(eng.state1.abs().max()) == 0.0
+        eng.scale_lr(0.1)
+        path = str(tmp_path / 'lstm_ctc_iter_7.ckpt')
+        checkpoint.save(eng, path)
+        cfg.TRAIN.SOLVER = 'Adam'
+        eng2 = Engine(get_network('LSTM_train'), device='cuda:0', seed=4)
+        checkpoint.restore(eng2, path)
+        assert abs(eng2.lr - 1e-4) < 1e-12 and abs(float(eng2.scalars[2]) - 1e-4) < 1e-12
+        eng3 = Engine(get_network('LSTM_test'), device='cuda:0', seed=5)
+        checkpoint.restore(eng3, path, with_optimizer=False)
+        assert not eng3.opt_ready
+        assert np.array_equal(eng3.state_arrays()['conv2/weights'], eng.state_arrays()['conv2/weights'])
+    finally:
+        cfg.TRAIN.SOLVER = old
