@@ -80,12 +80,21 @@ def _oracle_grads(params, x, labels, ll, sl, wd, sim, grad_rounding=True):
     return grads, float(ctc.detach())
 
 
-# Per-tensor bars for |g_dev - g_oracle|_2 / |g_oracle|_2 against the bf16-simulating oracle, which rounds values AND
-# activation gradients where the device stores bf16 (oracle/graph.py qa()).  Measured on MI355X (round 2, printed by the
-# test) with 2x headroom; the distance to the pure-fp32 oracle (= the bf16 noise itself) is printed beside it and bounded
-# loosely.  A structural error (wrong tap, missed mask, missed residual branch) is O(1) in both.
-GRAD_L2_BAR = {'default': 2e-2}
-GRAD_L2_BAR_FP32 = 8e-2
+# Bars for |g_dev - g_oracle|_2 / |g_oracle|_2, per tensor, against the bf16-simulating oracle (rounds values AND activation
+# gradients where the device stores bf16: oracle/graph.py qa()).  Measured on MI355X in round 2 (N = 8, W = 88, random init;
+# printed by the test): 5e-5 .. 9e-4 for the FC / LSTM / conv5 tensors, then growing smoothly through the conv stack —
+# conv4_2 6.9e-3, conv4_1 8.7e-3, conv3_2 1.1e-2, conv3_1 1.3e-2, conv2 1.6e-2, conv1 2.0e-2.  Switching the oracle's
+# gradient rounding off changes these numbers by < 3 % of their value, i.e. the residual is NOT storage noise of the gradients:
+# it is max-pool / ReLU routing that flips where device and oracle activations differ in the last bf16 bit (each flip moves a
+# whole gradient element), the same mechanism that puts the bf16-simulating oracle itself 2.4e-2 .. 9.9e-2 away from the
+# pure-fp32 oracle on these tensors.  Bars = 2x measured.  A wiring error (wrong tap, missed mask or residual branch, missing
+# exchange) is O(1) here; errors of a few percent inside ONE kernel are caught where routing cannot flip — the kernel-level
+# tests feed identical inputs to kernel and reference (test_gpu_kernels.py: conv fwd/dgrad/wgrad, BN, pools, LSTM, <= 1e-2).
+GRAD_L2_BAR = {'default': 4e-2, 'conv4_1/weights': 2e-2, 'conv4_1/conv4_1/beta': 2e-2, 'conv4_1/conv4_1/gamma': 2e-2,
+               'conv4_2/weights': 1.5e-2, 'conv4_2/conv4_2/beta': 5e-3, 'conv4_2/conv4_2/gamma': 2e-3,
+               'conv5/weights': 2e-3, 'conv5/biases': 2e-3, 'logits/weights': 1.5e-3, 'logits/biases': 5e-4,
+               'logits/fw/weights': 2e-3, 'logits/fw/biases': 2e-3, 'logits/bw/weights': 2e-3, 'logits/bw/biases': 2e-3}
+GRAD_L2_BAR_FP32 = 0.2       # distance to the pure-fp32 oracle (dominated by the forward rounding): measured <= 9.9e-2
 
 
 def test_train_step_parity(engine):
