@@ -82,10 +82,19 @@ int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* ou
 int ocr_gemm_tn_batched_bf16(const void* A, long lda, long strideA, const void* B, long ldb, long strideB, float* out, long ldo,
                              long strideOut, int Mk, int I, int J, int nbatch, float scale, int splits, float* colsum,
                              long strideColsum, void* stream);
-int ocr_set_wgrad_engine(int use_dma_tiles);   /* A/B knob: 1 (default) = LDS-DMA kernel where I,J % 128 == 0; 0 = register-staged kernel */
+/* A/B knob: 2 (default) = nine-tap slab kernel for conv weight gradients when a workspace is given (else as 1);
+ * 1 = LDS-DMA per-tap tiles + fp32 atomics where I,J % 128 == 0; 0 = register-staged kernel */
+int ocr_set_wgrad_engine(int engine);
 /* dw f32 [3][3][Cin][Cout] (TF HWIO) += conv weight gradient; dbias (may be NULL) += sum over pixels of dy */
 int ocr_conv3x3_wgrad_bf16(const void* x, const void* dy, float* dw, float* dbias, int Nb, int W, int H, int Cin,
                            int Cout, int splits, void* stream);
+
+/* the same through a caller-owned workspace of ocr_conv3x3_wgrad_workspace_size() bytes (0: shape not covered, the call then
+ * behaves like ocr_conv3x3_wgrad_bf16): all nine taps from one staged tile, per-split partial slabs summed in a fixed order by a
+ * second kernel — no atomics, bit-reproducible.  The workspace is scratch: neither zeroed by the caller nor kept. */
+int ocr_conv3x3_wgrad_workspace_size(int Nb, int W, int H, int Cin, int Cout, size_t* bytes);
+int ocr_conv3x3_wgrad_ws_bf16(const void* x, const void* dy, float* dw, float* dbias, int Nb, int W, int H, int Cin,
+                              int Cout, int splits, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- conv1 (Cin = 1), pooling, batch-norm, reductions, packing (network.py:160-191, 343-350, 176-178) -------- */
 int ocr_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int Nb, int W, int H, int Cout,

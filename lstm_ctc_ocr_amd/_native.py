@@ -36,6 +36,8 @@ _SIGS = {
     "ocr_conv3x3_bf16": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P], _I),
     "ocr_gemm_tn_bf16": ([_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _L, _F, _I, _P, _P], _I),
     "ocr_conv3x3_wgrad_bf16": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
+    "ocr_conv3x3_wgrad_workspace_size": ([_I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_size_t)], _I),
+    "ocr_conv3x3_wgrad_ws_bf16": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, ctypes.c_size_t, _P], _I),
     "ocr_conv1_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "ocr_conv1_wgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "ocr_eltwise_bf16": ([_I, _P, _P, _P, _L, _P], _I),

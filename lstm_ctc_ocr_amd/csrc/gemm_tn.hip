@@ -215,8 +215,12 @@ static int pick_splits(long tiles, int Mk) {
 int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* out, long ldo, int Mk, int I, int J, int mode,
                      int grp, int skip, long a_row_off, int cW, int cH, int cC, float scale, int splits, float* colsum,
                      hipStream_t stream, int nbatch = 1, long sA = 0, long sB = 0, long sO = 0, long sC = 0);
-static int g_use_tn2 = 1;
-extern "C" int ocr_set_wgrad_engine(int use_dma_tiles) { g_use_tn2 = use_dma_tiles != 0; return OCR_OK; }
+int wgrad9_try_dispatch(const void* x, const void* dy, float* dw, float* dbias, int Nb, int W, int H, int Cin, int Cout,
+                        void* workspace, size_t ws_bytes, hipStream_t stream);
+static int g_use_tn2 = 1, g_use_w9 = 1;
+// 2 (default): nine-tap slab kernel (wgrad9.hip) where a workspace is given and the shape is covered, else as 1;
+// 1: LDS-DMA per-tap tiles with fp32 atomics (gemm_tn2.hip); 0: register-staged kernel (this file)
+extern "C" int ocr_set_wgrad_engine(int engine) { g_use_tn2 = engine != 0; g_use_w9 = engine >= 2; return OCR_OK; }
 
 // out[I][ldo] += scale * A^T B   with A[Mk][lda] (row-group skip + fixed offset), B[Mk][ldb]
 extern "C" int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* out, long ldo,
@@ -255,6 +259,19 @@ extern "C" int ocr_gemm_tn_batched_bf16(const void* A, long lda, long strideA, c
         if (rc != OCR_OK) return rc;
     }
     return OCR_OK;
+}
+
+// the same with a caller-owned workspace (ocr_conv3x3_wgrad_workspace_size): deterministic slab reduction instead of atomics
+extern "C" int ocr_conv3x3_wgrad_bf16(const void* x, const void* dy, float* dw, float* dbias, int Nb, int W, int H,
+                                      int Cin, int Cout, int splits, void* stream);
+extern "C" int ocr_conv3x3_wgrad_ws_bf16(const void* x, const void* dy, float* dw, float* dbias, int Nb, int W, int H, int Cin,
+                                         int Cout, int splits, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !dy || !dw || Nb <= 0 || W <= 0 || H <= 0 || (Cin & 7) || (Cout & 7)) return OCR_ERR_INVALID;
+    if (g_use_w9 && workspace && splits <= 0) {
+        int rc = wgrad9_try_dispatch(x, dy, dw, dbias, Nb, W, H, Cin, Cout, workspace, workspace_bytes, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
+    return ocr_conv3x3_wgrad_bf16(x, dy, dw, dbias, Nb, W, H, Cin, Cout, splits, stream);
 }
 
 // dW[3][3][Cin][Cout] (fp32, TF layout) += sum over pixels of x[shifted pixel][ci] * dy[pixel][co]

@@ -154,6 +154,11 @@ class _ConvOp(_Op):
         if self.kind == 'full':
             N, W, H, C = s
             sp.buf[self.key + '/col'] = torch.empty((N * o[1], self.kh * H * C), dtype=BF16, device=dev)
+        if self.kind == '3x3':      # scratch of the slab weight-gradient kernel: one buffer per plan, shared by all layers (one stream)
+            need = ops.conv3x3_wgrad_workspace_bytes(s[0], s[1], s[2], self.ci, self.co)
+            have = sp.buf.get('wgrad_ws')
+            if need and (have is None or have.numel() < need):
+                sp.buf['wgrad_ws'] = torch.empty(need, dtype=torch.uint8, device=dev)
 
     def pack_jobs(self):
         if self.kind == 'c1':
@@ -222,7 +227,7 @@ class _ConvOp(_Op):
         pdy, finish = e.grad_dst(sp, self.prev)
         pmask = self.prev.y(sp) if self.prev.mask_in_consumer else None
         if self.kind == '3x3':
-            ops.conv3x3_wgrad(x, dz, dw, dbias=db)      # bias gradient rides on the weight-gradient pass
+            ops.conv3x3_wgrad(x, dz, dw, dbias=db, workspace=sp.buf.get('wgrad_ws'))   # bias gradient rides on the same pass
             if pdy is not None:
                 ops.conv3x3(dz, self.wdgrad.view(self.ci, 3, 3, self.co), out=pdy, mask=pmask)
                 finish()

@@ -147,10 +147,23 @@ def lstm_xh(x2d, hout, seq_len, xh, Nb, T, D, U):
     return xh
 
 
-def conv3x3_wgrad(x, dy, dw, splits=0, dbias=None):
+def conv3x3_wgrad_workspace_bytes(Nb, W, H, Cin, Cout):
+    """Scratch bytes of the slab (atomic-free, deterministic) weight-gradient kernel; 0 when the shape is not covered."""
+    sz = ctypes.c_size_t(0)
+    call("ocr_conv3x3_wgrad_workspace_size", Nb, W, H, Cin, Cout, ctypes.byref(sz))
+    return sz.value
+
+
+def conv3x3_wgrad(x, dy, dw, splits=0, dbias=None, workspace=None):
+    """dw [3,3,Cin,Cout] f32 += weight gradient; dbias += column sums of dy.  With `workspace` (uint8 tensor of at least
+    conv3x3_wgrad_workspace_bytes) the nine-tap slab kernel runs where it applies."""
     Nb, W, H, Cin = x.shape
     Cout = dy.shape[-1]
-    call("ocr_conv3x3_wgrad_bf16", ptr(_dev(x)), ptr(dy), ptr(dw), ptr(dbias), Nb, W, H, Cin, Cout, splits, _st())
+    if workspace is not None:
+        call("ocr_conv3x3_wgrad_ws_bf16", ptr(_dev(x)), ptr(dy), ptr(dw), ptr(dbias), Nb, W, H, Cin, Cout, splits,
+             ptr(workspace), workspace.numel(), _st())
+    else:
+        call("ocr_conv3x3_wgrad_bf16", ptr(_dev(x)), ptr(dy), ptr(dw), ptr(dbias), Nb, W, H, Cin, Cout, splits, _st())
     return dw
 
 

@@ -223,7 +223,8 @@ def _conv_ref(x, w, b):   # x [N,W,H,C], w HWIO
 
 
 @pytest.mark.parametrize("Nb,W,H,Ci,Co", [(4, 16, 8, 64, 128), (2, 12, 4, 256, 512), (64, 64, 4, 256, 512), (3, 20, 16, 64, 128),
-                                          (16, 32, 16, 64, 128), (64, 128, 8, 64, 256), (5, 52, 4, 128, 192)])
+                                          (16, 32, 16, 64, 128), (64, 128, 8, 64, 256), (5, 52, 4, 128, 192), (32, 64, 4, 512, 512),
+                                          (7, 22, 8, 128, 256)])
 def test_conv3x3_fwd_dgrad_wgrad(dev, Nb, W, H, Ci, Co):
     x = bf(gen((Nb, W, H, Ci), 1)); w = bf(gen((3, 3, Ci, Co), 2, 0.05)); b = gen((Co,), 3)
     ref = _conv_ref(x, w, b)
@@ -248,6 +249,24 @@ def test_conv3x3_fwd_dgrad_wgrad(dev, Nb, W, H, Ci, Co):
     assert relerr(dbias.cpu(), dy.reshape(-1, Co).sum(0)) < 1e-4          # bias gradient fused into the same pass
     ops.conv3x3_wgrad(x.to(dev).to(BF), dy.to(dev).to(BF), dw, splits=2, dbias=dbias)
     assert relerr(dw.cpu(), 2 * wr.grad) < 1e-4 and relerr(dbias.cpu(), 2 * dy.reshape(-1, Co).sum(0)) < 1e-4
+    # nine-tap slab kernel (workspace form): same contract, no atomics -> bit-identical from run to run
+    nbytes = ops.conv3x3_wgrad_workspace_bytes(Nb, W, H, Ci, Co)
+    print('wgrad workspace bytes', nbytes)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    ws.fill_(0x7f)                                                    # scratch is neither zeroed nor kept: poison it
+    runs = []
+    for _ in range(2):
+        dw2 = torch.zeros((3, 3, Ci, Co), dtype=torch.float32, device=dev)
+        db2 = torch.zeros(Co, dtype=torch.float32, device=dev)
+        ops.conv3x3_wgrad(x.to(dev).to(BF), dy.to(dev).to(BF), dw2, dbias=db2, workspace=ws)
+        runs.append((dw2.cpu(), db2.cpu()))
+    assert relerr(runs[0][0], wr.grad) < 1e-4, relerr(runs[0][0], wr.grad)
+    assert relerr(runs[0][1], dy.reshape(-1, Co).sum(0)) < 1e-4
+    if nbytes:
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    dw2 = torch.ones((3, 3, Ci, Co), dtype=torch.float32, device=dev)        # "+=" semantics like the atomics path
+    ops.conv3x3_wgrad(x.to(dev).to(BF), dy.to(dev).to(BF), dw2, workspace=ws)
+    assert relerr(dw2.cpu() - 1.0, wr.grad) < 1e-4
 
 
 @pytest.mark.parametrize("Mk,I,J", [(4032, 512, 2048), (4032, 256, 1024), (4032, 512, 64), (100, 72, 136), (300, 128, 128), (1000, 256, 384)])

@@ -30,6 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--json", default=None)
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--only-conv", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     Nb = args.batch
@@ -55,7 +56,17 @@ def main():
         dx = torch.empty_like(x)
         rec(name + ".dgrad", timeit(lambda: ops.conv3x3(y, wd, out=dx, mask=x)), fl)
         dw = torch.zeros(3, 3, Ci, Co, device=dev)
-        rec(name + ".wgrad", timeit(lambda: ops.conv3x3_wgrad(x, y, dw)), fl)
+        db = torch.zeros(Co, device=dev)
+        rec(name + ".wgrad_atomics", timeit(lambda: ops.conv3x3_wgrad(x, y, dw, dbias=db)), fl)
+        wsz = ops.conv3x3_wgrad_workspace_bytes(Nb, W, H, Ci, Co)
+        if wsz:
+            ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+            rec(name + ".wgrad_slab", timeit(lambda: ops.conv3x3_wgrad(x, y, dw, dbias=db, workspace=ws)), fl)
+    if args.only_conv:
+        if args.json:
+            os.makedirs(os.path.dirname(args.json), exist_ok=True)
+            json.dump(res, open(args.json, "w"), indent=1)
+        return
     # conv5 as GEMM, LSTM projection, FC
     T = 63
     x5 = torch.randn(Nb, 64, 1024, device=dev).to(BF); w5 = torch.randn(512, 2048, device=dev).to(BF)
