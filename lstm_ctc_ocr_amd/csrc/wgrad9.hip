@@ -23,6 +23,8 @@
 //     taken from the dY tile by the workgroups of ci tile 0) rides along.
 // Covered: Cin % 64 == 0, Cout % 64 == 0, H in {4, 8, 16}.  Everything else stays on gemm_tn2.hip / gemm_tn.hip.
 #include "common.h"
+#include <stdlib.h>
+#include <utility>
 
 struct W9Args {
     const bf16_t* X; const bf16_t* dY;       // [M][Cin], [M][Cout]
@@ -42,12 +44,346 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 constexpr int W9_NDMA = 5;                        // LDS-DMA instructions per wave and step (1 KiB each)
 constexpr int W9_STAGE = 8 * W9_NDMA * 1024;      // 40 KiB: halo rows | dY rows | spare
 constexpr int W9_NST = 3;
-constexpr int W9_LDS = 4 * 9 * 4 * 4 * 64 * 4;    // 147 456 B: the epilogue's half-sum exchange (> 3 stages)
+constexpr int W9_LDS = 4 * 9 * 4 * 4 * 64 * 4;    // 147 456 B: the epilogue's half-sum exchange (> 3 stages + 8 KiB zero block)
 
 #define W9_TR(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
 #define W9_WAIT(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
 
+// ---- the LDS read stream of one step, as compile-time tables --------------------------------------------------------------
+// Groups in issue (= return) order: B(block 0) | A(0,0) .. A(0,8) | B(block 1) | A(1,0) .. A(1,8); a B group is 8 reads, an A
+// group 2.  Tap n = 9 kk + t consumes A(kk,t) and B(kk).  Before tap n the stream is advanced to LA groups past A(n), as far as
+// the 4-bit lgkmcnt allows (at most 15 reads in flight); the wait of tap n is the number of reads younger than A(n).
+constexpr int w9_gsize(int p) { return (p == 0 || p == 10) ? 8 : 2; }
+constexpr int w9_gpos(int n) { return n < 9 ? 1 + n : 2 + n; }
+constexpr int w9_younger(int n, int upto) { int o = 0; for (int q = w9_gpos(n) + 1; q <= upto; ++q) o += w9_gsize(q); return o; }
+constexpr int w9_upto(int n, int LA) {
+    int p = w9_gpos(n) + LA;
+    if (p > 19) p = 19;
+    const int own = n == 0 ? 10 : 2;                // reads of A(n) itself (and of B(0) at the first tap) may still be in flight
+    while (own + w9_younger(n, p) > 15) --p;
+    return p;
+}
+
+// the same as tables (constant arrays indexed by the unrolled tap number fold to immediates; calls with loops may not)
+struct W9Tab { int upto[18]; int wait[18]; };
+constexpr W9Tab w9_make_tab(int LA) {
+    W9Tab t = {};
+    for (int n = 0; n < 18; ++n) { t.upto[n] = w9_upto(n, LA); t.wait[n] = w9_younger(n, t.upto[n]); }
+    return t;
+}
+template <int LA> struct W9T { static constexpr W9Tab tab = w9_make_tab(LA); };
+
+// continuous stream: positions 20.. are the next step's groups; at most 13 reads in flight (two more slots of the 4-bit
+// counter are left to the column-sum reads); every read older than A(n) was waited for at tap n - 1
+constexpr int w9c_younger(int n, int upto) { int o = 0; for (int q = w9_gpos(n) + 1; q <= upto; ++q) o += w9_gsize(q % 20); return o; }
+constexpr int w9c_upto(int n, int LA) {
+    int p = w9_gpos(n) + LA;
+    if (n == 9) p = p;                                  // (B(1) sits before A(1,0): already counted by the positions)
+    int own = 2;
+    if (n == 0) own = 10;                               // B(0) and A(0,0) of this step were fetched by the previous step's last taps
+    while (own + w9c_younger(n, p) > 13) --p;
+    return p;
+}
+constexpr W9Tab w9c_make_tab(int LA) {
+    W9Tab t = {};
+    for (int n = 0; n < 18; ++n) { t.upto[n] = w9c_upto(n, LA); t.wait[n] = w9c_younger(n, t.upto[n]); }
+    for (int n = 1; n < 18; ++n) if (t.upto[n] < t.upto[n - 1]) { t.upto[n] = t.upto[n - 1]; t.wait[n] = w9c_younger(n, t.upto[n]); }
+    return t;
+}
+template <int LA> struct W9C { static constexpr W9Tab tab = w9c_make_tab(LA); };
+
+__device__ long long* w9_dbg;                       // diagnostic: s_memtime stamps of workgroup 0 (ocr_wgrad9_debug)
+
+template <int LA /* A groups kept in flight ahead of the tap being multiplied */, int DMA_AT /* tap before which the next stage's DMA is issued */,
+          bool DBG, int ABL = 0 /* timing ablations (wrong results): 1 no fragment reads, 2 no DMA after the prologue, 3 no MFMA, 4 no masks */,
+          int DMA_STEP = 0 /* 0: the five DMA pieces in one block before tap DMA_AT; k: one piece every k taps from DMA_AT on */,
+          bool STAG = false /* waves of pixel half 1 issue their DMA block nine taps later than those of half 0 */,
+          bool REDIR = false /* SAME padding along the feature axis by reading a zero row (address select, no ALU op on the fragment) */>
 __global__ __launch_bounds__(512) void wgrad9_kernel(W9Args g) {
+    constexpr int NSLOT = LA + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wave & 3, kh = wave >> 2;
+    const int H = g.cH, W = g.cW;
+    int split, tile;
+    {
+        const int b = blockIdx.x, T = g.T_ci * g.T_co;
+        if (g.map == 1) { const int x = b & 7, q = b >> 3; split = (q / T) * 8 + x; tile = q % T; }
+        else if (g.map == 2) { const int x = b & 7, q = b >> 3, G = 8 / g.S; split = x / G; tile = (x % G) * (T / G) + q; }
+        else { split = b / T; tile = b % T; }
+    }
+    const int ti = tile / g.T_co, tj = tile % g.T_co;
+    const int ci0 = ti * 64, co0 = tj * 64;
+    const int kbeg = split * g.k_per_split;
+    const int kend = min(g.M, kbeg + g.k_per_split);
+    const int nsteps = kend > kbeg ? (kend - kbeg + 127) >> 7 : 0;
+    const int NR = 128 + 2 * H + 2;                 // halo rows a step needs
+    const int nhalo = (NR + 7) >> 3;                // DMA instructions covering them (8 rows of 128 B each)
+    const int NRp = nhalo << 3;
+    const bool do_cs = g.cs_part != nullptr && ti == 0;
+    const bf16_t* zero = (const bf16_t*)w9_zero_page;
+
+    // ---- DMA geometry: instruction u = wave + 8 i covers stage bytes [u KiB, (u + 1) KiB): lane -> row 8u' + (lane >> 3),
+    //      LDS chunk position lane & 7, which holds SOURCE chunk q (slot XOR (row >> 1) & 3; (8u' + rr) >> 1 & 3 == rr >> 1 & 3)
+    const int rr = lane >> 3, pp = lane & 7;
+    const int qsrc = ((((pp >> 1) ^ ((rr >> 1) & 3)) << 1) | (pp & 1)) * 8;       // first channel of the source chunk
+    const bf16_t* src[W9_NDMA];
+    int pix[W9_NDMA];
+#pragma unroll
+    for (int i = 0; i < W9_NDMA; ++i) {
+        const int u = wave + 8 * i;
+        src[i] = zero; pix[i] = 0x40000000;            // spare piece: always the zero page
+        if (u < nhalo) {
+            const int r = 8 * u + rr;
+            pix[i] = (r < NR) ? kbeg - (H + 1) + r : 0x40000000;
+            src[i] = g.X + (long)(kbeg - (H + 1) + r) * g.Cin + ci0 + qsrc;
+        } else if (u < nhalo + 16) {
+            const int r = 8 * (u - nhalo) + rr;
+            pix[i] = kbeg + r;
+            src[i] = g.dY + (long)(kbeg + r) * g.Cout + co0 + qsrc;
+        }
+    }
+    auto stage_load = [&](int step, int buf) {
+        unsigned char* st = smem + buf * W9_STAGE;
+#pragma unroll
+        for (int i = 0; i < W9_NDMA; ++i) {
+            const int u = wave + 8 * i;
+            const int px = pix[i] + step * 128;
+            const bf16_t* s = zero;
+            if (u < nhalo) { if (px >= 0 && px < g.M) s = src[i] + (long)step * 128 * g.Cin; }
+            else if (u < nhalo + 16) { if (px < kend) s = src[i] + (long)step * 128 * g.Cout; }
+            __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(st + u * 1024), 16, 0, 0);
+        }
+    };
+
+    auto dma_one = [&](int i, int step, int buf) {       // piece i of this wave (i is a constant after unrolling)
+        const int u = wave + 8 * i;
+        const int px = pix[i] + step * 128;
+        const bf16_t* s = zero;
+        if (u < nhalo) { if (px >= 0 && px < g.M) s = src[i] + (long)step * 128 * g.Cin; }
+        else if (u < nhalo + 16) { if (px < kend) s = src[i] + (long)step * 128 * g.Cout; }
+        __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(smem + buf * W9_STAGE + u * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment addressing (loop invariant): lane (g4, L) supplies row 4 g4 + (L >> 2) of a 4 x 16 block, 8-byte piece L & 3
+    const int g4 = lane >> 4, L = lane & 15;
+    const int rowl = kh * 64 + 4 * g4 + (L >> 2);
+    unsigned offA[9], offB[4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int a0 = rowl + (H + 1) + (t / 3 - 1) * H + (t % 3 - 1);          // halo row of this lane's pixel for tap t
+        offA[t] = a0 * 128 + ((cb ^ ((a0 >> 1) & 3)) << 5) + (L & 3) * 8;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) offB[c] = NRp * 128 + rowl * 128 + ((c ^ ((rowl >> 1) & 3)) << 5) + (L & 3) * 8;
+    // SAME padding along the feature axis: element e of a transposed read is pixel row 4 g4 + e (+16, +32 k: same h, H | 16)
+    const unsigned mlo = ((4 * g4) % H == 0) ? 0xffff0000u : 0xffffffffu;         // taps with dh = -1: element 0 has h == 0
+    const unsigned mhi = ((4 * g4 + 4) % H == 0) ? 0x0000ffffu : 0xffffffffu;     // taps with dh = +1: element 3 has h == H - 1
+    // REDIR: the lane that SUPPLIES a padded element to the transposing read (row L >> 2 of its 4 x 16 block) reads 8 zero bytes
+    // instead — an address select folded into the loop-invariant per-tap offsets: offA of such a lane is absolute (zero block
+    // behind the stages) and its stage base is 0.  Nothing touches the fragment between the read and the MFMA (the AND / select
+    // version made the compiler copy every fragment into one operand tuple: each copy waited for the previous tap's MFMAs —
+    // measured 11 us of 75 on conv4_2).
+    constexpr unsigned ZOFF = W9_NST * W9_STAGE;                                   // 8 KiB of zeros (offsets up to 6 KiB are added)
+    const bool red_m = (L >> 2) == 0 && (4 * g4) % H == 0;                        // taps with dh = -1: element 0 of the block has h == 0
+    const bool red_p = (L >> 2) == 3 && (4 * g4 + 4) % H == 0;                    // taps with dh = +1: element 3 has h == H - 1
+    const unsigned zabs = lds0 + ZOFF + (L & 3) * 8;                              // this lane's 8 zero bytes
+    if (REDIR) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dh = t % 3 - 1;
+            if ((dh < 0 && red_m) || (dh > 0 && red_p)) offA[t] = zabs;
+        }
+        *(u32x4*)(smem + ZOFF + tid * 16) = (u32x4){0, 0, 0, 0};                  // 512 threads x 16 B (visible after the first barrier)
+    }
+    const int hs = H == 4 ? 2 : (H == 8 ? 3 : 4);                                // log2 H
+    const int ncol = 32 >> hs;                                                   // image columns per 32-pixel block
+    int wc = (kbeg >> hs) % W;                                                   // column (within its image) of the step's first pixel
+    const int lc0 = (4 * g4) >> hs, lc1 = (4 * g4 + 16) >> hs;                   // this lane's column inside a 32-pixel block (both reads)
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // column-sum geometry: thread -> source chunk tid & 7 (8 channels), rows (tid >> 3) and (tid >> 3) + 64 of the dY tile
+    const int csq = tid & 7, csr = tid >> 3;
+    const unsigned offC = NRp * 128 + csr * 128 + (((((csq >> 1) ^ ((csr >> 1) & 3)) << 1) | (csq & 1)) << 4);   // (csr + 64) >> 1 & 3 same
+
+#pragma unroll
+    for (int p = 0; p < W9_NST - 1; ++p)
+        if (p < nsteps) stage_load(p, p);
+    int cur = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+        if (DBG) st0 = __builtin_amdgcn_s_memtime();
+        if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W9_NDMA) : "memory");     // the next step may stay in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (DBG) st1 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (DBG) st2 = __builtin_amdgcn_s_memtime();
+        const unsigned sb = lds0 + cur * W9_STAGE;
+        const unsigned sbm = (REDIR && red_m) ? 0u : sb, sbp = (REDIR && red_p) ? 0u : sb;      // stage base as seen by the dh = -1 / +1 taps
+
+        s16x4 alo[NSLOT], ahi[NSLOT], blo[2][4], bhi[2][4];
+        bool bnd = false;                    // does the current 32-pixel block touch image column 0 or W - 1 ? (wave-uniform)
+        int w0 = 0, w1 = 0;                  // this lane's image column for the two reads (valid when bnd)
+        // REDIR: "no neighbour column" (w == 0 for dw = -1, w == W - 1 for dw = +1) as an address select too, per 32-pixel block
+        bool zl_m[2], zh_m[2], zl_p[2], zh_p[2];
+        if (REDIR) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                int cbase = wc + ((kh * 64 + kb * 32) >> hs);
+                while (cbase >= W) cbase -= W;
+                const bool bd = cbase == 0 || cbase + ncol >= W;
+                int c0 = cbase + lc0, c1 = cbase + lc1;
+                if (c0 >= W) c0 -= W;
+                if (c1 >= W) c1 -= W;
+                zl_m[kb] = bd && c0 == 0; zh_m[kb] = bd && c1 == 0; zl_p[kb] = bd && c0 == W - 1; zh_p[kb] = bd && c1 == W - 1;
+            }
+        }
+#define W9_ISSUE(P_) do { \
+            if (ABL == 1 || ABL == 5) break; \
+            if ((P_) == 0 || (P_) == 10) { \
+                const int kb_ = (P_) == 0 ? 0 : 1; \
+                _Pragma("unroll") for (int c = 0; c < 4; ++c) { W9_TR(blo[kb_][c], sb + offB[c], kb_ * 32 * 128); W9_TR(bhi[kb_][c], sb + offB[c], kb_ * 32 * 128 + 16 * 128); } \
+            } else { \
+                const int m_ = (P_) < 10 ? (P_) - 1 : (P_) - 2, kb_ = m_ / 9, tt_ = m_ % 9; \
+                const unsigned sa_ = (tt_ % 3 == 0 ? sbm : (tt_ % 3 == 2 ? sbp : sb)) + offA[tt_]; \
+                unsigned sl_ = sa_, sh_ = sa_; \
+                if (REDIR && tt_ / 3 == 0) { sl_ = zl_m[kb_] ? zabs : sa_; sh_ = zh_m[kb_] ? zabs : sa_; } \
+                if (REDIR && tt_ / 3 == 2) { sl_ = zl_p[kb_] ? zabs : sa_; sh_ = zh_p[kb_] ? zabs : sa_; } \
+                W9_TR(alo[m_ % NSLOT], sl_, kb_ * 32 * 128); W9_TR(ahi[m_ % NSLOT], sh_, kb_ * 32 * 128 + 16 * 128); \
+            } } while (0)
+#pragma unroll
+        for (int P = 0; P < 20; ++P)
+            if (P <= W9T<LA>::tab.upto[0]) W9_ISSUE(P);
+#pragma unroll
+        for (int n = 0; n < 18; ++n) {
+            const int kk = n / 9, t = n % 9;
+            if (DMA_STEP == 0 && (n == DMA_AT || (STAG && n == DMA_AT + 9)) && (!STAG || (n == DMA_AT) == (kh == 0))) {
+                // the buffer of step + 2 was last read in step - 1: free since this step's barrier
+                if (step + 2 < nsteps && ABL != 2 && ABL != 5) { int nb = cur + 2; if (nb >= W9_NST) nb -= W9_NST; stage_load(step + 2, nb); }
+                if (DBG) st3 = __builtin_amdgcn_s_memtime();
+            }
+            if (DMA_STEP > 0 && n >= DMA_AT && (n - DMA_AT) % DMA_STEP == 0 && (n - DMA_AT) / DMA_STEP < W9_NDMA) {
+                if (step + 2 < nsteps && ABL != 2) { int nb = cur + 2; if (nb >= W9_NST) nb -= W9_NST; dma_one((n - DMA_AT) / DMA_STEP, step + 2, nb); }
+                if (DBG) st3 = __builtin_amdgcn_s_memtime();
+            }
+            if (t == 0 && !REDIR) {
+                int cbase = wc + ((kh * 64 + kk * 32) >> hs);
+                while (cbase >= W) cbase -= W;
+                bnd = cbase == 0 || cbase + ncol >= W;
+                w0 = cbase + lc0; w1 = cbase + lc1;           // < 2 W (the plan requires W >= 32 / H)
+                if (w0 >= W) w0 -= W;
+                if (w1 >= W) w1 -= W;
+            }
+            if (n > 0) {                         // advance the read stream
+#pragma unroll
+                for (int P = 0; P < 20; ++P)
+                    if (P > W9T<LA>::tab.upto[n - 1] && P <= W9T<LA>::tab.upto[n]) W9_ISSUE(P);
+            }
+            switch (W9T<LA>::tab.wait[n]) {              // folds: n is a constant after unrolling
+                case 0: W9_WAIT(0); break;   case 2: W9_WAIT(2); break;   case 4: W9_WAIT(4); break;   case 6: W9_WAIT(6); break;
+                case 8: W9_WAIT(8); break;   case 10: W9_WAIT(10); break; case 12: W9_WAIT(12); break; default: W9_WAIT(14); break;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (DBG && n == 0) st4 = __builtin_amdgcn_s_memtime();
+            u32x2 lo = __builtin_bit_cast(u32x2, alo[n % NSLOT]), hi = __builtin_bit_cast(u32x2, ahi[n % NSLOT]);
+            const int dh = t % 3 - 1, dw = t / 3 - 1;
+            if (ABL == 1 || ABL == 5) { asm volatile("" : "+v"(lo), "+v"(hi)); }
+            if (dh < 0 && ABL != 4 && !REDIR) { lo.x &= mlo; hi.x &= mlo; }
+            if (dh > 0 && ABL != 4 && !REDIR) { lo.y &= mhi; hi.y &= mhi; }
+            if (dw != 0 && bnd && ABL != 4 && !REDIR) {      // rare (two blocks per image): the neighbour column does not exist
+                const int bad = dw < 0 ? 0 : W - 1;
+                if (w0 == bad) { lo.x = 0; lo.y = 0; }
+                if (w1 == bad) { hi.x = 0; hi.y = 0; }
+            }
+            const u32x4 av = {lo.x, lo.y, hi.x, hi.y};
+            const bf16x8 fa = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const u32x2 bl = __builtin_bit_cast(u32x2, blo[kk][c]), bh = __builtin_bit_cast(u32x2, bhi[kk][c]);
+                const u32x4 bv = {bl.x, bl.y, bh.x, bh.y};
+                if (ABL == 3) { asm volatile("" :: "v"(av), "v"(bv)); continue; }
+                acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, __builtin_bit_cast(bf16x8, bv), acc[t][c], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef W9_ISSUE
+        if (do_cs) {            // bias gradient: column sums of the dY tile (rows past kend are zero-filled)
+            u32x4 v0, v1;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(v0) : "v"(sb + offC));
+            asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(v1) : "v"(sb + offC));
+            W9_WAIT(0);
+            __builtin_amdgcn_sched_barrier(0);
+            cs[0] += bf_lo(v0.x) + bf_lo(v1.x); cs[1] += bf_hi(v0.x) + bf_hi(v1.x); cs[2] += bf_lo(v0.y) + bf_lo(v1.y); cs[3] += bf_hi(v0.y) + bf_hi(v1.y);
+            cs[4] += bf_lo(v0.z) + bf_lo(v1.z); cs[5] += bf_hi(v0.z) + bf_hi(v1.z); cs[6] += bf_lo(v0.w) + bf_lo(v1.w); cs[7] += bf_hi(v0.w) + bf_hi(v1.w);
+        }
+        if (DBG && blockIdx.x == 0 && lane == 0 && w9_dbg != nullptr && step < 64) {
+            long long* d = w9_dbg + (wave * 64 + step) * 8;
+            d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = st4; d[5] = __builtin_amdgcn_s_memtime();
+        }
+        wc += 128 >> hs;
+        while (wc >= W) wc -= W;
+        cur = (cur + 1 == W9_NST) ? 0 : cur + 1;
+    }
+    __syncthreads();                                   // every DMA has landed and every tile is dead: LDS is reused below
+
+    if (do_cs) {
+        float* red = (float*)smem;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = cs[e];
+        __syncthreads();
+        if (tid < 64) {                                // channel tid = chunk tid >> 3, element tid & 7; 64 row groups
+            float s = 0.f;
+            for (int u = 0; u < 64; ++u) s += red[(u * 8 + (tid >> 3)) * 8 + (tid & 7)];
+            g.cs_part[(long)split * g.Cout + co0 + tid] = s;
+        }
+        __syncthreads();
+    }
+    // sum the two pixel halves: waves kh = 1 hand their accumulators over through LDS ([wave][tap][c][r][lane], conflict free).
+    // (Tried: meeting in LDS as a [tap][ci][co] tile image — ds_add_f32 from the second half, 16-byte slab stores by all eight
+    // waves: +40 us per layer, LDS float atomics are slow; the slab write is bound by its 37.7 MB anyway.)
+    float* xch = (float*)smem + cb * (9 * 4 * 4 * 64) + lane;
+    if (kh == 1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xch[((t * 4 + c) * 4 + r) * 64] = acc[t][c][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+        float* slab = g.part + (long)split * 9 * g.Cin * g.Cout;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = ci0 + cb * 16 + g4 * 4 + r, co = co0 + c * 16 + L;
+                    slab[((long)t * g.Cin + ci) * g.Cout + co] = acc[t][c][r] + xch[((t * 4 + c) * 4 + r) * 64];
+                }
+    }
+}
+
+// Continuous-stream form of the kernel above (measured with s_memtime stamps: after the per-step barrier every wave spent
+// 750-1100 cycles issuing its five LDS-DMA pieces and 400-900 more waiting for the first fragments, with the matrix pipe
+// idle; 4800 cycles per step against 2304 of MFMA).  Here
+//   * the workgroup barrier sits in the MIDDLE of a step (before tap NB): it orders "stage step+1 has landed for everyone" and
+//     "everyone has left step-1" (so its buffer may be refilled) — a whole step before anybody needs either;
+//   * hence the LDS read stream never stops: the last taps of a step already fetch B(0), A(0,0).. of the next step from the
+//     next stage, there is no read prologue behind a barrier;
+//   * the five DMA pieces of stage step+2 are issued one at a time between the MFMA groups of taps NB+1, NB+3, ...
+template <int LA /* A groups kept in flight */, int NSLOT /* A fragment slots: LA + 1 <= NSLOT, 18 % NSLOT == 0 */, int NB /* tap of the barrier */, bool DBG>
+__global__ __launch_bounds__(512) void wgrad9c_kernel(W9Args g) {
+    static_assert(18 % NSLOT == 0 && LA + 1 <= NSLOT && NB + 9 < 18, "slot rotation must close over a step");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,6 +440,15 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(W9Args g) {
         }
     };
 
+    auto dma_one = [&](int i, int step, int buf) {       // piece i of this wave (compile-time i after unrolling)
+        const int u = wave + 8 * i;
+        const int px = pix[i] + step * 128;
+        const bf16_t* s = zero;
+        if (u < nhalo) { if (px >= 0 && px < g.M) s = src[i] + (long)step * 128 * g.Cin; }
+        else if (u < nhalo + 16) { if (px < kend) s = src[i] + (long)step * 128 * g.Cout; }
+        __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(smem + buf * W9_STAGE + u * 1024), 16, 0, 0);
+    };
+
     // ---- fragment addressing (loop invariant): lane (g4, L) supplies row 4 g4 + (L >> 2) of a 4 x 16 block, 8-byte piece L & 3
     const int g4 = lane >> 4, L = lane & 15;
     const int rowl = kh * 64 + 4 * g4 + (L >> 2);
@@ -137,26 +482,53 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(W9Args g) {
 #pragma unroll
     for (int p = 0; p < W9_NST - 1; ++p)
         if (p < nsteps) stage_load(p, p);
+    if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W9_NDMA) : "memory");       // stage 0 landed (stage 1 may stay in flight)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    s16x4 alo[NSLOT], ahi[NSLOT], blo[2][4], bhi[2][4];
+    u32x4 cv0 = {0, 0, 0, 0}, cv1 = {0, 0, 0, 0};
+#define W9_ISSUE(P_, SB_) do { \
+        const int q_ = (P_) % 20; \
+        if (q_ == 0 || q_ == 10) { \
+            const int kb_ = q_ == 0 ? 0 : 1; \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) { W9_TR(blo[kb_][c], (SB_) + offB[c], kb_ * 32 * 128); W9_TR(bhi[kb_][c], (SB_) + offB[c], kb_ * 32 * 128 + 16 * 128); } \
+        } else { \
+            const int m_ = q_ < 10 ? q_ - 1 : q_ - 2, kb_ = m_ / 9, tt_ = m_ % 9; \
+            W9_TR(alo[m_ % NSLOT], (SB_) + offA[tt_], kb_ * 32 * 128); W9_TR(ahi[m_ % NSLOT], (SB_) + offA[tt_], kb_ * 32 * 128 + 16 * 128); \
+        } } while (0)
+    if (nsteps > 0) {                        // read-stream prologue of step 0: what the last tap of a step fetches for its successor
+#pragma unroll
+        for (int P = 20; P < 40; ++P)
+            if (P <= W9C<LA>::tab.upto[17]) W9_ISSUE(P, lds0);
+    }
     int cur = 0;
     for (int step = 0; step < nsteps; ++step) {
-        if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W9_NDMA) : "memory");     // the next step may stay in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (step + 2 < nsteps) { int nb = cur + 2; if (nb >= W9_NST) nb -= W9_NST; stage_load(step + 2, nb); }
-        const unsigned sb = lds0 + cur * W9_STAGE;
-
-        s16x4 alo[4], ahi[4], blo[2][4], bhi[2][4];
-        // prologue of the read stream: B of block 0, A of taps 0 and 1
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { W9_TR(blo[0][c], sb + offB[c], 0); W9_TR(bhi[0][c], sb + offB[c], 16 * 128); }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) { W9_TR(alo[t], sb + offA[t], 0); W9_TR(ahi[t], sb + offA[t], 16 * 128); }
+        long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+        if (DBG) st0 = __builtin_amdgcn_s_memtime();
+        const int nxt = (cur + 1 == W9_NST) ? 0 : cur + 1, nn = (nxt + 1 == W9_NST) ? 0 : nxt + 1;
+        const unsigned sb = lds0 + cur * W9_STAGE, sbn = lds0 + nxt * W9_STAGE;
+        const bool more = step + 1 < nsteps, more2 = step + 2 < nsteps;
         bool bnd = false;                    // does the current 32-pixel block touch image column 0 or W - 1 ? (wave-uniform)
         int w0 = 0, w1 = 0;                  // this lane's image column for the two reads (valid when bnd)
 #pragma unroll
         for (int n = 0; n < 18; ++n) {
             const int kk = n / 9, t = n % 9;
+            if (n == NB) {
+                // own DMA pieces of stage step+1 (issued a step ago) have landed; after the barrier that holds for every wave's
+                // pieces, and every wave has left step-1: its buffer (= the one of step+2) may be refilled
+                if (DBG) st1 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (DBG) st2 = __builtin_amdgcn_s_memtime();
+                if (do_cs) {                 // bias gradient: this step's dY tile, two 16-byte reads riding in the stream
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(cv0) : "v"(sb + offC));
+                    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(cv1) : "v"(sb + offC));
+                }
+            }
+            if (n > NB && ((n - NB) & 1) && (n - NB) / 2 < W9_NDMA && more2) dma_one((n - NB) / 2, step + 2, nn);
+            if (DBG && n == NB + 2 * W9_NDMA) st3 = __builtin_amdgcn_s_memtime();
             if (t == 0) {
                 int cbase = wc + ((kh * 64 + kk * 32) >> hs);
                 while (cbase >= W) cbase -= W;
@@ -165,22 +537,22 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(W9Args g) {
                 if (w0 >= W) w0 -= W;
                 if (w1 >= W) w1 -= W;
             }
-            // keep the stream two taps ahead; across the block boundary: next block's B at tap 7, its taps 0 / 1 at tap 8
-            if (t <= 6) { W9_TR(alo[(n + 2) & 3], sb + offA[t + 2], kk * 32 * 128); W9_TR(ahi[(n + 2) & 3], sb + offA[t + 2], kk * 32 * 128 + 16 * 128); }
-            if (kk == 0 && t == 7) {
+            // advance the read stream: positions 0..19 are this step's groups, 20.. the next step's (from the next stage)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { W9_TR(blo[1][c], sb + offB[c], 32 * 128); W9_TR(bhi[1][c], sb + offB[c], 32 * 128 + 16 * 128); }
+            for (int P = 0; P < 40; ++P) {
+                const int prev = n == 0 ? W9C<LA>::tab.upto[17] - 20 : W9C<LA>::tab.upto[n - 1];
+                if (P > prev && P <= W9C<LA>::tab.upto[n]) {
+                    if (P < 20) W9_ISSUE(P, sb);
+                    else if (more) W9_ISSUE(P, sbn);
+                }
             }
-            if (kk == 0 && t == 8) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) { W9_TR(alo[(n + 1 + u) & 3], sb + offA[u], 32 * 128); W9_TR(ahi[(n + 1 + u) & 3], sb + offA[u], 32 * 128 + 16 * 128); }
+            switch (W9C<LA>::tab.wait[n]) {              // folds: n is a constant after unrolling
+                case 0: W9_WAIT(0); break;   case 2: W9_WAIT(2); break;   case 4: W9_WAIT(4); break;   case 6: W9_WAIT(6); break;
+                case 8: W9_WAIT(8); break;   case 10: W9_WAIT(10); break; case 12: W9_WAIT(12); break; default: W9_WAIT(13); break;
             }
-            // reads younger than tap t's that may stay in flight (LDS returns in order)
-            if (t <= 6) W9_WAIT(4);
-            else if (t == 7) { if (kk == 0) W9_WAIT(10); else W9_WAIT(2); }
-            else { if (kk == 0) W9_WAIT(12); else W9_WAIT(0); }
             __builtin_amdgcn_sched_barrier(0);
-            u32x2 lo = __builtin_bit_cast(u32x2, alo[n & 3]), hi = __builtin_bit_cast(u32x2, ahi[n & 3]);
+            if (DBG && n == 0) st4 = __builtin_amdgcn_s_memtime();
+            u32x2 lo = __builtin_bit_cast(u32x2, alo[n % NSLOT]), hi = __builtin_bit_cast(u32x2, ahi[n % NSLOT]);
             const int dh = t % 3 - 1, dw = t / 3 - 1;
             if (dh < 0) { lo.x &= mlo; hi.x &= mlo; }
             if (dh > 0) { lo.y &= mhi; hi.y &= mhi; }
@@ -199,19 +571,21 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(W9Args g) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (do_cs) {            // bias gradient: column sums of the dY tile (rows past kend are zero-filled)
-            u32x4 v0, v1;
-            asm volatile("ds_read_b128 %0, %1" : "=v"(v0) : "v"(sb + offC));
-            asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(v1) : "v"(sb + offC));
-            W9_WAIT(0);
-            __builtin_amdgcn_sched_barrier(0);
-            cs[0] += bf_lo(v0.x) + bf_lo(v1.x); cs[1] += bf_hi(v0.x) + bf_hi(v1.x); cs[2] += bf_lo(v0.y) + bf_lo(v1.y); cs[3] += bf_hi(v0.y) + bf_hi(v1.y);
-            cs[4] += bf_lo(v0.z) + bf_lo(v1.z); cs[5] += bf_hi(v0.z) + bf_hi(v1.z); cs[6] += bf_lo(v0.w) + bf_lo(v1.w); cs[7] += bf_hi(v0.w) + bf_hi(v1.w);
+        if (do_cs) {            // the two reads were issued 12 taps (>= 24 younger reads, all waited for in order) ago
+            asm volatile("" : "+v"(cv0), "+v"(cv1));
+            cs[0] += bf_lo(cv0.x) + bf_lo(cv1.x); cs[1] += bf_hi(cv0.x) + bf_hi(cv1.x); cs[2] += bf_lo(cv0.y) + bf_lo(cv1.y); cs[3] += bf_hi(cv0.y) + bf_hi(cv1.y);
+            cs[4] += bf_lo(cv0.z) + bf_lo(cv1.z); cs[5] += bf_hi(cv0.z) + bf_hi(cv1.z); cs[6] += bf_lo(cv0.w) + bf_lo(cv1.w); cs[7] += bf_hi(cv0.w) + bf_hi(cv1.w);
+        }
+        if (DBG && blockIdx.x == 0 && lane == 0 && w9_dbg != nullptr && step < 64) {
+            long long* d = w9_dbg + (wave * 64 + step) * 8;
+            d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = st4; d[5] = __builtin_amdgcn_s_memtime();
         }
         wc += 128 >> hs;
         while (wc >= W) wc -= W;
-        cur = (cur + 1 == W9_NST) ? 0 : cur + 1;
+        cur = nxt;
     }
+#undef W9_ISSUE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                                   // every DMA has landed and every tile is dead: LDS is reused below
 
     if (do_cs) {
@@ -226,7 +600,9 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(W9Args g) {
         }
         __syncthreads();
     }
-    // sum the two pixel halves: waves kh = 1 hand their accumulators over through LDS ([wave][tap][c][r][lane], conflict free)
+    // sum the two pixel halves: waves kh = 1 hand their accumulators over through LDS ([wave][tap][c][r][lane], conflict free).
+    // (Tried: meeting in LDS as a [tap][ci][co] tile image — ds_add_f32 from the second half, 16-byte slab stores by all eight
+    // waves: +40 us per layer, LDS float atomics are slow; the slab write is bound by its 37.7 MB anyway.)
     float* xch = (float*)smem + cb * (9 * 4 * 4 * 64) + lane;
     if (kh == 1) {
 #pragma unroll
@@ -251,20 +627,38 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(W9Args g) {
     }
 }
 
-// dw[i] += sum_s part[s][i] (fixed order: deterministic);  dbias[co] += sum_s cs_part[s][co]
+// dw[i] += sum_s part[s][i];  dbias[co] += sum_s cs_part[s][co] — fixed summation order: deterministic.
+// A workgroup handles 32 float4 columns; its 8 thread rows take the slabs s = row, row + 8, ... and meet in LDS (a plain
+// loop over S = 128 slabs by 72 workgroups left conv2's 37 MB of partials to a handful of CUs).
 __global__ __launch_bounds__(256) void wgrad9_reduce_kernel(float* __restrict__ dw, const float* __restrict__ part, long n4, long slab4,
                                                             int S, float* __restrict__ dbias, const float* __restrict__ cs_part, int Cout) {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        f32x4 a = ((const f32x4*)dw)[i];
-        for (int s = 0; s < S; ++s) a += ((const f32x4*)part)[s * slab4 + i];
-        ((f32x4*)dw)[i] = a;
+    __shared__ f32x4 red[8][32];
+    const int col = threadIdx.x & 31, row = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + col;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+        f32x4 b = {0.f, 0.f, 0.f, 0.f}, c = b, d = b;
+        int s = row;
+        for (; s + 24 < S; s += 32) {                    // four slabs in flight per thread
+            a += ((const f32x4*)part)[s * slab4 + i];        b += ((const f32x4*)part)[(s + 8) * slab4 + i];
+            c += ((const f32x4*)part)[(s + 16) * slab4 + i]; d += ((const f32x4*)part)[(s + 24) * slab4 + i];
+        }
+        for (; s < S; s += 8) a += ((const f32x4*)part)[s * slab4 + i];
+        a = (a + b) + (c + d);
+    }
+    red[row][col] = a;
+    __syncthreads();
+    if (row == 0 && i < n4) {
+        f32x4 t = ((const f32x4*)dw)[i];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][col];
+        ((f32x4*)dw)[i] = t;
     }
     if (dbias != nullptr && blockIdx.x == 0)
         for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
-            float a = dbias[c];
-            for (int s = 0; s < S; ++s) a += cs_part[(long)s * Cout + c];
-            dbias[c] = a;
+            float t = dbias[c];
+            for (int s = 0; s < S; ++s) t += cs_part[(long)s * Cout + c];
+            dbias[c] = t;
         }
 }
 
@@ -273,13 +667,20 @@ struct W9Plan { int S, k_per_split, map, T_ci, T_co; size_t bytes; };
 static bool w9_plan(int M, int W, int H, int Cin, int Cout, W9Plan* p) {
     if ((Cin & 63) || (Cout & 63) || (H != 4 && H != 8 && H != 16) || M < 512 || (M % H) || W * H < 32) return false;
     const int T_ci = Cin / 64, T_co = Cout / 64, T = T_ci * T_co;
+    static int smax = -1;                       // A/B knob OCR_W9_SMAX: cap on the split count (partial slabs cost 2 x 147 KB x workgroups of HBM traffic)
+    if (smax < 0) { const char* e = getenv("OCR_W9_SMAX"); smax = e ? atoi(e) : 64; if (smax < 1) smax = 1; }
     int S = 1;
-    while ((long)S * 2 * T <= 256 && M / (S * 2) >= 512) S *= 2;           // one workgroup per CU, at least four steps each
+    while ((long)S * 2 * T <= 256 && S * 2 <= smax && M / (S * 2) >= 512) S *= 2;   // <= one workgroup per CU, >= four steps each
     p->S = S; p->T_ci = T_ci; p->T_co = T_co;
     p->k_per_split = ceil_div(ceil_div(M, S), 128) * 128;
     p->map = S >= 8 ? 1 : ((T % (8 / S)) == 0 ? 2 : 0);
     p->bytes = (size_t)S * ((size_t)9 * Cin * Cout + Cout) * sizeof(float);
     return true;
+}
+
+extern "C" int ocr_wgrad9_debug(void* dbg /* device int64[8 waves][64 steps][8] or NULL */) {
+    long long* q = (long long*)dbg;
+    return hipMemcpyToSymbol(HIP_SYMBOL(w9_dbg), &q, sizeof(q)) == hipSuccess ? OCR_OK : OCR_ERR_MEMOPS;
 }
 
 extern "C" int ocr_conv3x3_wgrad_workspace_size(int Nb, int W, int H, int Cin, int Cout, size_t* bytes) {
@@ -295,20 +696,56 @@ int wgrad9_try_dispatch(const void* x, const void* dy, float* dw, float* dbias, 
     W9Plan p;
     const int M = Nb * W * H;
     if (!workspace || !w9_plan(M, W, H, Cin, Cout, &p) || ws_bytes < p.bytes) return -1;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)wgrad9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W9_LDS) != hipSuccess) return OCR_ERR_EXEC;
-        attr = true;
-    }
+    static int variant = -1;                    // A/B knob OCR_W9_VARIANT (see the table below); default 0
+    if (variant < 0) { const char* e = getenv("OCR_W9_VARIANT"); variant = e ? atoi(e) : 0; }
     W9Args g = {};
     g.X = (const bf16_t*)x; g.dY = (const bf16_t*)dy; g.M = M; g.Cin = Cin; g.Cout = Cout; g.cW = W; g.cH = H;
     g.k_per_split = p.k_per_split; g.S = p.S; g.T_ci = p.T_ci; g.T_co = p.T_co; g.map = p.map;
     g.part = (float*)workspace;
     g.cs_part = dbias ? g.part + (size_t)p.S * 9 * Cin * Cout : nullptr;
-    wgrad9_kernel<<<p.S * p.T_ci * p.T_co, 512, W9_LDS, stream>>>(g);
+    const int grid = p.S * p.T_ci * p.T_co;
+#define W9_LAUNCH(LA_, AT_, DBG_, ...) do { \
+        static bool attr = false; \
+        if (!attr) { if (hipFuncSetAttribute((const void*)wgrad9_kernel<LA_, AT_, DBG_, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, W9_LDS) != hipSuccess) return OCR_ERR_EXEC; attr = true; } \
+        wgrad9_kernel<LA_, AT_, DBG_, ##__VA_ARGS__><<<grid, 512, W9_LDS, stream>>>(g); } while (0)
+#define W9C_LAUNCH(LA_, NS_, NB_, DBG_) do { \
+        static bool attr = false; \
+        if (!attr) { if (hipFuncSetAttribute((const void*)wgrad9c_kernel<LA_, NS_, NB_, DBG_>, hipFuncAttributeMaxDynamicSharedMemorySize, W9_LDS) != hipSuccess) return OCR_ERR_EXEC; attr = true; } \
+        wgrad9c_kernel<LA_, NS_, NB_, DBG_><<<grid, 512, W9_LDS, stream>>>(g); } while (0)
+    switch (variant) {
+        case 1: W9_LAUNCH(3, 0, false); break;
+        case 2: W9_LAUNCH(4, 0, false); break;
+        case 3: W9_LAUNCH(2, 3, false); break;
+        case 4: W9_LAUNCH(4, 3, false); break;
+        case 5: W9_LAUNCH(6, 3, false); break;
+        case 6: W9C_LAUNCH(2, 3, 4, false); break;
+        case 7: W9C_LAUNCH(5, 6, 4, false); break;
+        case 8: W9C_LAUNCH(3, 6, 4, false); break;
+        case 9: W9C_LAUNCH(2, 3, 2, false); break;
+        case 16: W9C_LAUNCH(2, 3, 4, true); break;
+        case 17: W9C_LAUNCH(5, 6, 4, true); break;
+        case 10: W9_LAUNCH(2, 0, true); break;
+        case 30: W9_LAUNCH(2, 3, false, 0, 0, false, true); break;      // redirect masks
+        case 31: W9_LAUNCH(2, 3, false, 0, 0, true, true); break;       // + DMA block staggered between the pixel halves
+        case 32: W9_LAUNCH(3, 3, false, 0, 0, false, true); break;      // LA 3
+        case 33: W9_LAUNCH(3, 3, false, 0, 0, true, true); break;
+        case 34: W9_LAUNCH(2, 1, false, 0, 0, true, true); break;
+        case 35: W9_LAUNCH(2, 3, false, 5, 0, false, true); break;      // ablation: MFMA only (no reads, no DMA)
+        case 36: W9_LAUNCH(2, 3, false, 1, 0, false, true); break;      // ablation: no reads
+        case 37: W9_LAUNCH(2, 3, false, 2, 0, false, true); break;      // ablation: no DMA
+        case 21: W9_LAUNCH(2, 3, false, 1); break;
+        case 22: W9_LAUNCH(2, 3, false, 2); break;
+        case 23: W9_LAUNCH(2, 3, false, 3); break;
+        case 24: W9_LAUNCH(2, 3, false, 4); break;
+        case 14: W9_LAUNCH(4, 3, true); break;
+        case 40: W9_LAUNCH(2, 0, false); break;                         // first version: AND / select masks, DMA right behind the barrier
+        default: W9_LAUNCH(2, 3, false, 0, 0, false, true); break;      // measured best (r2): look-ahead 2, DMA block before tap 3, zero-row padding
+    }
+#undef W9_LAUNCH
+#undef W9C_LAUNCH
     OCR_CHECK_LAUNCH();
     const long n4 = (long)9 * Cin * Cout / 4;
-    int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+    const int blocks = (int)((n4 + 31) / 32);
     wgrad9_reduce_kernel<<<blocks, 256, 0, stream>>>(dw, g.part, n4, n4, p.S, dbias, g.cs_part, Cout);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
