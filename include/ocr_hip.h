@@ -67,8 +67,8 @@ int ocr_ctc_beam_decode(const float* activations, const int* input_lengths, int 
 int ocr_gemm_nt_bf16(const void* P, long ldp, const void* Q, long ldq, void* out, long ldo, int M, int N, int K,
                      const float* bias, const void* mask, long ldmask, int flags, int splits, int row_group,
                      int row_skip, int swap_inner, int swap_outer, void* stream);
-/* engine selector for A/B measurements: 1 (default) = tap-reuse halo conv + 256-row LDS-DMA GEMM tiles, 0 = 128x128 tiles,
- * 2 / 3 = LDS-DMA tiles (two / three stage) without the halo kernel */
+/* engine selector for A/B measurements: 1 (default) = tap-reuse halo conv + 256-row LDS-DMA GEMM tiles, 4 = ping-pong halo conv
+ * (waves of a SIMD half a step apart; slower, kept for A/B), 0 = 128x128 tiles, 2 / 3 = LDS-DMA tiles without the halo kernels */
 int ocr_set_gemm_engine(int use_large_tile);
 /* 3x3 SAME stride-1 convolution, x bf16 [Nb,W,H,Cin], wpack bf16 [Cout][3][3][Cin], y [Nb,W,H,Cout]
  * (conv_single network.py:160-191; also its data gradient with flipped/transposed weights) */
@@ -165,6 +165,10 @@ int ocr_optim_set_lr(void* scalars, double lr, int multiply, void* stream);
 int ocr_optim_step(float* params, float* grads, float* state1, float* state2, long n, long reg_begin, long reg_end,
                    float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
                    void* scalars, void* stream);
+
+/* diagnostics: s_memtime stamps of workgroup 0 (NULL = off); device int64 [8 waves][64 steps][8] / [8][80][8] */
+int ocr_wgrad9_debug(void* dbg);
+int ocr_conv_pp_debug(void* dbg);
 
 /* ---- device probes used by the test-suite (not part of the hot path) ------------------------------------------ */
 /* ds_read_b64_tr_b16 lane-semantics probe: LDS holds shorts 0..8191 (value = element index); lane l reads at

@@ -64,4 +64,16 @@ __device__ __forceinline__ float tanhf_(float x) {
     return copysignf(t, x);
 }
 
+// LDS-DMA of 16 bytes per lane in SADDR form: address = uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset (one VGPR), LDS
+// destination = uniform base in M0 + lane * 16.  With a loop-invariant lane offset and a scalar base that advances per step a
+// piece costs a handful of scalar instructions — the builtin with a per-lane 64-bit pointer (+ zero-page select) measured
+// 200-260 cycles per piece in the convolution kernels (tools/pp_stamps.py), mostly address arithmetic.
+// Not counted by the compiler: the caller waits with s_waitcnt vmcnt(N).  s_nop 4: an SGPR written by SALU just before may not
+// be read by VMEM earlier; s_nop 0: M0 write -> LDS-DMA.  M0 is saved / restored (the compiler owns it).
+__device__ __forceinline__ void dma16_saddr(unsigned lds_dst, unsigned voff, const void* sbase) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+}
+
 __host__ __device__ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

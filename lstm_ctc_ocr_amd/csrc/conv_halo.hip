@@ -29,7 +29,8 @@ __device__ u32x4 igh_zero_page[4];
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BN, int NW /* waves per workgroup: 8 (256 pixels, one workgroup per CU) or 4 (128 pixels, two per CU) */>
+template <int BN, int NW /* waves per workgroup: 8 (256 pixels, one workgroup per CU) or 4 (128 pixels, two per CU) */,
+          int ABL = 0 /* timing ablations (wrong results): 1 no fragment reads, 2 no DMA after the prologue, 5 neither (MFMA + barrier only) */>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 8 * NW */) {
     constexpr int BM = 32 * NW;
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
@@ -138,8 +139,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         {
             int ntap = tap + 1, nchunk = chunk;
             if (ntap == 9) { ntap = 0; ++nchunk; }
-            if (s + 1 < nsteps) load_q(ntap * C + nchunk * 64, (s + 1) & 1);
-            if (tap == 0 && chunk + 1 < nchunks) load_p(chunk + 1, (chunk + 1) & 1);
+            if (ABL != 2 && ABL != 5) {
+                if (s + 1 < nsteps) load_q(ntap * C + nchunk * 64, (s + 1) & 1);
+                if (tap == 0 && chunk + 1 < nchunks) load_p(chunk + 1, (chunk + 1) & 1);
+            }
         }
         const int shift = (H + 1) + (tap / 3 - 1) * H + (tap % 3 - 1);       // halo row of local pixel 0 for this tap
         const unsigned qa = qfrag0 + (s & 1) * QB;
@@ -153,6 +156,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // fragments were issued first and LDS returns in order — and lgkmcnt(0) before the second.  hipcc's own schedule
         // interleaved small read groups with the MFMAs and drained lgkmcnt(0) five times per step.
         u32x4 afr[2][FN], bfr[2][FM];
+        if (ABL == 1 || ABL == 5) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int a = 0; a < FN; ++a) asm volatile("" : "=v"(afr[kk][a]));
+#pragma unroll
+                for (int b = 0; b < FM; ++b) asm volatile("" : "=v"(bfr[kk][b]));
+            }
+        } else
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const unsigned qk = qa ^ (kk * 64);
@@ -216,22 +228,31 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
 }
 
-template <int BN, int NW>
-static int launch_halo(const HaloArgs& g, hipStream_t stream) {
+template <int BN, int NW, int ABL = 0>
+static int launch_halo_(const HaloArgs& g, hipStream_t stream) {
     constexpr int BM = 32 * NW;
     const int NR = BM + 2 * g.cH + 2;
     const int NRpad = (NR + 8 * NW) / (8 * NW) * (8 * NW);       // strictly greater than NR: the spare rows are the zero rows
     const int lds = 2 * NRpad * 128 + 2 * BN * 128;              // halo stages, weight stages
     static int lds_set = 0;
     if (lds > lds_set) {
-        if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, NW, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return OCR_ERR_EXEC;
         lds_set = lds;
     }
     int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
-    conv_halo_kernel<BN, NW><<<mt * nt, 64 * NW, lds, stream>>>(g, NRpad);
+    conv_halo_kernel<BN, NW, ABL><<<mt * nt, 64 * NW, lds, stream>>>(g, NRpad);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
+}
+template <int BN, int NW>
+static int launch_halo(const HaloArgs& g, hipStream_t stream) {
+    static int abl = -1;                        // timing ablations for tools/halo_variants.py (OCR_HALO_ABL; results are wrong)
+    if (abl < 0) { const char* e = getenv("OCR_HALO_ABL"); abl = e ? atoi(e) : 0; }
+    if (abl == 1) return launch_halo_<BN, NW, 1>(g, stream);
+    if (abl == 2) return launch_halo_<BN, NW, 2>(g, stream);
+    if (abl == 5) return launch_halo_<BN, NW, 5>(g, stream);
+    return launch_halo_<BN, NW, 0>(g, stream);
 }
 
 // -1 = shape not covered (caller falls back to igemm.hip / gemm.hip)
