@@ -127,6 +127,8 @@ int ocr_pack_conv_dgrad(const float* w, void* out, int Cin, int Cout, void* stre
  *  const float* src; bf16* dst; long n; int block_start, nblocks;}  with block_start ascending */
 int ocr_pack_jobs(const void* jobs, int njobs, int total_blocks, void* stream);
 int ocr_cast_f32_bf16(const float* in, void* out, long n, void* stream);
+/* uint8 pixels -> fp32 in [0, 1] (= u8 / 255, correctly rounded: identical to the host's `astype(float32) / 255.`, gen.py:59-65); n % 4 == 0 */
+int ocr_u8_to_unit_f32(const void* in, float* out, long n, void* stream);
 int ocr_cast2d_f32_bf16(const float* in, long ldin, void* out, long ldout, int rows, int cols, void* stream);
 int ocr_tnc_to_ntc_bf16(const float* in, void* out, int T, int N, int C, float scale, void* stream);
 int ocr_conv5_col2im(const void* col, void* dx, int Nb, int W, int HC, void* stream);

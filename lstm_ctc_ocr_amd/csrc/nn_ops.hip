@@ -935,6 +935,24 @@ extern "C" int ocr_cast_f32_bf16(const float* in, void* out, long n, void* strea
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
+// pixels as the generator produces them (uint8) -> the fp32 [0, 1] input the graph is fed with: x = u8 / 255 exactly as
+// numpy's `astype(float32) / 255.` does on the host (gen.py:59-65) — IEEE division, not a multiply by 1/255
+__global__ void u8_to_unit_f32_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, long n4) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const uint32_t p = ((const uint32_t*)in)[i];
+        f32x4 v = {__fdiv_rn((float)(p & 0xff), 255.0f), __fdiv_rn((float)((p >> 8) & 0xff), 255.0f),
+                   __fdiv_rn((float)((p >> 16) & 0xff), 255.0f), __fdiv_rn((float)(p >> 24), 255.0f)};
+        ((f32x4*)out)[i] = v;
+    }
+}
+extern "C" int ocr_u8_to_unit_f32(const void* in, float* out, long n, void* stream) {
+    if (!in || !out || n < 0 || (n & 3)) return OCR_ERR_INVALID;
+    if (n == 0) return OCR_OK;
+    u8_to_unit_f32_kernel<<<grid_for(n / 4), 256, 0, (hipStream_t)stream>>>((const uint8_t*)in, out, n / 4);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
 extern "C" int ocr_cast2d_f32_bf16(const float* in, long ldin, void* out, long ldout, int rows, int cols, void* stream) {
     if (!in || !out || rows <= 0 || cols <= 0 || (cols & 3) || (ldin & 3) || (ldout & 3)) return OCR_ERR_INVALID;
     cast2d_f32_bf16_kernel<<<grid_for((long)rows * (cols >> 2)), 256, 0, (hipStream_t)stream>>>(in, ldin, (bf16_t*)out, ldout, rows, cols);

@@ -29,3 +29,15 @@ def allreduce_sum_(flat, group=None, force=False):
 def rank_seed(base_seed, rank):
     """Independent, reproducible data stream per rank."""
     return int(base_seed) + 1000003 * int(rank)
+
+
+def mean_scalar(value, device=None, group=None):
+    """Mean of a Python float over the ranks (every rank calls it at the same iteration)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return float(value)
+    backend = dist.get_backend(group)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item()) / dist.get_world_size(group)

@@ -272,6 +272,12 @@ def cast_bf16(src, dst):
     return dst
 
 
+def u8_to_unit_f32(src_u8, dst_f32):
+    """dst = src / 255 (fp32, correctly rounded) — device-side form of groupBatch's `astype(float32) / 255.`"""
+    call("ocr_u8_to_unit_f32", ptr(_dev(src_u8)), ptr(dst_f32), src_u8.numel(), _st())
+    return dst_f32
+
+
 def cast2d_bf16(src, ldin, dst, ldout, rows, cols):
     call("ocr_cast2d_f32_bf16", ptr(_dev(src)), ldin, ptr(dst), ldout, rows, cols, _st())
     return dst

