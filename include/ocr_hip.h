@@ -133,6 +133,22 @@ int ocr_cast2d_f32_bf16(const float* in, long ldin, void* out, long ldout, int r
 int ocr_tnc_to_ntc_bf16(const float* in, void* out, int T, int N, int C, float scale, void* stream);
 int ocr_conv5_col2im(const void* col, void* dx, int Nb, int W, int HC, void* stream);
 
+/* ---- layers of the reference DSL outside the shipped graphs (lstm_ctc_ocr_amd/csrc/dsl_ops.hip) --------------- */
+/* stand-alone batch_normalization with the stored (moving) statistics — is_training=False, network.py:466-473 */
+int ocr_bn_infer_fwd(const void* x, void* y, const float* gamma, const float* beta, const float* mean, const float* var,
+                     long M, int C, float eps, int relu, void* stream);
+int ocr_bn_infer_bwd(const void* x, const void* y, const void* dy, void* dx, const float* gamma, const float* mean,
+                     const float* var, float* dgamma, float* dbeta, long M, int C, float eps, int relu, void* stream);
+/* tf.nn.dropout (network.py:626-628): out = keep(i) ? in / keep_prob : 0; keep(i) = hash(seed, *step_counter, i) < keep_prob —
+ * the same call with the same arguments on the gradient is the backward pass (nothing stored); step_counter: device double or NULL */
+int ocr_dropout_bf16(const void* in, void* out, long n, unsigned seed, const void* step_counter, float keep_prob, void* stream);
+/* tf.nn.avg_pool, window == stride in {1,2}^2 (network.py:352-359); backward: src = dy (pooled), dst = dx */
+int ocr_avgpool_bf16(const void* src, void* dst, int Nb, int W, int H, int C, int kw, int kh, int backward, void* stream);
+/* strided pick y[n,wo,ho,:] = x[n, wo*sw+ow, ho*sh+oh, :] (a strided convolution = stride-1 convolution + pick) / its transpose */
+int ocr_subsample_bf16(const void* src, void* dst, int Nb, int W, int H, int C, int Wo, int Ho, int sw, int sh, int ow, int oh,
+                       int backward, void* stream);
+int ocr_softmax_f32(const float* in, float* out, long rows, int C, void* stream);     /* network.py:441-447, last axis */
+
 /* ---- bidirectional LSTM (bi_lstm network.py:97-129; TF-1.0 LSTMCell gate order i,j,f,o, forget_bias 1.0) ----- */
 int ocr_lstm_fwd_step(const float* xproj, const void* whT_packed, const int* seq_len, void* hout, float* gates,
                       float* cell, int Nb, int T, int U, int step, float forget_bias, void* stream);

@@ -48,6 +48,12 @@ _SIGS = {
     "ocr_bn_workspace_bytes": ([_L, _I], ctypes.c_size_t),
     "ocr_bn_train_fwd": ([_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P, _P], _I),
     "ocr_bn_train_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P], _I),
+    "ocr_bn_infer_fwd": ([_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P], _I),
+    "ocr_bn_infer_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P], _I),
+    "ocr_dropout_bf16": ([_P, _P, _L, ctypes.c_uint, _P, _F, _P], _I),
+    "ocr_avgpool_bf16": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "ocr_subsample_bf16": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    "ocr_softmax_f32": ([_P, _P, _L, _I, _P], _I),
     "ocr_colsum_bf16": ([_P, _P, _L, _I, _L, _P], _I),
     "ocr_pack_transpose": ([_P, _P, _I, _I, _L, _I, _P], _I),
     "ocr_pack_conv_dgrad": ([_P, _P, _I, _I, _P], _I),

@@ -95,12 +95,10 @@ class _ConvOp(_Op):
         a = node.attrs
         self.kh, self.kw, self.co, self.ci = a['k_h'], a['k_w'], a['c_o'], a['c_i']
         self.bn, self.relu, self.biased, self.padding = a['bn'], a['relu'], a['biased'], a['padding']
-        if (a['s_h'], a['s_w']) != (1, 1):
-            raise NotImplementedError('%s: only stride-1 convolutions are lowered' % self.name)
-        if not self.biased:
-            raise NotImplementedError('%s: un-biased convolutions are not lowered yet' % self.name)
+        # strides: the op itself always runs at stride 1; Engine._lower appends a _SubsampleOp (a strided convolution is the
+        # stride-1 convolution evaluated at every s-th position)
         if self.ci == 1:
-            if (self.kh, self.kw, self.padding) != (3, 3, 'SAME') or self.co != 64 or self.bn:
+            if (self.kh, self.kw, self.padding) != (3, 3, 'SAME') or self.co != 64 or self.bn or not self.biased:
                 raise NotImplementedError('%s: the single-channel input conv is lowered for 3x3 SAME, 64 filters' % self.name)
             self.kind = 'c1'
         elif (self.kh, self.kw, self.padding) == (3, 3, 'SAME'):
@@ -174,7 +172,7 @@ class _ConvOp(_Op):
         e = self.eng
         x = self.prev.y(sp)
         s, o = sp.shape[self.key]
-        bias = e.param(self.name + '/biases')
+        bias = e.param(self.name + '/biases') if self.biased else None
         if self.fused_pool is not None:
             ops.conv1_pool_fwd(x, e.param(self.name + '/weights'), bias, out=self.fused_pool.y(sp))
             return
@@ -220,7 +218,7 @@ class _ConvOp(_Op):
                              e.grad('%s/%s/beta' % (self.name, self.name)), self.relu, sp.buf[self.key + '/bnws'],
                              out=dz.view(M, self.co))
         dw = e.grad(self.name + '/weights')
-        db = e.grad(self.name + '/biases')
+        db = e.grad(self.name + '/biases') if self.biased else None
         if self.kind == 'c1':
             ops.conv1_wgrad(x, dz, dw, db)
             return
@@ -365,6 +363,227 @@ class _ReluOp(_Op):
 
     def bwd(self, sp):
         self.eng.deliver(sp, self.prev, self.dy(sp), mask=self.y(sp))
+
+
+class _SubsampleOp(_Op):
+    """Second half of a strided convolution (Network.conv / conv_single with s_h, s_w > 1, network.py:193-216): picks every
+    s-th position of the stride-1 result.  TF SAME: out = ceil(in / s), pad_before = max((out-1) s + k - in, 0) // 2, so output
+    o is the stride-1 output at o s + (k-1)//2 - pad_before."""
+
+    def __init__(self, eng, node, prev):
+        super(_SubsampleOp, self).__init__(eng, node, prev)
+        a = node.attrs
+        self.sw, self.sh, self.kw, self.kh = a['s_h'], a['s_w'], a['k_h'], a['k_w']      # reference "height" = our time axis W
+        if a['padding'] != 'SAME':
+            raise NotImplementedError('%s: strided convolution is lowered for SAME padding' % self.name)
+
+    def dy_needed(self):
+        return True
+
+    @staticmethod
+    def _geom(n, k, s):
+        out = -(-n // s)
+        before = max((out - 1) * s + k - n, 0) // 2
+        return out, (k - 1) // 2 - before
+
+    def out_shape(self, s):
+        N, W, H, C = s
+        Wo, self.ow = self._geom(W, self.kw, self.sw)
+        Ho, self.oh = self._geom(H, self.kh, self.sh)
+        return (N, Wo, Ho, C)
+
+    def alloc(self, sp, s):
+        o = self.out_shape(s)
+        sp.shape[self.key] = (s, o)
+        sp.buf[self.key + '/y'] = torch.empty(o, dtype=BF16, device=self.eng.device)
+        sp.buf[self.key + '/dy'] = torch.empty(o, dtype=BF16, device=self.eng.device)
+
+    def fwd(self, sp):
+        (N, W, H, C), (_, Wo, Ho, _) = sp.shape[self.key]
+        ops.subsample(self.prev.y(sp), self.y(sp), N, W, H, C, Wo, Ho, self.sw, self.sh, self.ow, self.oh)
+
+    def bwd(self, sp):
+        (N, W, H, C), (_, Wo, Ho, _) = sp.shape[self.key]
+        pdy, finish = self.eng.grad_dst(sp, self.prev)
+        if pdy is not None:
+            ops.subsample(self.dy(sp), pdy, N, W, H, C, Wo, Ho, self.sw, self.sh, self.ow, self.oh, backward=True)
+            if self.prev.mask_in_consumer:
+                ops.eltwise(2, pdy, self.prev.y(sp), pdy)
+            finish()
+
+
+class _BatchNormOp(_Op):
+    """Network.batch_normalization (network.py:466-473): batch statistics when is_training, else the stored moving ones."""
+
+    def __init__(self, eng, node, prev):
+        super(_BatchNormOp, self).__init__(eng, node, prev)
+        self.relu, self.training = node.attrs['relu'], node.attrs['is_training']
+
+    def dy_needed(self):
+        return True
+
+    def out_shape(self, s):
+        return s
+
+    def alloc(self, sp, s):
+        dev, C = self.eng.device, s[-1]
+        sp.shape[self.key] = (s, s)
+        sp.buf[self.key + '/y'] = torch.empty(s, dtype=BF16, device=dev)
+        sp.buf[self.key + '/dy'] = torch.empty(s, dtype=BF16, device=dev)
+        sp.buf[self.key + '/dx'] = torch.empty(s, dtype=BF16, device=dev)
+        if self.training:
+            M = int(np.prod(s[:-1]))
+            sp.buf[self.key + '/mean'] = torch.empty(C, dtype=F32, device=dev)
+            sp.buf[self.key + '/rstd'] = torch.empty(C, dtype=F32, device=dev)
+            sp.buf[self.key + '/bnws'] = ops.bn_workspace(M, C, dev)
+
+    def _x(self, sp):
+        if self.prev.mask_in_consumer:
+            raise NotImplementedError('%s: batch_normalization behind a fused-ReLU convolution is not lowered' % self.name)
+        return self.prev.y(sp)
+
+    def fwd(self, sp):
+        e, (s, _) = self.eng, sp.shape[self.key]
+        C = s[-1]
+        M = int(np.prod(s[:-1]))
+        x, y = self._x(sp).view(M, C), self.y(sp).view(M, C)
+        if self.training:
+            ops.bn_train_fwd(x, e.param(self.name + '/gamma'), e.param(self.name + '/beta'), BN_EPS, self.relu, sp.buf[self.key + '/bnws'],
+                             out=y, save_mean=sp.buf[self.key + '/mean'], save_rstd=sp.buf[self.key + '/rstd'])
+        else:
+            ops.bn_infer_fwd(x, e.param(self.name + '/gamma'), e.param(self.name + '/beta'), e.param(self.name + '/moving_mean'),
+                             e.param(self.name + '/moving_variance'), BN_EPS, self.relu, y)
+
+    def bwd(self, sp):
+        e, (s, _) = self.eng, sp.shape[self.key]
+        C = s[-1]
+        M = int(np.prod(s[:-1]))
+        x, y, dy, dx = self._x(sp).view(M, C), self.y(sp).view(M, C), self.dy(sp).view(M, C), sp.buf[self.key + '/dx'].view(M, C)
+        if self.training:
+            ops.bn_train_bwd(x, y, dy, e.param(self.name + '/gamma'), sp.buf[self.key + '/mean'], sp.buf[self.key + '/rstd'],
+                             e.grad(self.name + '/gamma'), e.grad(self.name + '/beta'), self.relu, sp.buf[self.key + '/bnws'], out=dx)
+        else:
+            ops.bn_infer_bwd(x, y, dy, e.param(self.name + '/gamma'), e.param(self.name + '/moving_mean'),
+                             e.param(self.name + '/moving_variance'), e.grad(self.name + '/gamma'), e.grad(self.name + '/beta'), BN_EPS,
+                             self.relu, dx)
+        e.deliver(sp, self.prev, sp.buf[self.key + '/dx'])
+
+
+class _DropoutOp(_Op):
+    """Network.dropout = tf.nn.dropout(x, keep_prob) (network.py:626-628).  keep_prob is the value the driver feeds: 0.5 in
+    training steps (train.py:126), 1.0 otherwise (train.py:156, test.py:75) — Engine.train_keep_prob / inference = 1."""
+
+    def __init__(self, eng, node, prev):
+        super(_DropoutOp, self).__init__(eng, node, prev)
+        self.mask_in_consumer = False
+        import zlib
+        self.seed = zlib.crc32(self.name.encode()) ^ 0x5bd1e995
+
+    def dy_needed(self):
+        return True
+
+    def out_shape(self, s):
+        return s
+
+    def alloc(self, sp, s):
+        sp.shape[self.key] = (s, s)
+        sp.buf[self.key + '/y'] = torch.empty(s, dtype=BF16, device=self.eng.device)
+        sp.buf[self.key + '/dy'] = torch.empty(s, dtype=BF16, device=self.eng.device)
+        sp.buf[self.key + '/dx'] = torch.empty(s, dtype=BF16, device=self.eng.device)
+
+    def _kp(self):
+        return float(self.eng.train_keep_prob) if self.eng.training else 1.0
+
+    def fwd(self, sp):
+        x = self.prev.y(sp)
+        if self.prev.mask_in_consumer:
+            raise NotImplementedError('%s: dropout directly behind a fused-ReLU convolution is not lowered' % self.name)
+        ops.dropout(x, self.y(sp), self.seed, self.eng.step_counter(), self._kp())
+
+    def bwd(self, sp):
+        ops.dropout(self.dy(sp), sp.buf[self.key + '/dx'], self.seed, self.eng.step_counter(), self._kp())
+        self.eng.deliver(sp, self.prev, sp.buf[self.key + '/dx'])
+
+
+class _AvgPoolOp(_PoolOp):
+    """Network.avg_pool (network.py:352-359), window == stride."""
+
+    def fwd(self, sp):
+        (N, W, H, C), _ = sp.shape[self.key]
+        x = self.prev.y(sp)
+        if self.prev.mask_in_consumer:
+            pass            # the ReLU is already applied to the stored activation; only its BACKWARD is deferred to the consumer
+        ops.avgpool(x, self.y(sp), N, W, H, C, self.kw_t, self.kh_f)
+
+    def bwd(self, sp):
+        (N, W, H, C), _ = sp.shape[self.key]
+        pdy, finish = self.eng.grad_dst(sp, self.prev)
+        if pdy is not None:
+            ops.avgpool(self.dy(sp), pdy, N, W, H, C, self.kw_t, self.kh_f, backward=True)
+            if self.prev.mask_in_consumer:
+                ops.eltwise(2, pdy, self.prev.y(sp), pdy)
+            finish()
+
+
+class _ConcatOp(_Op):
+    """Network.concat along the channel axis (network.py:154-158, axis = 3): copies, no arithmetic."""
+
+    def __init__(self, eng, node, prev):
+        super(_ConcatOp, self).__init__(eng, node, prev)
+        if node.attrs.get('axis') not in (3, -1):
+            raise NotImplementedError('%s: concat is lowered along the channel axis only' % self.name)
+
+    def dy_needed(self):
+        return True
+
+    def out_shape(self, s):
+        return tuple(s[:-1]) + (sum(self._cin),)
+
+    def alloc(self, sp, s):
+        self._cin = [sp.oshape[p.key][-1] for p in self.inputs]
+        o = self.out_shape(s)
+        sp.shape[self.key] = (s, o)
+        sp.buf[self.key + '/y'] = torch.empty(o, dtype=BF16, device=self.eng.device)
+        sp.buf[self.key + '/dy'] = torch.empty(o, dtype=BF16, device=self.eng.device)
+        for i, c in enumerate(self._cin):
+            sp.buf['%s/part%d' % (self.key, i)] = torch.empty(tuple(s[:-1]) + (c,), dtype=BF16, device=self.eng.device)
+
+    def fwd(self, sp):
+        y, off = self.y(sp), 0
+        for p, c in zip(self.inputs, self._cin):
+            if p.mask_in_consumer:
+                raise NotImplementedError('%s: concat of a fused-ReLU convolution output is not lowered' % self.name)
+            y[..., off:off + c].copy_(p.y(sp))
+            off += c
+
+    def bwd(self, sp):
+        dy, off = self.dy(sp), 0
+        for i, (p, c) in enumerate(zip(self.inputs, self._cin)):
+            part = sp.buf['%s/part%d' % (self.key, i)]
+            part.copy_(dy[..., off:off + c])
+            self.eng.deliver(sp, p, part)
+            off += c
+
+
+class _SoftmaxOp(_Op):
+    """Network.softmax (network.py:441-447) over the last axis of fp32 logits — an inference output (CTC takes unnormalised
+    activations, so nothing differentiates through it in this engine)."""
+
+    def out_shape(self, s):
+        return s
+
+    def alloc(self, sp, s):
+        sp.shape[self.key] = (s, s)
+        sp.buf[self.key + '/y'] = torch.empty(s, dtype=F32, device=self.eng.device)
+
+    def dy(self, sp):
+        return None
+
+    def fwd(self, sp):
+        ops.softmax(self.prev.y(sp), self.y(sp))
+
+    def bwd(self, sp):
+        raise NotImplementedError('%s: softmax is an inference output; the loss takes the unnormalised logits' % self.name)
 
 
 class _BiLstmOp(_Op):
@@ -517,7 +736,7 @@ class ShapePlan(object):
         self.labels = torch.zeros(N * eng.max_label_len, dtype=I32, device=dev)
         self.labels_len = torch.zeros(N, dtype=I32, device=dev)
         self.seq_len = torch.ones(N, dtype=I32, device=dev)
-        self.oshape = {'data': (N, W, eng.num_features)}
+        self.oshape = {'data': (N, W, eng.num_features)}       # output shape per op key (multi-input ops look their inputs up here)
         self.scratch = {}
         self.dy_done = set()
         for op in eng.ops:
@@ -579,6 +798,9 @@ class Engine(object):
                     if owner == op.name:
                         assert (self.offsets[name] >= self.late_begin) == (i >= self.split_op), (op.name, name)
         self.plans = {}
+        self.training = False                            # set by the run bodies: dropout keeps everything outside training steps
+        self.train_keep_prob = 0.5                       # what the reference feeds in training steps (train.py:126)
+        self._zero_step = torch.zeros(1, dtype=torch.float64, device=self.device)
         self.opt_ready = False
         self.graph_opt = None
         self.iteration = 0
@@ -709,8 +931,9 @@ class Engine(object):
     def _lower(self, net):
         """Topological lowering of the plan reachable from 'logits' (a chain for the shipped models, a DAG with residual
         adds for deeper extractors).  Only data edges count: the second input of bi_lstm is the time_step_len slot."""
-        table = {'conv': _ConvOp, 'max_pool': _PoolOp, 'reshape_squeeze': _ViewOp, 'dropout': _ViewOp, 'bi_lstm': _BiLstmOp,
-                 'add': _AddOp, 'relu': _ReluOp}
+        table = {'conv': _ConvOp, 'max_pool': _PoolOp, 'reshape_squeeze': _ViewOp, 'dropout': _DropoutOp, 'bi_lstm': _BiLstmOp,
+                 'add': _AddOp, 'relu': _ReluOp, 'batch_norm': _BatchNormOp, 'avg_pool': _AvgPoolOp, 'concat': _ConcatOp,
+                 'softmax': _SoftmaxOp}
         data_op = _InputOp(self)
         data_op.dy_needed = lambda: False
         built = {}
@@ -718,14 +941,23 @@ class Engine(object):
         for nd in execution_order(net.get_output('logits')):
             if nd.op not in table:
                 raise NotImplementedError('layer %r (%s) has no gfx950 lowering yet' % (nd.op, nd.name))
-            ins = [data_op if i.op == 'input' else built[id(i)] for i in (nd.inputs if nd.op == 'add' else nd.inputs[:1])]
+            ins = [data_op if i.op == 'input' else built[id(i)] for i in (nd.inputs if nd.op in ('add', 'concat') else nd.inputs[:1])]
             op = table[nd.op](self, nd, ins[0])
             op.inputs = ins
             op.key = '%02d:%s' % (len(self.ops), nd.name)
             for i in ins:
                 i.grad_owner().consumers += 1
-            built[id(nd)] = op
             self.ops.append(op)
+            if nd.op == 'conv' and (nd.attrs['s_h'], nd.attrs['s_w']) != (1, 1):       # strided: stride-1 convolution + strided pick
+                if nd.attrs['bn']:
+                    raise NotImplementedError('%s: a strided convolution with batch norm is not lowered' % nd.name)
+                sub = _SubsampleOp(self, nd, op)
+                sub.name = nd.name + '/stride'
+                sub.inputs, sub.key = [op], '%02d:%s/stride' % (len(self.ops), nd.name)
+                op.consumers += 1
+                self.ops.append(sub)
+                op = sub
+            built[id(nd)] = op
         if self.fuse_conv1_pool:
             for a, b in zip(self.ops[:-1], self.ops[1:]):
                 if (isinstance(a, _ConvOp) and a.kind == 'c1' and a.relu and isinstance(b, _PoolOp) and b.prev is a
@@ -808,7 +1040,12 @@ class Engine(object):
                 d.copy_(t, non_blocking=True)
 
     # ------------------------------------------------------------------ forward / backward bodies (capturable)
-    def _forward(self, sp):
+    def step_counter(self):
+        """Device double counting the completed optimiser steps (scalars[6]) — the per-step salt of the dropout masks."""
+        return self.scalars[6:7] if self.opt_ready else self._zero_step
+
+    def _forward(self, sp, training=False):
+        self.training = training
         for op in self.ops:
             op.fwd(sp)
 
@@ -853,7 +1090,7 @@ class Engine(object):
         parallel runs: the exchange of the late gradients is issued between the two)."""
         def body1():
             self.grads.zero_()
-            self._forward(sp)
+            self._forward(sp, training=True)
             self._loss_and_backward(sp)
 
         def body2():
@@ -877,7 +1114,7 @@ class Engine(object):
 
         def fb():
             self.grads.zero_()
-            self._forward(sp)
+            self._forward(sp, training=True)
             self._loss_and_backward(sp)
             self._backward_early(sp)
 
@@ -897,7 +1134,7 @@ class Engine(object):
         def body():
             if which == 'fb':
                 self.grads.zero_()
-            self._forward(sp)
+            self._forward(sp, training=(which == 'fb'))
             if which == 'fb':
                 self._loss_and_backward(sp)
                 self._backward_early(sp)

@@ -16,7 +16,7 @@ import numpy as np
 
 def execution_order(output_node):
     """Plan nodes reachable from `output_node` in the order the engine executes them: depth-first post-order over DATA edges
-    (only `add` has two; the second input of bi_lstm is the time_step_len slot).  Input slots are not listed."""
+    (`add` and `concat` have several; the second input of bi_lstm is the time_step_len slot).  Input slots are not listed."""
     import sys
     sys.setrecursionlimit(max(sys.getrecursionlimit(), 10000))
     seen, order = set(), []
@@ -25,7 +25,7 @@ def execution_order(output_node):
         if nd.op == 'input' or id(nd) in seen:
             return
         seen.add(id(nd))
-        for i in (nd.inputs if nd.op == 'add' else nd.inputs[:1]):
+        for i in (nd.inputs if nd.op in ('add', 'concat') else nd.inputs[:1]):
             visit(i)
         order.append(nd)
 

@@ -170,8 +170,9 @@ class Network(object):
 
     @layer
     def lstm(self, input, num_hids, num_layers, name, img_shape=None, trainable=True):
-        raise NotImplementedError('unidirectional stacked `lstm` is not used by the shipped models '
-                                  '(LSTM_train.py:38 uses bi_lstm); not lowered yet')
+        raise NotImplementedError('unidirectional stacked `lstm` (network.py:130-152) is not used by the shipped models '
+                                  '(LSTM_train.py:38 uses bi_lstm) and has no gfx950 lowering: the recurrent kernels are '
+                                  'written for the two directions of bi_lstm')
 
     @layer
     def conv_single(self, input, k_h, k_w, c_o, s_h, s_w, name, c_i=None, bn=False, biased=True, relu=True,
@@ -230,7 +231,9 @@ class Network(object):
 
     @layer
     def concat(self, input, axis, name):
-        return Node('concat', name, list(input), axis=axis)
+        ch = [i.channels for i in input]
+        return Node('concat', name, list(input), axis=axis, channels=(sum(ch) if axis in (3, -1) and all(c is not None for c in ch) else
+                                                                     input[0].channels))
 
     @layer
     def add(self, input, name):
@@ -238,10 +241,15 @@ class Network(object):
 
     @layer
     def batch_normalization(self, input, name, relu=True, is_training=False):
+        """tf.contrib.layers.batch_norm(scale, center, is_training, scope=name) [+ ReLU] — network.py:466-473.  is_training=False
+        (the reference's default) normalises with the stored moving statistics, which the reference never updates (no
+        UPDATE_OPS dependency: SURVEY Q2), i.e. moving_mean = 0, moving_variance = 1 unless a checkpoint says otherwise."""
         c = input.channels
         self.make_var('%s/beta' % name, [c], 'zeros')
         self.make_var('%s/gamma' % name, [c], 'ones')
-        return Node('batch_norm', name, [input], relu=relu, channels=c)
+        self.make_var('%s/moving_mean' % name, [c], 'zeros', trainable=False)
+        self.make_var('%s/moving_variance' % name, [c], 'ones', trainable=False)
+        return Node('batch_norm', name, [input], relu=relu, is_training=bool(is_training), channels=c)
 
     @layer
     def dropout(self, input, keep_prob, name):

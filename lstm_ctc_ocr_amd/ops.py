@@ -241,6 +241,41 @@ def bn_train_bwd(x2d, y2d, dy2d, gamma, save_mean, save_rstd, dgamma, dbeta, rel
     return out
 
 
+def bn_infer_fwd(x2d, gamma, beta, mean, var, eps, relu, out):
+    M, C = x2d.shape
+    call("ocr_bn_infer_fwd", ptr(_dev(x2d)), ptr(out), ptr(gamma), ptr(beta), ptr(mean), ptr(var), M, C, float(eps), int(relu), _st())
+    return out
+
+
+def bn_infer_bwd(x2d, y2d, dy2d, gamma, mean, var, dgamma, dbeta, eps, relu, out):
+    M, C = x2d.shape
+    call("ocr_bn_infer_bwd", ptr(_dev(x2d)), ptr(y2d), ptr(dy2d), ptr(out), ptr(gamma), ptr(mean), ptr(var), ptr(dgamma), ptr(dbeta),
+         M, C, float(eps), int(relu), _st())
+    return out
+
+
+def dropout(src, dst, seed, step_counter, keep_prob):
+    """dst = keep ? src / keep_prob : 0 with keep = hash(seed, *step_counter, index) < keep_prob (forward and backward alike)."""
+    call("ocr_dropout_bf16", ptr(_dev(src)), ptr(dst), src.numel(), int(seed) & 0xffffffff, ptr(step_counter), float(keep_prob), _st())
+    return dst
+
+
+def avgpool(src, dst, Nb, W, H, C, kw, kh, backward=False):
+    call("ocr_avgpool_bf16", ptr(_dev(src)), ptr(dst), Nb, W, H, C, kw, kh, int(backward), _st())
+    return dst
+
+
+def subsample(src, dst, Nb, W, H, C, Wo, Ho, sw, sh, ow, oh, backward=False):
+    call("ocr_subsample_bf16", ptr(_dev(src)), ptr(dst), Nb, W, H, C, Wo, Ho, sw, sh, ow, oh, int(backward), _st())
+    return dst
+
+
+def softmax(src_f32, dst_f32):
+    C = src_f32.shape[-1]
+    call("ocr_softmax_f32", ptr(_dev(src_f32)), ptr(dst_f32), src_f32.numel() // C, C, _st())
+    return dst_f32
+
+
 def colsum(a2d, out, M=None, C=None, lda=None):
     M = a2d.shape[0] if M is None else M
     C = a2d.shape[1] if C is None else C

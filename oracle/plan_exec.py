@@ -1,13 +1,56 @@
 """ORACLE (test infrastructure): executes ANY network plan built with the layer DSL (lstm_ctc_ocr_amd.network) on the CPU
 with the same op restatements as oracle/graph.py — used for configurations that are not in the reference (residual
 extractors, stacked BiLSTMs), where there is no fixed graph to transcribe.  Differentiable through torch autograd."""
+import zlib
+
+import numpy as np
 import torch
+import torch.nn.functional as F
 
 from . import graph as og
 
 
-def forward(net, params, x, seq_len, sim_bf16=False, keep=False):
-    """net: a lstm_ctc_ocr_amd Network (plan only, never the engine); params: {TF-style name: tensor}."""
+def _same_pad(n, k, s):
+    """TF SAME padding along one axis: (before, after)."""
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return total // 2, total - total // 2
+
+
+def conv_general(x, w, b, padding, s_t, s_f, sim, first=False):
+    """tf.nn.conv2d(NHWC, HWIO, strides [1, s_t, s_f, 1]) on the reference layout [N, W(time), H(feature), C]."""
+    xin = x.permute(0, 3, 1, 2)
+    wt = w.permute(3, 2, 0, 1)
+    if not first:
+        wt = og.q(wt, sim)
+    if padding == 'SAME':
+        pt, pf = _same_pad(x.shape[1], w.shape[0], s_t), _same_pad(x.shape[2], w.shape[1], s_f)
+        xin = F.pad(xin, (pf[0], pf[1], pt[0], pt[1]))
+    y = F.conv2d(xin, wt, None, stride=(s_t, s_f)).permute(0, 2, 3, 1)
+    return y if b is None else y + b
+
+
+def dropout_mask(shape, name, step, keep_prob):
+    """The device's mask (csrc/dsl_ops.hip): keep(i) = mix(mix(i ^ seed) + step * 0x9e3779b9) < keep_prob * 2^32."""
+    def mix(h):
+        h = h.astype(np.uint64)
+        h ^= h >> np.uint64(16); h = (h * np.uint64(0x85ebca6b)) & np.uint64(0xffffffff)
+        h ^= h >> np.uint64(13); h = (h * np.uint64(0xc2b2ae35)) & np.uint64(0xffffffff)
+        h ^= h >> np.uint64(16)
+        return h
+    seed = np.uint64((zlib.crc32(name.encode()) ^ 0x5bd1e995) & 0xffffffff)
+    n = int(np.prod(shape))
+    idx = np.arange(n, dtype=np.uint64)
+    h = mix((mix(idx ^ seed) + np.uint64((int(step) * 0x9e3779b9) & 0xffffffff)) & np.uint64(0xffffffff))
+    if keep_prob >= 1.0:
+        return torch.ones(shape)
+    return torch.from_numpy((h < np.uint64(int(float(np.float32(keep_prob)) * 4294967296.0))).astype(np.float32).reshape(shape))
+
+
+def forward(net, params, x, seq_len, sim_bf16=False, keep=False, keep_prob=1.0, step=0):
+    """net: a lstm_ctc_ocr_amd Network (plan only, never the engine); params: {TF-style name: tensor}.
+    keep_prob / step: what the driver feeds the dropout layers (0.5 in training steps, train.py:126) and the number of
+    completed optimiser steps (the salt of the device's dropout mask)."""
     sim = sim_bf16
     cache, inter = {}, {}
 
@@ -19,7 +62,8 @@ def forward(net, params, x, seq_len, sim_bf16=False, keep=False):
         elif nd.op == 'conv':
             a = nd.attrs
             h = ev(nd.inputs[0])
-            z = og.conv_single(h, params[nd.name + '/weights'], params[nd.name + '/biases'], a['padding'], sim, first=(a['c_i'] == 1))
+            z = conv_general(h, params[nd.name + '/weights'], params.get(nd.name + '/biases') if a['biased'] else None, a['padding'],
+                             a['s_h'], a['s_w'], sim, first=(a['c_i'] == 1))
             if a['bn']:
                 z = og.qa(z, sim)
                 z = og.batch_norm_train(z, params['%s/%s/gamma' % (nd.name, nd.name)], params['%s/%s/beta' % (nd.name, nd.name)])
@@ -36,7 +80,25 @@ def forward(net, params, x, seq_len, sim_bf16=False, keep=False):
             h = ev(nd.inputs[0])
             out = h.reshape(h.shape[0], h.shape[1] * h.shape[2], h.shape[3])
         elif nd.op == 'dropout':
-            out = ev(nd.inputs[0])
+            h = ev(nd.inputs[0])
+            kp = float(np.float32(keep_prob))
+            out = og.qa(h * dropout_mask(tuple(h.shape), nd.name, step, keep_prob) * float(np.float32(1.0) / np.float32(kp)), sim)
+        elif nd.op == 'batch_norm':
+            h = ev(nd.inputs[0])
+            if nd.attrs['is_training']:
+                z = og.batch_norm_train(h, params[nd.name + '/gamma'], params[nd.name + '/beta'])
+            else:
+                z = (h - params[nd.name + '/moving_mean']) * torch.rsqrt(params[nd.name + '/moving_variance'] + og.BN_EPS) * \
+                    params[nd.name + '/gamma'] + params[nd.name + '/beta']
+            out = og.qa(torch.relu(z) if nd.attrs['relu'] else z, sim)
+        elif nd.op == 'avg_pool':
+            h = ev(nd.inputs[0])
+            out = og.qa(F.avg_pool2d(h.permute(0, 3, 1, 2), kernel_size=(nd.attrs['k_h'], nd.attrs['k_w']),
+                                     stride=(nd.attrs['s_h'], nd.attrs['s_w'])).permute(0, 2, 3, 1), sim)
+        elif nd.op == 'concat':
+            out = torch.cat([ev(i) for i in nd.inputs], dim=3)
+        elif nd.op == 'softmax':
+            out = torch.softmax(ev(nd.inputs[0]), dim=-1)
         elif nd.op == 'bi_lstm':
             feat = ev(nd.inputs[0])
             fw = og.lstm_direction(feat, seq_len, params[nd.name + '/fw/weights'], params[nd.name + '/fw/biases'], False, sim)
