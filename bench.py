@@ -59,20 +59,28 @@ def synth_batches(n_batches, seed, device):
 
 
 def conv_roofline(eng, device):
-    """Every launch of the dominant kernel (conv_halo_kernel: 5 forward + 5 data-gradient 3x3 convolutions per step) timed
-    with HIP events on the launch stream; achieved = sum(algorithmic flop) / sum(time)."""
+    """Every launch of the dominant kernel (conv_halo_kernel: the 3x3 SAME convolutions of the workload that was timed — forward
+    and data gradient) timed with HIP events on the launch stream; achieved = sum(algorithmic flop) / sum(time).
+    The layer shapes are read from the plan the timed steps ran (the widest one for variable-width batches)."""
     from lstm_ctc_ocr_amd import ops
-    RB = 64                      # always the headline configuration's layer shapes (batch 64, W = 256)
-    shapes = [(128, 16, 64, 128), (64, 8, 128, 256), (64, 8, 256, 256), (64, 4, 256, 512), (64, 4, 512, 512)]
+    sp = max(eng.plans.values(), key=lambda p: p.W)
+    shapes, first = [], True
+    for op in eng.ops:
+        if getattr(op, 'kind', None) == '3x3':
+            (N, W, H, Ci), _ = sp.shape[op.key]
+            shapes.append((N, W, H, Ci, op.co, hasattr(op, 'wdgrad')))
     tot_fl, tot_t, n_launch = 0.0, 0.0, 0
-    for (W, H, Ci, Co) in shapes:
-        x = torch.randn(RB, W, H, Ci, device=device).to(torch.bfloat16)
-        y = torch.randn(RB, W, H, Co, device=device).to(torch.bfloat16)
+    for (N, W, H, Ci, Co, has_dgrad) in shapes:
+        x = torch.randn(N, W, H, Ci, device=device).to(torch.bfloat16)
+        y = torch.randn(N, W, H, Co, device=device).to(torch.bfloat16)
         wf = (torch.randn(Co, 3, 3, Ci, device=device) * 0.05).to(torch.bfloat16)
         wd = (torch.randn(Ci, 3, 3, Co, device=device) * 0.05).to(torch.bfloat16)
         b = torch.zeros(Co, device=device)
         oy, ox = torch.empty_like(y), torch.empty_like(x)
-        for fn in (lambda: ops.conv3x3(x, wf, out=oy, bias=b, relu=True), lambda: ops.conv3x3(y, wd, out=ox, mask=x)):
+        fns = [lambda: ops.conv3x3(x, wf, out=oy, bias=b, relu=True)]
+        if has_dgrad:
+            fns.append(lambda: ops.conv3x3(y, wd, out=ox, mask=x))
+        for fn in fns:
             for _ in range(3):
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -82,45 +90,65 @@ def conv_roofline(eng, device):
             e1.record()
             torch.cuda.synchronize()
             tot_t += e0.elapsed_time(e1) * 1e-3 / 10
-            tot_fl += 2.0 * RB * W * H * 9 * Ci * Co
+            tot_fl += 2.0 * N * W * H * 9 * Ci * Co
             n_launch += 1
     ach = tot_fl / tot_t
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")
-    if os.path.exists(pmc):            # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-    return {"bound": "mfma", "kernel": "conv_halo_kernel<BN,NW> (implicit-GEMM 3x3 SAME conv, forward + data gradient: 10 launches/step)",
+    # HBM bytes per launch and matrix-pipe occupancy from the separate rocprofv3 --pmc passes of the latest round
+    # (profiles/rNN_pmc_conv.json, made by tools/pmc_conv_summary.py; FETCH_SIZE doubled: the guide's gfx950 correction)
+    traffic, mfma_busy, src = None, None, None
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv*.json")))
+    if cands:
+        src = os.path.basename(cands[-1])
+        pm = json.load(open(cands[-1]))
+        traffic, mfma_busy = pm.get("hbm_bytes_per_launch"), pm.get("mfma_busy_frac")
+    return {"bound": "mfma", "kernel": "conv_halo_kernel<BN,NW> (implicit-GEMM 3x3 SAME conv, forward + data gradient: %d launches/step)" % n_launch,
             "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK,
             "avg_launch_us": tot_t / n_launch * 1e6, "algorithmic_gflop_per_launch": tot_fl / n_launch / 1e9,
-            "traffic": traffic, "traffic_note": "HBM bytes per launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), "
-            "profiles/r01_pmc_conv_traffic.json; algorithmic bytes per launch = 34.3 MB"}
+            "traffic": traffic, "mfma_busy_frac": mfma_busy,
+            "traffic_note": "HBM bytes per launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) and SQ_VALU_MFMA_BUSY_CYCLES / "
+                            "available SIMD cycles, headline shapes, from profiles/%s" % src}
 
 
 def cpu_baseline(budget_s=12.0):
-    """The CPU oracle's training step (fp32 torch-CPU restatement of the TF1 graph) on a bounded sample."""
+    """The CPU oracle (fp32 torch-CPU restatement of the TF1 graph — TensorFlow itself cannot run here) on bounded samples:
+    `value` = training steps of the headline shape (W = 256, 10 characters; batch 8 to stay within seconds);
+    `c1_*`  = BASELINE configs[0] (4-character captcha, W = 88, batch 8): training steps, and forward + greedy decode."""
+    from oracle import decode as odec
     from oracle import graph as og
     # 16 threads: the oracle's ops are small (8 images); with one thread per core of a 256-core host the same step was
     # measured 250x SLOWER (344 s instead of ~1.4 s) from thread oversubscription — `cores` reports what was really used
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
-    n = 8
-    rng = np.random.RandomState(0)
-    x = torch.from_numpy(rng.rand(n, WIDTH, 32).astype(np.float32))
-    labels = rng.randint(1, 63, n * LABEL_LEN).astype(np.int32)
-    ll = np.full(n, LABEL_LEN, np.int32)
-    sl = [WIDTH // 4 - 1] * n
-    params = og.init_params()
-    state = {}
-    params, *_ = og.train_step(params, state, (x, labels, ll, sl), 1e-4, 1e-5)      # untimed warm-up step
-    t0 = time.time()
-    steps = 0
-    while True:
-        params, *_ = og.train_step(params, state, (x, labels, ll, sl), 1e-4, 1e-5)
-        steps += 1
-        if time.time() - t0 > budget_s or steps >= 120:
-            break
-    dt = time.time() - t0
-    return {"value": n * steps / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d training steps of %d images (W=256, L=10) with the fp32 CPU oracle" % (steps, n)}
+
+    def train_rate(W, L, budget):
+        n = 8
+        rng = np.random.RandomState(0)
+        x = torch.from_numpy(rng.rand(n, W, 32).astype(np.float32))
+        labels = rng.randint(1, 63, n * L).astype(np.int32)
+        ll = np.full(n, L, np.int32)
+        sl = [W // 4 - 1] * n
+        params, state = og.init_params(), {}
+        params, *_ = og.train_step(params, state, (x, labels, ll, sl), 1e-4, 1e-5)      # untimed warm-up step
+        t0, steps = time.time(), 0
+        while True:
+            params, *_ = og.train_step(params, state, (x, labels, ll, sl), 1e-4, 1e-5)
+            steps += 1
+            if time.time() - t0 > budget or steps >= 120:
+                break
+        return n * steps / (time.time() - t0), steps, params, x, sl
+
+    v, steps, _, _, _ = train_rate(WIDTH, LABEL_LEN, budget_s)
+    c1, c1_steps, params, x, sl = train_rate(88, 4, 5.0)
+    t0, reps = time.time(), 0
+    with torch.no_grad():
+        while time.time() - t0 < 3.0:
+            odec.greedy_decode(og.forward(params, x, sl).numpy(), np.asarray(sl))
+            reps += 1
+    fwd = 8 * reps / (time.time() - t0)
+    return {"value": v, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d training steps of %d images (W=256, L=10) with the fp32 CPU oracle" % (steps, 8),
+            "c1_train_images_per_sec": c1, "c1_forward_greedy_images_per_sec": fwd,
+            "c1_sample": "BASELINE configs[0]: %d training steps / %d forward+greedy-decode passes of 8 images (W=88, L=4)" % (c1_steps, reps)}
 
 
 def main():

@@ -25,7 +25,7 @@ import torch
 from . import dist as ocr_dist
 from . import ops
 from ._native import NativeError
-from .layout import FlatLayout, execution_order
+from .layout import FlatLayout, execution_order, init_host_parameters
 from ._native import call as nat_call
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
@@ -857,29 +857,7 @@ class Engine(object):
         return self._view(self.params_bf16, name)
 
     def _init_params(self, seed):
-        g = torch.Generator().manual_seed(int(seed))
-        host = torch.zeros(self.n_total, dtype=F32)
-        for name, s in self.specs.items():
-            n = int(np.prod(s.shape))
-            init = s.init
-            if init == 'zeros':
-                v = torch.zeros(n)
-            elif init == 'ones':
-                v = torch.ones(n)
-            elif init == 'xavier_uniform':          # tf.contrib.layers.xavier_initializer (network.py:168)
-                kh, kw, ci, co = s.shape
-                lim = math.sqrt(6.0 / (kh * kw * ci + kh * kw * co))
-                v = (torch.rand(n, generator=g) * 2 - 1) * lim
-            elif init == 'glorot_uniform':          # TF variable-scope default for the LSTMCell matrix
-                lim = math.sqrt(6.0 / (s.shape[0] + s.shape[1]))
-                v = (torch.rand(n, generator=g) * 2 - 1) * lim
-            elif isinstance(init, tuple) and init[0] == 'variance_scaling':   # factor, FAN_AVG, truncated normal (network.py:119)
-                std = math.sqrt(1.3 * init[1] / ((s.shape[0] + s.shape[1]) / 2.0))
-                v = torch.fmod(torch.randn(n, generator=g), 2.0) * std
-            else:
-                raise ValueError('unknown initializer %r for %s' % (init, name))
-            host[self.offsets[name]:self.offsets[name] + n] = v
-        self.params.copy_(host)
+        self.params.copy_(init_host_parameters(self.specs, self.offsets, self.n_total, seed))
 
     def load_arrays(self, arrays):
         """{TF variable name: numpy array} -> parameters (shapes must match the TF layouts)."""

@@ -98,3 +98,44 @@ class FlatLayout(object):
         self.n_total = off
         self.reg_range = (bounds[1], bounds[3])        # [early regularised | late regularised]
         self.late_begin = bounds[2]                    # gradients of [late_begin, n_total) are complete after backward part 1
+
+
+def init_host_parameters(specs, offsets, n_total, seed):
+    """Initial values of every variable, as ONE flat fp32 host tensor in the engine's layout.  Pure host code (torch CPU
+    generator): the engine and the CPU golden-vector scripts draw identical parameters from the same seed.
+    Initialisers of the reference: xavier-uniform conv weights, zero biases (network.py:168-169), BN gamma 1 / beta 0 /
+    moving_mean 0 / moving_variance 1, LSTMCell matrix glorot-uniform (TF variable-scope default), FC
+    variance_scaling(0.01, FAN_AVG, truncated normal) (network.py:119)."""
+    import math
+    import torch
+    g = torch.Generator().manual_seed(int(seed))
+    host = torch.zeros(n_total, dtype=torch.float32)
+    for name, s in specs.items():
+        n = int(np.prod(s.shape))
+        init = s.init
+        if init == 'zeros':
+            v = torch.zeros(n)
+        elif init == 'ones':
+            v = torch.ones(n)
+        elif init == 'xavier_uniform':          # tf.contrib.layers.xavier_initializer (network.py:168)
+            kh, kw, ci, co = s.shape
+            lim = math.sqrt(6.0 / (kh * kw * ci + kh * kw * co))
+            v = (torch.rand(n, generator=g) * 2 - 1) * lim
+        elif init == 'glorot_uniform':          # TF variable-scope default for the LSTMCell matrix
+            lim = math.sqrt(6.0 / (s.shape[0] + s.shape[1]))
+            v = (torch.rand(n, generator=g) * 2 - 1) * lim
+        elif isinstance(init, tuple) and init[0] == 'variance_scaling':   # factor, FAN_AVG, truncated normal (network.py:119)
+            std = math.sqrt(1.3 * init[1] / ((s.shape[0] + s.shape[1]) / 2.0))
+            v = torch.fmod(torch.randn(n, generator=g), 2.0) * std
+        else:
+            raise ValueError('unknown initializer %r for %s' % (init, name))
+        host[offsets[name]:offsets[name] + n] = v
+    return host
+
+
+def host_parameters(net, seed, align=64):
+    """{TF variable name: fp32 tensor} exactly as Engine(net, seed=seed) initialises them — without a GPU."""
+    order = [nd.name for nd in execution_order(net.get_output('logits'))]
+    lay = FlatLayout(net.param_specs.values(), align, order=order)
+    flat = init_host_parameters(lay.specs, lay.offsets, lay.n_total, seed)
+    return {name: flat[lay.offsets[name]:lay.offsets[name] + int(np.prod(s.shape))].view(s.shape).clone() for name, s in lay.specs.items()}

@@ -1,0 +1,64 @@
+"""Golden vectors for BASELINE.json configs[4] at FULL size: ResNet-34-style extractor [3,4,6,3] + 2 stacked BiLSTM(512) + CTC
+over a 96-class alphabet, batch 32, W = 256 — not in the reference, expressed through its DSL (lstm_ctc_ocr_amd/models.py) and
+evaluated by the plan-walking CPU oracle (oracle/plan_exec.py) on seeded parameters (lstm_ctc_ocr_amd.layout.host_parameters:
+the same draw Engine(seed) makes) and a seeded batch.     python tests/golden/make_deep_golden.py   -> tests/golden/deep_c4.npz
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, '..', '..'))
+from lstm_ctc_ocr_amd.config import cfg  # noqa: E402
+from lstm_ctc_ocr_amd.layout import host_parameters  # noqa: E402
+from oracle import decode as odec  # noqa: E402
+from oracle import graph as og  # noqa: E402
+from oracle import plan_exec  # noqa: E402
+
+SEED, N, W, L = 5, 32, 256, 6
+
+
+def inputs():
+    r = np.random.RandomState(3204)
+    x = r.rand(N, W, 32).astype(np.float32)
+    widths = r.randint(W // 2, W + 1, N); widths[0] = W
+    for n in range(N):
+        x[n, widths[n]:] = 0.0
+    sl = (widths // 4 - 1).astype(np.int32)
+    ll = r.randint(3, L + 1, N).astype(np.int32)
+    labels = r.randint(1, 95, int(ll.sum())).astype(np.int32)
+    return x, labels, ll, sl
+
+
+def build():
+    from lstm_ctc_ocr_amd import models
+    cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, cfg.TRAIN.NUM_HID = 96, 2, 512
+    return models.RESNET_train()
+
+
+def main():
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    net = build()
+    params = host_parameters(net, SEED)
+    x, labels, ll, sl = inputs()
+    out = {}
+    with torch.no_grad():
+        for tag, sim in (('fp32', False), ('bf16sim', True)):
+            t0 = time.time()
+            lg = plan_exec.forward(net, params, torch.from_numpy(x), sl.tolist(), sim_bf16=sim)
+            costs = og._CTC.apply(lg, labels, ll, sl).numpy()
+            out['logits_' + tag] = lg.numpy().astype(np.float32)
+            out['costs_' + tag] = costs.astype(np.float64)
+            print(tag, 'forward %.1f s, mean cost %.5f' % (time.time() - t0, costs.mean()))
+    out['greedy_bf16sim'] = odec.dense(odec.greedy_decode(out['logits_bf16sim'], sl))
+    out['param_checksum'] = np.float64(sum(float(v.double().abs().sum()) for v in params.values()))
+    out['x_checksum'] = np.float64(np.abs(x.astype(np.float64)).sum())
+    np.savez_compressed(os.path.join(HERE, 'deep_c4.npz'), **out)
+    print('n_params', sum(v.numel() for v in params.values()), 'wrote deep_c4.npz')
+
+
+if __name__ == '__main__':
+    main()
