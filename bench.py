@@ -210,6 +210,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = eng.last_loss()
+    # the same loop the way lib/lstm/train.py:130,139 runs it — the loss is fetched (one host sync) after EVERY step; reported
+    # beside `value`, never as `value`
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        x, labels, ll, sl = batches[i % len(batches)]
+        eng.train_step(x, labels, ll, sl, fetch_loss=True)
+    torch.cuda.synchronize()
+    dt_fetch = time.perf_counter() - t1
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -226,6 +235,7 @@ def main():
                                     "(BASELINE.json configs[4])"),
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world, "hipgraph": not args.no_graphs},
             "final_loss": loss,
+            "with_loss_fetch_every_step": {"value": BATCH * world * args.steps / dt_fetch, "ms_per_step": dt_fetch / args.steps * 1e3},
             "model_tflops_per_gpu": value / world * TRAIN_GFLOP_PER_IMG * 1e9 / 1e12,
         }
         if args.workload != "fixed":

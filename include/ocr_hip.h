@@ -129,6 +129,16 @@ int ocr_pack_jobs(const void* jobs, int njobs, int total_blocks, void* stream);
 int ocr_cast_f32_bf16(const float* in, void* out, long n, void* stream);
 /* uint8 pixels -> fp32 in [0, 1] (= u8 / 255, correctly rounded: identical to the host's `astype(float32) / 255.`, gen.py:59-65); n % 4 == 0 */
 int ocr_u8_to_unit_f32(const void* in, float* out, long n, void* stream);
+/* What train.py:130,139 fetches after sess.run, gathered on the device into out[4] (doubles): mean per-sample CTC cost, sum w^2 of
+ * the regularised parameters (scalars[1]) and the global gradient norm (scalars[7]) of the optimiser block (scalars may be NULL),
+ * and a bit mask of the non-zero error words (word_addrs: device array of nwords <= 32 device addresses of int error words). */
+int ocr_step_report(const float* costs, int n, const double* scalars, const void* word_addrs, int nwords, double* out, void* stream);
+/* One launch binding a DEVICE-resident batch to the engine's fixed input buffers (the feed_dict of train.py:126-130 once the
+ * batch is already in HBM): pixels -> x (uint8 / 255 when pixels_are_u8, else an fp32 copy; n_pixels % 4 == 0) and the
+ * int32 vectors seq_len, flat labels, labels_len (counts may be 0 for inference). */
+int ocr_bind_batch(const void* pixels, int pixels_are_u8, float* x, long n_pixels, const int* seq_len, int* seq_len_dst, int n_seq,
+                   const int* labels, int* labels_dst, int n_labels, const int* labels_len, int* labels_len_dst, int n_labels_len,
+                   void* stream);
 int ocr_cast2d_f32_bf16(const float* in, long ldin, void* out, long ldout, int rows, int cols, void* stream);
 int ocr_tnc_to_ntc_bf16(const float* in, void* out, int T, int N, int C, float scale, void* stream);
 int ocr_conv5_col2im(const void* col, void* dx, int Nb, int W, int HC, void* stream);

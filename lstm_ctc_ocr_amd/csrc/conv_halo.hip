@@ -146,9 +146,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
         const int shift = (H + 1) + (tap / 3 - 1) * H + (tap % 3 - 1);       // halo row of local pixel 0 for this tap
         const unsigned qa = qfrag0 + (s & 1) * QB;
-        const unsigned pbase = (chunk & 1) * PBYTES + prow0 + shift * 128 + ((fq ^ ((frow + shift) & 7)) << 4);
+        // the zero rows (NR and NR + 1, both spare: NR is even, NRpad a multiple of 32 above it) are read at the SAME position of
+        // their 256 bytes as the real row would be: a redirected lane then uses the 4 of 64 banks the swizzle gave it, instead of
+        // piling onto banks 0-3 (PMC r02: 0.15-0.20 conflict cycles per LDS-active
+        // cycle at H = 4 / 8, where 1/4 resp. 1/8 of the lanes are redirected for six of the nine taps)
+        const unsigned psw = (fq ^ ((frow + shift) & 7)) << 4;
+        const unsigned pbase = (chunk & 1) * PBYTES + prow0 + shift * 128 + psw;
         unsigned pa[FM];
-        const unsigned zoff = (chunk & 1) * PBYTES + NR * 128;
+        const unsigned zoff = (chunk & 1) * PBYTES + NR * 128 + (((frow + shift) & 1) << 7) + psw;    // rows NR, NR + 1: address bits 0-7 (the bank) unchanged
 #pragma unroll
         for (int b = 0; b < FM; ++b) pa[b] = ((vmask[b] >> tap) & 1u) ? pbase + b * 2048 : zoff;
         // All 16 fragment reads of the step are issued back to back as inline asm (the compiler does not count them, so it adds

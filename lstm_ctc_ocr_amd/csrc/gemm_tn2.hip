@@ -308,7 +308,8 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
             if (splits <= 0 && wg > 512) cost += (wg - 512) * 4.0e6;       // a third, ragged round of workgroups
             if (cost < best) { best = cost; bXS = XS; bXJ = XJ; bXI = XI; bS = S; }
         }
-    if (const char* e = getenv("OCR_TN2_PART")) {            // experiment knob: "XS,XJ,XI,S"
+    static const char* part_env = getenv("OCR_TN2_PART");    // experiment knob "XS,XJ,XI,S", read once per process
+    if (const char* e = part_env) {
         int xs, xj, xi, sp;
         if (sscanf(e, "%d,%d,%d,%d", &xs, &xj, &xi, &sp) == 4 && xs * xj * xi == 8 && IT % xi == 0 && JT % xj == 0 && sp % xs == 0 && sp >= 1) {
             bXS = xs; bXJ = xj; bXI = xi; bS = sp; best = 0;

@@ -376,12 +376,18 @@ static int seq_rows_per_wg_default(int Nb, int U) {
         if ((U / 16) * 2 * ceil_div(Nb, rows) <= 256) return rows;
     return 0;
 }
+// environment knobs are looked up ONCE per process (the launch path runs every step when graphs are off)
+static int seq_env_int(const char* name, int slot, int dflt) {
+    static int val[2], seen[2];
+    if (!seen[slot]) { const char* e = getenv(name); val[slot] = e ? atoi(e) : dflt; seen[slot] = 1; }
+    return val[slot];
+}
 static int seq_rows_per_wg(int Nb, int U) {
     // measured at N = 64 (us per step fwd / bwd, group counters on separate cache lines): 16 rows 2.6 / 3.2, 32 rows
     // 3.0 / 4.1, 64 rows 3.6 / 6.2 - the per-step cost is the hand-off payload a CU has to pull (about 65 GB/s per CU)
     // plus a fixed ~2 us of store-drain + counter + poll, so the smallest batch tile that still fits one WG per CU wins.
-    const char* e = getenv("OCR_LSTM_ROWS");            // experiment knob: force 16 / 32 / 64 rows per workgroup
-    int want = e ? atoi(e) : 0;
+    static int want = -1;                               // experiment knob, read once: force 16 / 32 / 64 rows per workgroup
+    if (want < 0) { const char* e = getenv("OCR_LSTM_ROWS"); want = e ? atoi(e) : 0; if (want < 0) want = 0; }
     for (int rows = 16; rows <= 64; rows *= 2) {
         if (want && rows != want) continue;
         if ((U / 16) * 2 * ceil_div(Nb, rows) <= 256) return rows;
@@ -421,7 +427,7 @@ extern "C" int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, cons
     else fill_words_kernel<<<256, 256, 0, stream>>>((unsigned*)hout, (long)Nb * T * 2 * U / 2, 0xFFFFFFFFu, (unsigned*)sync, words);
     OCR_CHECK_LAUNCH();
     LstmSeqFwdArgs a = {xproj, (const bf16_t*)whT_packed, seq_len, (bf16_t*)hout, gates, cell, (unsigned*)sync,
-                        (int*)sync + words - 1, Nb, T, U, forget_bias, g_lstm_dbg, getenv("OCR_LSTM_PRESLEEP_F") ? atoi(getenv("OCR_LSTM_PRESLEEP_F")) : 0};
+                        (int*)sync + words - 1, Nb, T, U, forget_bias, g_lstm_dbg, seq_env_int("OCR_LSTM_PRESLEEP_F", 0, 0)};
     dim3 grid(U / 16, 2, nz);
     const dim3 g1(16 * 8 * ceil_div(2 * nz, 8));
 #define LAUNCH_FWD(P, G) do { if (rows == 16) lstm_fwd_seq_kernel<8, 1, P><<<G, 64, 0, stream>>>(a); \
@@ -448,7 +454,7 @@ extern "C" int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, con
     else fill_words_kernel<<<256, 256, 0, stream>>>((unsigned*)dz, (long)Nb * T * 8 * U / 2, 0xFFFFFFFFu, (unsigned*)sync, words);
     OCR_CHECK_LAUNCH();
     LstmSeqBwdArgs a = {(const bf16_t*)wh, ldw, w_dir_stride, seq_len, (const bf16_t*)dhout, gates, cell, (bf16_t*)dz,
-                        (unsigned*)sync, (int*)sync + words - 1, Nb, T, U, g_lstm_dbg, getenv("OCR_LSTM_PRESLEEP") ? atoi(getenv("OCR_LSTM_PRESLEEP")) : 4};
+                        (unsigned*)sync, (int*)sync + words - 1, Nb, T, U, g_lstm_dbg, seq_env_int("OCR_LSTM_PRESLEEP", 1, 4)};
     dim3 grid(U / 16, 2, nz);
     const dim3 g1(16 * 8 * ceil_div(2 * nz, 8));
 #define LAUNCH_BWD(P, G) do { if (rows == 16) lstm_bwd_seq_kernel<32, 1, P><<<G, 64, 0, stream>>>(a); \

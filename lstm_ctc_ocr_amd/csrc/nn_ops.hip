@@ -953,6 +953,63 @@ extern "C" int ocr_u8_to_unit_f32(const void* in, float* out, long n, void* stre
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
+// One launch that makes a device-resident batch the graph's input: pixels (uint8 -> x / 255, or fp32 copied) plus the three
+// small int32 vectors.  Four separate D2D copies were four blit kernels (~5 us each) with a queue barrier in front of each.
+__global__ void bind_batch_kernel(const void* __restrict__ pix, int is_u8, float* __restrict__ x, long n4,
+                                  const int* __restrict__ s0, int* __restrict__ d0, int n0, const int* __restrict__ s1, int* __restrict__ d1, int n1,
+                                  const int* __restrict__ s2, int* __restrict__ d2, int n2) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        if (is_u8) {
+            const uint32_t p = ((const uint32_t*)pix)[i];
+            ((f32x4*)x)[i] = (f32x4){__fdiv_rn((float)(p & 0xff), 255.0f), __fdiv_rn((float)((p >> 8) & 0xff), 255.0f),
+                                     __fdiv_rn((float)((p >> 16) & 0xff), 255.0f), __fdiv_rn((float)(p >> 24), 255.0f)};
+        } else {
+            ((f32x4*)x)[i] = ((const f32x4*)pix)[i];
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1) {
+        for (int i = threadIdx.x; i < n0; i += blockDim.x) d0[i] = s0[i];
+        for (int i = threadIdx.x; i < n1; i += blockDim.x) d1[i] = s1[i];
+        for (int i = threadIdx.x; i < n2; i += blockDim.x) d2[i] = s2[i];
+    }
+}
+extern "C" int ocr_bind_batch(const void* pixels, int pixels_are_u8, float* x, long n_pixels, const int* seq_len, int* seq_len_dst, int n_seq,
+                              const int* labels, int* labels_dst, int n_labels, const int* labels_len, int* labels_len_dst, int n_labels_len,
+                              void* stream) {
+    if (!pixels || !x || n_pixels <= 0 || (n_pixels & 3) || n_seq < 0 || n_labels < 0 || n_labels_len < 0) return OCR_ERR_INVALID;
+    if ((n_seq && (!seq_len || !seq_len_dst)) || (n_labels && (!labels || !labels_dst)) || (n_labels_len && (!labels_len || !labels_len_dst)))
+        return OCR_ERR_INVALID;
+    if (((size_t)pixels & (pixels_are_u8 ? 3 : 15)) || ((size_t)x & 15)) return OCR_ERR_INVALID;
+    bind_batch_kernel<<<grid_for(n_pixels / 4), 256, 0, (hipStream_t)stream>>>(pixels, pixels_are_u8, x, n_pixels / 4, seq_len, seq_len_dst, n_seq,
+                                                                              labels, labels_dst, n_labels, labels_len, labels_len_dst, n_labels_len);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+// Everything the training loop reads back after a step, gathered into 4 doubles so that ONE 32-byte D2H copy follows:
+// out[0] = mean per-sample CTC cost (summed in double, fixed order), out[1] = scalars[1] (sum w^2 of the regularised range),
+// out[2] = scalars[7] (global gradient norm), out[3] = bit i set <=> error word i (last int of words[i]) is non-zero.
+__global__ void step_report_kernel(const float* __restrict__ costs, int n, const double* __restrict__ scalars,
+                                   const long long* __restrict__ words, int nwords, double* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) s += (double)costs[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) {
+        unsigned bits = 0;
+        for (int i = 0; i < nwords; ++i) if (*(const int*)words[i] != 0) bits |= 1u << i;
+        out[0] = s / (double)n;
+        out[1] = scalars ? scalars[1] : 0.0;
+        out[2] = scalars ? scalars[7] : 0.0;
+        out[3] = (double)bits;
+    }
+}
+extern "C" int ocr_step_report(const float* costs, int n, const double* scalars, const void* word_addrs, int nwords, double* out, void* stream) {
+    if (!costs || n <= 0 || !out || nwords < 0 || nwords > 32 || (nwords && !word_addrs)) return OCR_ERR_INVALID;
+    step_report_kernel<<<1, 64, 0, (hipStream_t)stream>>>(costs, n, scalars, (const long long*)word_addrs, nwords, out);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
 extern "C" int ocr_cast2d_f32_bf16(const float* in, long ldin, void* out, long ldout, int rows, int cols, void* stream) {
     if (!in || !out || rows <= 0 || cols <= 0 || (cols & 3) || (ldin & 3) || (ldout & 3)) return OCR_ERR_INVALID;
     cast2d_f32_bf16_kernel<<<grid_for((long)rows * (cols >> 2)), 256, 0, (hipStream_t)stream>>>(in, ldin, (bf16_t*)out, ldout, rows, cols);

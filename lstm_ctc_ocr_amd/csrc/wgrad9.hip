@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(W9Args g) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int dh = t % 3 - 1;
-            if ((dh < 0 && red_m) || (dh > 0 && red_p)) offA[t] = zabs;
+            if ((dh < 0 && red_m) || (dh > 0 && red_p)) offA[t] = lds0 + ZOFF + (offA[t] & 255);     // same banks as the real row (immediates are multiples of 256)
         }
         *(u32x4*)(smem + ZOFF + tid * 16) = (u32x4){0, 0, 0, 0};                  // 512 threads x 16 B (visible after the first barrier)
     }

@@ -994,28 +994,34 @@ class Engine(object):
 
     # ------------------------------------------------------------------ input binding
     def _bind(self, sp, data, seq_len, labels=None, labels_len=None):
-        sl = torch.as_tensor(np.asarray(seq_len, np.int32)) if not torch.is_tensor(seq_len) else seq_len
+        def as_i32(v):
+            return v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v, np.int32))
+        sl = as_i32(seq_len)
+        lab = ll = None
+        if labels is not None:
+            lab, ll = as_i32(labels), as_i32(labels_len)
+            if lab.numel() > sp.labels.numel():
+                raise ValueError('flat label vector longer than batch * max_label_len (%d)' % sp.labels.numel())
+        ints = [t for t in (sl, lab, ll) if t is not None]
+        if (torch.is_tensor(data) and data.is_cuda and data.dtype in (torch.uint8, F32) and data.is_contiguous()
+                and data.numel() == sp.x.numel() and all(t.is_cuda and t.dtype == I32 and t.is_contiguous() for t in ints)
+                and sl.numel() == sp.seq_len.numel() and (ll is None or ll.numel() == sp.labels_len.numel())):
+            # device-resident batch (prefetching pipeline, bench): ONE kernel binds pixels (uint8 -> / 255, a quarter of the H2D
+            # bytes) and the three int vectors.  Per-tensor copies were four blit kernels (hipMemcpyAsync D2D, ~5 us each, each
+            # preceded by a queue barrier that left the GPU idle at the start of every step).
+            ops.bind_batch(data, sp.x, sl, sp.seq_len, lab, sp.labels, ll, sp.labels_len)
+            return
         if torch.is_tensor(data) and data.dtype == torch.uint8:
-            # raw pixels (the prefetching input pipeline hands over uint8, a quarter of the H2D bytes): / 255 on the device
             ops.u8_to_unit_f32(data if data.is_cuda else data.to(self.device, non_blocking=True), sp.x)
             dsts, srcs = [sp.seq_len], [sl]
         else:
             x = torch.as_tensor(np.asarray(data, np.float32)) if not torch.is_tensor(data) else data
             dsts, srcs = [sp.x, sp.seq_len], [x, sl]
-        if labels is not None:
-            lab = torch.as_tensor(np.asarray(labels, np.int32)) if not torch.is_tensor(labels) else labels
-            ll = torch.as_tensor(np.asarray(labels_len, np.int32)) if not torch.is_tensor(labels_len) else labels_len
-            if lab.numel() > sp.labels.numel():
-                raise ValueError('flat label vector longer than batch * max_label_len (%d)' % sp.labels.numel())
+        if lab is not None:
             dsts += [sp.labels[:lab.numel()], sp.labels_len]
             srcs += [lab, ll]
-        if all(t.is_cuda and t.dtype == d.dtype and t.shape == d.shape for t, d in zip(srcs, dsts)):
-            # device-resident batch: multi-tensor copy kernels instead of one blit (hipMemcpyAsync) per tensor — a blit is
-            # preceded by a queue barrier that left the GPU idle for ~9 us at the start of every step
-            torch._foreach_copy_(dsts, srcs)
-        else:
-            for d, t in zip(dsts, srcs):
-                d.copy_(t, non_blocking=True)
+        for d, t in zip(dsts, srcs):
+            d.copy_(t, non_blocking=True)
 
     # ------------------------------------------------------------------ forward / backward bodies (capturable)
     def step_counter(self):
@@ -1238,28 +1244,25 @@ class Engine(object):
         return None
 
     def last_loss(self):
-        """Loss of the last step: mean CTC cost of the local batch + L2 term.  ONE host synchronisation: per-sample costs, the
-        optimiser's scalar block and the persistent-LSTM time-out words are copied into one pinned host buffer with asynchronous
-        D2H copies and a single stream wait (four blocking .cpu() / .item() round trips cost ~0.1 ms per iteration of the
-        training loop, which fetches the loss every step like the reference: train.py:130,139)."""
+        """Loss of the last step: mean CTC cost of the local batch + L2 term.  ONE tiny kernel gathers the mean cost, the
+        optimiser's scalars and the persistent-LSTM time-out words into 4 doubles, ONE 32-byte D2H copy into pinned memory and ONE
+        stream wait follow (four blocking .cpu() / .item() round trips cost ~0.1 ms per iteration of the training loop, which
+        fetches the loss every step like the reference: train.py:130,139; four async copies were four blit kernels)."""
         sp = self.last_plan
         words = getattr(sp, 'lstm_sync', ())
-        host = getattr(sp, '_report', None)
-        if host is None:
-            host = sp._report = (torch.empty(sp.N, dtype=F32).pin_memory(), torch.empty(8, dtype=torch.float64).pin_memory(),
-                                 torch.zeros(max(1, len(words)), dtype=I32).pin_memory())
-        host[0].copy_(sp.costs, non_blocking=True)
-        if self.opt_ready:
-            host[1].copy_(self.scalars[:8], non_blocking=True)
-        for i, word in enumerate(words):
-            host[2][i:i + 1].copy_(word[-1:], non_blocking=True)
+        rep = getattr(sp, '_report', None)
+        if rep is None:
+            addrs = torch.tensor([w[-1:].data_ptr() for w in words], dtype=torch.int64, device=self.device) if words else None
+            rep = sp._report = (torch.zeros(4, dtype=torch.float64, device=self.device), torch.zeros(4, dtype=torch.float64).pin_memory(), addrs)
+        dev, host, addrs = rep
+        ops.step_report(sp.costs, self.scalars if self.opt_ready else None, addrs, dev)
+        host.copy_(dev, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
-        sc = host[1].numpy()
-        ctc = float(host[0].numpy().mean())
-        reg = 0.5 * float(self.cfg.TRAIN.WEIGHT_DECAY) * float(sc[1]) if (self.cfg.TRAIN.WEIGHT_DECAY > 0 and self.opt_ready) else 0.0
-        self.last_ctc, self.last_reg, self.last_gnorm = ctc, reg, float(sc[7]) if self.opt_ready else 0.0
-        for i, word in enumerate(words):
-            if int(host[2][i]) != 0:
-                raise NativeError('persistent LSTM %s kernel: inter-workgroup wait timed out (results invalid); counters %s'
-                                  % (('forward', 'backward')[i % 2], word[::64].tolist()))
+        ctc, reg2, gnorm, bits = (float(v) for v in host.numpy())
+        reg = 0.5 * float(self.cfg.TRAIN.WEIGHT_DECAY) * reg2 if (self.cfg.TRAIN.WEIGHT_DECAY > 0 and self.opt_ready) else 0.0
+        self.last_ctc, self.last_reg, self.last_gnorm = ctc, reg, gnorm if self.opt_ready else 0.0
+        if bits != 0.0:
+            bad = [i for i in range(len(words)) if (int(bits) >> i) & 1]
+            raise NativeError('persistent LSTM %s kernel: inter-workgroup wait timed out (results invalid); counters %s'
+                              % (('forward', 'backward')[bad[0] % 2], words[bad[0]][::64].tolist()))
         return ctc + reg

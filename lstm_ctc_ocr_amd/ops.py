@@ -313,6 +313,26 @@ def u8_to_unit_f32(src_u8, dst_f32):
     return dst_f32
 
 
+def bind_batch(pixels, x, seq_len, seq_len_dst, labels=None, labels_dst=None, labels_len=None, labels_len_dst=None):
+    """One launch: device pixels (uint8 -> / 255, or fp32) -> x, plus the int32 vectors into their fixed buffers."""
+    is_u8 = pixels.dtype == torch.uint8
+    assert pixels.is_contiguous() and pixels.numel() == x.numel() and (is_u8 or pixels.dtype == torch.float32)
+    for t in (seq_len, labels, labels_len):
+        assert t is None or (t.dtype == torch.int32 and t.is_contiguous())
+    nl = 0 if labels is None else labels.numel()
+    call("ocr_bind_batch", ptr(_dev(pixels)), int(is_u8), ptr(x), pixels.numel(), ptr(_dev(seq_len)), ptr(seq_len_dst), seq_len.numel(),
+         ptr(_dev(labels)) if nl else None, ptr(labels_dst) if nl else None, nl,
+         ptr(_dev(labels_len)) if labels_len is not None else None, ptr(labels_len_dst) if labels_len is not None else None,
+         0 if labels_len is None else labels_len.numel(), _st())
+
+
+def step_report(costs, scalars, word_addrs, out):
+    """out[0..3] (double) = mean cost, scalars[1], scalars[7], bit mask of non-zero error words (see ocr_step_report)."""
+    nw = 0 if word_addrs is None else word_addrs.numel()
+    call("ocr_step_report", ptr(_dev(costs)), costs.numel(), ptr(scalars), ptr(word_addrs) if nw else None, nw, ptr(out), _st())
+    return out
+
+
 def cast2d_bf16(src, ldin, dst, ldout, rows, cols):
     call("ocr_cast2d_f32_bf16", ptr(_dev(src)), ldin, ptr(dst), ldout, rows, cols, _st())
     return dst

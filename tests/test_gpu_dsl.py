@@ -163,3 +163,41 @@ def test_dsl_kernels(dev):
     ops.bn_infer_bwd(x.to(dev), y, dyv.to(dev), gamma.to(dev), mean.to(dev), var.to(dev), dg, db, 1e-3, True, dx)
     # the device masks with ITS (bf16) output; elements whose pre-activation rounds across zero differ — compare in L2
     assert l2(dx.float().cpu(), xr.grad) < 2e-2 and l2(dg.cpu(), gr.grad) < 2e-2 and l2(db.cpu(), br.grad) < 2e-2
+
+
+def test_bind_batch_and_step_report(dev):
+    """The two host-boundary kernels of a training iteration: ocr_bind_batch (device batch -> the engine's fixed input buffers,
+    uint8 / 255 exactly as groupBatch's astype(float32) / 255., gen.py:59-65) and ocr_step_report (what train.py:130,139 fetches)."""
+    g = torch.Generator().manual_seed(5)
+    N, W, Hh, L = 8, 96, 32, 40
+    pix = torch.randint(0, 256, (N, W, Hh), dtype=torch.uint8, generator=g)
+    sl = torch.randint(1, 24, (N,), dtype=torch.int32, generator=g)
+    lab = torch.randint(1, 60, (L,), dtype=torch.int32, generator=g)
+    ll = torch.randint(1, 8, (N,), dtype=torch.int32, generator=g)
+    for src in (pix, pix.float() / 3.0):
+        x = torch.full((N, W, Hh), -1.0, device=dev)
+        d_sl = torch.full((N,), -1, dtype=torch.int32, device=dev)
+        d_lab = torch.full((N * 10,), -1, dtype=torch.int32, device=dev)
+        d_ll = torch.full((N,), -1, dtype=torch.int32, device=dev)
+        ops.bind_batch(src.to(dev), x, sl.to(dev), d_sl, lab.to(dev), d_lab, ll.to(dev), d_ll)
+        want = (src.numpy().astype(np.float32) / 255.) if src.dtype == torch.uint8 else src.numpy()
+        assert np.array_equal(x.cpu().numpy(), want)                      # bit-exact (IEEE division on the device)
+        assert torch.equal(d_sl.cpu(), sl) and torch.equal(d_ll.cpu(), ll)
+        assert torch.equal(d_lab.cpu()[:L], lab) and bool((d_lab.cpu()[L:] == -1).all())
+    # inference form: no labels
+    x = torch.empty((N, W, Hh), device=dev); d_sl = torch.zeros((N,), dtype=torch.int32, device=dev)
+    ops.bind_batch(pix.to(dev), x, sl.to(dev), d_sl)
+    assert torch.equal(d_sl.cpu(), sl)
+
+    costs = torch.rand(64, generator=g) * 30
+    sc = torch.arange(16, dtype=torch.float64) * 1.5
+    words = [torch.zeros(65, dtype=torch.int32, device=dev) for _ in range(3)]
+    words[1][-1] = 7
+    addrs = torch.tensor([w[-1:].data_ptr() for w in words], dtype=torch.int64, device=dev)
+    out = torch.zeros(4, dtype=torch.float64, device=dev)
+    ops.step_report(costs.to(dev), sc.to(dev), addrs, out)
+    o = out.cpu().numpy()
+    assert abs(o[0] - float(costs.double().mean())) < 1e-12 and o[1] == 1.5 and o[2] == 10.5 and o[3] == 2.0
+    ops.step_report(costs.to(dev), None, None, out)
+    o = out.cpu().numpy()
+    assert o[1] == 0.0 and o[2] == 0.0 and o[3] == 0.0
