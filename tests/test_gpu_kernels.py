@@ -115,6 +115,42 @@ def test_ctc_known_answer(dev):
     assert np.abs(g - exp).max() < 1e-5
 
 
+def test_warpctc_abi_compute_ctc_loss(dev):
+    """warp-ctc's own entry points (include/warpctc_abi.h: host labels / lengths / costs, ctcOptions by value) — the call
+    warpctc_tensorflow.ctc makes (network.py:653-654): published known-answer vector, a ragged batch against the fp64 oracle
+    and against ocr_ctc_loss, a non-zero blank, the autograd twin, and the loud refusal of CTC_CPU."""
+    from lstm_ctc_ocr_amd import warpctc
+    from lstm_ctc_ocr_amd._native import NativeError
+    acts = torch.tensor([[[0.1, 0.6, 0.1, 0.1, 0.1]], [[0.1, 0.1, 0.6, 0.1, 0.1]]], device=dev)
+    costs, grads = warpctc.compute(acts, [1, 2], [2], [2])
+    assert abs(float(costs[0]) - 2.46286) < 1e-5
+    exp = np.full((2, 5), 0.177031); exp[0, 1] = exp[1, 2] = -0.708125
+    assert np.abs(grads.cpu().numpy().reshape(2, 5) - exp).max() < 1e-5
+    costs0, none = warpctc.compute(acts, [1, 2], [2], [2], want_grad=False)           # gradients == NULL: score only
+    assert none is None and abs(float(costs0[0]) - 2.46286) < 1e-5
+
+    rng = np.random.RandomState(11)
+    T, N, C = 40, 6, 20
+    for blank in (0, C - 1):
+        a = torch.from_numpy(rng.randn(T, N, C).astype(np.float32) * 2).to(dev)
+        ll = np.array([5, 1, 9, 0, 12, 30], np.int32)                    # the last one is infeasible at its input length
+        il = np.array([40, 7, 33, 12, 25, 20], np.int32)
+        lo = 1 if blank == 0 else 0
+        fl = np.concatenate([rng.randint(lo, lo + C - 1, n) for n in ll]).astype(np.int32)
+        ref_c, ref_g = octc.ctc_loss_c(a.cpu().numpy(), fl, ll, il, blank)
+        costs, grads = warpctc.compute(a, fl, ll, il, blank_label=blank)
+        assert np.allclose(costs.numpy(), ref_c, rtol=1e-4, atol=1e-4)
+        assert np.abs(grads.cpu().numpy() - ref_g).max() < 5e-4
+        assert float(costs[5]) == 0.0 and float(grads[:, 5].abs().max()) == 0.0
+        # differentiable twin: d(sum_n w_n cost_n)/d activations = w_n * gradient_n
+        a2 = a.clone().requires_grad_(True)
+        w = torch.arange(1, N + 1, dtype=torch.float32, device=dev)
+        (warpctc.ctc(a2, fl, ll, il, blank_label=blank) * w).sum().backward()
+        assert np.abs(a2.grad.cpu().numpy() - ref_g * np.arange(1, N + 1)[None, :, None]).max() < 3e-3
+    with pytest.raises(NativeError):
+        warpctc.compute(acts, [1, 2], [2], [2], loc=warpctc.CTC_CPU)
+
+
 def test_ctc_c2_shape(dev):
     rng = np.random.RandomState(0)
     _ctc_case(dev, 63, 64, 64, [10] * 64, [63] * 64, 1)
