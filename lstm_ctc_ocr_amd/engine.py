@@ -17,6 +17,7 @@ optimiser math.  oracle/graph.py(sim_bf16=True) rounds at the same points.
 """
 import math
 
+import contextlib
 import os
 
 import numpy as np
@@ -225,12 +226,14 @@ class _ConvOp(_Op):
         pdy, finish = e.grad_dst(sp, self.prev)
         pmask = self.prev.y(sp) if self.prev.mask_in_consumer else None
         if self.kind == '3x3':
-            ops.conv3x3_wgrad(x, dz, dw, dbias=db, workspace=sp.buf.get('wgrad_ws'))   # bias gradient rides on the same pass
+            with e.wgrad_side():
+                ops.conv3x3_wgrad(x, dz, dw, dbias=db, workspace=sp.buf.get('wgrad_ws'))   # bias gradient rides on the same pass
             if pdy is not None:
                 ops.conv3x3(dz, self.wdgrad.view(self.ci, 3, 3, self.co), out=pdy, mask=pmask)
                 finish()
         elif self.kind == '1x1':
-            ops.gemm_tn(x.view(M, self.ci), dz.view(M, self.co), dw.view(self.ci, self.co), colsum=db)
+            with e.wgrad_side():
+                ops.gemm_tn(x.view(M, self.ci), dz.view(M, self.co), dw.view(self.ci, self.co), colsum=db)
             if pdy is not None:
                 wsh = e.shadow(self.name + '/weights').view(self.ci, self.co)      # Q[n = ci][k = co]
                 ops.gemm_nt(dz.view(M, self.co), wsh, out=pdy.view(M, self.ci),
@@ -240,8 +243,9 @@ class _ConvOp(_Op):
             N, W, H, C = s
             Wo = o[1]
             K = self.kh * H * C
-            ops.gemm_tn(x, dz.view(M, self.co), dw.view(K, self.co), Mk=M, I=K, J=self.co, lda=H * C, ldb=self.co,
-                        ldo=self.co, row_group=Wo, row_skip=self.kh - 1, colsum=db)
+            with e.wgrad_side():
+                ops.gemm_tn(x, dz.view(M, self.co), dw.view(K, self.co), Mk=M, I=K, J=self.co, lda=H * C, ldb=self.co,
+                            ldo=self.co, row_group=Wo, row_skip=self.kh - 1, colsum=db)
             if pdy is not None:
                 if pmask is not None or self.kh != 2:
                     raise NotImplementedError('%s: data gradient of a full-height VALID conv is lowered for k_h = 2 '
@@ -686,7 +690,8 @@ class _BiLstmOp(_Op):
         if self.with_fc:
             dl = b[self.key + '/dy']
             # FC: dW += H^T dL, db += colsum dL, dH = dL Wfc^T
-            ops.gemm_tn(hout, dl, e.grad(self.name + '/weights'), colsum=e.grad(self.name + '/biases'))
+            with e.wgrad_side():
+                ops.gemm_tn(hout, dl, e.grad(self.name + '/weights'), colsum=e.grad(self.name + '/biases'))
             ops.gemm_nt(dl, e.shadow(self.name + '/weights'), out=b[self.key + '/dhout'])
         # BPTT, both directions per launch
         wsh = e.shadow(self.name + '/fw/weights')
@@ -703,20 +708,21 @@ class _BiLstmOp(_Op):
         x = self.prev.y(sp).view(R, D)
         gw = [e.grad('%s/%s/weights' % (self.name, tag)) for tag in ('fw', 'bw')]
         gb = [e.grad('%s/%s/biases' % (self.name, tag)) for tag in ('fw', 'bw')]
-        if (D + U) % 128 == 0 and (4 * U) % 128 == 0:
-            # dW_d[D+U, 4U] = [x | h_prev,d]^T dz_d for both directions in ONE launch (the TF LSTMCell matrix is applied to
-            # concat([x_t, h_{t-1}]), network.py:104-107): 4 short-K weight-gradient launches become 1
-            xh = b[self.key + '/xh']
-            ops.lstm_xh(x, hout, sp.seq_len, xh, N, T, D, U)
-            ops.gemm_tn_batched(xh, D + U, R * (D + U), dz, 8 * U, 4 * U, gw[0], 4 * U, e.offset(self.name + '/bw/weights') -
-                                e.offset(self.name + '/fw/weights'), R, D + U, 4 * U, 2, colsum=gb[0],
-                                strideColsum=e.offset(self.name + '/bw/biases') - e.offset(self.name + '/fw/biases'))
-        else:
-            ops.lstm_hprev(hout, sp.seq_len, b[self.key + '/hprev'], N, T, U)
-            for d in range(2):
-                dzd = dz[:, d * 4 * U:(d + 1) * 4 * U]
-                ops.gemm_tn(x, dzd, gw[d][:D], Mk=R, I=D, J=4 * U, lda=D, ldb=8 * U, ldo=4 * U, colsum=gb[d])
-                ops.gemm_tn(b[self.key + '/hprev'][d], dzd, gw[d][D:], Mk=R, I=U, J=4 * U, lda=U, ldb=8 * U, ldo=4 * U)
+        with e.wgrad_side():
+            if (D + U) % 128 == 0 and (4 * U) % 128 == 0:
+                # dW_d[D+U, 4U] = [x | h_prev,d]^T dz_d for both directions in ONE launch (the TF LSTMCell matrix is applied to
+                # concat([x_t, h_{t-1}]), network.py:104-107): 4 short-K weight-gradient launches become 1
+                xh = b[self.key + '/xh']
+                ops.lstm_xh(x, hout, sp.seq_len, xh, N, T, D, U)
+                ops.gemm_tn_batched(xh, D + U, R * (D + U), dz, 8 * U, 4 * U, gw[0], 4 * U, e.offset(self.name + '/bw/weights') -
+                                    e.offset(self.name + '/fw/weights'), R, D + U, 4 * U, 2, colsum=gb[0],
+                                    strideColsum=e.offset(self.name + '/bw/biases') - e.offset(self.name + '/fw/biases'))
+            else:
+                ops.lstm_hprev(hout, sp.seq_len, b[self.key + '/hprev'], N, T, U)
+                for d in range(2):
+                    dzd = dz[:, d * 4 * U:(d + 1) * 4 * U]
+                    ops.gemm_tn(x, dzd, gw[d][:D], Mk=R, I=D, J=4 * U, lda=D, ldb=8 * U, ldo=4 * U, colsum=gb[d])
+                    ops.gemm_tn(b[self.key + '/hprev'][d], dzd, gw[d][D:], Mk=R, I=U, J=4 * U, lda=U, ldb=8 * U, ldo=4 * U)
         pdy, finish = e.grad_dst(sp, self.prev)
         if pdy is not None:
             pmask = self.prev.y(sp).view(R, D) if self.prev.mask_in_consumer else None
@@ -781,6 +787,14 @@ class Engine(object):
             self.world = int(os.environ['OCR_FAKE_WORLD'])
             self.force_allreduce = True
         self.overlap_allreduce = os.environ.get('OCR_OVERLAP_ALLREDUCE', '1') != '0'
+        # OCR_WGRAD_STREAM=1: weight gradients on a side stream (forked after the producer of dz, joined at the end of each
+        # backward body; parallel branches of the hipGraph).  Measured (tools/side_stream_probe.py, A/B of the whole step): two
+        # convolution kernels do not overlap at all (wgrad2 + dgrad2: 89.6 us sequential, 91.6 us on two streams) and the step
+        # time is unchanged (1.513 vs 1.507 ms), so the default stays one stream.  Only the persistent LSTM kernels (128 one-wave
+        # workgroups) hide a concurrent kernel (wgrad2 + lstm_fwd: 197 -> 155 us) — and nothing in the step is independent of them.
+        self.wgrad_stream = (torch.cuda.Stream(self.device) if self.device.type == 'cuda' and
+                             os.environ.get('OCR_WGRAD_STREAM', '0') == '1' else None)
+        self._side_used = False
         self.comm_stream = torch.cuda.Stream(device=self.device)
         self._lower(net)                                 # operators first: the parameter layout follows their EXECUTION order
         self._layout(net)
@@ -1047,10 +1061,28 @@ class Engine(object):
             ops.tnc_to_ntc_bf16(sp.ctc_grad, self.ops[-1].dy(sp), scale)
         for op in reversed(self.ops[self.split_op:]):
             op.bwd(sp)
+        self._join_side()
 
     def _backward_early(self, sp):
         for op in reversed(self.ops[:self.split_op]):
             op.bwd(sp)
+        self._join_side()
+
+    @contextlib.contextmanager
+    def wgrad_side(self):
+        """Launches inside run on the weight-gradient stream, ordered after everything issued on the current stream so far."""
+        if self.wgrad_stream is None:
+            yield
+            return
+        self.wgrad_stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._side_used = True
+        with torch.cuda.stream(self.wgrad_stream):
+            yield
+
+    def _join_side(self):
+        if self._side_used:
+            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
+            self._side_used = False
 
     def _capture(self, fn):
         """hipGraph capture of fn() with Python's cyclic garbage collector paused: a collection that frees device tensors of
