@@ -159,18 +159,21 @@ int ocr_subsample_bf16(const void* src, void* dst, int Nb, int W, int H, int C, 
                        int backward, void* stream);
 int ocr_softmax_f32(const float* in, float* out, long rows, int C, void* stream);     /* network.py:441-447, last axis */
 
-/* ---- bidirectional LSTM (bi_lstm network.py:97-129; TF-1.0 LSTMCell gate order i,j,f,o, forget_bias 1.0) ----- */
+/* ---- LSTM (bi_lstm network.py:97-129, lstm network.py:130-152; TF-1.0 LSTMCell gate order i,j,f,o, forget_bias 1.0) -----
+ * ndir = 2: forward | backward direction (bidirectional_dynamic_rnn, backward reversed within each length);  ndir = 1: forward only
+ * (dynamic_rnn).  Row strides of the per-step tensors follow it: xproj / dz [R][ndir][4U], hout / dhout [R][ndir*U],
+ * gates [ndir][R][4U], cell [ndir][R][U]. */
 int ocr_lstm_fwd_step(const float* xproj, const void* whT_packed, const int* seq_len, void* hout, float* gates,
-                      float* cell, int Nb, int T, int U, int step, float forget_bias, void* stream);
+                      float* cell, int Nb, int T, int U, int step, float forget_bias, int ndir, void* stream);
 int ocr_lstm_bwd_step(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
                       const float* gates, const float* cell, void* dz, float* dc_state, int Nb, int T, int U,
-                      int step, void* stream);
+                      int step, int ndir, void* stream);
 /* whole-sequence (persistent) variants: one launch for all T steps; the 16 workgroups of a (direction, 16-row batch tile)
  * group exchange h_t / dz_t through the output tensor itself (hout / dz), which the call first fills with the bf16 pattern
  * 0xFFFF ("not written yet") — see ocr_set_lstm_proto for the hand-off protocols.  `sync`: ocr_lstm_seq_sync_words(Nb) int32
  * words of scratch (cleared by the call; last word = spin-timeout error flag, non-zero => results invalid).
- * ocr_lstm_seq_supported() tells whether the shape is covered (U == 256 and the grid fits one workgroup per CU); otherwise
- * use the step entry points. */
+ * ocr_lstm_seq_supported() tells whether the shape is covered (two directions, U == 256 and the grid fits one workgroup per
+ * CU); otherwise use the step entry points. */
 int ocr_lstm_seq_supported(int Nb, int U);
 int ocr_lstm_seq_sync_words(int Nb);
 int ocr_lstm_seq_debug(void* dbg /* device int64[4*T] phase stamps of workgroup 0, NULL = off */);
@@ -181,10 +184,10 @@ int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, const int* seq
 /* hand-off protocol of the persistent kernels: 2 (default) = data-as-flag inside one XCD's L2 — needs workgroups with equal
  * (id & 7) on one XCD, see ocr_probe_xcc; 1 = data-as-flag through memory (sc1), 0 = counters (sc1): placement independent */
 int ocr_set_lstm_proto(int proto);
-int ocr_lstm_hprev(const void* hout, const int* seq_len, void* hprev, int Nb, int T, int U, void* stream);
-/* xh [2][Nb*T][D+U] = [x | h_{t-1} in direction order]: operand of the LSTMCell-matrix weight gradient (one GEMM per direction) */
-int ocr_lstm_xh(const void* x, const void* hout, const int* seq_len, void* xh, int Nb, int T, int D, int U, void* stream);
-int ocr_lstm_pack_bias(const float* b_fw, const float* b_bw, float* out, int U, void* stream);
+int ocr_lstm_hprev(const void* hout, const int* seq_len, void* hprev, int Nb, int T, int U, int ndir, void* stream);
+/* xh [ndir][Nb*T][D+U] = [x | h_{t-1} in direction order]: operand of the LSTMCell-matrix weight gradient (one GEMM per direction) */
+int ocr_lstm_xh(const void* x, const void* hout, const int* seq_len, void* xh, int Nb, int T, int D, int U, int ndir, void* stream);
+int ocr_lstm_pack_bias(const float* b_fw, const float* b_bw /* NULL when ndir == 1 */, float* out, int U, int ndir, void* stream);
 
 /* ---- optimiser (train.py:73-85: clip_by_global_norm 10.0 + Adam / Momentum / RMSProp; L2 of network.py:630-637) */
 int ocr_optim_scalar_count(void);   /* doubles in the caller-owned `scalars` block: 8 of state + per-step partial-sum bins */

@@ -31,7 +31,7 @@ _SIGS = {
     "ocr_gemm_nt_bf16": ([_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P], _I),
     "ocr_set_gemm_engine": ([_I], _I),
     "ocr_gemm_tn_batched_bf16": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _F, _I, _P, _L, _P], _I),
-    "ocr_lstm_xh": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "ocr_lstm_xh": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "ocr_set_wgrad_engine": ([_I], _I),
     "ocr_conv3x3_bf16": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P], _I),
     "ocr_gemm_tn_bf16": ([_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _L, _F, _I, _P, _P], _I),
@@ -65,15 +65,15 @@ _SIGS = {
     "ocr_cast2d_f32_bf16": ([_P, _L, _P, _L, _I, _I, _P], _I),
     "ocr_tnc_to_ntc_bf16": ([_P, _P, _I, _I, _I, _F, _P], _I),
     "ocr_conv5_col2im": ([_P, _P, _I, _I, _I, _P], _I),
-    "ocr_lstm_fwd_step": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P], _I),
-    "ocr_lstm_bwd_step": ([_P, _L, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "ocr_lstm_fwd_step": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P], _I),
+    "ocr_lstm_bwd_step": ([_P, _L, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "ocr_lstm_seq_supported": ([_I, _I], _I),
     "ocr_lstm_seq_debug": ([_P], _I),
     "ocr_lstm_seq_sync_words": ([_I], _I),
     "ocr_lstm_fwd_seq": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P], _I),
     "ocr_lstm_bwd_seq": ([_P, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
-    "ocr_lstm_hprev": ([_P, _P, _P, _I, _I, _I, _P], _I),
-    "ocr_lstm_pack_bias": ([_P, _P, _P, _I, _P], _I),
+    "ocr_lstm_hprev": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "ocr_lstm_pack_bias": ([_P, _P, _P, _I, _I, _P], _I),
     "ocr_optim_scalar_count": ([], _I),
     "ocr_optim_init": ([_P, _D, _P], _I),
     "ocr_optim_set_lr": ([_P, _D, _I, _P], _I),

@@ -31,6 +31,7 @@ struct LstmFwdArgs {
     int Nb, T, U;
     int step;
     float forget_bias;
+    int ND;                 // directions: 2 = fw | bw (bi_lstm), 1 = forward only (Network.lstm); row strides are ND * U / ND * 4U
 };
 
 __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdArgs a) {
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdArgs a) {
     for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // prefetch the operands that do not depend on the MFMA result
     const int ul0 = q * 4;
-    const float* xp = a.xproj + row * (8L * U) + (long)d * 4 * U + (long)ub * 64 + ul0;
+    const float* xp = a.xproj + row * ((long)a.ND * 4 * U) + (long)d * 4 * U + (long)ub * 64 + ul0;
     f32x4 xi = {0.f, 0.f, 0.f, 0.f}, xj = xi, xf = xi, xo = xi, cprev = xi;
     if (active) {
         xi = *(const f32x4*)(xp + 0); xj = *(const f32x4*)(xp + 16); xf = *(const f32x4*)(xp + 32); xo = *(const f32x4*)(xp + 48);
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdArgs a) {
     }
     if (s > 0) {
         const bf16_t* wbase = a.whT + ((long)d * 4 * U + (long)ub * 64 + nl) * U + q * 8;
-        const bf16_t* hbase = a.hout + rowp * (2L * U) + (long)d * U + q * 8;
+        const bf16_t* hbase = a.hout + rowp * ((long)a.ND * U) + (long)d * U + q * 8;
         // K = U is consumed in chunks of 128 with all 20 operand loads of a chunk in flight at once
         for (int kc = 0; kc < U; kc += 128) {
             bf16x8 b[4], w[4][4];
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(LstmFwdArgs a) {
     }
     // lane owns units u = ub*16 + q*4 + r (r = 0..3) of batch row n, gate g in acc[g][r]
     if (!nvalid) return;
-    bf16_t* hdst = a.hout + row * (2L * U) + (long)d * U + ub * 16 + ul0;
+    bf16_t* hdst = a.hout + row * ((long)a.ND * U) + (long)d * U + ub * 16 + ul0;
     if (!active) {
         if (s < T) { u32x2 z = {0u, 0u}; *(u32x2*)hdst = z; }
         return;
@@ -122,6 +123,7 @@ struct LstmBwdArgs {
     float* dc_state;        // [2][Nb][U]  (zeroed before the first call)
     int Nb, T, U;
     int step;
+    int ND;
 };
 
 __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdArgs a) {
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdArgs a) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
     if (s + 1 < T) {
         const bf16_t* wbase = a.wh + (long)d * a.w_dir_stride + ((long)ub * 16 + nl) * a.ldw + q * 8;
-        const bf16_t* zbase = a.dz + rown * (8L * U) + (long)d * 4 * U + q * 8;
+        const bf16_t* zbase = a.dz + rown * ((long)a.ND * 4 * U) + (long)d * 4 * U + q * 8;
         const int K = 4 * U;
         for (int k0 = 0; k0 < K; k0 += 256) {
             bf16x8 w[8], z[8];
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdArgs a) {
     if (!nvalid) return;
     const int ul0 = q * 4;                    // lane owns units ub*16 + ul0 + r
     const int u0 = ub * 16 + ul0;
-    bf16_t* zdst = a.dz + row * (8L * U) + (long)d * 4 * U + u0;
+    bf16_t* zdst = a.dz + row * ((long)a.ND * 4 * U) + (long)d * 4 * U + u0;
     float* dcs = a.dc_state + ((long)d * a.Nb + nn) * U + u0;
     if (!active) {
         if (s < T) {
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdArgs a) {
     f32x4 dh = (acc0 + acc1) + (acc2 + acc3);
     if (!has_next) dh = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
-        u32x2 g2 = *(const u32x2*)(a.dhout + row * (2L * U) + (long)d * U + u0);
+        u32x2 g2 = *(const u32x2*)(a.dhout + row * ((long)a.ND * U) + (long)d * U + u0);
         dh[0] += bf_lo(g2.x); dh[1] += bf_hi(g2.x); dh[2] += bf_lo(g2.y); dh[3] += bf_hi(g2.y);
     }
     const float* gsrc = a.gates + ((long)d * R + row) * (4L * U) + (long)ub * 64 + ul0;
@@ -216,10 +218,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdArgs a) {
 // hprev[d][row(n,t)][U] = h at the step before (n,t) in direction d's own order, 0 at the first step / padding.
 // (operand of the W_h weight-gradient GEMM)
 __global__ void lstm_hprev_kernel(const bf16_t* __restrict__ hout, const int* __restrict__ seq_len,
-                                  bf16_t* __restrict__ hprev, int Nb, int T, int U) {
+                                  bf16_t* __restrict__ hprev, int Nb, int T, int U, int ND) {
     const int groups = U >> 3;
     const long R = (long)Nb * T;
-    const long total = 2L * R * groups;
+    const long total = (long)ND * R * groups;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         int gq = (int)(idx % groups);
         long q = idx / groups;
@@ -230,7 +232,7 @@ __global__ void lstm_hprev_kernel(const bf16_t* __restrict__ hout, const int* __
         u32x4 v = {0, 0, 0, 0};
         if (t < len) {
             int tp = (d == 0) ? t - 1 : t + 1;
-            if (tp >= 0 && tp < len) v = *(const u32x4*)(hout + ((long)n * T + tp) * (2L * U) + (long)d * U + gq * 8);
+            if (tp >= 0 && tp < len) v = *(const u32x4*)(hout + ((long)n * T + tp) * ((long)ND * U) + (long)d * U + gq * 8);
         }
         *(u32x4*)(hprev + ((long)d * R + row) * U + gq * 8) = v;
     }
@@ -239,10 +241,10 @@ __global__ void lstm_hprev_kernel(const bf16_t* __restrict__ hout, const int* __
 // xh[d][row(n,t)][D + U] = [x(n,t) | h at the step before (n,t) in direction d's own order]: the operand of ONE weight-gradient
 // GEMM per direction for the whole TF LSTMCell matrix [D + U, 4U] (concat([x_t, h_{t-1}]) of network.py:104-107)
 __global__ void lstm_xh_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ hout, const int* __restrict__ seq_len,
-                               bf16_t* __restrict__ xh, int Nb, int T, int D, int U) {
+                               bf16_t* __restrict__ xh, int Nb, int T, int D, int U, int ND) {
     const int groups = (D + U) >> 3, dgroups = D >> 3;
     const long R = (long)Nb * T;
-    const long total = 2L * R * groups;
+    const long total = (long)ND * R * groups;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int gq = (int)(idx % groups);
         const long q = idx / groups;
@@ -256,7 +258,7 @@ __global__ void lstm_xh_kernel(const bf16_t* __restrict__ x, const bf16_t* __res
             const int len = min(seq_len[n], T);
             if (t < len) {
                 const int tp = (d == 0) ? t - 1 : t + 1;
-                if (tp >= 0 && tp < len) v = *(const u32x4*)(hout + ((long)n * T + tp) * (2L * U) + (long)d * U + (gq - dgroups) * 8);
+                if (tp >= 0 && tp < len) v = *(const u32x4*)(hout + ((long)n * T + tp) * ((long)ND * U) + (long)d * U + (gq - dgroups) * 8);
             }
         }
         *(u32x4*)(xh + ((long)d * R + row) * (D + U) + gq * 8) = v;
@@ -265,9 +267,9 @@ __global__ void lstm_xh_kernel(const bf16_t* __restrict__ x, const bf16_t* __res
 
 // packed-column permutation used by the forward operands (see header)
 __global__ void lstm_pack_bias_kernel(const float* __restrict__ b_fw, const float* __restrict__ b_bw,
-                                      float* __restrict__ out, int U) {
+                                      float* __restrict__ out, int U, int ND) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 8 * U) {
+    if (i < ND * 4 * U) {
         int d = i / (4 * U), c = i % (4 * U);
         int g = c / U, u = c % U;
         int p = (u / 16) * 64 + g * 16 + (u % 16);
@@ -280,46 +282,46 @@ __global__ void lstm_pack_bias_kernel(const float* __restrict__ b_fw, const floa
 // ------------------------------------------------------------------------------------------
 extern "C" int ocr_lstm_fwd_step(const float* xproj, const void* whT_packed, const int* seq_len, void* hout,
                                  float* gates, float* cell, int Nb, int T, int U, int step, float forget_bias,
-                                 void* stream) {
+                                 int ndir, void* stream) {
     if (!xproj || !whT_packed || !seq_len || !hout || !gates || !cell) return OCR_ERR_INVALID;
-    if (Nb <= 0 || T <= 0 || U <= 0 || (U & 31) || step < 0 || step >= T) return OCR_ERR_INVALID;
-    LstmFwdArgs a = {xproj, (const bf16_t*)whT_packed, seq_len, (bf16_t*)hout, gates, cell, Nb, T, U, step, forget_bias};
-    dim3 grid(U / 16, 2, ceil_div(Nb, 64));
+    if (Nb <= 0 || T <= 0 || U <= 0 || (U & 31) || step < 0 || step >= T || (ndir != 1 && ndir != 2)) return OCR_ERR_INVALID;
+    LstmFwdArgs a = {xproj, (const bf16_t*)whT_packed, seq_len, (bf16_t*)hout, gates, cell, Nb, T, U, step, forget_bias, ndir};
+    dim3 grid(U / 16, ndir, ceil_div(Nb, 64));
     lstm_fwd_step_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
 extern "C" int ocr_lstm_bwd_step(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
                                  const float* gates, const float* cell, void* dz, float* dc_state, int Nb, int T,
-                                 int U, int step, void* stream) {
+                                 int U, int step, int ndir, void* stream) {
     if (!wh || !seq_len || !dhout || !gates || !cell || !dz || !dc_state) return OCR_ERR_INVALID;
-    if (Nb <= 0 || T <= 0 || U <= 0 || (U & 31) || step < 0 || step >= T) return OCR_ERR_INVALID;
+    if (Nb <= 0 || T <= 0 || U <= 0 || (U & 31) || step < 0 || step >= T || (ndir != 1 && ndir != 2)) return OCR_ERR_INVALID;
     LstmBwdArgs a = {(const bf16_t*)wh, ldw, w_dir_stride, seq_len, (const bf16_t*)dhout, gates, cell, (bf16_t*)dz,
-                     dc_state, Nb, T, U, step};
-    dim3 grid(U / 16, 2, ceil_div(Nb, 64));
+                     dc_state, Nb, T, U, step, ndir};
+    dim3 grid(U / 16, ndir, ceil_div(Nb, 64));
     lstm_bwd_step_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
-extern "C" int ocr_lstm_hprev(const void* hout, const int* seq_len, void* hprev, int Nb, int T, int U, void* stream) {
-    if (!hout || !seq_len || !hprev || (U & 7)) return OCR_ERR_INVALID;
-    long total = 2L * Nb * T * (U >> 3);
+extern "C" int ocr_lstm_hprev(const void* hout, const int* seq_len, void* hprev, int Nb, int T, int U, int ndir, void* stream) {
+    if (!hout || !seq_len || !hprev || (U & 7) || (ndir != 1 && ndir != 2)) return OCR_ERR_INVALID;
+    long total = (long)ndir * Nb * T * (U >> 3);
     int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-    lstm_hprev_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)hout, seq_len, (bf16_t*)hprev, Nb, T, U);
+    lstm_hprev_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)hout, seq_len, (bf16_t*)hprev, Nb, T, U, ndir);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
-extern "C" int ocr_lstm_xh(const void* x, const void* hout, const int* seq_len, void* xh, int Nb, int T, int D, int U, void* stream) {
-    if (!x || !hout || !seq_len || !xh || (U & 7) || (D & 7)) return OCR_ERR_INVALID;
-    long total = 2L * Nb * T * ((D + U) >> 3);
+extern "C" int ocr_lstm_xh(const void* x, const void* hout, const int* seq_len, void* xh, int Nb, int T, int D, int U, int ndir, void* stream) {
+    if (!x || !hout || !seq_len || !xh || (U & 7) || (D & 7) || (ndir != 1 && ndir != 2)) return OCR_ERR_INVALID;
+    long total = (long)ndir * Nb * T * ((D + U) >> 3);
     int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
-    lstm_xh_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)hout, seq_len, (bf16_t*)xh, Nb, T, D, U);
+    lstm_xh_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)hout, seq_len, (bf16_t*)xh, Nb, T, D, U, ndir);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
-extern "C" int ocr_lstm_pack_bias(const float* b_fw, const float* b_bw, float* out, int U, void* stream) {
-    if (!b_fw || !b_bw || !out || (U & 15)) return OCR_ERR_INVALID;
-    lstm_pack_bias_kernel<<<ceil_div(8 * U, 256), 256, 0, (hipStream_t)stream>>>(b_fw, b_bw, out, U);
+extern "C" int ocr_lstm_pack_bias(const float* b_fw, const float* b_bw, float* out, int U, int ndir, void* stream) {
+    if (!b_fw || (ndir == 2 && !b_bw) || !out || (U & 15) || (ndir != 1 && ndir != 2)) return OCR_ERR_INVALID;
+    lstm_pack_bias_kernel<<<ceil_div(ndir * 4 * U, 256), 256, 0, (hipStream_t)stream>>>(b_fw, b_bw, out, U, ndir);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }

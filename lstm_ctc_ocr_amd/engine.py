@@ -591,98 +591,109 @@ class _SoftmaxOp(_Op):
 
 
 class _BiLstmOp(_Op):
+    """bi_lstm (network.py:97-129: ND = 2 directions of LSTMCell(num_hids // 2)) and one cell of the unidirectional stacked `lstm`
+    (network.py:130-152: ND = 1, LSTMCell(num_hids)), optionally followed by the FC + [N,T] -> [T,N] transpose."""
+
     def __init__(self, eng, node, prev):
         super(_BiLstmOp, self).__init__(eng, node, prev)
         a = node.attrs
-        self.U, self.C, self.D = a['num_hids'] // 2, a['nclasses'], a['din']
-        self.with_fc = a.get('with_fc', True)       # False: a hidden layer of a stacked BiLSTM, output = [N, T, 2U]
+        self.ND = 2 if node.op == 'bi_lstm' else 1
+        self.U, self.C, self.D = a['num_hids'] // self.ND, a['nclasses'], a['din']
+        self.cells = a.get('cells') or [self.name + '/fw', self.name + '/bw']       # variable-name prefix of each direction's LSTMCell
+        self.fc = a.get('fc', self.name)                                            # variable-name prefix of the FC
+        self.with_fc = a.get('with_fc', True)       # False: a hidden layer of a stack, output = [N, T, ND * U]
         if self.U % 32 or self.D % 32 or self.C % 8:
-            raise NotImplementedError('%s: needs hidden %% 64 == 0, input features %% 32 == 0, classes %% 8 == 0' % self.name)
-        dev, U, D, C = eng.device, self.U, self.D, self.C
-        self.wxT = torch.empty((8 * U, D), dtype=BF16, device=dev)
-        self.whT = torch.empty((2, 4 * U, U), dtype=BF16, device=dev)
-        self.bias = torch.empty(8 * U, dtype=F32, device=dev)
-        self.wfcT = torch.empty((C, 2 * U), dtype=BF16, device=dev) if self.with_fc else None
-        self.wcat = torch.empty((D, 8 * U), dtype=BF16, device=dev)
+            raise NotImplementedError('%s: needs hidden units per direction %% 32 == 0, input features %% 32 == 0, classes %% 8 == 0' % self.name)
+        dev, U, D, C, ND = eng.device, self.U, self.D, self.C, self.ND
+        self.wxT = torch.empty((ND * 4 * U, D), dtype=BF16, device=dev)
+        self.whT = torch.empty((ND, 4 * U, U), dtype=BF16, device=dev)
+        self.bias = torch.empty(ND * 4 * U, dtype=F32, device=dev)
+        self.wfcT = torch.empty((C, ND * U), dtype=BF16, device=dev) if self.with_fc else None
+        self.wcat = torch.empty((D, ND * 4 * U), dtype=BF16, device=dev)
 
     def dy_needed(self):
         return True
 
     def out_shape(self, s):
         N, T, D = s
-        return (T, N, self.C) if self.with_fc else (N, T, 2 * self.U)
+        return (T, N, self.C) if self.with_fc else (N, T, self.ND * self.U)
 
     def y(self, sp):
         if self.with_fc:
             return sp.buf[self.key + '/y']
         (N, T, _), _ = sp.shape[self.key]
-        return sp.buf[self.key + '/hout'].view(N, T, 2 * self.U)
+        return sp.buf[self.key + '/hout'].view(N, T, self.ND * self.U)
 
     def dy(self, sp):
         if self.with_fc:
             return sp.buf[self.key + '/dy']
         (N, T, _), _ = sp.shape[self.key]
-        return sp.buf[self.key + '/dhout'].view(N, T, 2 * self.U)
+        return sp.buf[self.key + '/dhout'].view(N, T, self.ND * self.U)
+
+    def _persistent(self, N):
+        return self.ND == 2 and self.eng.persistent_lstm and ops.lstm_seq_supported(N, self.U)
 
     def alloc(self, sp, s):
         N, T, D = s
-        U, C, dev = self.U, self.C, self.eng.device
+        U, C, ND, dev = self.U, self.C, self.ND, self.eng.device
         R = N * T
         sp.shape[self.key] = (s, self.out_shape(s))
         b = sp.buf
-        b[self.key + '/xproj'] = torch.empty((R, 8 * U), dtype=F32, device=dev)
-        b[self.key + '/hout'] = torch.zeros((R, 2 * U), dtype=BF16, device=dev)
-        b[self.key + '/gates'] = torch.zeros((2, R, 4 * U), dtype=F32, device=dev)
-        b[self.key + '/cell'] = torch.zeros((2, R, U), dtype=F32, device=dev)
+        b[self.key + '/xproj'] = torch.empty((R, ND * 4 * U), dtype=F32, device=dev)
+        b[self.key + '/hout'] = torch.zeros((R, ND * U), dtype=BF16, device=dev)
+        b[self.key + '/gates'] = torch.zeros((ND, R, 4 * U), dtype=F32, device=dev)
+        b[self.key + '/cell'] = torch.zeros((ND, R, U), dtype=F32, device=dev)
         if self.with_fc:
             b[self.key + '/y'] = torch.empty((T, N, C), dtype=F32, device=dev)      # logits, time-major
             b[self.key + '/dy'] = torch.empty((R, C), dtype=BF16, device=dev)       # d loss / d logits, [N,T,C]
-        b[self.key + '/dhout'] = torch.empty((R, 2 * U), dtype=BF16, device=dev)
-        b[self.key + '/dz'] = torch.zeros((R, 8 * U), dtype=BF16, device=dev)
-        b[self.key + '/dc'] = torch.zeros((2, N, U), dtype=F32, device=dev)
-        b[self.key + '/hprev'] = torch.empty((2, R, U), dtype=BF16, device=dev)
-        b[self.key + '/xh'] = torch.empty((2, R, self.D + U), dtype=BF16, device=dev)
-        b[self.key + '/sync_f'] = torch.zeros(ops.lstm_seq_sync_words(N), dtype=I32, device=dev)
-        b[self.key + '/sync_b'] = torch.zeros(ops.lstm_seq_sync_words(N), dtype=I32, device=dev)
-        sp.lstm_sync = getattr(sp, 'lstm_sync', ()) + (b[self.key + '/sync_f'], b[self.key + '/sync_b'])
+        b[self.key + '/dhout'] = torch.empty((R, ND * U), dtype=BF16, device=dev)
+        b[self.key + '/dz'] = torch.zeros((R, ND * 4 * U), dtype=BF16, device=dev)
+        b[self.key + '/dc'] = torch.zeros((ND, N, U), dtype=F32, device=dev)
+        b[self.key + '/hprev'] = torch.empty((ND, R, U), dtype=BF16, device=dev)
+        b[self.key + '/xh'] = torch.empty((ND, R, self.D + U), dtype=BF16, device=dev)
+        if self.ND == 2:
+            b[self.key + '/sync_f'] = torch.zeros(ops.lstm_seq_sync_words(N), dtype=I32, device=dev)
+            b[self.key + '/sync_b'] = torch.zeros(ops.lstm_seq_sync_words(N), dtype=I32, device=dev)
+            sp.lstm_sync = getattr(sp, 'lstm_sync', ()) + (b[self.key + '/sync_f'], b[self.key + '/sync_b'])
 
     def pack_jobs(self):
-        e, U, D = self.eng, self.U, self.D
+        e, U, D, ND = self.eng, self.U, self.D, self.ND
         jobs = []
-        for d, tag in enumerate(('fw', 'bw')):
-            w = e.param('%s/%s/weights' % (self.name, tag))                  # [D+U, 4U], gate-major columns
+        for d, cell in enumerate(self.cells):
+            w = e.param(cell + '/weights')                  # [D+U, 4U], gate-major columns
             jobs.append(dict(type=0, R=D, Cc=4 * U, ldin=4 * U, lstm_units=U, src=w[:D], dst=self.wxT[d * 4 * U:(d + 1) * 4 * U]))
             jobs.append(dict(type=0, R=U, Cc=4 * U, ldin=4 * U, lstm_units=U, src=w[D:], dst=self.whT[d]))
-            jobs.append(dict(type=2, R=D, Cc=4 * U, ldin=4 * U, ldout=8 * U, src=w, dst=self.wcat[:, d * 4 * U:]))
+            jobs.append(dict(type=2, R=D, Cc=4 * U, ldin=4 * U, ldout=ND * 4 * U, src=w, dst=self.wcat[:, d * 4 * U:]))
         if self.with_fc:
-            wf = e.param(self.name + '/weights')
+            wf = e.param(self.fc + '/weights')
             jobs.append(dict(type=0, R=wf.shape[0], Cc=wf.shape[1], ldin=wf.shape[1], src=wf, dst=self.wfcT))
         return jobs
 
     def refresh(self):
         e = self.eng
-        ops.lstm_pack_bias(e.param(self.name + '/fw/biases'), e.param(self.name + '/bw/biases'), self.bias, self.U)
+        ops.lstm_pack_bias(e.param(self.cells[0] + '/biases'), e.param(self.cells[1] + '/biases') if self.ND == 2 else None,
+                           self.bias, self.U, self.ND)
 
     def fwd(self, sp):
-        e, U, C = self.eng, self.U, self.C
+        e, U, C, ND = self.eng, self.U, self.C, self.ND
         (N, T, D), _ = sp.shape[self.key]
         R = N * T
         b = sp.buf
         x = self.prev.y(sp).view(R, D)
         ops.gemm_nt(x, self.wxT, out=b[self.key + '/xproj'], bias=self.bias)
-        if self.eng.persistent_lstm and ops.lstm_seq_supported(N, U):
+        if self._persistent(N):
             ops.lstm_fwd_seq(b[self.key + '/xproj'], self.whT, sp.seq_len, b[self.key + '/hout'], b[self.key + '/gates'],
                              b[self.key + '/cell'], N, T, U, b[self.key + '/sync_f'], 1.0)
         else:
             for s in range(T):
                 ops.lstm_fwd_step(b[self.key + '/xproj'], self.whT, sp.seq_len, b[self.key + '/hout'],
-                                  b[self.key + '/gates'], b[self.key + '/cell'], N, T, U, s, 1.0)
+                                  b[self.key + '/gates'], b[self.key + '/cell'], N, T, U, s, 1.0, ND)
         if self.with_fc:
             ops.gemm_nt(b[self.key + '/hout'], self.wfcT, out=b[self.key + '/y'].view(R, C),
-                        bias=e.param(self.name + '/biases'), rowswap=(T, N))
+                        bias=e.param(self.fc + '/biases'), rowswap=(T, N))
 
     def bwd(self, sp):
-        e, U, C, D = self.eng, self.U, self.C, self.D
+        e, U, C, D, ND = self.eng, self.U, self.C, self.D, self.ND
         (N, T, _), _ = sp.shape[self.key]
         R = N * T
         b = sp.buf
@@ -691,38 +702,38 @@ class _BiLstmOp(_Op):
             dl = b[self.key + '/dy']
             # FC: dW += H^T dL, db += colsum dL, dH = dL Wfc^T
             with e.wgrad_side():
-                ops.gemm_tn(hout, dl, e.grad(self.name + '/weights'), colsum=e.grad(self.name + '/biases'))
-            ops.gemm_nt(dl, e.shadow(self.name + '/weights'), out=b[self.key + '/dhout'])
-        # BPTT, both directions per launch
-        wsh = e.shadow(self.name + '/fw/weights')
-        stride = e.offset(self.name + '/bw/weights') - e.offset(self.name + '/fw/weights')
-        if self.eng.persistent_lstm and ops.lstm_seq_supported(N, U):
+                ops.gemm_tn(hout, dl, e.grad(self.fc + '/weights'), colsum=e.grad(self.fc + '/biases'))
+            ops.gemm_nt(dl, e.shadow(self.fc + '/weights'), out=b[self.key + '/dhout'])
+        # BPTT, all directions per launch
+        wsh = e.shadow(self.cells[0] + '/weights')
+        stride = e.offset(self.cells[1] + '/weights') - e.offset(self.cells[0] + '/weights') if ND == 2 else 0
+        if self._persistent(N):
             ops.lstm_bwd_seq(wsh[D:], 4 * U, stride, sp.seq_len, b[self.key + '/dhout'], b[self.key + '/gates'],
                              b[self.key + '/cell'], b[self.key + '/dz'], N, T, U, b[self.key + '/sync_b'])
         else:
             b[self.key + '/dc'].zero_()
             for s in range(T - 1, -1, -1):
                 ops.lstm_bwd_step(wsh[D:], 4 * U, stride, sp.seq_len, b[self.key + '/dhout'], b[self.key + '/gates'],
-                                  b[self.key + '/cell'], b[self.key + '/dz'], b[self.key + '/dc'], N, T, U, s)
+                                  b[self.key + '/cell'], b[self.key + '/dz'], b[self.key + '/dc'], N, T, U, s, ND)
         dz = b[self.key + '/dz']
         x = self.prev.y(sp).view(R, D)
-        gw = [e.grad('%s/%s/weights' % (self.name, tag)) for tag in ('fw', 'bw')]
-        gb = [e.grad('%s/%s/biases' % (self.name, tag)) for tag in ('fw', 'bw')]
+        gw = [e.grad(cell + '/weights') for cell in self.cells]
+        gb = [e.grad(cell + '/biases') for cell in self.cells]
         with e.wgrad_side():
             if (D + U) % 128 == 0 and (4 * U) % 128 == 0:
-                # dW_d[D+U, 4U] = [x | h_prev,d]^T dz_d for both directions in ONE launch (the TF LSTMCell matrix is applied to
+                # dW_d[D+U, 4U] = [x | h_prev,d]^T dz_d for all directions in ONE launch (the TF LSTMCell matrix is applied to
                 # concat([x_t, h_{t-1}]), network.py:104-107): 4 short-K weight-gradient launches become 1
                 xh = b[self.key + '/xh']
-                ops.lstm_xh(x, hout, sp.seq_len, xh, N, T, D, U)
-                ops.gemm_tn_batched(xh, D + U, R * (D + U), dz, 8 * U, 4 * U, gw[0], 4 * U, e.offset(self.name + '/bw/weights') -
-                                    e.offset(self.name + '/fw/weights'), R, D + U, 4 * U, 2, colsum=gb[0],
-                                    strideColsum=e.offset(self.name + '/bw/biases') - e.offset(self.name + '/fw/biases'))
+                ops.lstm_xh(x, hout, sp.seq_len, xh, N, T, D, U, ND)
+                ops.gemm_tn_batched(xh, D + U, R * (D + U), dz, ND * 4 * U, 4 * U, gw[0], 4 * U, stride, R, D + U, 4 * U, ND,
+                                    colsum=gb[0],
+                                    strideColsum=(e.offset(self.cells[1] + '/biases') - e.offset(self.cells[0] + '/biases')) if ND == 2 else 0)
             else:
-                ops.lstm_hprev(hout, sp.seq_len, b[self.key + '/hprev'], N, T, U)
-                for d in range(2):
+                ops.lstm_hprev(hout, sp.seq_len, b[self.key + '/hprev'], N, T, U, ND)
+                for d in range(ND):
                     dzd = dz[:, d * 4 * U:(d + 1) * 4 * U]
-                    ops.gemm_tn(x, dzd, gw[d][:D], Mk=R, I=D, J=4 * U, lda=D, ldb=8 * U, ldo=4 * U, colsum=gb[d])
-                    ops.gemm_tn(b[self.key + '/hprev'][d], dzd, gw[d][D:], Mk=R, I=U, J=4 * U, lda=U, ldb=8 * U, ldo=4 * U)
+                    ops.gemm_tn(x, dzd, gw[d][:D], Mk=R, I=D, J=4 * U, lda=D, ldb=ND * 4 * U, ldo=4 * U, colsum=gb[d])
+                    ops.gemm_tn(b[self.key + '/hprev'][d], dzd, gw[d][D:], Mk=R, I=U, J=4 * U, lda=U, ldb=ND * 4 * U, ldo=4 * U)
         pdy, finish = e.grad_dst(sp, self.prev)
         if pdy is not None:
             pmask = self.prev.y(sp).view(R, D) if self.prev.mask_in_consumer else None
@@ -923,7 +934,7 @@ class Engine(object):
     def _lower(self, net):
         """Topological lowering of the plan reachable from 'logits' (a chain for the shipped models, a DAG with residual
         adds for deeper extractors).  Only data edges count: the second input of bi_lstm is the time_step_len slot."""
-        table = {'conv': _ConvOp, 'max_pool': _PoolOp, 'reshape_squeeze': _ViewOp, 'dropout': _DropoutOp, 'bi_lstm': _BiLstmOp,
+        table = {'conv': _ConvOp, 'max_pool': _PoolOp, 'reshape_squeeze': _ViewOp, 'dropout': _DropoutOp, 'bi_lstm': _BiLstmOp, 'lstm': _BiLstmOp,
                  'add': _AddOp, 'relu': _ReluOp, 'batch_norm': _BatchNormOp, 'avg_pool': _AvgPoolOp, 'concat': _ConcatOp,
                  'softmax': _SoftmaxOp}
         data_op = _InputOp(self)

@@ -127,6 +127,8 @@ def init_host_parameters(specs, offsets, n_total, seed):
         elif isinstance(init, tuple) and init[0] == 'variance_scaling':   # factor, FAN_AVG, truncated normal (network.py:119)
             std = math.sqrt(1.3 * init[1] / ((s.shape[0] + s.shape[1]) / 2.0))
             v = torch.fmod(torch.randn(n, generator=g), 2.0) * std
+        elif isinstance(init, tuple) and init[0] == 'truncated_normal':   # tf.truncated_normal_initializer(stddev) (network.py:144)
+            v = torch.fmod(torch.randn(n, generator=g), 2.0) * float(init[1])
         else:
             raise ValueError('unknown initializer %r for %s' % (init, name))
         host[offsets[name]:offsets[name] + n] = v

@@ -170,9 +170,32 @@ class Network(object):
 
     @layer
     def lstm(self, input, num_hids, num_layers, name, img_shape=None, trainable=True):
-        raise NotImplementedError('unidirectional stacked `lstm` (network.py:130-152) is not used by the shipped models '
-                                  '(LSTM_train.py:38 uses bi_lstm) and has no gfx950 lowering: the recurrent kernels are '
-                                  'written for the two directions of bi_lstm')
+        """Unidirectional stacked LSTM + FC (network.py:130-152): MultiRNNCell of num_layers LSTMCell(num_hids) under
+        tf.nn.dynamic_rnn (forward in time, outputs zero past each length), then logits = h W + b, time-major.  Variable names
+        as TF 1.0 creates them: <name>/rnn/multi_rnn_cell/cell_<i>/lstm_cell/{weights [D+U, 4U], biases [4U]}, <name>/weights
+        (truncated_normal(0.1), L2-regularised), <name>/biases."""
+        from .config import cfg
+        img, img_len = input[0], input[1]
+        nl = max(1, int(num_layers))
+        for li in range(nl):
+            din = img.channels
+            cell = '%s/rnn/multi_rnn_cell/cell_%d/lstm_cell' % (name, li)
+            self.make_var(cell + '/weights', [din + num_hids, 4 * num_hids], 'glorot_uniform', trainable)
+            self.make_var(cell + '/biases', [4 * num_hids], 'zeros', trainable)
+            last = li == nl - 1
+            if last:
+                self.make_var(name + '/weights', [num_hids, cfg.NCLASSES], ('truncated_normal', 0.1), trainable,
+                              regularizer=self.l2_regularizer(cfg.TRAIN.WEIGHT_DECAY))
+                self.make_var(name + '/biases', [cfg.NCLASSES], 'zeros', trainable)
+            # a hidden layer is named like its cell's variable scope, so that layout.layer_of (longest layer-name prefix) attributes
+            # the cell's variables to the op that produces their gradients
+            lname = name if last else '%s/rnn/multi_rnn_cell/cell_%d' % (name, li)
+            node = Node('lstm', lname, [img, img_len], num_hids=num_hids, num_layers=1, nclasses=cfg.NCLASSES, din=din,
+                        with_fc=last, cells=[cell], fc=name, channels=cfg.NCLASSES if last else num_hids)
+            if not last:
+                self.layers[lname] = node
+            img = node
+        return img
 
     @layer
     def conv_single(self, input, k_h, k_w, c_o, s_h, s_w, name, c_i=None, bn=False, biased=True, relu=True,

@@ -142,8 +142,8 @@ def gemm_tn_batched(A, lda, strideA, B, ldb, strideB, out, ldo, strideOut, Mk, I
     return out
 
 
-def lstm_xh(x2d, hout, seq_len, xh, Nb, T, D, U):
-    call("ocr_lstm_xh", ptr(_dev(x2d)), ptr(hout), ptr(seq_len), ptr(xh), Nb, T, D, U, _st())
+def lstm_xh(x2d, hout, seq_len, xh, Nb, T, D, U, ndir=2):
+    call("ocr_lstm_xh", ptr(_dev(x2d)), ptr(hout), ptr(seq_len), ptr(xh), Nb, T, D, U, ndir, _st())
     return xh
 
 
@@ -350,14 +350,14 @@ def conv5_col2im(col, dx, Nb, W, HC):
 
 
 # ----------------------------------------------------------------------------------------------- LSTM
-def lstm_fwd_step(xproj, whT, seq_len, hout, gates, cell, Nb, T, U, step, forget_bias=1.0):
+def lstm_fwd_step(xproj, whT, seq_len, hout, gates, cell, Nb, T, U, step, forget_bias=1.0, ndir=2):
     call("ocr_lstm_fwd_step", ptr(_dev(xproj)), ptr(whT), ptr(seq_len), ptr(hout), ptr(gates), ptr(cell), Nb, T, U, step,
-         float(forget_bias), _st())
+         float(forget_bias), ndir, _st())
 
 
-def lstm_bwd_step(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, dc_state, Nb, T, U, step):
+def lstm_bwd_step(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, dc_state, Nb, T, U, step, ndir=2):
     call("ocr_lstm_bwd_step", ptr(_dev(wh)), ldw, w_dir_stride, ptr(seq_len), ptr(dhout), ptr(gates), ptr(cell), ptr(dz),
-         ptr(dc_state), Nb, T, U, step, _st())
+         ptr(dc_state), Nb, T, U, step, ndir, _st())
 
 
 def lstm_seq_supported(Nb, U):
@@ -378,12 +378,12 @@ def lstm_bwd_seq(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, Nb, T, 
          Nb, T, U, ptr(sync), _st())
 
 
-def lstm_hprev(hout, seq_len, hprev, Nb, T, U):
-    call("ocr_lstm_hprev", ptr(_dev(hout)), ptr(seq_len), ptr(hprev), Nb, T, U, _st())
+def lstm_hprev(hout, seq_len, hprev, Nb, T, U, ndir=2):
+    call("ocr_lstm_hprev", ptr(_dev(hout)), ptr(seq_len), ptr(hprev), Nb, T, U, ndir, _st())
 
 
-def lstm_pack_bias(b_fw, b_bw, out, U):
-    call("ocr_lstm_pack_bias", ptr(_dev(b_fw)), ptr(b_bw), ptr(out), U, _st())
+def lstm_pack_bias(b_fw, b_bw, out, U, ndir=2):
+    call("ocr_lstm_pack_bias", ptr(_dev(b_fw)), ptr(b_bw), ptr(out), U, ndir, _st())
 
 
 # ----------------------------------------------------------------------------------------------- optimiser

@@ -110,6 +110,17 @@ def forward(net, params, x, seq_len, sim_bf16=False, keep=False, keep_prob=1.0, 
                 out = og.qa(lg.reshape(N, T, -1).permute(1, 0, 2).contiguous(), sim, fwd=False)
             else:
                 out = hcat
+        elif nd.op == 'lstm':                # dynamic_rnn over one LSTMCell of the MultiRNNCell stack (network.py:130-152)
+            feat = ev(nd.inputs[0])
+            cell = nd.attrs['cells'][0]
+            h = og.lstm_direction(feat, seq_len, params[cell + '/weights'], params[cell + '/biases'], False, sim)
+            if nd.attrs.get('with_fc', True):
+                N, T, _ = h.shape
+                fc = nd.attrs['fc']
+                lg = h.reshape(N * T, -1) @ og.q(params[fc + '/weights'], sim) + params[fc + '/biases']
+                out = og.qa(lg.reshape(N, T, -1).permute(1, 0, 2).contiguous(), sim, fwd=False)
+            else:
+                out = h
         else:
             raise NotImplementedError(nd.op)
         cache[id(nd)] = out

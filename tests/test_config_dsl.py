@@ -209,3 +209,51 @@ def test_own_cli_drivers_parse_and_open_a_session(monkeypatch, tmp_path, capsys)
                 cfg[k].update(v)
             else:
                 cfg[k] = v
+
+
+def test_unidirectional_lstm_layer_plan_and_oracle():
+    """Network.lstm (network.py:130-152): MultiRNNCell of LSTMCell(num_hids) under dynamic_rnn + FC.  Plan, TF variable names /
+    shapes / initialisers, ownership of the cells' variables (the hidden layer's op, for the data-parallel buckets) and the
+    plan-walking oracle (zeros past each length, logits time-major)."""
+    import torch
+    from lstm_ctc_ocr_amd.config import cfg
+    from lstm_ctc_ocr_amd.layout import FlatLayout, execution_order, host_parameters
+    from lstm_ctc_ocr_amd.network import Network
+    from oracle import plan_exec
+
+    class Net(Network):
+        def __init__(self):
+            self.inputs = []
+            self.layers = {'data': self.placeholder('data', 'float32', [None, None, 32]),
+                           'time_step_len': self.placeholder('time_step_len', 'int32', [None])}
+            self.trainable = True
+            self.setup()
+
+        def setup(self):
+            (self.feed('data').conv_single(3, 3, 64, 1, 1, name='c1', c_i=1).max_pool(2, 2, 2, 2, padding='VALID', name='p1')
+                 .max_pool(2, 2, 2, 2, padding='VALID', name='p2').max_pool(1, 2, 1, 2, padding='VALID', name='p3')
+                 .max_pool(1, 2, 1, 2, padding='VALID', name='p4')
+                 .conv_single(2, 2, 64, 1, 1, padding='VALID', name='c5', relu=False).reshape_squeeze_layer(d=64, name='rs'))
+            self.feed('rs', 'time_step_len').lstm(32, 3, name='logits')
+
+    net = Net()
+    order = [nd.name for nd in execution_order(net.get_output('logits'))]
+    assert order[-3:] == ['logits/rnn/multi_rnn_cell/cell_0', 'logits/rnn/multi_rnn_cell/cell_1', 'logits']
+    sp = net.param_specs
+    assert tuple(sp['logits/rnn/multi_rnn_cell/cell_0/lstm_cell/weights'].shape) == (64 + 32, 128)
+    assert tuple(sp['logits/rnn/multi_rnn_cell/cell_2/lstm_cell/weights'].shape) == (32 + 32, 128)
+    assert tuple(sp['logits/weights'].shape) == (32, cfg.NCLASSES) and sp['logits/weights'].regularized
+    assert sp['logits/weights'].init == ('truncated_normal', 0.1)
+    lay = FlatLayout(sp.values(), 64, order=order)
+    assert lay.owner['logits/rnn/multi_rnn_cell/cell_1/lstm_cell/biases'] == 'logits/rnn/multi_rnn_cell/cell_1'
+    assert lay.owner['logits/rnn/multi_rnn_cell/cell_2/lstm_cell/weights'] == 'logits'
+    params = host_parameters(net, 5)
+    assert float(params['logits/weights'].abs().max()) <= 0.2 + 1e-6          # truncated at two standard deviations
+    x = torch.rand(3, 64, 32, generator=torch.Generator().manual_seed(0))
+    lens = [15, 4, 9]
+    logits, inter = plan_exec.forward(net, params, x, lens, sim_bf16=False, keep=True)
+    assert tuple(logits.shape) == (15, 3, cfg.NCLASSES)
+    h0 = inter['logits/rnn/multi_rnn_cell/cell_0']
+    assert float(h0[1, 4:].abs().max()) == 0.0 and float(h0[1, :4].abs().max()) > 0.0
+    # past its length a sample's logits are the FC bias alone
+    assert torch.allclose(logits[4:, 1], params['logits/biases'].expand(11, -1), atol=1e-6)

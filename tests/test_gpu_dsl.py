@@ -108,6 +108,73 @@ def test_wide_dsl_network_matches_oracle(dev):
         cfg.TRAIN.WEIGHT_DECAY = old
 
 
+class UniLstmNet(WideDslNet):
+    """conv stack -> `lstm` (network.py:130-152): two stacked unidirectional LSTMCell(64) + FC, ragged lengths."""
+
+    def setup(self):
+        (self.feed('data').conv_single(3, 3, 64, 1, 1, name='c1', c_i=1).max_pool(2, 2, 2, 2, padding='VALID', name='p1')
+             .conv_single(3, 3, 64, 1, 1, name='c2').max_pool(2, 2, 2, 2, padding='VALID', name='p2')
+             .max_pool(1, 2, 1, 2, padding='VALID', name='p3').max_pool(1, 2, 1, 2, padding='VALID', name='p4')
+             .conv_single(2, 2, 128, 1, 1, padding='VALID', name='c5', relu=False)
+             .reshape_squeeze_layer(d=128, name='rs'))
+        self.feed('rs', 'time_step_len').lstm(64, 2, name='logits')
+
+
+def test_unidirectional_stacked_lstm_matches_oracle(dev):
+    old = cfg.TRAIN.WEIGHT_DECAY
+    cfg.TRAIN.WEIGHT_DECAY = 0.0
+    try:
+        net = UniLstmNet()
+        names = set(net.param_specs)
+        for li in range(2):                                   # TF-1.0 variable names of MultiRNNCell / dynamic_rnn
+            assert 'logits/rnn/multi_rnn_cell/cell_%d/lstm_cell/weights' % li in names
+        assert tuple(net.param_specs['logits/rnn/multi_rnn_cell/cell_1/lstm_cell/weights'].shape) == (64 + 64, 256)
+        assert tuple(net.param_specs['logits/weights'].shape) == (64, cfg.NCLASSES)
+        eng = Engine(net, device='cuda:0', seed=11)
+        g = torch.Generator().manual_seed(2)
+        arrays = {n: (0.1 * (torch.rand(sp.shape, generator=g) - 0.5)).numpy() for n, sp in eng.specs.items() if n.endswith('biases')}
+        eng.load_arrays(arrays)
+        params = {k: torch.from_numpy(v) for k, v in eng.state_arrays().items()}
+        rng = np.random.RandomState(5)
+        N, W = 16, 96
+        T = W // 4 - 1
+        x = rng.rand(N, W, 32).astype(np.float32)
+        sl = rng.randint(5, T + 1, N).astype(np.int32); sl[0] = T; sl[1] = 1
+        ll = np.minimum(rng.randint(1, 5, N), sl).astype(np.int32)
+        lab = rng.randint(1, 63, int(ll.sum())).astype(np.int32)
+        logits = eng.forward(x, sl).float().cpu()
+        ref = plan_exec.forward(net, params, torch.from_numpy(x), sl.tolist(), sim_bf16=True)
+        assert tuple(logits.shape) == (T, N, cfg.NCLASSES)
+        for n in range(N):
+            assert float((logits[:sl[n], n] - ref[:sl[n], n]).abs().max()) < 1e-2
+        leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        lg = plan_exec.forward(net, leaves, torch.from_numpy(x), sl.tolist(), sim_bf16=True)
+        costs = og._CTC.apply(lg, lab, ll, np.asarray(sl, np.int32))
+        costs.mean().backward()
+        sp = eng.plan(N, W)
+        eng._bind(sp, x, sl, lab, ll)
+        eng._run(sp, 'fb')
+        torch.cuda.synchronize()
+        dev_cost = float(sp.costs.cpu().numpy().mean())
+        assert abs(dev_cost - float(costs.mean())) / float(costs.mean()) < 2e-3, (dev_cost, float(costs.mean()))
+        bad = []
+        for name in eng.specs:
+            r = leaves[name].grad
+            if r is None or float(r.abs().max()) < 1e-9:
+                continue
+            e = l2(eng.grad(name).cpu(), r)
+            print('grad %-56s L2-rel %.3e' % (name, e))
+            if not e < 5e-3:                      # measured 3e-5 .. 6e-4 on MI355X (round 2)
+                bad.append((name, e))
+        assert not bad, bad
+        eng.setup_optimizer('Adam', 1e-3)
+        l0 = eng.train_step(x, lab, ll, sl)
+        l1 = [eng.train_step(x, lab, ll, sl) for _ in range(20)][-1]
+        assert np.isfinite(l1) and l1 < l0
+    finally:
+        cfg.TRAIN.WEIGHT_DECAY = old
+
+
 def test_dsl_kernels(dev):
     g = torch.Generator().manual_seed(2)
     r = lambda *s: torch.rand(*s, generator=g) * 2 - 1
