@@ -96,3 +96,20 @@ class GeneratorEnqueuer(object):
         if backend.processes:
             backend.queue.close()
         self._backend, self._workers, self.queue = None, [], None
+
+    def get(self):
+        """Generator over the queued items while the enqueuer runs (data_util.py:115-128): `None` items are skipped, an empty
+        queue is polled every `wait_time` seconds; ends when stop() is called, or when the source generator is exhausted and the
+        queue has been drained."""
+        while True:
+            q, running = self.queue, self.is_running()
+            if q is None:
+                return
+            try:
+                item = q.get(timeout=self.wait_time)
+            except queue.Empty:
+                if not running:             # source exhausted and queue drained (the reference drops what is still queued)
+                    return
+                continue
+            if item is not None:
+                yield item

@@ -127,6 +127,18 @@ def _resize(img, nw, nh):
     return np.array(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
 
 
+def padded_width(max_w):
+    """Width a batch is padded to: the widest sample rounded up to POOL_SCALE (gen.py:54), or — opt-in, OCR_WIDTH_BUCKET=b — to
+    the next multiple of b.  Bucketing bounds the number of distinct shapes (one engine plan + hipGraphs per width: <= 9 instead
+    of <= 61 for W in [80, 320] at b = 32) and evens out data-parallel ranks; per-sample time steps are unaffected, only
+    batch-norm statistics see the extra zero columns."""
+    q = cfg.POOL_SCALE
+    b = int(os.environ.get('OCR_WIDTH_BUCKET', '0') or 0)
+    if b > 0:
+        q = -(-b // cfg.POOL_SCALE) * cfg.POOL_SCALE
+    return int(math.ceil(max_w / q) * q)
+
+
 def groupBatch(imgs, labels):
     max_w = -sys.maxsize
     time_steps, label_len, label_vec, img_batch = [], [], [], []
@@ -139,7 +151,7 @@ def groupBatch(imgs, labels):
         time_steps.append(nw // cfg.POOL_SCALE + cfg.OFFSET_TIME_STEP)
         label_vec.extend(encode_maps[c] for c in labels[i])
         label_len.append(len(labels[i]))
-    max_w = int(math.ceil(max_w / cfg.POOL_SCALE) * cfg.POOL_SCALE)
+    max_w = padded_width(max_w)
     for img in imgs:
         w = img.shape[1]
         pad = [(0, 0), (0, max_w - w)] + [(0, 0)] * (img.ndim - 2)

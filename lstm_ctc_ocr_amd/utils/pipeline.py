@@ -71,7 +71,7 @@ def group_batch_u8(imgs, labels, layout, meta, pix):
         code = [gen.encode_maps[c] for c in labels[i]]
         meta[_HDR + i] = len(code)
         lab.extend(code)
-    W = int(-(-max_w // cfg.POOL_SCALE) * cfg.POOL_SCALE)
+    W = gen.padded_width(max_w)                      # POOL_SCALE, or the opt-in OCR_WIDTH_BUCKET
     if W > layout.max_w or len(lab) > B * layout.max_label:
         raise ValueError('batch does not fit its slot (W %d > %d or %d labels)' % (W, layout.max_w, len(lab)))
     out = pix[:B * W * cfg.NUM_FEATURES].reshape(B, W, cfg.NUM_FEATURES)
@@ -118,7 +118,7 @@ class SharedBatchRing(object):
         max_len = gen_kwargs.get('max_len') or cfg.MAX_LEN
         if max_w is None:
             canvas = 600 if gen_kwargs.get('px_per_char') else gen_kwargs.get('width', 160)
-            max_w = -(-int(cfg.IMG_HEIGHT / 60.0 * canvas + 1) // cfg.POOL_SCALE) * cfg.POOL_SCALE
+            max_w = gen.padded_width(int(cfg.IMG_HEIGHT / 60.0 * canvas + 1))
         self.layout = SlotLayout(batch_size, max_w, max_label or max_len)
         self.pool = int(pool)
         self.nslots = self.pool or slots or max(4, 2 * workers)

@@ -40,6 +40,25 @@ def test_enqueuer_threads():
     assert not e.is_running()
 
 
+def test_enqueuer_get_generator():
+    """GeneratorEnqueuer.get() (data_util.py:115-128): a generator over the queue that skips None and ends with the enqueuer."""
+    from lstm_ctc_ocr_amd.utils.data_util import GeneratorEnqueuer
+
+    def src():
+        for i in range(6):
+            yield None if i == 2 else i
+    enq = GeneratorEnqueuer(src(), use_multiprocessing=False, wait_time=0.01)
+    enq.start(workers=1, max_queue_size=4)
+    got = []
+    for item in enq.get():
+        got.append(item)
+        if len(got) == 5:
+            break
+    enq.stop()
+    assert got == [0, 1, 3, 4, 5]
+    assert list(enq.get()) == []              # stopped: nothing more
+
+
 def test_data_streams_differ_per_rank_and_per_stream(monkeypatch):
     """Round-1 finding: every data-parallel rank drew the SAME samples (and the validation batch replayed the first training
     batch).  Seeds now depend on $RANK and on the stream kind; two ranks' first batches and train/val batches differ."""
@@ -111,3 +130,18 @@ def test_pool_mode_cycles_a_fixed_dataset():
             assert int(ring.slot(i)['pixels'].sum()) == sums[i]      # never re-rendered
     finally:
         ring.close()
+
+
+def test_width_bucketing_is_opt_in(monkeypatch):
+    """OCR_WIDTH_BUCKET=32 pads every batch to a multiple of 32 columns (fewer engine plans, even data-parallel ranks); the
+    default stays the reference's POOL_SCALE rounding (gen.py:54) and per-sample time steps never change."""
+    from lstm_ctc_ocr_amd.utils import gen
+    rng = np.random.RandomState(0)
+    imgs = [rng.randint(0, 255, (60, w), dtype=np.uint8) for w in (160, 200, 333)]
+    labels = ['ab', 'cde', 'f']
+    batch, _, _, steps = gen.groupBatch([i.copy() for i in imgs], labels)
+    assert batch[0].shape[0] == 180 and steps == [85 // 4 - 1 + 0 * 1, 106 // 4 - 1, 177 // 4 - 1]
+    monkeypatch.setenv('OCR_WIDTH_BUCKET', '32')
+    batch2, _, _, steps2 = gen.groupBatch([i.copy() for i in imgs], labels)
+    assert batch2[0].shape[0] == 192 and steps2 == steps
+    assert np.array_equal(batch2[2][:180], batch[2]) and float(np.abs(batch2[2][180:]).max()) == 0.0
