@@ -101,7 +101,8 @@ int ocr_conv1_fwd(const float* x, const float* w, const float* bias, void* y, in
                   int relu, void* stream);
 int ocr_conv1_wgrad(const float* x, const void* dz, float* dw, float* db, int Nb, int W, int H, int Cout,
                     void* stream);
-/* element-wise bf16 (n % 8 == 0): op 0 out = a + b (Network.add), 1 out = relu(a) (Network.relu), 2 out = b > 0 ? a : 0 */
+/* element-wise bf16 (n % 8 == 0): op 0 out = a + b (Network.add), 1 out = relu(a) (Network.relu), 2 out = b > 0 ? a : 0,
+ * 3 out = relu(a + b) (add + relu of a residual block in one pass), 4 out += b > 0 ? a : 0 (ReLU backward accumulated) */
 int ocr_eltwise_bf16(int op, const void* a, const void* b, void* out, long n, void* stream);
 /* conv1 + ReLU + 2x2 max-pool in one pass (LSTM_train.py:24-25); the backward recomputes the window instead of reading a
  * stored 67 MB activation: p / dp are the POOLED map [Nb, W/2, H/2, Cout] */

@@ -276,7 +276,9 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
         const long mt4 = (M + 127) / 128;
         if (NRp / 32 == 5 || NRp / 32 == 6) {                                // counted vmcnt literals exist for 5 and 6
             if (Cout >= 128 && mt4 * ((Cout + 127) / 128) >= 448) return launch_halo<128, 4>(g, stream);
-            if (mt4 * ((Cout + 63) / 64) >= 448 || nw == 4) return launch_halo<64, 4>(g, stream);
+            // otherwise the smallest tile: it has the most workgroups, and every alternative below leaves CUs idle (a 256-channel
+            // layer at M = 8192 is 256 workgroups here against 64 of the 8-wave 256 x 128 tile)
+            if (nw != 8) return launch_halo<64, 4>(g, stream);
         } else if (nw == 4) return -1;
     }
     const int NRpad = (256 + 2 * H + 2 + 64) / 64 * 64;

@@ -759,15 +759,23 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
 // ============================================================================================
 // element-wise bf16 helpers for residual graphs (Network.add network.py:461-463, Network.relu :340-341)
 //   op 0: out = a + b        op 1: out = max(a, 0)        op 2: out = (b > 0) ? a : 0   (ReLU backward: a = dy, b = y)
+//   op 3: out = max(a + b, 0)  (residual add + ReLU)        op 4: out += (b > 0) ? a : 0   (ReLU backward accumulated into out)
 // ============================================================================================
 __global__ __launch_bounds__(256) void eltwise_bf16_kernel(int op, const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                                            bf16_t* __restrict__ out, long n8) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-        float x[8], y[8], o[8];
+        float x[8], y[8], o[8], z[8];
         unpack8(*(const u32x4*)(a + i * 8), x);
         if (op != 1) unpack8(*(const u32x4*)(b + i * 8), y);
+        if (op == 4) unpack8(*(const u32x4*)(out + i * 8), z);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) o[c] = (op == 0) ? x[c] + y[c] : (op == 1 ? fmaxf(x[c], 0.f) : (y[c] > 0.f ? x[c] : 0.f));
+        for (int c = 0; c < 8; ++c) {
+            if (op == 0) o[c] = x[c] + y[c];
+            else if (op == 1) o[c] = fmaxf(x[c], 0.f);
+            else if (op == 2) o[c] = y[c] > 0.f ? x[c] : 0.f;
+            else if (op == 3) o[c] = fmaxf(x[c] + y[c], 0.f);         // = relu(bf16(a + b)): rounding is monotone and keeps the sign
+            else o[c] = z[c] + (y[c] > 0.f ? x[c] : 0.f);
+        }
         u32x4 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
         *(u32x4*)(out + i * 8) = pk;
     }
@@ -803,7 +811,7 @@ extern "C" int ocr_conv1_wgrad(const float* x, const void* dz, float* dw, float*
     return OCR_OK;
 }
 extern "C" int ocr_eltwise_bf16(int op, const void* a, const void* b, void* out, long n, void* stream) {
-    if (!a || !out || (op != 1 && !b) || op < 0 || op > 2 || n <= 0 || (n & 7)) return OCR_ERR_INVALID;
+    if (!a || !out || (op != 1 && !b) || op < 0 || op > 4 || n <= 0 || (n & 7)) return OCR_ERR_INVALID;
     eltwise_bf16_kernel<<<grid_for(n / 8, 4096), 256, 0, (hipStream_t)stream>>>(op, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / 8);
     OCR_CHECK_LAUNCH();
     return OCR_OK;

@@ -340,12 +340,14 @@ class _AddOp(_Op):
         sp.buf[self.key + '/y'] = torch.empty(s, dtype=BF16, device=self.eng.device)
         sp.buf[self.key + '/dy'] = torch.empty(s, dtype=BF16, device=self.eng.device)
 
+    relu = False               # True: the Network.relu that follows (its only consumer) is computed here, y = relu(a + b)
+
     def fwd(self, sp):
-        ops.eltwise(0, self.inputs[0].y(sp), self.inputs[1].y(sp), self.y(sp))
+        ops.eltwise(3 if self.relu else 0, self.inputs[0].y(sp), self.inputs[1].y(sp), self.y(sp))
 
     def bwd(self, sp):
         for p in self.inputs:
-            self.eng.deliver(sp, p, self.dy(sp))
+            self.eng.deliver(sp, p, self.dy(sp), mask=self.y(sp) if self.relu else None)
 
 
 class _ReluOp(_Op):
@@ -357,16 +359,30 @@ class _ReluOp(_Op):
     def out_shape(self, s):
         return s
 
+    fused_into = None          # the _AddOp that computes relu(a + b) itself: this op is then a view of it (no buffers, no launches)
+
     def alloc(self, sp, s):
         sp.shape[self.key] = (s, s)
-        sp.buf[self.key + '/y'] = torch.empty(s, dtype=BF16, device=self.eng.device)
-        sp.buf[self.key + '/dy'] = torch.empty(s, dtype=BF16, device=self.eng.device)
+        if self.fused_into is None:
+            sp.buf[self.key + '/y'] = torch.empty(s, dtype=BF16, device=self.eng.device)
+            sp.buf[self.key + '/dy'] = torch.empty(s, dtype=BF16, device=self.eng.device)
+
+    def y(self, sp):
+        return self.fused_into.y(sp) if self.fused_into is not None else sp.buf[self.key + '/y']
+
+    def dy(self, sp):
+        return self.fused_into.dy(sp) if self.fused_into is not None else sp.buf[self.key + '/dy']
+
+    def grad_owner(self):
+        return self.fused_into.grad_owner() if self.fused_into is not None else self
 
     def fwd(self, sp):
-        ops.eltwise(1, self.prev.y(sp), None, self.y(sp))
+        if self.fused_into is None:
+            ops.eltwise(1, self.prev.y(sp), None, self.y(sp))
 
     def bwd(self, sp):
-        self.eng.deliver(sp, self.prev, self.dy(sp), mask=self.y(sp))
+        if self.fused_into is None:
+            self.eng.deliver(sp, self.prev, self.dy(sp), mask=self.y(sp))
 
 
 class _SubsampleOp(_Op):
@@ -961,6 +977,13 @@ class Engine(object):
                 self.ops.append(sub)
                 op = sub
             built[id(nd)] = op
+        if os.environ.get('OCR_FUSE_ADD_RELU', '1') != '0':
+            # residual blocks: add -> relu (the add's only consumer) as ONE pass forward, and one masked delivery per input backward
+            for r in self.ops:
+                a = r.prev
+                if isinstance(r, _ReluOp) and isinstance(a, _AddOp) and a.consumers == 1:
+                    a.relu, r.fused_into = True, a
+                    a.consumers = r.consumers
         if self.fuse_conv1_pool:
             for a, b in zip(self.ops[:-1], self.ops[1:]):
                 if (isinstance(a, _ConvOp) and a.kind == 'c1' and a.relu and isinstance(b, _PoolOp) and b.prev is a
@@ -1007,9 +1030,7 @@ class Engine(object):
         elif mask is None:
             ops.eltwise(0, d, g, d)
         else:
-            tmp = self._scratch(sp, d)
-            ops.eltwise(2, g, mask.view(d.shape), tmp)
-            ops.eltwise(0, d, tmp, d)
+            ops.eltwise(4, g, mask.view(d.shape), d)        # d += mask > 0 ? g : 0
 
     def plan(self, N, W):
         key = (N, W)

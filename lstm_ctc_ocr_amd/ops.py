@@ -183,7 +183,8 @@ def conv1_wgrad(x, dz, dw, db):
 
 
 def eltwise(op, a, b, out):
-    """op 0: out = a + b ; 1: out = relu(a) ; 2: out = (b > 0) ? a : 0   (bf16, numel % 8 == 0)"""
+    """op 0: out = a + b ; 1: out = relu(a) ; 2: out = (b > 0) ? a : 0 ; 3: out = relu(a + b) ; 4: out += (b > 0) ? a : 0
+    (bf16, numel % 8 == 0)"""
     call("ocr_eltwise_bf16", op, ptr(_dev(a)), ptr(b), ptr(out), a.numel(), _st())
     return out
 

@@ -183,6 +183,19 @@ def test_dsl_kernels(dev):
     out = torch.empty_like(a, device=dev)
     ops.softmax(a.to(dev), out)
     assert float((out.cpu() - torch.softmax(a, -1)).abs().max()) < 1e-6
+    # element-wise: add, relu, relu-mask, fused add+relu (== relu of the bf16-rounded sum), masked accumulate
+    ea, eb = r(4, 33, 8, 16).to(BF), r(4, 33, 8, 16).to(BF)
+    eo = torch.empty_like(ea, device=dev)
+    ops.eltwise(0, ea.to(dev), eb.to(dev), eo)
+    assert torch.equal(eo.cpu(), (ea.float() + eb.float()).to(BF))
+    ops.eltwise(3, ea.to(dev), eb.to(dev), eo)
+    assert torch.equal(eo.cpu(), torch.relu((ea.float() + eb.float()).to(BF)))
+    ops.eltwise(2, ea.to(dev), eb.to(dev), eo)
+    assert torch.equal(eo.cpu(), torch.where(eb.float() > 0, ea, torch.zeros_like(ea)))
+    acc = r(4, 33, 8, 16).to(BF)
+    eacc = acc.to(dev).clone()
+    ops.eltwise(4, ea.to(dev), eb.to(dev), eacc)
+    assert torch.equal(eacc.cpu(), (acc.float() + torch.where(eb.float() > 0, ea.float(), torch.zeros(()))).to(BF))
     # strided pick and its transpose are adjoint; TF SAME geometry for k = 3, s = 2: offset 1 on an even axis, 0 on an odd one
     Nb, W, H, C = 3, 9, 8, 16
     x = r(Nb, W, H, C).to(BF)
