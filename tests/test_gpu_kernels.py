@@ -406,7 +406,7 @@ def test_maxpool(dev, kw, kh):
     assert maxerr(dx.float().cpu(), xr.grad * (x > 0)) == 0.0
 
 
-@pytest.mark.parametrize("M,C", [(16384, 512), (1000, 64)])
+@pytest.mark.parametrize("M,C", [(16384, 512), (1000, 64), (4096, 512), (65536, 64), (8200, 128)])   # > 4 M elements: three launches; else two
 def test_batchnorm(dev, M, C):
     x = bf(gen((M, C), 1) * 2 + 0.5); gamma = gen((C,), 2) + 1.5; beta = gen((C,), 3)
     xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
