@@ -1126,7 +1126,10 @@ class Engine(object):
         was = gc.isenabled()
         gc.disable()
         try:
-            with torch.cuda.graph(g):
+            # thread_local: other threads keep issuing work while this one captures — the input pipeline's feeder thread (H2D copies
+            # on its own stream) and, with several ranks, RCCL's watchdog; in the default global mode any of their calls may
+            # invalidate the capture
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 fn()
         finally:
             if was:
