@@ -210,6 +210,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = eng.last_loss()
+    dp_check = None
+    if world > 1:
+        # data-parallel self-check on the hardware the line was measured on: every rank applied the same all-reduced gradient, so
+        # the replicas' parameters must be bit-identical; their data streams are rank-seeded, so their local losses must differ
+        chk = torch.stack([eng.params.double().sum(), eng.params.double().abs().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ls = torch.tensor([loss], dtype=torch.float64, device=device)
+        llo, lhi = ls.clone(), ls.clone()
+        dist.all_reduce(llo, op=dist.ReduceOp.MIN); dist.all_reduce(lhi, op=dist.ReduceOp.MAX)
+        dp_check = {"replicas_bit_identical": bool(torch.equal(lo, hi)), "local_loss_min": float(llo.item()), "local_loss_max": float(lhi.item())}
     # the same loop the way lib/lstm/train.py:130,139 runs it — the loss is fetched (one host sync) after EVERY step; reported
     # beside `value`, never as `value`
     torch.cuda.synchronize()
@@ -235,6 +246,7 @@ def main():
                                     "(BASELINE.json configs[4])"),
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world, "hipgraph": not args.no_graphs},
             "final_loss": loss,
+            "dp_check": dp_check,
             "with_loss_fetch_every_step": {"value": BATCH * world * args.steps / dt_fetch, "ms_per_step": dt_fetch / args.steps * 1e3},
             "model_tflops_per_gpu": value / world * TRAIN_GFLOP_PER_IMG * 1e9 / 1e12,
         }
