@@ -74,6 +74,12 @@ int ocr_set_gemm_engine(int use_large_tile);
  * (conv_single network.py:160-191; also its data gradient with flipped/transposed weights) */
 int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int Nb, int W, int H, int Cin, int Cout,
                      const float* bias, const void* mask, int flags, void* stream);
+/* conv3x3 + bias + ReLU AND the max-pool behind it from one epilogue (LSTM_train.py:26-33): y [Nb,W,H,Cout] and pooled
+ * [Nb, W/kw, H/kh, Cout]; (kw, kh) = (1, 2) (feature axis) or (2, 2).  ocr_conv3x3_pool_supported() != 0 tells whether the shape is
+ * covered; otherwise run ocr_conv3x3_bf16 + ocr_maxpool_fwd (ocr_conv3x3_relu_pool_bf16 then returns 2). */
+int ocr_conv3x3_pool_supported(int Nb, int W, int H, int Cin, int Cout, int kw, int kh);
+int ocr_conv3x3_relu_pool_bf16(const void* x, const void* wpack, void* y, void* pooled, int Nb, int W, int H, int Cin, int Cout,
+                               const float* bias, int kw, int kh, void* stream);
 /* out[I][ldo] (f32) += scale * A^T B, A bf16 [Mk][lda], B bf16 [Mk][ldb]  (weight gradients of matmul layers);
  * colsum (may be NULL): colsum[j] += scale * sum_m B[m][j] — the bias gradient, produced by the same pass */
 int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* out, long ldo, int Mk, int I, int J,

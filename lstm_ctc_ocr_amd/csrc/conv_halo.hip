@@ -23,6 +23,7 @@ struct HaloArgs {
     int M, N, C;                          // C % 64 == 0
     int cW, cH;
     bf16_t* out; const float* bias; const bf16_t* mask; int flags;
+    bf16_t* pool; int pool_kind;          // max-pool of the (ReLU'd) output written by the same epilogue: 0 none, 1 feature pairs (1 x 2), 2 2 x 2
 };
 
 __device__ u32x4 igh_zero_page[4];
@@ -229,6 +230,34 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             pk.x = pack_bf2(v.x, v.y);
             pk.y = pack_bf2(v.z, v.w);
             *(u32x2*)(g.out + (long)m * g.N + n) = pk;
+            if (g.pool_kind) {
+                // max-pool window of this pixel (max_pool after the ReLU: LSTM_train.py:27-33).  Rounding to bf16 is monotone, so
+                // the max of the fp32 values, rounded, is the max of the stored bf16 values.  Feature-axis neighbour = pixel m ^ 1 =
+                // lane ^ 1; time-axis neighbour = pixel m +- H: lane ^ H for H = 4, 8, the same lane of fragment b ^ 1 for H = 16.
+                // (M is a multiple of 2 H, tiles start at multiples of 32 pixels: a window never straddles tiles or the m < M bound.)
+                f32x4 mx = v;
+                if (g.pool_kind == 2) {
+                    if (H == 16) {
+                        f32x4 u = acc[a][b ^ 1] + bv[a];
+                        u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
+                        mx.x = fmaxf(mx.x, u.x); mx.y = fmaxf(mx.y, u.y); mx.z = fmaxf(mx.z, u.z); mx.w = fmaxf(mx.w, u.w);
+                    } else {
+                        mx.x = fmaxf(mx.x, __shfl_xor(mx.x, H, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, H, 64));
+                        mx.z = fmaxf(mx.z, __shfl_xor(mx.z, H, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, H, 64));
+                    }
+                }
+                mx.x = fmaxf(mx.x, __shfl_xor(mx.x, 1, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, 1, 64));
+                mx.z = fmaxf(mx.z, __shfl_xor(mx.z, 1, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, 1, 64));
+                const int h = m % H, col = m / H;
+                const bool writer = !(h & 1) && (g.pool_kind == 1 || !(col & 1));
+                if (writer) {
+                    const long pidx = g.pool_kind == 1 ? (long)(m >> 1) : (long)(col >> 1) * (H >> 1) + (h >> 1);
+                    u32x2 pp;
+                    pp.x = pack_bf2(mx.x, mx.y);
+                    pp.y = pack_bf2(mx.z, mx.w);
+                    *(u32x2*)(g.pool + pidx * g.N + n) = pp;
+                }
+            }
         }
     }
 }
@@ -262,15 +291,21 @@ static int launch_halo(const HaloArgs& g, hipStream_t stream) {
 
 // -1 = shape not covered (caller falls back to igemm.hip / gemm.hip)
 int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
-                      const void* mask, int flags, hipStream_t stream) {
+                      const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind) {
     if ((Cin & 63) || (Cout & 3) || M < 1024 || H > 30) return -1;
     if (flags & ~(IGH_BIAS | IGH_RELU | IGH_MASK)) return -1;
+    if (pool_kind) {         // fused max-pool: ReLU epilogue without mask, even feature axis, 2 x 2 only for H in {4, 8, 16} and even W
+        if (!pool || (flags & IGH_MASK) || !(flags & IGH_RELU) || (H & 1) || (Cout & 3) || (Cout % 64 && Cout % 128)) return -1;
+        if (pool_kind == 2 && ((H != 4 && H != 8 && H != 16) || (W & 1))) return -1;
+        if (pool_kind != 1 && pool_kind != 2) return -1;
+        if (M % (pool_kind == 2 ? 2 * H : 2)) return -1;
+    }
     // Tile choice.  128-pixel workgroups of 4 waves leave room for TWO workgroups per CU (80 KiB of LDS each): they drift out
     // of phase, so one's MFMA burst covers the other's barrier / DMA-issue / LDS-read phase (+5-7 % where the grid then still
     // has two workgroups for every CU).  Otherwise 256-pixel workgroups of 8 waves, one per CU.
     static int nw = -1;                                  // A/B knob OCR_HALO_NW: 8 / 4 force one kind, unset = by grid size
     if (nw < 0) { const char* e = getenv("OCR_HALO_NW"); nw = e ? atoi(e) : 0; }
-    HaloArgs g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags};
+    HaloArgs g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind};
     if (nw != 8) {
         const int NR = 128 + 2 * H + 2, NRp = (NR + 32) / 32 * 32;
         const long mt4 = (M + 127) / 128;

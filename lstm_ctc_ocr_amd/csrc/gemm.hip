@@ -255,7 +255,7 @@ int ig_try_dispatch(const void* P, long ldp, const void* Q, long ldq, void* out,
                     const float* bias, const void* mask, long ldmask, int flags, int mode, int grp, int skip, int cW,
                     int cH, int cC, int swap_inner, int swap_outer, hipStream_t stream);
 int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
-                      const void* mask, int flags, hipStream_t stream);
+                      const void* mask, int flags, hipStream_t stream, void* pool = nullptr, int pool_kind = 0);
 int pp_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
                     const void* mask, int flags, hipStream_t stream);
 static int g_use_igemm = 1, g_use_halo = 1, g_use_pp = 0;
@@ -319,4 +319,24 @@ extern "C" int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int N
         if (rc >= 0) return rc;
     }
     return dispatch_gemm(g, 1, 1, (hipStream_t)stream);
+}
+// conv3x3 + bias + ReLU with the max-pool that follows it (LSTM_train.py:26-33: conv2 -> pool2 2 x 2, conv3_2 / conv4_2 -> 1 x 2
+// over the feature axis) written by the same epilogue: y (kept for the backward pass) AND pooled.  kw = window along W (time),
+// kh = window along H (feature): (1, 2) or (2, 2).  Only the halo kernel has this epilogue: OCR_ERR_INVALID when the shape is
+// not covered (ocr_conv3x3_pool_supported tells beforehand) - the caller then runs ocr_conv3x3_bf16 + ocr_maxpool_fwd.
+static int conv3x3_pool_kind(int kw, int kh) { return (kw == 1 && kh == 2) ? 1 : ((kw == 2 && kh == 2) ? 2 : 0); }
+extern "C" int ocr_conv3x3_pool_supported(int Nb, int W, int H, int Cin, int Cout, int kw, int kh) {
+    const long M = (long)Nb * W * H;
+    const int kind = conv3x3_pool_kind(kw, kh);
+    if (!g_use_halo || g_use_pp || !kind || (Cin & 63) || (Cout & 63) || M < 1024 || M > 0x7fffffffL || H > 30 || (H & 1)) return 0;
+    if (kind == 2 && ((H != 4 && H != 8 && H != 16) || (W & 1))) return 0;
+    const int NR = 128 + 2 * H + 2, NRp = (NR + 32) / 32 * 32;           // the 4-wave instances (counted vmcnt literals for 5 and 6)
+    return NRp / 32 == 5 || NRp / 32 == 6;
+}
+extern "C" int ocr_conv3x3_relu_pool_bf16(const void* x, const void* wpack, void* y, void* pooled, int Nb, int W, int H, int Cin,
+                                          int Cout, const float* bias, int kw, int kh, void* stream) {
+    if (!x || !wpack || !y || !pooled || !bias || !ocr_conv3x3_pool_supported(Nb, W, H, Cin, Cout, kw, kh)) return OCR_ERR_INVALID;
+    int rc = halo_try_dispatch(x, wpack, y, Nb * W * H, W, H, Cin, Cout, bias, nullptr, EPI_BIAS | EPI_RELU, (hipStream_t)stream, pooled,
+                               conv3x3_pool_kind(kw, kh));
+    return rc >= 0 ? rc : OCR_ERR_INVALID;
 }

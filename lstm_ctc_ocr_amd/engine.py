@@ -135,6 +135,8 @@ class _ConvOp(_Op):
         return (N, W, H, self.co)
 
     fused_pool = None          # set by Engine._lower: conv1 + ReLU + 2x2 max-pool run as one kernel, no full-res activation
+    pool_after = None          # set by Engine._lower: the max-pool that follows this 3x3 conv + ReLU; where the shape allows, the conv's
+                               # epilogue writes the pooled tensor too (the full-resolution output is still kept for the backward pass)
 
     def alloc(self, sp, s):
         o = self.out_shape(s)
@@ -153,6 +155,11 @@ class _ConvOp(_Op):
         if self.kind == 'full':
             N, W, H, C = s
             sp.buf[self.key + '/col'] = torch.empty((N * o[1], self.kh * H * C), dtype=BF16, device=dev)
+        if self.pool_after is not None:
+            p = self.pool_after
+            sp.fused_pools = getattr(sp, 'fused_pools', set())
+            if ops.conv3x3_pool_supported(s[0], s[1], s[2], self.ci, self.co, p.kw_t, p.kh_f):
+                sp.fused_pools.add(p.key)
         if self.kind == '3x3':      # scratch of the slab weight-gradient kernel: one buffer per plan, shared by all layers (one stream)
             need = ops.conv3x3_wgrad_workspace_bytes(s[0], s[1], s[2], self.ci, self.co)
             have = sp.buf.get('wgrad_ws')
@@ -183,7 +190,10 @@ class _ConvOp(_Op):
             return
         tgt = sp.buf[self.key + '/z'] if self.bn else y
         relu_now = self.relu and not self.bn
-        if self.kind == '3x3':
+        if self.kind == '3x3' and self.pool_after is not None and self.pool_after.key in sp.fused_pools:
+            p = self.pool_after
+            ops.conv3x3_relu_pool(x, self.wpack.view(self.co, 3, 3, self.ci), y, p.y(sp), bias, p.kw_t, p.kh_f)
+        elif self.kind == '3x3':
             ops.conv3x3(x, self.wpack.view(self.co, 3, 3, self.ci), out=tgt, bias=bias, relu=relu_now)
         elif self.kind == '1x1':
             Mx = s[0] * s[1] * s[2]
@@ -284,7 +294,7 @@ class _PoolOp(_Op):
     fused_into = None          # the conv1 op that computes this pool's output itself
 
     def fwd(self, sp):
-        if self.fused_into is None:
+        if self.fused_into is None and self.key not in getattr(sp, 'fused_pools', ()):      # else: written by the producing conv's epilogue
             ops.maxpool_fwd(self.prev.y(sp), self.kw_t, self.kh_f, out=self.y(sp))
 
     def bwd(self, sp):
@@ -984,6 +994,12 @@ class Engine(object):
                 if isinstance(r, _ReluOp) and isinstance(a, _AddOp) and a.consumers == 1:
                     a.relu, r.fused_into = True, a
                     a.consumers = r.consumers
+        if os.environ.get('OCR_FUSE_CONV_POOL', '1') != '0':
+            for b in self.ops:
+                a = b.prev
+                if (isinstance(b, _PoolOp) and isinstance(a, _ConvOp) and a.kind == '3x3' and a.relu and not a.bn and a.biased
+                        and a.consumers == 1 and (b.kw_t, b.kh_f) in ((1, 2), (2, 2))):
+                    a.pool_after = b
         if self.fuse_conv1_pool:
             for a, b in zip(self.ops[:-1], self.ops[1:]):
                 if (isinstance(a, _ConvOp) and a.kind == 'c1' and a.relu and isinstance(b, _PoolOp) and b.prev is a

@@ -120,6 +120,18 @@ def conv3x3(x, wpack, out=None, *, bias=None, relu=False, mask=None):
     return out
 
 
+def conv3x3_pool_supported(Nb, W, H, Cin, Cout, kw, kh):
+    return bool(nat.lib().ocr_conv3x3_pool_supported(Nb, W, H, Cin, Cout, kw, kh))
+
+
+def conv3x3_relu_pool(x, wpack, out, pooled, bias, kw, kh):
+    """out = relu(conv3x3(x) + bias) and pooled = max_pool(out, window (kw along W, kh along H)) from one launch."""
+    Nb, W, H, Cin = x.shape
+    call("ocr_conv3x3_relu_pool_bf16", ptr(_dev(x)), ptr(wpack), ptr(out), ptr(pooled), Nb, W, H, Cin, wpack.shape[0], ptr(bias),
+         kw, kh, _st())
+    return out, pooled
+
+
 def gemm_tn(A, B, out, *, Mk=None, I=None, J=None, lda=None, ldb=None, ldo=None, row_group=0, row_skip=0,
             a_row_off=0, scale=1.0, splits=0, colsum=None):
     """out[I][J] (f32) += scale * A^T B;  colsum[J] += scale * column sums of B (bias gradient) when given."""

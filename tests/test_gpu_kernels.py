@@ -406,6 +406,36 @@ def test_maxpool(dev, kw, kh):
     assert maxerr(dx.float().cpu(), xr.grad * (x > 0)) == 0.0
 
 
+@pytest.mark.parametrize("Nb,W,H,Ci,Co,kw,kh", [(64, 128, 16, 64, 128, 2, 2), (64, 64, 8, 256, 256, 1, 2), (64, 64, 4, 512, 512, 1, 2),
+                                               (8, 64, 8, 64, 64, 2, 2), (16, 32, 4, 128, 192, 2, 2), (5, 26, 16, 64, 64, 1, 2),
+                                               (3, 40, 10, 64, 128, 1, 2)])
+def test_conv3x3_relu_pool_fused_equals_unfused(dev, Nb, W, H, Ci, Co, kw, kh):
+    """conv + bias + ReLU with the following max-pool written by the same epilogue (LSTM_train.py:26-33): the full-resolution output
+    and the pooled tensor are bit-identical to conv3x3 followed by maxpool_fwd."""
+    if not ops.conv3x3_pool_supported(Nb, W, H, Ci, Co, kw, kh):
+        pytest.skip("shape not covered by the fused epilogue")
+    x = gen((Nb, W, H, Ci), 1).to(dev).to(BF)
+    wp = (gen((Co, 3, 3, Ci), 2) * 0.05).to(dev).to(BF)
+    b = gen((Co,), 3).to(dev)
+    y0 = ops.conv3x3(x, wp, bias=b, relu=True)
+    p0 = ops.maxpool_fwd(y0, kw, kh)
+    y1 = torch.full_like(y0, 7.0)
+    p1 = torch.full_like(p0, 7.0)
+    ops.conv3x3_relu_pool(x, wp, y1, p1, b, kw, kh)
+    assert torch.equal(y1, y0) and torch.equal(p1, p0)
+    assert float(p0.float().abs().max()) > 0
+
+
+def test_conv3x3_pool_fusion_refuses_uncovered_shapes(dev):
+    from lstm_ctc_ocr_amd._native import NativeError
+    assert not ops.conv3x3_pool_supported(4, 32, 16, 32, 64, 2, 2)          # C_in % 64
+    assert not ops.conv3x3_pool_supported(4, 33, 16, 64, 64, 2, 2)          # odd W for a 2 x 2 window
+    assert not ops.conv3x3_pool_supported(4, 32, 16, 64, 64, 2, 1)          # window along W only
+    x = torch.zeros(4, 33, 16, 64, dtype=BF, device=dev); wp = torch.zeros(64, 3, 3, 64, dtype=BF, device=dev)
+    with pytest.raises(NativeError):
+        ops.conv3x3_relu_pool(x, wp, torch.empty_like(x), torch.empty(4, 16, 8, 64, dtype=BF, device=dev), torch.zeros(64, device=dev), 2, 2)
+
+
 @pytest.mark.parametrize("M,C", [(16384, 512), (1000, 64), (4096, 512), (65536, 64), (8200, 128)])   # > 4 M elements: three launches; else two
 def test_batchnorm(dev, M, C):
     x = bf(gen((M, C), 1) * 2 + 0.5); gamma = gen((C,), 2) + 1.5; beta = gen((C,), 3)
