@@ -535,7 +535,8 @@ def test_lstm_fwd_bwd(dev, N, T, D, U, lens, persistent):
     ref = torch.cat([fw, bw], 2)
     st = _lstm_device_forward(dev, x, seq_len, Ws, bs, U, persistent)
     got = st["hout"].float().cpu().reshape(N, T, 2 * U)
-    assert maxerr(got, ref.detach()) < 2e-2, maxerr(got, ref.detach())
+    # measured on MI355X (round 2): <= 3.9e-3 = one bf16 ulp of |h| in [0.5, 1) (a rounding flip of the stored h), usually 0 .. 1e-3
+    assert maxerr(got, ref.detach()) < 8e-3, maxerr(got, ref.detach())
     # ---- backward
     dh = bf(gen((N, T, 2 * U), 9))
     ref.backward(dh)
@@ -560,13 +561,15 @@ def test_lstm_fwd_bwd(dev, N, T, D, U, lens, persistent):
         dW = torch.zeros((D + U, 4 * U), device=dev); dbias = torch.zeros(4 * U, device=dev)
         ops.gemm_tn(st["xd"], dz[:, d * 4 * U:(d + 1) * 4 * U], dW[:D], Mk=R, I=D, J=4 * U, lda=D, ldb=8 * U, ldo=4 * U, colsum=dbias)
         ops.gemm_tn(hprev[d], dz[:, d * 4 * U:(d + 1) * 4 * U], dW[D:], Mk=R, I=U, J=4 * U, lda=U, ldb=8 * U, ldo=4 * U)
-        assert relerr(dW.cpu(), Wr[d].grad) < 3e-2, ("dW", d, relerr(dW.cpu(), Wr[d].grad))
-        assert relerr(dbias.cpu(), br[d].grad) < 3e-2, ("db", d, relerr(dbias.cpu(), br[d].grad))
+        # max-abs error relative to the largest entry; measured 1.6e-3 .. 4.3e-3 (dW), 1.2e-3 .. 3.1e-3 (db), 3.2e-3 .. 4.3e-3 (dx):
+        # bf16 storage of dz and dh
+        assert relerr(dW.cpu(), Wr[d].grad) < 1e-2, ("dW", d, relerr(dW.cpu(), Wr[d].grad))
+        assert relerr(dbias.cpu(), br[d].grad) < 1e-2, ("db", d, relerr(dbias.cpu(), br[d].grad))
     wcat = torch.empty((D, 8 * U), dtype=BF, device=dev)
     for d in range(2):
         ops.cast2d_bf16(Ws[d].to(dev), 4 * U, wcat[:, d * 4 * U:], 8 * U, D, 4 * U)
     dx = ops.gemm_nt(dz, wcat)
-    assert relerr(dx.float().cpu().reshape(N, T, D), xr.grad) < 3e-2
+    assert relerr(dx.float().cpu().reshape(N, T, D), xr.grad) < 1e-2
 
 
 # ------------------------------------------------------------------------------------------- optimiser
