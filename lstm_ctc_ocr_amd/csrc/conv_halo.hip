@@ -31,9 +31,10 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int BN, int NW /* waves per workgroup: 8 (256 pixels, one workgroup per CU) or 4 (128 pixels, two per CU) */,
-          int ABL = 0 /* timing ablations (wrong results): 1 no fragment reads, 2 no DMA after the prologue, 5 neither (MFMA + barrier only) */>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 8 * NW */) {
-    constexpr int BM = 32 * NW;
+          int ABL = 0 /* timing ablations (wrong results): 1 no fragment reads, 2 no DMA after the prologue, 5 neither (MFMA + barrier only) */,
+          int RPW = 32 /* pixels of the tile per wave: 32, or 16 = "dense": 8 waves on a 128-pixel tile, two such workgroups per CU = 4 waves per SIMD */>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(RPW == 16 ? 4 : 2, RPW == 16 ? 4 : 2))) void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 8 * NW */) {
+    constexpr int BM = RPW * NW;
     constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
     constexpr int WM = BM / WAVES_M, FM = WM / 16, FN = 4;
     constexpr int QB = BN * 128, QI = BN / (8 * NW);
@@ -128,7 +129,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int s = 0; s < nsteps; ++s) {
         // Q(s) was issued one step ago; at tap 1 the halo of the NEXT chunk was issued right after it and may stay in flight
         if (tap == 1 && chunk + 1 < nchunks) {
-            if (PI == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            if (PI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (PI == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else if (PI == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 f32x4 mx = v;
                 if (g.pool_kind == 2) {
                     if (H == 16) {
-                        f32x4 u = acc[a][b ^ 1] + bv[a];
+                        f32x4 u = acc[a][FM > 1 ? (b ^ 1) : 0] + bv[a];      // (instances with FM == 1 are not dispatched for this case)
                         u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
                         mx.x = fmaxf(mx.x, u.x); mx.y = fmaxf(mx.y, u.y); mx.z = fmaxf(mx.z, u.z); mx.w = fmaxf(mx.w, u.w);
                     } else {
@@ -262,20 +264,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
 }
 
-template <int BN, int NW, int ABL = 0>
+template <int BN, int NW, int ABL = 0, int RPW = 32>
 static int launch_halo_(const HaloArgs& g, hipStream_t stream) {
-    constexpr int BM = 32 * NW;
+    constexpr int BM = RPW * NW;
     const int NR = BM + 2 * g.cH + 2;
     const int NRpad = (NR + 8 * NW) / (8 * NW) * (8 * NW);       // strictly greater than NR: the spare rows are the zero rows
     const int lds = 2 * NRpad * 128 + 2 * BN * 128;              // halo stages, weight stages
     static int lds_set = 0;
     if (lds > lds_set) {
-        if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, NW, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, NW, ABL, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return OCR_ERR_EXEC;
         lds_set = lds;
     }
     int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
-    conv_halo_kernel<BN, NW, ABL><<<mt * nt, 64 * NW, lds, stream>>>(g, NRpad);
+    conv_halo_kernel<BN, NW, ABL, RPW><<<mt * nt, 64 * NW, lds, stream>>>(g, NRpad);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
@@ -306,6 +308,16 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
     static int nw = -1;                                  // A/B knob OCR_HALO_NW: 8 / 4 force one kind, unset = by grid size
     if (nw < 0) { const char* e = getenv("OCR_HALO_NW"); nw = e ? atoi(e) : 0; }
     HaloArgs g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind};
+    static int dense = -1;                               // A/B knob OCR_HALO_DENSE=1: 8 waves per 128-pixel tile (4 waves per SIMD with two workgroups per CU)
+    if (dense < 0) { const char* e = getenv("OCR_HALO_DENSE"); dense = e ? atoi(e) : 0; }
+    if (dense && nw != 8) {
+        const int NRd = (128 + 2 * H + 2 + 64) / 64 * 64;
+        const long mt4 = (M + 127) / 128;
+        if (NRd / 64 == 3) {
+            if (Cout >= 128 && mt4 * ((Cout + 127) / 128) >= 448) return launch_halo_<128, 8, 0, 16>(g, stream);
+            if (!(pool_kind == 2 && H == 16)) return launch_halo_<64, 8, 0, 16>(g, stream);     // one fragment per wave: no partner fragment
+        }
+    }
     if (nw != 8) {
         const int NR = 128 + 2 * H + 2, NRp = (NR + 32) / 32 * 32;
         const long mt4 = (M + 127) / 128;
