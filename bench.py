@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 BATCH, WIDTH, LABEL_LEN = 64, 256, 10
 MFMA_BF16_PEAK = 2.5e15      # dense bf16, MI355X_MICROARCH.md
+PEAK_CLOCK_MHZ = 2400            # 256 CUs x 4 SIMDs x 1024 flop/clk x 2.4 GHz = 2.5 PFLOP/s
 TRAIN_GFLOP_PER_IMG = 10.09
 
 
@@ -70,6 +71,11 @@ def conv_roofline(eng, device):
             (N, W, H, Ci), _ = sp.shape[op.key]
             shapes.append((N, W, H, Ci, op.co, hasattr(op, 'wdgrad')))
     tot_fl, tot_t, n_launch = 0.0, 0.0, 0
+    # shader clock the kernel really runs at: workgroup 0 stamps {shader-clock counter, 100 MHz wall clock} at entry and exit
+    from lstm_ctc_ocr_amd import _native as nat
+    clk = torch.zeros(4, dtype=torch.int64, device=device)
+    nat.call("ocr_conv_halo_clock_debug", clk.data_ptr())
+    clk_cycles = clk_ticks = 0.0
     for (N, W, H, Ci, Co, has_dgrad) in shapes:
         x = torch.randn(N, W, H, Ci, device=device).to(torch.bfloat16)
         y = torch.randn(N, W, H, Co, device=device).to(torch.bfloat16)
@@ -83,6 +89,7 @@ def conv_roofline(eng, device):
         for fn in fns:
             for _ in range(3):
                 fn()
+            clk.zero_()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
@@ -92,7 +99,12 @@ def conv_roofline(eng, device):
             tot_t += e0.elapsed_time(e1) * 1e-3 / 10
             tot_fl += 2.0 * N * W * H * 9 * Ci * Co
             n_launch += 1
+            c = clk.cpu().numpy()                       # last of the ten back-to-back launches
+            if c[3] > c[1]:
+                clk_cycles += float(c[2] - c[0]); clk_ticks += float(c[3] - c[1])
+    nat.call("ocr_conv_halo_clock_debug", None)
     ach = tot_fl / tot_t
+    mhz = clk_cycles / clk_ticks * 100.0 if clk_ticks else None
     # HBM bytes per launch and matrix-pipe occupancy from the separate rocprofv3 --pmc passes of the latest round
     # (profiles/rNN_pmc_conv.json, made by tools/pmc_conv_summary.py; FETCH_SIZE doubled: the guide's gfx950 correction)
     traffic, mfma_busy, src = None, None, None
@@ -106,6 +118,9 @@ def conv_roofline(eng, device):
             "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK,
             "avg_launch_us": tot_t / n_launch * 1e6, "algorithmic_gflop_per_launch": tot_fl / n_launch / 1e9,
             "traffic": traffic, "mfma_busy_frac": mfma_busy,
+            "shader_clock_mhz": mhz, "frac_of_peak_at_that_clock": (ach / (MFMA_BF16_PEAK * mhz / PEAK_CLOCK_MHZ)) if mhz else None,
+            "clock_note": "shader clock measured inside the kernel (s_memtime / s_memrealtime of workgroup 0, time-weighted over the launches); "
+                          "`peak` is the guide's dense bf16 figure at %d MHz" % PEAK_CLOCK_MHZ,
             "traffic_note": "HBM bytes per launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) and SQ_VALU_MFMA_BUSY_CYCLES / "
                             "available SIMD cycles, headline shapes, from profiles/%s" % src}
 

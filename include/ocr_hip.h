@@ -74,6 +74,9 @@ int ocr_set_gemm_engine(int use_large_tile);
  * (conv_single network.py:160-191; also its data gradient with flipped/transposed weights) */
 int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int Nb, int W, int H, int Cin, int Cout,
                      const float* bias, const void* mask, int flags, void* stream);
+/* diagnostic: workgroup 0 of the halo convolution kernel stamps {shader clock counter, 100 MHz wall clock} at entry and exit into
+ * dbg (device int64[4]; NULL = off) */
+int ocr_conv_halo_clock_debug(void* dbg);
 /* conv3x3 + bias + ReLU AND the max-pool behind it from one epilogue (LSTM_train.py:26-33): y [Nb,W,H,Cout] and pooled
  * [Nb, W/kw, H/kh, Cout]; (kw, kh) = (1, 2) (feature axis) or (2, 2).  ocr_conv3x3_pool_supported() != 0 tells whether the shape is
  * covered; otherwise run ocr_conv3x3_bf16 + ocr_maxpool_fwd (ocr_conv3x3_relu_pool_bf16 then returns 2). */

@@ -27,6 +27,9 @@ struct HaloArgs {
 };
 
 __device__ u32x4 igh_zero_page[4];
+// diagnostic (ocr_conv_halo_clock_debug): workgroup 0 stamps {shader-clock counter, 100 MHz wall clock} at entry and exit, so the
+// tool can tell the clock the kernel really ran at (tools/clock_probe.py)
+__device__ long long* g_halo_clk;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -47,6 +50,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(RPW == 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int H = g.cH, C = g.C;
+    long long* const clk = g_halo_clk;
+    if (clk && blockIdx.x == 0 && tid == 0) { clk[0] = (long long)__builtin_amdgcn_s_memtime(); clk[1] = (long long)wall_clock64(); }
     const int NR = BM + 2 * H + 2;                     // halo rows actually needed
     const int PI = NRpad / (8 * NW);                   // halo DMA instructions per wave (8 rows each)
 
@@ -262,6 +267,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(RPW == 
             }
         }
     }
+    if (clk && blockIdx.x == 0 && tid == 0) { clk[2] = (long long)__builtin_amdgcn_s_memtime(); clk[3] = (long long)wall_clock64(); }
 }
 
 template <int BN, int NW, int ABL = 0, int RPW = 32>
@@ -334,4 +340,9 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
     if (Cout >= 128 && (long)mt * ((Cout + 127) / 128) >= 200) return launch_halo<128, 8>(g, stream);
     if (Cout >= 128 && (long)mt * ((Cout + 63) / 64) < 256) return launch_halo<128, 8>(g, stream);
     return launch_halo<64, 8>(g, stream);
+}
+
+extern "C" int ocr_conv_halo_clock_debug(void* dbg /* device int64[4] or NULL */) {
+    long long* p = (long long*)dbg;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_halo_clk), &p, sizeof(p)) == hipSuccess ? OCR_OK : OCR_ERR_EXEC;
 }
