@@ -187,8 +187,9 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(W9Args g) {
     // version made the compiler copy every fragment into one operand tuple: each copy waited for the previous tap's MFMAs —
     // measured 11 us of 75 on conv4_2).
     constexpr unsigned ZOFF = W9_NST * W9_STAGE;                                   // 8 KiB of zeros (offsets up to 6 KiB are added)
-    const bool red_m = (L >> 2) == 0 && (4 * g4) % H == 0;                        // taps with dh = -1: element 0 of the block has h == 0
-    const bool red_p = (L >> 2) == 3 && (4 * g4 + 4) % H == 0;                    // taps with dh = +1: element 3 has h == H - 1
+    const int hsup = (4 * g4 + (L >> 2)) % H;                                     // feature row of the element this lane supplies (H = 2: a 4-row block spans two columns)
+    const bool red_m = hsup == 0;                                                 // taps with dh = -1: no row above
+    const bool red_p = hsup == H - 1;                                             // taps with dh = +1: no row below
     const unsigned zabs = lds0 + ZOFF + (L & 3) * 8;                              // this lane's 8 zero bytes
     if (REDIR) {
 #pragma unroll
@@ -198,10 +199,10 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(W9Args g) {
         }
         *(u32x4*)(smem + ZOFF + tid * 16) = (u32x4){0, 0, 0, 0};                  // 512 threads x 16 B (visible after the first barrier)
     }
-    const int hs = H == 4 ? 2 : (H == 8 ? 3 : 4);                                // log2 H
+    const int hs = H == 2 ? 1 : (H == 4 ? 2 : (H == 8 ? 3 : 4));                  // log2 H
     const int ncol = 32 >> hs;                                                   // image columns per 32-pixel block
     int wc = (kbeg >> hs) % W;                                                   // column (within its image) of the step's first pixel
-    const int lc0 = (4 * g4) >> hs, lc1 = (4 * g4 + 16) >> hs;                   // this lane's column inside a 32-pixel block (both reads)
+    const int lc0 = (4 * g4 + (L >> 2)) >> hs, lc1 = (4 * g4 + (L >> 2) + 16) >> hs;   // column (inside a 32-pixel block) of the element this lane supplies, both reads
 
     f32x4 acc[9][4];
 #pragma unroll
@@ -463,10 +464,10 @@ __global__ __launch_bounds__(512) void wgrad9c_kernel(W9Args g) {
     // SAME padding along the feature axis: element e of a transposed read is pixel row 4 g4 + e (+16, +32 k: same h, H | 16)
     const unsigned mlo = ((4 * g4) % H == 0) ? 0xffff0000u : 0xffffffffu;         // taps with dh = -1: element 0 has h == 0
     const unsigned mhi = ((4 * g4 + 4) % H == 0) ? 0x0000ffffu : 0xffffffffu;     // taps with dh = +1: element 3 has h == H - 1
-    const int hs = H == 4 ? 2 : (H == 8 ? 3 : 4);                                // log2 H
+    const int hs = H == 2 ? 1 : (H == 4 ? 2 : (H == 8 ? 3 : 4));                  // log2 H
     const int ncol = 32 >> hs;                                                   // image columns per 32-pixel block
     int wc = (kbeg >> hs) % W;                                                   // column (within its image) of the step's first pixel
-    const int lc0 = (4 * g4) >> hs, lc1 = (4 * g4 + 16) >> hs;                   // this lane's column inside a 32-pixel block (both reads)
+    const int lc0 = (4 * g4 + (L >> 2)) >> hs, lc1 = (4 * g4 + (L >> 2) + 16) >> hs;   // column (inside a 32-pixel block) of the element this lane supplies, both reads
 
     f32x4 acc[9][4];
 #pragma unroll
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(256) void wgrad9_reduce_kernel(float* __restrict__ 
 struct W9Plan { int S, k_per_split, map, T_ci, T_co; size_t bytes; };
 
 static bool w9_plan(int M, int W, int H, int Cin, int Cout, W9Plan* p) {
-    if ((Cin & 63) || (Cout & 63) || (H != 4 && H != 8 && H != 16) || M < 512 || (M % H) || W * H < 32) return false;
+    if ((Cin & 63) || (Cout & 63) || (H != 2 && H != 4 && H != 8 && H != 16) || M < 512 || (M % H) || W * H < 32) return false;
     const int T_ci = Cin / 64, T_co = Cout / 64, T = T_ci * T_co;
     static int smax = -1;                       // A/B knob OCR_W9_SMAX: cap on the split count (partial slabs cost 2 x 147 KB x workgroups of HBM traffic)
     if (smax < 0) { const char* e = getenv("OCR_W9_SMAX"); smax = e ? atoi(e) : 64; if (smax < 1) smax = 1; }
@@ -712,7 +713,7 @@ int wgrad9_try_dispatch(const void* x, const void* dy, float* dw, float* dbias, 
         static bool attr = false; \
         if (!attr) { if (hipFuncSetAttribute((const void*)wgrad9c_kernel<LA_, NS_, NB_, DBG_>, hipFuncAttributeMaxDynamicSharedMemorySize, W9_LDS) != hipSuccess) return OCR_ERR_EXEC; attr = true; } \
         wgrad9c_kernel<LA_, NS_, NB_, DBG_><<<grid, 512, W9_LDS, stream>>>(g); } while (0)
-    switch (variant) {
+    switch (H == 2 ? 0 : variant) {             // H = 2 (a 4-row read block spans two image columns): only the redirecting default handles it
         case 1: W9_LAUNCH(3, 0, false); break;
         case 2: W9_LAUNCH(4, 0, false); break;
         case 3: W9_LAUNCH(2, 3, false); break;

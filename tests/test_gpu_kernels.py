@@ -260,7 +260,7 @@ def _conv_ref(x, w, b):   # x [N,W,H,C], w HWIO
 
 @pytest.mark.parametrize("Nb,W,H,Ci,Co", [(4, 16, 8, 64, 128), (2, 12, 4, 256, 512), (64, 64, 4, 256, 512), (3, 20, 16, 64, 128),
                                           (16, 32, 16, 64, 128), (64, 128, 8, 64, 256), (5, 52, 4, 128, 192), (32, 64, 4, 512, 512),
-                                          (7, 22, 8, 128, 256)])
+                                          (7, 22, 8, 128, 256), (32, 64, 2, 512, 512), (3, 18, 2, 64, 128), (9, 64, 2, 128, 64)])
 def test_conv3x3_fwd_dgrad_wgrad(dev, Nb, W, H, Ci, Co):
     x = bf(gen((Nb, W, H, Ci), 1)); w = bf(gen((3, 3, Ci, Co), 2, 0.05)); b = gen((Co,), 3)
     ref = _conv_ref(x, w, b)
