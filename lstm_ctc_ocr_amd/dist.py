@@ -22,7 +22,14 @@ def allreduce_sum_(flat, group=None, force=False):
         flat.mul_(float(fake))      # (a real kernel on the current stream, so stream ordering is exercised like RCCL's)
         return flat
     if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if flat.is_cuda and dist.get_backend(group) == 'gloo':
+            # gloo (tests: several ranks sharing one GPU) is staged through the host on the CURRENT stream, so the ordering against
+            # the producing / consuming kernels is the same as with the RCCL call
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 
 

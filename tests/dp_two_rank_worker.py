@@ -1,0 +1,60 @@
+"""Worker of tests/test_gpu_dp_two_ranks.py: ONE of two data-parallel ranks that share GPU 0 (gloo process group; the engine's
+schedule, buckets, streams and scaling are the real ones, only the transport differs from RCCL).
+    python tests/dp_two_rank_worker.py <rank> <port> <overlap 0|1> <out.npz>"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, port, overlap, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    os.environ['OCR_OVERLAP_ALLREDUCE'] = overlap
+    os.environ.update(RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0')
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=2)
+    from lstm_ctc_ocr_amd.config import cfg
+    from lstm_ctc_ocr_amd.engine import Engine
+    from lstm_ctc_ocr_amd.models import get_network
+    cfg.TRAIN.WEIGHT_DECAY = 0.0                       # the gradient buffer then holds exactly the exchanged gradient after a step
+    eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
+    assert eng.world == 2 and eng.split_op > 0
+    eng.setup_optimizer('Adam', 1e-3)
+    N, W, L = 8, 64, 3
+    rng = np.random.RandomState(100 + rank)            # every rank its own data (what utils/gen.stream_seed does for the generator)
+    batches = []
+    for _ in range(3):
+        x = rng.rand(N, W, 32).astype(np.float32)
+        lab = rng.randint(1, 63, N * L).astype(np.int32)
+        batches.append((x, lab, np.full(N, L, np.int32), np.full(N, W // 4 - 1, np.int32)))
+    # local gradient of the first batch (forward + backward only: no exchange, no update), already scaled by 1 / (N * world)
+    x, lab, ll, sl = batches[0]
+    sp = eng.plan(N, W)
+    eng._bind(sp, x, sl, lab, ll)
+    eng._run(sp, 'fb')
+    torch.cuda.synchronize()
+    local = eng.grads.clone()
+    both = [torch.zeros_like(local, device='cpu') for _ in range(2)]
+    dist.all_gather(both, local.cpu())
+    losses = [eng.train_step(*batches[0][:1], batches[0][1], batches[0][2], batches[0][3])]
+    torch.cuda.synchronize()
+    exchanged = eng.grads.clone().cpu()
+    for b in batches[1:]:
+        losses.append(eng.train_step(b[0], b[1], b[2], b[3]))
+    torch.cuda.synchronize()
+    params = eng.params.clone().cpu()
+    theirs = [torch.zeros_like(params) for _ in range(2)]
+    dist.all_gather(theirs, params)
+    np.savez(out, losses=np.array(losses), exchanged=exchanged.numpy(), sum_local=(both[0] + both[1]).numpy(),
+             local_differs=float((both[0] - both[1]).abs().max()), replicas_equal=bool(torch.equal(theirs[0], theirs[1])),
+             params=params.numpy(), late_begin=eng.late_begin, n_total=eng.n_total)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
