@@ -35,11 +35,15 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int BN, int NW /* waves per workgroup: 8 (256 pixels, one workgroup per CU) or 4 (128 pixels, two per CU) */,
           int ABL = 0 /* timing ablations (wrong results): 1 no fragment reads, 2 no DMA after the prologue, 5 neither (MFMA + barrier only) */,
-          int RPW = 32 /* pixels of the tile per wave: 32, or 16 = "dense": 8 waves on a 128-pixel tile, two such workgroups per CU = 4 waves per SIMD */>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(RPW == 16 ? 4 : 2, RPW == 16 ? 4 : 2))) void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 8 * NW */) {
+          int RPW = 32 /* pixels of the tile per wave: 32, or 16 = "dense": 8 waves on a 128-pixel tile, two such workgroups per CU = 4 waves per SIMD */,
+          int FNV = 4 /* 16-channel fragments per wave: 4 (64 x 64 wave tiles), or 8 = "wide": 64 x 128 wave tiles, 0.375 instead of 0.5 LDS fragment
+                         reads per MFMA and half the weight DMA per flop, one 4-wave workgroup per CU */>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FNV == 8 ? 1 : (RPW == 16 ? 4 : 2), FNV == 8 ? 1 : (RPW == 16 ? 4 : 2))))
+void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 8 * NW */) {
     constexpr int BM = RPW * NW;
-    constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
-    constexpr int WM = BM / WAVES_M, FM = WM / 16, FN = 4;
+    constexpr int FN = FNV;
+    constexpr int WAVES_N = BN / (16 * FN), WAVES_M = NW / WAVES_N;
+    constexpr int WM = BM / WAVES_M, FM = WM / 16;
     constexpr int QB = BN * 128, QI = BN / (8 * NW);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int PBYTES = NRpad * 128;
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(RPW == 
     // (the zero row is row NR of the current halo stage: rows NR .. NRpad-1 exist only as padding of the DMA geometry and
     //  are filled from the zero page with every halo tile; NRpad > NR always holds)
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;          // LDS byte address of smem (0 for dynamic LDS, kept general)
-    const unsigned qfrag0 = (unsigned)(qbuf0 - smem) + (wn * 64 + frow) * 128 + ((fq ^ fx) << 4);   // + stage*QB, ^64 for kk = 1
+    const unsigned qfrag0 = (unsigned)(qbuf0 - smem) + (wn * (16 * FN) + frow) * 128 + ((fq ^ fx) << 4);   // + stage*QB, ^64 for kk = 1
     const unsigned prow0 = (wm * WM + frow) * 128;                                                  // + shift*128 + swizzle
     // prologue: weights of step 0, then halo of chunk 0
     load_q(0, 0);
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(RPW == 
     f32x4 bv[FN];
 #pragma unroll
     for (int a = 0; a < FN; ++a) {
-        const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+        const int n = n0 + wn * (16 * FN) + a * 16 + (lane >> 4) * 4;
         bv[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if ((flags & IGH_BIAS) && n < g.N) bv[a] = *(const f32x4*)(g.bias + n);
     }
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(RPW == 
         if (m >= g.M) continue;
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
-            const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+            const int n = n0 + wn * (16 * FN) + a * 16 + (lane >> 4) * 4;
             if (n >= g.N) continue;
             f32x4 v = acc[a][b] + bv[a];
             if (flags & IGH_RELU) {
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(RPW == 
     if (clk && blockIdx.x == 0 && tid == 0) { clk[2] = (long long)__builtin_amdgcn_s_memtime(); clk[3] = (long long)wall_clock64(); }
 }
 
-template <int BN, int NW, int ABL = 0, int RPW = 32>
+template <int BN, int NW, int ABL = 0, int RPW = 32, int FNV = 4>
 static int launch_halo_(const HaloArgs& g, hipStream_t stream) {
     constexpr int BM = RPW * NW;
     const int NR = BM + 2 * g.cH + 2;
@@ -278,12 +282,12 @@ static int launch_halo_(const HaloArgs& g, hipStream_t stream) {
     const int lds = 2 * NRpad * 128 + 2 * BN * 128;              // halo stages, weight stages
     static int lds_set = 0;
     if (lds > lds_set) {
-        if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, NW, ABL, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, NW, ABL, RPW, FNV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return OCR_ERR_EXEC;
         lds_set = lds;
     }
     int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
-    conv_halo_kernel<BN, NW, ABL, RPW><<<mt * nt, 64 * NW, lds, stream>>>(g, NRpad);
+    conv_halo_kernel<BN, NW, ABL, RPW, FNV><<<mt * nt, 64 * NW, lds, stream>>>(g, NRpad);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
@@ -323,6 +327,13 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
             if (Cout >= 128 && mt4 * ((Cout + 127) / 128) >= 448) return launch_halo_<128, 8, 0, 16>(g, stream);
             if (!(pool_kind == 2 && H == 16)) return launch_halo_<64, 8, 0, 16>(g, stream);     // one fragment per wave: no partner fragment
         }
+    }
+    static int wide = -1;                                // A/B knob OCR_HALO_WIDE=1: 64 x 128 wave tiles (128 pixels x 256 channels per 4-wave workgroup, one per CU)
+    if (wide < 0) { const char* e = getenv("OCR_HALO_WIDE"); wide = e ? atoi(e) : 0; }
+    if (wide && nw != 8 && Cout % 256 == 0) {
+        const int NRw = (128 + 2 * H + 2 + 32) / 32 * 32;
+        if ((NRw / 32 == 5 || NRw / 32 == 6) && (long)((M + 127) / 128) * (Cout / 256) >= 224)
+            return launch_halo_<256, 4, 0, 32, 8>(g, stream);
     }
     if (nw != 8) {
         const int NR = 128 + 2 * H + 2, NRp = (NR + 32) / 32 * 32;
