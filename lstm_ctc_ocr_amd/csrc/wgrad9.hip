@@ -629,30 +629,32 @@ __global__ __launch_bounds__(512) void wgrad9c_kernel(W9Args g) {
 }
 
 // dw[i] += sum_s part[s][i];  dbias[co] += sum_s cs_part[s][co] — fixed summation order: deterministic.
-// A workgroup handles 32 float4 columns; its 8 thread rows take the slabs s = row, row + 8, ... and meet in LDS (a plain
-// loop over S = 128 slabs by 72 workgroups left conv2's 37 MB of partials to a handful of CUs).
+// 256 threads = `rows` thread rows x (256 / rows) float4 columns, rows = S / 8 clamped to [1, 8]: every thread adds up to eight slabs
+// (s = row, row + rows, ...) with all its loads in flight, then the rows meet in LDS.  (One load per thread — eight rows for any S —
+// ran the S = 4 .. 16 layers at 2.8 TB/s; a plain loop over all slabs per column left conv2's S = 64 to a handful of CUs.)
 __global__ __launch_bounds__(256) void wgrad9_reduce_kernel(float* __restrict__ dw, const float* __restrict__ part, long n4, long slab4,
-                                                            int S, float* __restrict__ dbias, const float* __restrict__ cs_part, int Cout) {
-    __shared__ f32x4 red[8][32];
-    const int col = threadIdx.x & 31, row = threadIdx.x >> 5;
-    const long i = (long)blockIdx.x * 32 + col;
+                                                            int S, int rows, float* __restrict__ dbias, const float* __restrict__ cs_part, int Cout) {
+    __shared__ f32x4 red[256];
+    const int cols = 256 / rows;
+    const int col = threadIdx.x % cols, row = threadIdx.x / cols;
+    const long i = (long)blockIdx.x * cols + col;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (i < n4) {
         f32x4 b = {0.f, 0.f, 0.f, 0.f}, c = b, d = b;
+        const f32x4* p = (const f32x4*)part + i;
         int s = row;
-        for (; s + 24 < S; s += 32) {                    // four slabs in flight per thread
-            a += ((const f32x4*)part)[s * slab4 + i];        b += ((const f32x4*)part)[(s + 8) * slab4 + i];
-            c += ((const f32x4*)part)[(s + 16) * slab4 + i]; d += ((const f32x4*)part)[(s + 24) * slab4 + i];
+        for (; s + 3 * rows < S; s += 4 * rows) {        // four slabs per round, the rounds independent of each other
+            a += p[(long)s * slab4];              b += p[(long)(s + rows) * slab4];
+            c += p[(long)(s + 2 * rows) * slab4]; d += p[(long)(s + 3 * rows) * slab4];
         }
-        for (; s < S; s += 8) a += ((const f32x4*)part)[s * slab4 + i];
+        for (; s < S; s += rows) a += p[(long)s * slab4];
         a = (a + b) + (c + d);
     }
-    red[row][col] = a;
+    red[row * cols + col] = a;
     __syncthreads();
     if (row == 0 && i < n4) {
         f32x4 t = ((const f32x4*)dw)[i];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) t += red[r][col];
+        for (int r = 0; r < rows; ++r) t += red[r * cols + col];
         ((f32x4*)dw)[i] = t;
     }
     if (dbias != nullptr && blockIdx.x == 0)
@@ -746,8 +748,12 @@ int wgrad9_try_dispatch(const void* x, const void* dy, float* dw, float* dbias, 
 #undef W9C_LAUNCH
     OCR_CHECK_LAUNCH();
     const long n4 = (long)9 * Cin * Cout / 4;
-    const int blocks = (int)((n4 + 31) / 32);
-    wgrad9_reduce_kernel<<<blocks, 256, 0, stream>>>(dw, g.part, n4, n4, p.S, dbias, g.cs_part, Cout);
+    int rows = p.S / 8;
+    rows = rows < 1 ? 1 : (rows > 8 ? 8 : rows);
+    while (rows & (rows - 1)) rows &= rows - 1;                       // power of two
+    const int cols = 256 / rows;
+    const int blocks = (int)((n4 + cols - 1) / cols);
+    wgrad9_reduce_kernel<<<blocks, 256, 0, stream>>>(dw, g.part, n4, n4, p.S, rows, dbias, g.cs_part, Cout);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
