@@ -173,9 +173,10 @@ class SharedBatchRing(object):
 
 class DeviceBatchStream(object):
     """Iterator of device-resident batches: (pixels uint8 [B, W, 32], labels int32 [n], label_len int32 [B], steps int32 [B]).
-    `depth` staging buffers; the feeder thread keeps them full, copies run on their own stream."""
+    `depth` staging buffers; the feeder thread keeps them full, copies run on their own stream.  A returned batch stays valid until
+    the NEXT call of next() (its buffer is handed back to the feeder then)."""
 
-    def __init__(self, device, batch_size, workers=None, depth=3, seed=None, pool=None, **gen_kwargs):
+    def __init__(self, device, batch_size, workers=None, depth=4, seed=None, pool=None, **gen_kwargs):
         import torch
         self.torch = torch
         self.device = torch.device(device)
@@ -193,8 +194,15 @@ class DeviceBatchStream(object):
         self.d_meta = [torch.empty(lay.meta_words, dtype=torch.int32, device=self.device) for _ in range(depth)]
         self.d_pix = [torch.empty(lay.pix_bytes, dtype=torch.uint8, device=self.device) for _ in range(depth)]
         self.filled = [torch.cuda.Event() for _ in range(depth)]         # copy finished -> training stream may read
-        self.consumed = [None] * depth                                     # training stream finished reading -> feeder may overwrite
-        self.staged = queue.Queue(maxsize=depth - 1)
+        # Buffer ownership is explicit: the feeder may only fill a buffer it took from `free`, and a buffer only gets there when the
+        # consumer has moved on to the NEXT batch, together with an event recorded on the training stream behind everything that
+        # read it.  (The first version looked at a per-buffer "consumed" event that was still unset — or left over from the
+        # previous lap — while the consumer was about to bind that very buffer: the feeder overwrote batches that had been handed
+        # out but not read yet; one step in a few thousand trained on pixels of one batch with labels of another.)
+        self.free = queue.Queue()
+        for k in range(depth):
+            self.free.put((k, None))
+        self.staged = queue.Queue()
         self.halt = threading.Event()
         self.error = None
         self.thread = threading.Thread(target=self._feed, daemon=True)
@@ -213,17 +221,24 @@ class DeviceBatchStream(object):
     def _feed(self):
         torch = self.torch
         lay = self.ring.layout
-        k = 0
         try:
             torch.cuda.set_device(self.device)
             while not self.halt.is_set():
                 try:
-                    slot = self.ring.get(timeout=0.2)
+                    k, done = self.free.get(timeout=0.2)                  # a device buffer the consumer has let go of
                 except queue.Empty:
                     continue
+                slot = None
+                while slot is None and not self.halt.is_set():
+                    try:
+                        slot = self.ring.get(timeout=0.2)
+                    except queue.Empty:
+                        continue
+                if slot is None:
+                    break
                 info = self.ring.slot(slot)
-                if self.consumed[k] is not None:
-                    self.consumed[k].synchronize()                        # the step that read this buffer has passed it
+                if done is not None:
+                    done.synchronize()                                    # everything that read this buffer has finished
                 base = slot * lay.bytes
                 npix = info['B'] * info['W'] * cfg.NUM_FEATURES
                 with torch.cuda.stream(self.copy_stream):
@@ -232,14 +247,7 @@ class DeviceBatchStream(object):
                     self.filled[k].record(self.copy_stream)
                 self.filled[k].synchronize()                              # slot may go back to the workers
                 self.ring.release(slot)
-                item = (k, info['B'], info['W'], info['nlab'])
-                while not self.halt.is_set():
-                    try:
-                        self.staged.put(item, timeout=0.2)
-                        break
-                    except queue.Full:
-                        continue
-                k = (k + 1) % self.depth
+                self.staged.put((k, info['B'], info['W'], info['nlab']))
         except Exception as e:                                            # surface in the consumer
             self.error = e
 
@@ -256,10 +264,10 @@ class DeviceBatchStream(object):
                 break
             except queue.Empty:
                 continue
-        if self._last is not None:                   # the previous batch has been bound by now: its buffer may be refilled
-            ev = torch.cuda.Event()
+        if self._last is not None:                   # the caller asks for the next batch: the previous one has been bound (or dropped),
+            ev = torch.cuda.Event()                  # so its buffer goes back to the feeder, fenced behind the work issued so far
             ev.record(torch.cuda.current_stream(self.device))
-            self.consumed[self._last] = ev
+            self.free.put((self._last, ev))
         self._last = k
         torch.cuda.current_stream(self.device).wait_event(self.filled[k])
         meta = self.d_meta[k]
