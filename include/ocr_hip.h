@@ -74,6 +74,9 @@ int ocr_set_gemm_engine(int use_large_tile);
  * (conv_single network.py:160-191; also its data gradient with flipped/transposed weights) */
 int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int Nb, int W, int H, int Cin, int Cout,
                      const float* bias, const void* mask, int flags, void* stream);
+/* non-zero: ocr_conv3x3_bf16 accepts OCR_EPI_ACCUM for this shape (y (bf16) += result: the data gradient of a tensor with several
+ * consumers is added to what was already delivered, no scratch tensor + add pass) */
+int ocr_conv3x3_accum_supported(int Nb, int W, int H, int Cin, int Cout);
 /* diagnostic: workgroup 0 of the halo convolution kernel stamps {shader clock counter, 100 MHz wall clock} at entry and exit into
  * dbg (device int64[4]; NULL = off) */
 int ocr_conv_halo_clock_debug(void* dbg);

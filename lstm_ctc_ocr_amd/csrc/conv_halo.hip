@@ -16,7 +16,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-enum { IGH_BIAS = 1, IGH_RELU = 2, IGH_MASK = 16 };
+enum { IGH_BIAS = 1, IGH_RELU = 2, IGH_MASK = 16, IGH_ACCUM = 64 /* out (bf16) += value: a data gradient added to what another consumer already delivered */ };
 
 struct HaloArgs {
     const bf16_t* P; const bf16_t* Q;     // P [M pixels][C] ; Q [N][9*C]
@@ -237,6 +237,10 @@ void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 8 * NW */
                 if (!(bf_lo(mk.y) > 0.f)) v.z = 0.f;
                 if (!(bf_hi(mk.y) > 0.f)) v.w = 0.f;
             }
+            if (flags & IGH_ACCUM) {
+                const u32x2 old = *(const u32x2*)(g.out + (long)m * g.N + n);
+                v.x += bf_lo(old.x); v.y += bf_hi(old.x); v.z += bf_lo(old.y); v.w += bf_hi(old.y);
+            }
             u32x2 pk;
             pk.x = pack_bf2(v.x, v.y);
             pk.y = pack_bf2(v.z, v.w);
@@ -305,9 +309,9 @@ static int launch_halo(const HaloArgs& g, hipStream_t stream) {
 int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
                       const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind) {
     if ((Cin & 63) || (Cout & 3) || M < 1024 || H > 30) return -1;
-    if (flags & ~(IGH_BIAS | IGH_RELU | IGH_MASK)) return -1;
+    if (flags & ~(IGH_BIAS | IGH_RELU | IGH_MASK | IGH_ACCUM)) return -1;
     if (pool_kind) {         // fused max-pool: ReLU epilogue without mask, even feature axis, 2 x 2 only for H in {4, 8, 16} and even W
-        if (!pool || (flags & IGH_MASK) || !(flags & IGH_RELU) || (H & 1) || (Cout & 3) || (Cout % 64 && Cout % 128)) return -1;
+        if (!pool || (flags & (IGH_MASK | IGH_ACCUM)) || !(flags & IGH_RELU) || (H & 1) || (Cout & 3) || (Cout % 64 && Cout % 128)) return -1;
         if (pool_kind == 2 && ((H != 4 && H != 8 && H != 16) || (W & 1))) return -1;
         if (pool_kind != 1 && pool_kind != 2) return -1;
         if (M % (pool_kind == 2 ? 2 * H : 2)) return -1;
@@ -356,4 +360,11 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
 extern "C" int ocr_conv_halo_clock_debug(void* dbg /* device int64[4] or NULL */) {
     long long* p = (long long*)dbg;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_halo_clk), &p, sizeof(p)) == hipSuccess ? OCR_OK : OCR_ERR_EXEC;
+}
+
+// does the halo kernel take this shape (so that its epilogue-only features — accumulate, fused pool — may be asked for)?
+bool halo_covers(long M, int W, int H, int Cin, int Cout) {
+    if ((Cin & 63) || (Cout & 3) || M < 1024 || M > 0x7fffffffL || H > 30 || H < 1) return false;
+    const int NR4 = (128 + 2 * H + 2 + 32) / 32 * 32, NR8 = (256 + 2 * H + 2 + 64) / 64 * 64;
+    return NR4 / 32 == 5 || NR4 / 32 == 6 || NR8 / 64 == 5 || NR8 / 64 == 6;
 }

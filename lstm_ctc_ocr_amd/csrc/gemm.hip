@@ -292,6 +292,11 @@ extern "C" int ocr_gemm_nt_bf16(const void* P, long ldp, const void* Q, long ldq
     return dispatch_gemm(g, 0, splits, (hipStream_t)stream);
 }
 
+bool halo_covers(long M, int W, int H, int Cin, int Cout);
+// flags may carry OCR_EPI_ACCUM (y += result, bf16) only where this returns non-zero (the halo kernel's epilogue)
+extern "C" int ocr_conv3x3_accum_supported(int Nb, int W, int H, int Cin, int Cout) {
+    return g_use_halo && !g_use_pp && halo_covers((long)Nb * W * H, W, H, Cin, Cout);
+}
 // 3x3 SAME stride-1 convolution over the reference layout [Nb, W, H, C] as an implicit GEMM.
 // wpack is [Cout][3][3][Cin] bf16 (K-contiguous rows).  Used for the forward (wpack = packed
 // weights) and for dgrad (x := dY, wpack := flipped/transposed weights, Cin/Cout swapped).
@@ -305,6 +310,7 @@ extern "C" int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int N
     g.flags = flags & ~(EPI_ATOMIC | EPI_ROWSWAP);
     if ((flags & EPI_BIAS) && !bias) return OCR_ERR_INVALID;
     if ((flags & EPI_MASK) && !mask) return OCR_ERR_INVALID;
+    if ((flags & EPI_ACCUM) && !ocr_conv3x3_accum_supported(Nb, W, H, Cin, Cout)) return OCR_ERR_INVALID;      // bf16 accumulate: halo epilogue only
     if (g_use_pp && x && wpack && y && g.M > 0 && Cout > 0 && Cin > 0) {
         int rc = pp_try_dispatch(x, wpack, y, g.M, W, H, Cin, Cout, bias, mask, g.flags, (hipStream_t)stream);
         if (rc >= 0) return rc;

@@ -138,6 +138,8 @@ class _ConvOp(_Op):
         return (N, W, H, self.co)
 
     fused_pool = None          # set by Engine._lower: conv1 + ReLU + 2x2 max-pool run as one kernel, no full-res activation
+    mask_from = None           # set by Engine._lower: the fused add + relu that is this (BN, no ReLU) conv's only consumer: its batch-norm
+                               # backward reads the add's gradient and applies the add's ReLU mask itself (no masked copy pass)
     pool_after = None          # set by Engine._lower: the max-pool that follows this 3x3 conv + ReLU; where the shape allows, the conv's
                                # epilogue writes the pooled tensor too (the full-resolution output is still kept for the backward pass)
 
@@ -229,25 +231,32 @@ class _ConvOp(_Op):
         dz = dy
         if self.bn:
             dz = sp.buf[self.key + '/dz']
-            ops.bn_train_bwd(sp.buf[self.key + '/z'].view(M, self.co), self.y(sp).view(M, self.co), dy.view(M, self.co),
+            ymask, relu = self.y(sp), self.relu
+            if self.mask_from is not None:          # gradient and ReLU mask straight from the residual add + relu behind this layer
+                dy, ymask, relu = self.mask_from.dy(sp), self.mask_from.y(sp), True
+            ops.bn_train_bwd(sp.buf[self.key + '/z'].view(M, self.co), ymask.view(M, self.co), dy.view(M, self.co),
                              e.param('%s/%s/gamma' % (self.name, self.name)), sp.buf[self.key + '/mean'],
                              sp.buf[self.key + '/rstd'], e.grad('%s/%s/gamma' % (self.name, self.name)),
-                             e.grad('%s/%s/beta' % (self.name, self.name)), self.relu, sp.buf[self.key + '/bnws'],
+                             e.grad('%s/%s/beta' % (self.name, self.name)), relu, sp.buf[self.key + '/bnws'],
                              out=dz.view(M, self.co))
         dw = e.grad(self.name + '/weights')
         db = e.grad(self.name + '/biases') if self.biased else None
         if self.kind == 'c1':
             ops.conv1_wgrad(x, dz, dw, db)
             return
-        pdy, finish = e.grad_dst(sp, self.prev)
         pmask = self.prev.y(sp) if self.prev.mask_in_consumer else None
         if self.kind == '3x3':
             with e.wgrad_side():
                 ops.conv3x3_wgrad(x, dz, dw, dbias=db, workspace=sp.buf.get('wgrad_ws'))   # bias gradient rides on the same pass
+            # a producer with several consumers (residual graphs): where the halo kernel runs, its epilogue adds to what was already
+            # delivered instead of writing a scratch tensor that a second pass adds
+            pdy, finish, acc = e.grad_dst_acc(sp, self.prev, ops.conv3x3_accum_supported(o[0], o[1], o[2], self.co, self.ci))
             if pdy is not None:
-                ops.conv3x3(dz, self.wdgrad.view(self.ci, 3, 3, self.co), out=pdy, mask=pmask)
+                ops.conv3x3(dz, self.wdgrad.view(self.ci, 3, 3, self.co), out=pdy, mask=pmask, accumulate=acc)
                 finish()
-        elif self.kind == '1x1':
+            return
+        pdy, finish = e.grad_dst(sp, self.prev)
+        if self.kind == '1x1':
             with e.wgrad_side():
                 ops.gemm_tn(x.view(M, self.ci), dz.view(M, self.co), dw.view(self.ci, self.co), colsum=db)
             if pdy is not None:
@@ -363,6 +372,8 @@ class _AddOp(_Op):
 
     def bwd(self, sp):
         for p in self.inputs:
+            if getattr(p, 'mask_from', None) is self:
+                continue                            # that producer's batch-norm backward reads dy / y of this op directly
             self.eng.deliver(sp, p, self.dy(sp), mask=self.y(sp) if self.relu else None)
 
 
@@ -1010,6 +1021,10 @@ class Engine(object):
                 if isinstance(r, _ReluOp) and isinstance(a, _AddOp) and a.consumers == 1:
                     a.relu, r.fused_into = True, a
                     a.consumers = r.consumers
+                    for p in a.inputs:                 # a (BN, no ReLU) conv feeding only this add: mask applied inside its BN backward
+                        if (isinstance(p, _ConvOp) and p.bn and not p.relu and p.consumers == 1 and p.kind != 'c1'
+                                and a.inputs.count(p) == 1):
+                            p.mask_from = a
         if os.environ.get('OCR_FUSE_CONV_POOL', '1') != '0':
             for b in self.ops:
                 a = b.prev
@@ -1042,6 +1057,18 @@ class Engine(object):
             return d, (lambda: None)
         tmp = self._scratch(sp, d)
         return tmp, (lambda: ops.eltwise(0, d, tmp, d))
+
+    def grad_dst_acc(self, sp, producer, can_accumulate):
+        """grad_dst for a consumer whose kernel can add into the destination itself: (dst, finish, accumulate)."""
+        d = producer.dy(sp)
+        if d is None:
+            return None, (lambda: None), False
+        owner = producer.grad_owner()
+        first = owner.consumers <= 1 or owner.key not in sp.dy_done
+        if first or not can_accumulate:
+            dst, finish = self.grad_dst(sp, producer)
+            return dst, finish, False
+        return d, (lambda: None), True
 
     def deliver(self, sp, producer, grad, mask=None):
         """Pass-through gradient (add / relu backward): dy(producer) (+)= mask > 0 ? grad : 0."""

@@ -109,13 +109,19 @@ def gemm_nt(P, Q, out=None, *, M=None, N=None, K=None, ldp=None, ldq=None, ldo=N
     return out
 
 
-def conv3x3(x, wpack, out=None, *, bias=None, relu=False, mask=None):
-    """x bf16 [Nb, W, H, Cin]; wpack bf16 [Cout, 3, 3, Cin] -> bf16 [Nb, W, H, Cout]."""
+def conv3x3_accum_supported(Nb, W, H, Cin, Cout):
+    return bool(nat.lib().ocr_conv3x3_accum_supported(Nb, W, H, Cin, Cout))
+
+
+def conv3x3(x, wpack, out=None, *, bias=None, relu=False, mask=None, accumulate=False):
+    """x bf16 [Nb, W, H, Cin]; wpack bf16 [Cout, 3, 3, Cin] -> bf16 [Nb, W, H, Cout]  (accumulate: out += result)."""
     Nb, W, H, Cin = x.shape
     Cout = wpack.shape[0]
     if out is None:
+        assert not accumulate
         out = torch.empty((Nb, W, H, Cout), dtype=BF16, device=x.device)
-    flags = (EPI_BIAS if bias is not None else 0) | (EPI_RELU if relu else 0) | (EPI_MASK if mask is not None else 0)
+    flags = ((EPI_BIAS if bias is not None else 0) | (EPI_RELU if relu else 0) | (EPI_MASK if mask is not None else 0) |
+             (EPI_ACCUM if accumulate else 0))
     call("ocr_conv3x3_bf16", ptr(_dev(x)), ptr(wpack), ptr(out), Nb, W, H, Cin, Cout, ptr(bias), ptr(mask), flags, _st())
     return out
 

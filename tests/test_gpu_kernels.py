@@ -426,6 +426,28 @@ def test_conv3x3_relu_pool_fused_equals_unfused(dev, Nb, W, H, Ci, Co, kw, kh):
     assert float(p0.float().abs().max()) > 0
 
 
+def test_conv3x3_accumulate_epilogue(dev):
+    """OCR_EPI_ACCUM on the data-gradient convolution: out += masked result (a tensor with several consumers collects its gradient
+    without a scratch tensor + add pass) == bf16(out_old + fp32 result), and shapes outside the halo kernel refuse the flag."""
+    from lstm_ctc_ocr_amd._native import NativeError
+    Nb, W, H, Ci, Co = 8, 64, 8, 128, 64
+    assert ops.conv3x3_accum_supported(Nb, W, H, Ci, Co)
+    x = gen((Nb, W, H, Ci), 1).to(dev).to(BF); wp = (gen((Co, 3, 3, Ci), 2) * 0.05).to(dev).to(BF)
+    mask = gen((Nb, W, H, Co), 3).to(dev).to(BF)
+    old = gen((Nb, W, H, Co), 4).to(dev).to(BF)
+    plain = ops.conv3x3(x, wp, mask=mask)
+    out = old.clone()
+    ops.conv3x3(x, wp, out=out, mask=mask, accumulate=True)
+    want = (old.float() + plain.float())
+    # the fused form rounds once (fp32 sum -> bf16), the two-pass form twice: at most one bf16 ulp apart
+    assert float((out.float() - want).abs().max()) <= float(want.abs().max()) * 2.0 ** -7
+    assert float((out.float() - want.to(BF).float()).abs().mean()) < 1e-3
+    assert not ops.conv3x3_accum_supported(2, 8, 8, 64, 64)                 # M < 1024: not the halo kernel
+    xs = torch.zeros(2, 8, 8, 64, dtype=BF, device=dev); ws = torch.zeros(64, 3, 3, 64, dtype=BF, device=dev)
+    with pytest.raises(NativeError):
+        ops.conv3x3(xs, ws, out=torch.zeros(2, 8, 8, 64, dtype=BF, device=dev), accumulate=True)
+
+
 def test_conv3x3_pool_fusion_refuses_uncovered_shapes(dev):
     from lstm_ctc_ocr_amd._native import NativeError
     assert not ops.conv3x3_pool_supported(4, 32, 16, 32, 64, 2, 2)          # C_in % 64
