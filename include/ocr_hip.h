@@ -127,8 +127,10 @@ int ocr_maxpool_bwd(const void* x, const void* dy, void* dx, int Nb, int W, int 
 /* training-mode batch norm over rows of x[M][C] (network.py:176-178): batch statistics, biased variance.  `workspace` is
  * ocr_bn_workspace_bytes(M, C) bytes of caller-owned scratch (per-block partial sums; neither zeroed nor kept) */
 size_t ocr_bn_workspace_bytes(long M, int C);
+/* residual (bf16 [M][C], may be NULL): y = [relu](bf16(bn(x)) + residual) — the tail of a residual block (bn, Network.add,
+ * Network.relu) in the apply pass, bit-identical to the three separate passes */
 int ocr_bn_train_fwd(const void* x, void* y, const float* gamma, const float* beta, float* save_mean,
-                     float* save_rstd, long M, int C, float eps, int relu, void* workspace, void* stream);
+                     float* save_rstd, long M, int C, float eps, int relu, void* workspace, const void* residual, void* stream);
 int ocr_bn_train_bwd(const void* x, const void* y, const void* dy, void* dx, const float* gamma,
                      const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, long M, int C,
                      int relu, void* workspace, void* stream);

@@ -50,7 +50,7 @@ _SIGS = {
     "ocr_maxpool_fwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "ocr_maxpool_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "ocr_bn_workspace_bytes": ([_L, _I], ctypes.c_size_t),
-    "ocr_bn_train_fwd": ([_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P, _P], _I),
+    "ocr_bn_train_fwd": ([_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P, _P, _P], _I),
     "ocr_bn_train_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P], _I),
     "ocr_bn_infer_fwd": ([_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P], _I),
     "ocr_bn_infer_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P], _I),

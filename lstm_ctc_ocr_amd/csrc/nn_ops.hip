@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       long M, int C, int relu, int rows_per_block) {
+                                                       long M, int C, int relu, int rows_per_block, const bf16_t* __restrict__ res) {
     const int groups = C >> 3;
     const int rl = threadIdx.x / groups, gq = threadIdx.x % groups, rlanes = 256 / groups;
     if (rl >= rlanes) return;
@@ -469,9 +469,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
         float v[8], o[8];
         unpack8(*(const u32x4*)(x + r * C + gq * 8), v);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float t = (v[c] - mu[c]) * rs[c] * gm[c] + bt[c];
-            o[c] = relu ? fmaxf(t, 0.f) : t;
+        for (int c = 0; c < 8; ++c) o[c] = (v[c] - mu[c]) * rs[c] * gm[c] + bt[c];
+        if (res != nullptr) {
+            // residual block tail in the same pass: y = [relu](bf16(bn) + res) — the batch-norm output is rounded to bf16 first, so the
+            // result is bit-identical to batch-norm, add and relu as three passes (Network.add / Network.relu, network.py:340,461)
+            float q[8];
+            unpack8(*(const u32x4*)(res + r * C + gq * 8), q);
+            u32x4 rb = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+            unpack8(rb, o);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[c] += q[c];
+        }
+        if (relu) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[c] = fmaxf(o[c], 0.f);
         }
         u32x4 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
         *(u32x4*)(y + r * C + gq * 8) = pk;
@@ -868,7 +879,7 @@ extern "C" size_t ocr_bn_workspace_bytes(long M, int C) {
     return (size_t)nblk * 2 * C * sizeof(float) + 2 * (size_t)C * sizeof(double);
 }
 extern "C" int ocr_bn_train_fwd(const void* x, void* y, const float* gamma, const float* beta, float* save_mean,
-                                float* save_rstd, long M, int C, float eps, int relu, void* workspace, void* stream_) {
+                                float* save_rstd, long M, int C, float eps, int relu, void* workspace, const void* residual, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !y || !gamma || !beta || !save_mean || !save_rstd || !workspace || (C & 7) || C > 2048 || M <= 0)
         return OCR_ERR_INVALID;
@@ -881,7 +892,7 @@ extern "C" int ocr_bn_train_fwd(const void* x, void* y, const float* gamma, cons
     OCR_CHECK_LAUNCH();
     const int arows = 4 * rlanes;                                   // rows per block of the apply pass: 4 per thread
     bn_apply_kernel<<<ceil_div(M, (long)arows), 256, 0, stream>>>((const bf16_t*)x, (bf16_t*)y, save_mean, save_rstd, gamma,
-                                                                    beta, M, C, relu, arows);
+                                                                    beta, M, C, relu, arows, (const bf16_t*)residual);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }

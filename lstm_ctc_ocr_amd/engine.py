@@ -138,6 +138,8 @@ class _ConvOp(_Op):
         return (N, W, H, self.co)
 
     fused_pool = None          # set by Engine._lower: conv1 + ReLU + 2x2 max-pool run as one kernel, no full-res activation
+    tail_into = None           # set by Engine._lower: (add op, the add's other input) — this conv's batch-norm apply pass also does the
+                               # residual add + relu and writes the add's output (the add's forward is then a no-op)
     mask_from = None           # set by Engine._lower: the fused add + relu that is this (BN, no ReLU) conv's only consumer: its batch-norm
                                # backward reads the add's gradient and applies the add's ReLU mask itself (no masked copy pass)
     pool_after = None          # set by Engine._lower: the max-pool that follows this 3x3 conv + ReLU; where the shape allows, the conv's
@@ -213,10 +215,14 @@ class _ConvOp(_Op):
                         ldp=H * C, ldq=self.kh * H * C, bias=bias, relu=relu_now, row_group=Wo, row_skip=self.kh - 1)
         if self.bn:
             M = o[0] * o[1] * o[2]
+            res, relu = None, self.relu
+            if self.tail_into is not None:          # y_add = relu(bf16(bn(z)) + other input): written straight into the add's buffer
+                add, other = self.tail_into
+                y, res, relu = add.y(sp), other.y(sp).view(M, self.co), True
             ops.bn_train_fwd(tgt.view(M, self.co), e.param('%s/%s/gamma' % (self.name, self.name)),
-                             e.param('%s/%s/beta' % (self.name, self.name)), BN_EPS, self.relu,
+                             e.param('%s/%s/beta' % (self.name, self.name)), BN_EPS, relu,
                              sp.buf[self.key + '/bnws'], out=y.view(M, self.co),
-                             save_mean=sp.buf[self.key + '/mean'], save_rstd=sp.buf[self.key + '/rstd'])
+                             save_mean=sp.buf[self.key + '/mean'], save_rstd=sp.buf[self.key + '/rstd'], residual=res)
 
     def bwd(self, sp):
         e = self.eng
@@ -367,8 +373,11 @@ class _AddOp(_Op):
 
     relu = False               # True: the Network.relu that follows (its only consumer) is computed here, y = relu(a + b)
 
+    fwd_by = None              # the producing conv whose batch-norm apply pass writes this op's output (Engine._lower)
+
     def fwd(self, sp):
-        ops.eltwise(3 if self.relu else 0, self.inputs[0].y(sp), self.inputs[1].y(sp), self.y(sp))
+        if self.fwd_by is None:
+            ops.eltwise(3 if self.relu else 0, self.inputs[0].y(sp), self.inputs[1].y(sp), self.y(sp))
 
     def bwd(self, sp):
         for p in self.inputs:
@@ -1025,6 +1034,13 @@ class Engine(object):
                         if (isinstance(p, _ConvOp) and p.bn and not p.relu and p.consumers == 1 and p.kind != 'c1'
                                 and a.inputs.count(p) == 1):
                             p.mask_from = a
+                    # ... and the LAST such conv to execute also does the add + relu in its batch-norm apply pass
+                    cands = [p for p in a.inputs if getattr(p, 'mask_from', None) is a]
+                    if cands and len(a.inputs) == 2:
+                        p = max(cands, key=lambda q: self.ops.index(q))
+                        other = a.inputs[1] if a.inputs[0] is p else a.inputs[0]
+                        if isinstance(other, _InputOp) or self.ops.index(other) < self.ops.index(p):
+                            p.tail_into, a.fwd_by = (a, other), p
         if os.environ.get('OCR_FUSE_CONV_POOL', '1') != '0':
             for b in self.ops:
                 a = b.prev

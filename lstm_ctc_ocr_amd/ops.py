@@ -242,13 +242,14 @@ def bn_workspace(M, C, device):
     return torch.empty(int(nat.lib().ocr_bn_workspace_bytes(int(M), int(C))), dtype=torch.uint8, device=device)
 
 
-def bn_train_fwd(x2d, gamma, beta, eps, relu, workspace, out=None, save_mean=None, save_rstd=None):
+def bn_train_fwd(x2d, gamma, beta, eps, relu, workspace, out=None, save_mean=None, save_rstd=None, residual=None):
+    """residual (bf16 [M, C]): out = [relu](bf16(bn(x)) + residual) — batch norm, add and relu of a residual block in one apply pass"""
     M, C = x2d.shape
     if out is None: out = torch.empty_like(x2d)
     if save_mean is None: save_mean = torch.empty(C, dtype=F32, device=x2d.device)
     if save_rstd is None: save_rstd = torch.empty(C, dtype=F32, device=x2d.device)
     call("ocr_bn_train_fwd", ptr(_dev(x2d)), ptr(out), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_rstd), M, C,
-         float(eps), int(relu), ptr(workspace), _st())
+         float(eps), int(relu), ptr(workspace), ptr(residual), _st())
     return out, save_mean, save_rstd
 
 

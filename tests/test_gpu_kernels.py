@@ -469,6 +469,13 @@ def test_batchnorm(dev, M, C):
     y, sm, sr = ops.bn_train_fwd(xd, gamma.to(dev), beta.to(dev), 1e-3, True, ws)
     assert relerr(sm.cpu(), mu.detach()) < 1e-4 and relerr(sr.cpu(), torch.rsqrt(var + 1e-3).detach()) < 1e-4
     assert relerr(y.float().cpu(), bf(yr.detach())) < 1e-2
+    # residual-block tail in the apply pass: relu(bf16(bn) + res), bit-identical to batch norm (no relu), add, relu as separate passes
+    res = bf(gen((M, C), 7)).to(dev).to(BF)
+    y_plain, _, _ = ops.bn_train_fwd(xd, gamma.to(dev), beta.to(dev), 1e-3, False, ws)
+    want = torch.empty_like(y_plain)
+    ops.eltwise(3, y_plain, res, want)
+    y_tail, _, _ = ops.bn_train_fwd(xd, gamma.to(dev), beta.to(dev), 1e-3, True, ws, residual=res)
+    assert torch.equal(y_tail, want)
     dy = bf(gen((M, C), 4))
     # use the device's own (bf16) y for the mask so both sides agree on which outputs are exactly zero
     ydev = y.float().cpu()
