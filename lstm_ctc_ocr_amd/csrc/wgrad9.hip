@@ -98,7 +98,8 @@ template <int LA /* A groups kept in flight ahead of the tap being multiplied */
           bool DBG, int ABL = 0 /* timing ablations (wrong results): 1 no fragment reads, 2 no DMA after the prologue, 3 no MFMA, 4 no masks */,
           int DMA_STEP = 0 /* 0: the five DMA pieces in one block before tap DMA_AT; k: one piece every k taps from DMA_AT on */,
           bool STAG = false /* waves of pixel half 1 issue their DMA block nine taps later than those of half 0 */,
-          bool REDIR = false /* SAME padding along the feature axis by reading a zero row (address select, no ALU op on the fragment) */>
+          bool REDIR = false /* SAME padding along the feature axis by reading a zero row (address select, no ALU op on the fragment) */,
+          bool SADDR = false /* DMA with a scalar base + 32-bit lane offset (needs REDIR: rows outside the tensor are then never read from LDS) */>
 __global__ __launch_bounds__(512) void wgrad9_kernel(W9Args g) {
     constexpr int NSLOT = LA + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -145,12 +146,34 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(W9Args g) {
             src[i] = g.dY + (long)(kbeg + r) * g.Cout + co0 + qsrc;
         }
     }
+    // SADDR form: byte offset of this lane's 16 bytes from the tensor base at step 0 (halo rows before the tensor wrap to a huge
+    // unsigned value and are replaced below); 32 bits suffice: the plan admits M * C * 2 < 2^31
+    unsigned off0[W9_NDMA];
+#pragma unroll
+    for (int i = 0; i < W9_NDMA; ++i) {
+        const int u = wave + 8 * i;
+        off0[i] = 0;
+        if (u < nhalo) off0[i] = (unsigned)(((long)(kbeg - (H + 1) + 8 * u + rr) * g.Cin + ci0 + qsrc) * 2);
+        else if (u < nhalo + 16) off0[i] = (unsigned)(((long)(kbeg + 8 * (u - nhalo) + rr) * g.Cout + co0 + qsrc) * 2);
+    }
+    const unsigned safeX = (unsigned)((ci0 + qsrc) * 2);            // a valid address for halo rows outside the tensor (never read: redirected)
+    const bool tail = (kend & 127) != 0;                            // the last step of this split has dY rows past kend: zero page, old form
     auto stage_load = [&](int step, int buf) {
         unsigned char* st = smem + buf * W9_STAGE;
 #pragma unroll
         for (int i = 0; i < W9_NDMA; ++i) {
             const int u = wave + 8 * i;
             const int px = pix[i] + step * 128;
+            if (SADDR && u < nhalo) {
+                unsigned vo = off0[i] + (unsigned)step * (unsigned)(128 * 2) * (unsigned)g.Cin;
+                if ((unsigned)px >= (unsigned)g.M) vo = safeX;
+                dma16_saddr(lds0 + buf * W9_STAGE + u * 1024, vo, g.X);
+                continue;
+            }
+            if (SADDR && u < nhalo + 16 && !(tail && step == nsteps - 1)) {
+                dma16_saddr(lds0 + buf * W9_STAGE + u * 1024, off0[i] + (unsigned)step * (unsigned)(128 * 2) * (unsigned)g.Cout, g.dY);
+                continue;
+            }
             const bf16_t* s = zero;
             if (u < nhalo) { if (px >= 0 && px < g.M) s = src[i] + (long)step * 128 * g.Cin; }
             else if (u < nhalo + 16) { if (px < kend) s = src[i] + (long)step * 128 * g.Cout; }
@@ -742,6 +765,10 @@ int wgrad9_try_dispatch(const void* x, const void* dy, float* dw, float* dbias, 
         case 24: W9_LAUNCH(2, 3, false, 4); break;
         case 14: W9_LAUNCH(4, 3, true); break;
         case 40: W9_LAUNCH(2, 0, false); break;                         // first version: AND / select masks, DMA right behind the barrier
+        case 42:                                                        // scalar-base (SADDR) DMA form: measured 4 % slower (284 vs 272 us over the five layers)
+            if ((long)M * (Cin > Cout ? Cin : Cout) * 2 < 0x7fffffffL) W9_LAUNCH(2, 3, false, 0, 0, false, true, true);
+            else W9_LAUNCH(2, 3, false, 0, 0, false, true);
+            break;
         default: W9_LAUNCH(2, 3, false, 0, 0, false, true); break;      // measured best (r2): look-ahead 2, DMA block before tap 3, zero-row padding
     }
 #undef W9_LAUNCH
