@@ -1390,19 +1390,32 @@ class Engine(object):
         optimiser's scalars and the persistent-LSTM time-out words into 4 doubles, ONE 32-byte D2H copy into pinned memory and ONE
         stream wait follow (four blocking .cpu() / .item() round trips cost ~0.1 ms per iteration of the training loop, which
         fetches the loss every step like the reference: train.py:130,139; four async copies were four blit kernels)."""
+        return self.report_wait(self.report_async())
+
+    def report_async(self):
+        """Queue the report of the step that was just issued (kernel + 32-byte copy + event) and return a handle for report_wait().
+        The training loop waits for it one iteration LATER, so the host never drains the queue between two steps."""
         sp = self.last_plan
         words = getattr(sp, 'lstm_sync', ())
-        rep = getattr(sp, '_report', None)
-        if rep is None:
+        ring = getattr(sp, '_report', None)
+        if ring is None:
             addrs = torch.tensor([w[-1:].data_ptr() for w in words], dtype=torch.int64, device=self.device) if words else None
-            rep = sp._report = (torch.zeros(4, dtype=torch.float64, device=self.device), torch.zeros(4, dtype=torch.float64).pin_memory(), addrs)
-        dev, host, addrs = rep
-        ops.step_report(sp.costs, self.scalars if self.opt_ready else None, addrs, dev)
+            ring = sp._report = dict(addrs=addrs, i=0, slots=[(torch.zeros(4, dtype=torch.float64, device=self.device),
+                                                               torch.zeros(4, dtype=torch.float64).pin_memory(), torch.cuda.Event())
+                                                              for _ in range(2)])
+        ring['i'] ^= 1
+        dev, host, ev = ring['slots'][ring['i']]
+        ops.step_report(sp.costs, self.scalars if self.opt_ready else None, ring['addrs'], dev)
         host.copy_(dev, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
+        ev.record(torch.cuda.current_stream(self.device))
+        return (host, ev, words, self.opt_ready)
+
+    def report_wait(self, handle):
+        host, ev, words, opt_ready = handle
+        ev.synchronize()
         ctc, reg2, gnorm, bits = (float(v) for v in host.numpy())
-        reg = 0.5 * float(self.cfg.TRAIN.WEIGHT_DECAY) * reg2 if (self.cfg.TRAIN.WEIGHT_DECAY > 0 and self.opt_ready) else 0.0
-        self.last_ctc, self.last_reg, self.last_gnorm = ctc, reg, gnorm if self.opt_ready else 0.0
+        reg = 0.5 * float(self.cfg.TRAIN.WEIGHT_DECAY) * reg2 if (self.cfg.TRAIN.WEIGHT_DECAY > 0 and opt_ready) else 0.0
+        self.last_ctc, self.last_reg, self.last_gnorm = ctc, reg, gnorm if opt_ready else 0.0
         if bits != 0.0:
             bad = [i for i in range(len(words)) if (int(bits) >> i) & 1]
             raise NativeError('persistent LSTM %s kernel: inter-workgroup wait timed out (results invalid); counters %s'

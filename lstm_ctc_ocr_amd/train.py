@@ -103,34 +103,57 @@ class SolverWrapper(object):
         first = self._resume(eng) if restore else 1
 
         timer, best = Timer(), LOSS_SNAPSHOT_BAR
+        # The loss of iteration k is read while iteration k + 1 is already running (OCR_LOSS_LAG=1, default): the report is queued
+        # behind step k (one kernel + a 32-byte copy + an event) and waited for one iteration later, so the host never drains the
+        # queue between two steps.  Every line the reference prints is printed, for the same iteration number, one iteration
+        # later; a loss-triggered snapshot / validation therefore sees the weights one update further on.  OCR_LOSS_LAG=0 waits at
+        # once (sess.run semantics, train.py:130).
+        lag = os.environ.get('OCR_LOSS_LAG', '1') != '0'
+        state = {'best': best}
+
+        def on_loss(it, loss, elapsed):
+            if world > 1 and it % cfg.TRAIN.DISPLAY == 0:        # what is printed is the GLOBAL-batch loss (one tiny all-reduce, only
+                loss = ocr_dist.mean_scalar(loss, eng.device, eng.group)     # on the iterations that print: SURVEY 8e)
+            if not chief:
+                return False
+            if self.loss_log is not None:
+                self.loss_log.write('%d\t%.7f\n' % (it, loss))
+            if it % cfg.TRAIN.DISPLAY == 0:
+                print('iter: %d / %d, total loss: %.7f, lr: %.7f' % (it, max_iters, loss, eng.lr), end=' ')
+                print('speed: {:.3f}s / iter'.format(elapsed))
+            if loss < state['best']:
+                print('loss: ', loss, end=' ')
+                self.snapshot(eng, 1)
+                state['best'] = loss
+                print('accuracy: {:.5f}'.format(self._validate(eng, val_gen)))
+                return True
+            return False
+
+        pending = None
         for iter in range(first, max_iters):
             timer.tic()
             if iter != 0 and iter % cfg.TRAIN.STEPSIZE == 0:            # step decay of the learning rate
                 eng.scale_lr(cfg.TRAIN.GAMMA)
             images, labels, label_lens, steps = next(train_gen)
-            if hasattr(images, 'is_cuda'):                       # device-resident batch from the prefetching pipeline
-                loss = eng.train_step(images, labels, label_lens, steps)
+            if not hasattr(images, 'is_cuda'):                   # host lists of the legacy transport
+                images, labels, label_lens, steps = np.array(images), np.array(labels), np.array(label_lens), np.array(steps)
+            eng.train_step(images, labels, label_lens, steps, fetch_loss=False)
+            handle = eng.report_async()
+            fresh = False
+            if lag:
+                if pending is not None:
+                    fresh = on_loss(pending[0], eng.report_wait(pending[1]), pending[2])
+                pending = (iter, handle, timer.toc(average=False))
             else:
-                loss = eng.train_step(np.array(images), np.array(labels), np.array(label_lens), np.array(steps))
-            if world > 1 and iter % cfg.TRAIN.DISPLAY == 0:      # what is printed is the GLOBAL-batch loss (one tiny all-reduce, only
-                loss = ocr_dist.mean_scalar(loss, eng.device, eng.group)     # on the iterations that print: SURVEY 8e)
-            elapsed = timer.toc(average=False)
+                fresh = on_loss(iter, eng.report_wait(handle), timer.toc(average=False))
             if not chief:
                 continue
-            if self.loss_log is not None:
-                self.loss_log.write('%d\t%.7f\n' % (iter, loss))
-            if iter % cfg.TRAIN.DISPLAY == 0:
-                print('iter: %d / %d, total loss: %.7f, lr: %.7f' % (iter, max_iters, loss, eng.lr), end=' ')
-                print('speed: {:.3f}s / iter'.format(elapsed))
-            new_best = loss < best
-            if new_best:
-                print('loss: ', loss, end=' ')
-                self.snapshot(eng, 1)
-                best = loss
-            elif (iter + 1) % cfg.TRAIN.SNAPSHOT_ITERS == 0:
+            if (iter + 1) % cfg.TRAIN.SNAPSHOT_ITERS == 0 and not fresh:
                 self.snapshot(eng, iter)
-            if new_best or (iter + 1) % cfg.VAL.VAL_STEP == 0:
+            if (iter + 1) % cfg.VAL.VAL_STEP == 0 and not fresh:
                 print('accuracy: {:.5f}'.format(self._validate(eng, val_gen)))
+        if pending is not None:
+            on_loss(pending[0], eng.report_wait(pending[1]), pending[2])
         if self.loss_log is not None:
             self.loss_log.flush()
 

@@ -16,6 +16,9 @@ from lstm_ctc_ocr_amd.engine import Engine  # noqa: E402
 from lstm_ctc_ocr_amd.models import get_network  # noqa: E402
 
 
+LAG = True
+
+
 def run(eng, stream, iters, warm):
     it = iter(stream)
     losses = []
@@ -25,12 +28,22 @@ def run(eng, stream, iters, warm):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 0
+    pending = None
     for i in range(iters):
         b = next(it)
         x = b[0] if torch.is_tensor(b[0]) else np.array(b[0])
         rest = b[1:] if torch.is_tensor(b[0]) else [np.array(a) for a in b[1:]]
-        losses.append(eng.train_step(x, *rest))                     # fetch_loss=True: one host sync per iteration, like the reference
+        if LAG:                                                     # what lstm_ctc_ocr_amd/train.py does by default: the loss of
+            eng.train_step(x, *rest, fetch_loss=False)              # iteration k is read while iteration k + 1 runs
+            h = eng.report_async()
+            if pending is not None:
+                losses.append(eng.report_wait(pending))
+            pending = h
+        else:
+            losses.append(eng.train_step(x, *rest))                 # one host sync per iteration at once (sess.run semantics)
         n += x.shape[0]
+    if pending is not None:
+        losses.append(eng.report_wait(pending))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return n / dt, dt / iters * 1e3, float(np.mean(losses[-50:]))
@@ -42,9 +55,12 @@ def main():
     ap.add_argument('--legacy', action='store_true')
     ap.add_argument('--workers', type=int, default=0)
     ap.add_argument('--pool', type=int, default=0)
+    ap.add_argument('--no-lag', action='store_true', help='wait for every loss at once (OCR_LOSS_LAG=0 of the training loop)')
     a = ap.parse_args()
+    global LAG
+    LAG = not a.no_lag
     cfg_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lstm', 'lstm.yml'))
-    out = {'cpu_count': os.cpu_count(), 'affinity': len(os.sched_getaffinity(0)), 'pool': a.pool}
+    out = {'cpu_count': os.cpu_count(), 'affinity': len(os.sched_getaffinity(0)), 'pool': a.pool, 'loss_lag': LAG}
     try:
         out['cgroup_cpu_max'] = open('/sys/fs/cgroup/cpu.max').read().strip()
     except Exception:
