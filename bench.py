@@ -245,6 +245,19 @@ def main():
         eng.train_step(x, labels, ll, sl, fetch_loss=True)
     torch.cuda.synchronize()
     dt_fetch = time.perf_counter() - t1
+    # ... and the way lstm_ctc_ocr_amd/train.py runs it by default: every loss is read, one iteration behind (OCR_LOSS_LAG=1)
+    t2 = time.perf_counter()
+    pending = None
+    for i in range(args.steps):
+        x, labels, ll, sl = batches[i % len(batches)]
+        eng.train_step(x, labels, ll, sl, fetch_loss=False)
+        h = eng.report_async()
+        if pending is not None:
+            eng.report_wait(pending)
+        pending = h
+    eng.report_wait(pending)
+    torch.cuda.synchronize()
+    dt_lag = time.perf_counter() - t2
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -263,6 +276,7 @@ def main():
             "final_loss": loss,
             "dp_check": dp_check,
             "with_loss_fetch_every_step": {"value": BATCH * world * args.steps / dt_fetch, "ms_per_step": dt_fetch / args.steps * 1e3},
+            "with_loss_read_one_step_behind": {"value": BATCH * world * args.steps / dt_lag, "ms_per_step": dt_lag / args.steps * 1e3},
             "model_tflops_per_gpu": value / world * TRAIN_GFLOP_PER_IMG * 1e9 / 1e12,
         }
         if args.workload != "fixed":
