@@ -200,7 +200,8 @@ def main():
         cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, BATCH, net_name = 96, 2, 32, 'RESNET_train'
     eng = Engine(get_network(net_name), device=device, seed=cfg.RNG_SEED, use_graphs=not args.no_graphs)
     eng.setup_optimizer()
-    batches = (synth_batches if args.workload == 'fixed' else synth_batches_varwidth)(8, cfg.RNG_SEED + rank, device)
+    # fixed and deep: W = 256 for every batch (what their config strings say); varwidth: W in [80, 320] padded per batch
+    batches = (synth_batches_varwidth if args.workload == 'varwidth' else synth_batches)(8, cfg.RNG_SEED + rank, device)
 
     def step(i):
         x, labels, ll, sl = batches[i % len(batches)]
