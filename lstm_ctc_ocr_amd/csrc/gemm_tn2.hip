@@ -58,15 +58,18 @@ __device__ __forceinline__ bf16x8 tn2_frag(const unsigned char* a0) {
 }
 
 template <int MODE /*0 plain, 1 conv3x3, 2 conv3x3 with Cin == 64: taps (2p, 2p+1) share one 128-channel A tile*/,
-          int BKR /* rows of m per pipeline stage: 64 or 32 */, int NST /* LDS stages: 2..4 */>
-__global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
+          int BKR /* rows of m per pipeline stage: 64 or 32 */, int NST /* LDS stages: 2..4 */,
+          int NWV = 4 /* waves: 4 (64 x 64 wave tiles) or 8 (64 x 32 wave tiles: two waves per SIMD from ONE workgroup per CU, i.e. without
+                         doubling the split count and with it the atomic traffic) */>
+__global__ __launch_bounds__(64 * NWV) void gemm_tn2_kernel(Tn2Args g) {
     constexpr int TILE = BKR * 256;                  // bytes of one operand tile: BKR rows x 128 channels bf16
-    constexpr int NJ = BKR / 16;                     // DMA instructions per wave, operand and stage
+    constexpr int NJ = BKR / (4 * NWV);              // DMA instructions per wave, operand and stage
+    constexpr int FB = NWV == 4 ? 4 : 2;             // 16-column fragments of the wave tile along j
     constexpr int NKK = BKR / 32;                    // 32-row MFMA K steps per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NST stages x (A tile | B tile)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = wave >> 1, wj = wave & 1;
+    const int wi = NWV == 4 ? wave >> 1 : wave >> 2, wj = NWV == 4 ? (wave & 1) : (wave & 3);
     const int xcd = blockIdx.x & 7;
     int q = blockIdx.x >> 3;
     const int xs = xcd % g.XS, xj = (xcd / g.XS) % g.XJ, xi = xcd / (g.XS * g.XJ);
@@ -153,17 +156,17 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][FB];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < FB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
     int offa[4], offb[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) { offa[a] = tn2_frag_off(wi * 4 + a, lane); offb[a] = tn2_frag_off(wj * 4 + a, lane); }
+    for (int a = 0; a < 4; ++a) { offa[a] = tn2_frag_off(wi * 4 + a, lane); offb[a] = tn2_frag_off(wj * FB + (a < FB ? a : 0), lane); }
 
     {
         // NST stages, NST-1 steps in flight.  The counted wait at the top of step t retires stage t only (the 2*NJ DMA
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
 #pragma unroll
-                for (int f = 0; f < 8; ++f) {
+                for (int f = 0; f < 4 + FB; ++f) {
                     const unsigned ad = sbase + (f < 4 ? offa[f] : TILE + offb[f - 4]);
                     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(flo[kk][f]) : "v"(ad), "n"(kk * 32 * 256));
                     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fhi[kk][f]) : "v"(ad), "n"(kk * 32 * 256 + 16 * 256));
@@ -203,23 +206,23 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
             }
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
-                if (kk + 1 < NKK) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+                if (kk + 1 < NKK) { if (FB == 4) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); }
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 bf16x8 fr[8];
 #pragma unroll
-                for (int f = 0; f < 8; ++f) {
+                for (int f = 0; f < 4 + FB; ++f) {
                     s16x8 v = {flo[kk][f][0], flo[kk][f][1], flo[kk][f][2], flo[kk][f][3], fhi[kk][f][0], fhi[kk][f][1], fhi[kk][f][2], fhi[kk][f][3]};
                     fr[f] = __builtin_bit_cast(bf16x8, v);
                 }
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
+                    for (int b = 0; b < FB; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[a], fr[4 + b], acc[a][b], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (do_cs) {      // thread -> source chunk q = tid & 15 (8 columns), rows (tid >> 4) + 16 * i
+            if (do_cs && tid < 256) {      // thread -> source chunk q = tid & 15 (8 columns), rows (tid >> 4) + 16 * i
                 const int q = tid & 15;
 #pragma unroll
                 for (int i = 0; i < BKR / 16; ++i) {
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
     if (do_cs) {
         float* red = (float*)smem;                     // all tiles are dead after the last barrier
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = cs[e];
+        for (int e = 0; e < 8; ++e) if (tid < 256) red[tid * 8 + e] = cs[e];
         __syncthreads();
         if (tid < 128) {
             float t = 0.f;
@@ -257,8 +260,8 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(Tn2Args g) {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int j = j0 + wj * 64 + b * 16 + (lane & 15);
+        for (int b = 0; b < FB; ++b) {
+            const int j = j0 + wj * (16 * FB) + b * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = i0 + wi * 64 + a * 16 + (lane >> 4) * 4 + r;
@@ -287,7 +290,13 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
     // 32 KiB tile in flight per workgroup), so the fastest grids keep both workgroup slots of every CU filled: 400-512
     // workgroups.  Among the partitions (XS, XJ, XI) that reach that, take the least operand re-streaming plus atomic traffic
     // bytes(A) * XJ + bytes(B) * XI + 2 * S * bytes(out)   (fp32 atomics cost ~0.8 us per MB, tools/atomic_probe.py).
-    const double ideal = 432.0 / (double)tiles;
+    // plain products run on 8-wave workgroups, ONE per CU (two waves per SIMD without doubling the split count and its atomic
+    // traffic): conv5 30.3 -> 27.1 us, both BiLSTM directions 35.7 -> 32.9 us (tools/tn_split_sweep.py).  A/B knob OCR_TN2_NW=4.
+    static int nw8 = -1;
+    if (nw8 < 0) { const char* e = getenv("OCR_TN2_NW"); nw8 = (e && atoi(e) == 4) ? 0 : 1; }
+    const bool wide = nw8 && mode == 0;
+    const long wg_lo = wide ? 200 : 400, wg_hi = wide ? 256 : 512;
+    const double ideal = (wide ? 232.0 : 432.0) / (double)tiles;
     const double bytesA = 2.0 * Mk * (pair ? 64 : I) * nbatch, bytesB = 2.0 * Mk * J * nbatch, bytesO = 4.0 * taps * (pair ? 128 : I) * J * nbatch;
     double best = 1e300; int bXS = 1, bXJ = 1, bXI = 1, bS = 1;
     for (int XS = 8; XS >= 1; XS >>= 1)
@@ -299,13 +308,13 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
             else {
                 S = (int)(ideal / XS + 0.5) * XS;
                 if (S < XS) S = XS;
-                while (S > XS && ((long)S * tiles > 512 || S > maxs)) S -= XS;
+                while (S > XS && ((long)S * tiles > wg_hi || S > maxs)) S -= XS;
                 if (S > maxs && XS > 1) continue;
             }
             const long wg = (long)S * tiles;
             double cost = bytesA * XJ + bytesB * XI + 2.0 * S * bytesO;
-            if (splits <= 0 && wg < 400) cost += (400 - wg) * 40.0 * Mk;   // worth of a filled slot grows with the K loop
-            if (splits <= 0 && wg > 512) cost += (wg - 512) * 4.0e6;       // a third, ragged round of workgroups
+            if (splits <= 0 && wg < wg_lo) cost += (wg_lo - wg) * 40.0 * Mk;   // worth of a filled slot grows with the K loop
+            if (splits <= 0 && wg > wg_hi) cost += (wg - wg_hi) * 4.0e6;       // a third, ragged round of workgroups
             if (cost < best) { best = cost; bXS = XS; bXJ = XJ; bXI = XI; bS = S; }
         }
     static const char* part_env = getenv("OCR_TN2_PART");    // experiment knob "XS,XJ,XI,S", read once per process
@@ -328,7 +337,18 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
         if (!attr) { if (hipFuncSetAttribute((const void*)gemm_tn2_kernel<M_, BK_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC; attr = true; } \
         gemm_tn2_kernel<M_, BK_, NS_><<<grid, 256, lds, stream>>>(g); } while (0)
 #define TN2_MODE(BK_, NS_) do { if (km == 2) TN2_LAUNCH(2, BK_, NS_); else if (km == 1) TN2_LAUNCH(1, BK_, NS_); else TN2_LAUNCH(0, BK_, NS_); } while (0)
-    if (cfg == 1) TN2_MODE(32, 4);
+    if (wide) {                                    // 8 waves, 64-row stages x 2 (or x 3 with OCR_TN2_PIPE=3)
+        static bool attr8[2] = {false, false};
+        const int ns = cfg == 3 ? 3 : 2, lds = ns * 2 * 64 * 256;
+        if (ns == 3) {
+            if (!attr8[1]) { if (hipFuncSetAttribute((const void*)gemm_tn2_kernel<0, 64, 3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC; attr8[1] = true; }
+            gemm_tn2_kernel<0, 64, 3, 8><<<grid, 512, lds, stream>>>(g);
+        } else {
+            if (!attr8[0]) { if (hipFuncSetAttribute((const void*)gemm_tn2_kernel<0, 64, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC; attr8[0] = true; }
+            gemm_tn2_kernel<0, 64, 2, 8><<<grid, 512, lds, stream>>>(g);
+        }
+    }
+    else if (cfg == 1) TN2_MODE(32, 4);
     else if (cfg == 2) TN2_MODE(32, 3);
     else if (cfg == 3) TN2_MODE(64, 3);
     else TN2_MODE(64, 2);
