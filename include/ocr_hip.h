@@ -107,6 +107,15 @@ int ocr_conv3x3_wgrad_bf16(const void* x, const void* dy, float* dw, float* dbia
 int ocr_conv3x3_wgrad_workspace_size(int Nb, int W, int H, int Cin, int Cout, size_t* bytes);
 int ocr_conv3x3_wgrad_ws_bf16(const void* x, const void* dy, float* dw, float* dbias, int Nb, int W, int H, int Cin,
                               int Cout, int splits, void* workspace, size_t workspace_bytes, void* stream);
+/* Deferred form: a backward pass may keep the partial slabs of all its layers (one workspace per layer) and reduce them in ONE launch at
+ * its end — the per-layer reduce kernels are short and each is a dependent-kernel boundary.  Where the slab kernel covers the shape only it
+ * runs here: `job` (64 bytes of HOST memory) receives the pending reduction, *job_blocks its block count, *deferred = 1, and the
+ * workspace must stay untouched until ocr_wgrad9_reduce_jobs has run; otherwise the whole weight gradient is computed at once
+ * (*deferred = 0).  ocr_wgrad9_reduce_jobs takes a DEVICE table of such jobs whose int at byte offset 60 (`block_start`) the caller
+ * has set to the running sum of the preceding jobs' block counts; results are bit-identical to the per-layer form. */
+int ocr_conv3x3_wgrad_defer_bf16(const void* x, const void* dy, float* dw, float* dbias, int Nb, int W, int H, int Cin, int Cout,
+                                 void* workspace, size_t workspace_bytes, void* job, int* job_blocks, int* deferred, void* stream);
+int ocr_wgrad9_reduce_jobs(const void* jobs, int njobs, int total_blocks, void* stream);
 
 /* ---- conv1 (Cin = 1), pooling, batch-norm, reductions, packing (network.py:160-191, 343-350, 176-178) -------- */
 int ocr_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int Nb, int W, int H, int Cout,

@@ -42,6 +42,9 @@ _SIGS = {
     "ocr_conv3x3_wgrad_bf16": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "ocr_conv3x3_wgrad_workspace_size": ([_I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_size_t)], _I),
     "ocr_conv3x3_wgrad_ws_bf16": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, ctypes.c_size_t, _P], _I),
+    "ocr_conv3x3_wgrad_defer_bf16": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, ctypes.c_size_t, _P, ctypes.POINTER(_I),
+                                      ctypes.POINTER(_I), _P], _I),
+    "ocr_wgrad9_reduce_jobs": ([_P, _I, _I, _P], _I),
     "ocr_conv1_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "ocr_conv1_wgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "ocr_eltwise_bf16": ([_I, _P, _P, _P, _L, _P], _I),

@@ -216,7 +216,7 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
                      int grp, int skip, long a_row_off, int cW, int cH, int cC, float scale, int splits, float* colsum,
                      hipStream_t stream, int nbatch = 1, long sA = 0, long sB = 0, long sO = 0, long sC = 0);
 int wgrad9_try_dispatch(const void* x, const void* dy, float* dw, float* dbias, int Nb, int W, int H, int Cin, int Cout,
-                        void* workspace, size_t ws_bytes, hipStream_t stream);
+                        void* workspace, size_t ws_bytes, hipStream_t stream, void* defer_job = nullptr, int* defer_blocks = nullptr);
 static int g_use_tn2 = 1, g_use_w9 = 1;
 // 2 (default): nine-tap slab kernel (wgrad9.hip) where a workspace is given and the shape is covered, else as 1;
 // 1: LDS-DMA per-tap tiles with fp32 atomics (gemm_tn2.hip); 0: register-staged kernel (this file)
@@ -272,6 +272,22 @@ extern "C" int ocr_conv3x3_wgrad_ws_bf16(const void* x, const void* dy, float* d
         if (rc >= 0) return rc;
     }
     return ocr_conv3x3_wgrad_bf16(x, dy, dw, dbias, Nb, W, H, Cin, Cout, splits, stream);
+}
+
+// Deferred form for a backward pass that reduces the slabs of all its layers in ONE launch (ocr_wgrad9_reduce_jobs): where the slab
+// kernel covers the shape, only it runs here, `job` (64 bytes of HOST memory) receives the description of the pending reduction,
+// *job_blocks its block count and *deferred = 1; the workspace must then stay untouched until that reduction has run.  Otherwise the
+// whole weight gradient is computed at once as by ocr_conv3x3_wgrad_ws_bf16 and *deferred = 0.
+extern "C" int ocr_conv3x3_wgrad_defer_bf16(const void* x, const void* dy, float* dw, float* dbias, int Nb, int W, int H, int Cin,
+                                            int Cout, void* workspace, size_t workspace_bytes, void* job, int* job_blocks,
+                                            int* deferred, void* stream) {
+    if (!x || !dy || !dw || !job || !job_blocks || !deferred || Nb <= 0 || W <= 0 || H <= 0 || (Cin & 7) || (Cout & 7)) return OCR_ERR_INVALID;
+    *deferred = 0;
+    if (g_use_w9 && workspace) {
+        int rc = wgrad9_try_dispatch(x, dy, dw, dbias, Nb, W, H, Cin, Cout, workspace, workspace_bytes, (hipStream_t)stream, job, job_blocks);
+        if (rc >= 0) { if (rc == OCR_OK) *deferred = 1; return rc; }
+    }
+    return ocr_conv3x3_wgrad_bf16(x, dy, dw, dbias, Nb, W, H, Cin, Cout, 0, stream);
 }
 
 // dW[3][3][Cin][Cout] (fp32, TF layout) += sum over pixels of x[shifted pixel][ci] * dy[pixel][co]

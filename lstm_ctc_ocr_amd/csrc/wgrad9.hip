@@ -655,12 +655,12 @@ __global__ __launch_bounds__(512) void wgrad9c_kernel(W9Args g) {
 // 256 threads = `rows` thread rows x (256 / rows) float4 columns, rows = S / 8 clamped to [1, 8]: every thread adds up to eight slabs
 // (s = row, row + rows, ...) with all its loads in flight, then the rows meet in LDS.  (One load per thread — eight rows for any S —
 // ran the S = 4 .. 16 layers at 2.8 TB/s; a plain loop over all slabs per column left conv2's S = 64 to a handful of CUs.)
-__global__ __launch_bounds__(256) void wgrad9_reduce_kernel(float* __restrict__ dw, const float* __restrict__ part, long n4, long slab4,
-                                                            int S, int rows, float* __restrict__ dbias, const float* __restrict__ cs_part, int Cout) {
+__device__ __forceinline__ void w9_reduce_body(float* __restrict__ dw, const float* __restrict__ part, long n4, long slab4, int S, int rows,
+                                               float* __restrict__ dbias, const float* __restrict__ cs_part, int Cout, int blk) {
     __shared__ f32x4 red[256];
     const int cols = 256 / rows;
     const int col = threadIdx.x % cols, row = threadIdx.x / cols;
-    const long i = (long)blockIdx.x * cols + col;
+    const long i = (long)blk * cols + col;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (i < n4) {
         f32x4 b = {0.f, 0.f, 0.f, 0.f}, c = b, d = b;
@@ -680,12 +680,31 @@ __global__ __launch_bounds__(256) void wgrad9_reduce_kernel(float* __restrict__ 
         for (int r = 0; r < rows; ++r) t += red[r * cols + col];
         ((f32x4*)dw)[i] = t;
     }
-    if (dbias != nullptr && blockIdx.x == 0)
+    if (dbias != nullptr && blk == 0)
         for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
             float t = dbias[c];
             for (int s = 0; s < S; ++s) t += cs_part[(long)s * Cout + c];
             dbias[c] = t;
         }
+}
+__global__ __launch_bounds__(256) void wgrad9_reduce_kernel(float* __restrict__ dw, const float* __restrict__ part, long n4, long slab4,
+                                                            int S, int rows, float* __restrict__ dbias, const float* __restrict__ cs_part, int Cout) {
+    w9_reduce_body(dw, part, n4, slab4, S, rows, dbias, cs_part, Cout, blockIdx.x);
+}
+// The reductions of SEVERAL layers in one launch (ocr_wgrad9_reduce_jobs): the per-layer reduce kernels are short (10 - 19 us, the
+// smallest ones bound by their launch, not by their 19 MB) and each ends a dependent-kernel boundary; a backward pass that
+// keeps every layer's slabs until its end pays for one launch instead of five.  Same per-element summation order as the
+// per-layer kernel, hence bit-identical results.
+struct W9ReduceJob {        // 64 bytes, mirrored by lstm_ctc_ocr_amd/engine.py (numpy structured dtype)
+    float* dw; const float* part; float* dbias; const float* cs_part;
+    long n4, slab4;
+    int S, rows, Cout, block_start;
+};
+__global__ __launch_bounds__(256) void wgrad9_reduce_jobs_kernel(const W9ReduceJob* __restrict__ jobs, int njobs) {
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block_start) ++j;
+    const W9ReduceJob jb = jobs[j];
+    w9_reduce_body(jb.dw, jb.part, jb.n4, jb.slab4, jb.S, jb.rows, jb.dbias, jb.cs_part, jb.Cout, (int)blockIdx.x - jb.block_start);
 }
 
 struct W9Plan { int S, k_per_split, map, T_ci, T_co; size_t bytes; };
@@ -718,7 +737,7 @@ extern "C" int ocr_conv3x3_wgrad_workspace_size(int Nb, int W, int H, int Cin, i
 
 // -1: shape not covered or workspace too small (caller falls back to the atomics kernels)
 int wgrad9_try_dispatch(const void* x, const void* dy, float* dw, float* dbias, int Nb, int W, int H, int Cin, int Cout,
-                        void* workspace, size_t ws_bytes, hipStream_t stream) {
+                        void* workspace, size_t ws_bytes, hipStream_t stream, void* defer_job, int* defer_blocks) {
     W9Plan p;
     const int M = Nb * W * H;
     if (!workspace || !w9_plan(M, W, H, Cin, Cout, &p) || ws_bytes < p.bytes) return -1;
@@ -780,7 +799,21 @@ int wgrad9_try_dispatch(const void* x, const void* dy, float* dw, float* dbias, 
     while (rows & (rows - 1)) rows &= rows - 1;                       // power of two
     const int cols = 256 / rows;
     const int blocks = (int)((n4 + cols - 1) / cols);
+    if (defer_job != nullptr) {                                       // the caller runs this reduction later, with others, in one launch
+        W9ReduceJob jb = {dw, g.part, dbias, g.cs_part, n4, n4, p.S, rows, Cout, 0};
+        *(W9ReduceJob*)defer_job = jb;
+        *defer_blocks = blocks;
+        return OCR_OK;
+    }
     wgrad9_reduce_kernel<<<blocks, 256, 0, stream>>>(dw, g.part, n4, n4, p.S, rows, dbias, g.cs_part, Cout);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+
+extern "C" int ocr_wgrad9_reduce_jobs(const void* jobs, int njobs, int total_blocks, void* stream) {
+    static_assert(sizeof(W9ReduceJob) == 64, "W9ReduceJob is mirrored by engine.py");
+    if (!jobs || njobs <= 0 || total_blocks <= 0) return OCR_ERR_INVALID;
+    wgrad9_reduce_jobs_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>((const W9ReduceJob*)jobs, njobs);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }

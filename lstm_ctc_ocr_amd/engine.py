@@ -167,10 +167,14 @@ class _ConvOp(_Op):
             sp.fused_pools = getattr(sp, 'fused_pools', set())
             if ops.conv3x3_pool_supported(s[0], s[1], s[2], self.ci, self.co, p.kw_t, p.kh_f):
                 sp.fused_pools.add(p.key)
-        if self.kind == '3x3':      # scratch of the slab weight-gradient kernel: one buffer per plan, shared by all layers (one stream)
+        if self.kind == '3x3':      # scratch of the slab weight-gradient kernel
             need = ops.conv3x3_wgrad_workspace_bytes(s[0], s[1], s[2], self.ci, self.co)
             have = sp.buf.get('wgrad_ws')
-            if need and (have is None or have.numel() < need):
+            if need and self.eng.defer_w9:
+                # one buffer PER LAYER: the slabs stay until the end of the backward pass, where ONE launch reduces all layers'
+                # (Engine._flush_w9) — ~20 MB per layer of 288 GB against four dependent launches less per step
+                sp.buf[self.key + '/w9ws'] = torch.empty(need, dtype=torch.uint8, device=dev)
+            elif need and (have is None or have.numel() < need):     # one buffer per plan, shared by all layers (one stream)
                 sp.buf['wgrad_ws'] = torch.empty(need, dtype=torch.uint8, device=dev)
 
     def shadow_params(self):
@@ -252,8 +256,14 @@ class _ConvOp(_Op):
             return
         pmask = self.prev.y(sp) if self.prev.mask_in_consumer else None
         if self.kind == '3x3':
+            own_ws = sp.buf.get(self.key + '/w9ws')
             with e.wgrad_side():
-                ops.conv3x3_wgrad(x, dz, dw, dbias=db, workspace=sp.buf.get('wgrad_ws'))   # bias gradient rides on the same pass
+                if own_ws is not None:      # slab kernel now, the reduction with the other layers' at the end of the pass
+                    job, nblk = ops.conv3x3_wgrad_deferred(x, dz, dw, db, own_ws)
+                    if job is not None:
+                        sp.w9_pending.append((job, nblk))
+                else:
+                    ops.conv3x3_wgrad(x, dz, dw, dbias=db, workspace=sp.buf.get('wgrad_ws'))   # bias gradient rides on the same pass
             # a producer with several consumers (residual graphs): where the halo kernel runs, its epilogue adds to what was already
             # delivered instead of writing a scratch tensor that a second pass adds
             pdy, finish, acc = e.grad_dst_acc(sp, self.prev, ops.conv3x3_accum_supported(o[0], o[1], o[2], self.co, self.ci))
@@ -811,6 +821,7 @@ class ShapePlan(object):
         self.oshape = {'data': (N, W, eng.num_features)}       # output shape per op key (multi-input ops look their inputs up here)
         self.scratch = {}
         self.dy_done = set()
+        self.w9_pending, self.w9_tables = [], {}    # deferred weight-gradient reductions of the running backward pass / their device tables
         for op in eng.ops:
             s = self.oshape[op.prev.key]
             op.alloc(self, s)
@@ -861,6 +872,9 @@ class Engine(object):
         self.wgrad_stream = (torch.cuda.Stream(self.device) if self.device.type == 'cuda' and
                              os.environ.get('OCR_WGRAD_STREAM', '0') == '1' else None)
         self._side_used = False
+        # OCR_W9_DEFER=0: every 3x3 weight gradient reduces its slabs right behind its own kernel (five reduce launches per step
+        # for the CRNN); default: one merged reduction per backward body (bit-identical sums)
+        self.defer_w9 = os.environ.get('OCR_W9_DEFER', '1') != '0'
         self.comm_stream = torch.cuda.Stream(device=self.device)
         self._lower(net)                                 # operators first: the parameter layout follows their EXECUTION order
         self._layout(net)
@@ -1154,8 +1168,9 @@ class Engine(object):
         for op in self.ops:
             op.fwd(sp)
 
-    def _loss_and_backward(self, sp):
+    def _loss_and_backward(self, sp, flush=True):
         sp.dy_done = set()
+        sp.w9_pending = []
         logits = self.ops[-1].y(sp)
         # loss = mean over the GLOBAL batch -> d loss / d cost_n = 1 / (N * world)   (network.py:655)
         scale = ocr_dist.loss_scale(sp.N, self.world)
@@ -1169,11 +1184,37 @@ class Engine(object):
         for op in reversed(self.ops[self.split_op:]):
             op.bwd(sp)
         self._join_side()
+        if flush:
+            self._flush_w9(sp)
 
     def _backward_early(self, sp):
         for op in reversed(self.ops[:self.split_op]):
             op.bwd(sp)
         self._join_side()
+        self._flush_w9(sp)
+
+    W9_JOB_DTYPE = np.dtype([('dw', '<u8'), ('part', '<u8'), ('dbias', '<u8'), ('cs_part', '<u8'), ('n4', '<i8'), ('slab4', '<i8'),
+                             ('S', '<i4'), ('rows', '<i4'), ('Cout', '<i4'), ('block_start', '<i4')])   # == struct W9ReduceJob (wgrad9.hip)
+
+    def _flush_w9(self, sp):
+        """ONE launch for the slab reductions the 3x3 weight-gradient kernels of this backward body left pending (dw += sum of the
+        slabs, db += column sums).  The job table depends only on the plan's buffers, so it is uploaded once — on the eager run
+        that precedes every capture — and the captured graphs replay the launch with the same device table."""
+        pend, sp.w9_pending = sp.w9_pending, []
+        if not pend:
+            return
+        raw = b''.join(job for job, _ in pend)
+        ent = sp.w9_tables.get(raw)
+        if ent is None:
+            tab = np.frombuffer(raw, dtype=self.W9_JOB_DTYPE).copy()
+            assert tab.itemsize == 64 and len(tab) == len(pend)
+            start = 0
+            for i, (_, nblk) in enumerate(pend):
+                tab['block_start'][i] = start
+                start += nblk
+            dev = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
+            ent = sp.w9_tables[raw] = (dev, len(pend), start)
+        ops.wgrad9_reduce_jobs(*ent)
 
     @contextlib.contextmanager
     def wgrad_side(self):
@@ -1241,7 +1282,7 @@ class Engine(object):
         def fb():
             self.grads.zero_()
             self._forward(sp, training=True)
-            self._loss_and_backward(sp)
+            self._loss_and_backward(sp, flush=False)      # one merged weight-gradient reduction at the end of the whole backward
             self._backward_early(sp)
 
         if getattr(sp, 'graph_step', None) is None:
@@ -1262,7 +1303,7 @@ class Engine(object):
                 self.grads.zero_()
             self._forward(sp, training=(which == 'fb'))
             if which == 'fb':
-                self._loss_and_backward(sp)
+                self._loss_and_backward(sp, flush=False)
                 self._backward_early(sp)
 
         if not self.use_graphs:

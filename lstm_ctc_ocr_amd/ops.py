@@ -185,6 +185,23 @@ def conv3x3_wgrad(x, dy, dw, splits=0, dbias=None, workspace=None):
     return dw
 
 
+def conv3x3_wgrad_deferred(x, dy, dw, dbias, workspace):
+    """The slab kernel only; the reduction dw += sum of the slabs (and dbias) is left to wgrad9_reduce_jobs at the end of the backward
+    pass.  Returns (job, nblocks): `job` = the 64 bytes describing the pending reduction (struct W9ReduceJob) — or None when the shape
+    is not covered and the whole weight gradient was computed at once.  `workspace` must not be touched until the jobs have run."""
+    Nb, W, H, Cin = x.shape
+    Cout = dy.shape[-1]
+    job = (ctypes.c_ubyte * 64)()
+    nblk, deferred = ctypes.c_int(0), ctypes.c_int(0)
+    call("ocr_conv3x3_wgrad_defer_bf16", ptr(_dev(x)), ptr(dy), ptr(dw), ptr(dbias), Nb, W, H, Cin, Cout, ptr(workspace),
+         workspace.numel(), ctypes.cast(job, ctypes.c_void_p), ctypes.byref(nblk), ctypes.byref(deferred), _st())
+    return (bytes(job), nblk.value) if deferred.value else (None, 0)
+
+
+def wgrad9_reduce_jobs(table, njobs, total_blocks):
+    call("ocr_wgrad9_reduce_jobs", ptr(_dev(table)), njobs, total_blocks, _st())
+
+
 # ----------------------------------------------------------------------------------------------- HBM-bound layers
 def conv1_fwd(x, w, bias, relu=True, out=None):
     Nb, W, H = x.shape

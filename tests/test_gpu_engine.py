@@ -135,6 +135,38 @@ def test_train_step_parity(engine):
     assert not bad, bad
 
 
+def test_deferred_weight_gradient_reduction_is_bit_identical(dev, monkeypatch):
+    """OCR_W9_DEFER (default on): the 3x3 weight-gradient slab kernels leave their reductions pending and ONE launch at the end of
+    the backward body adds all layers' slabs — same per-element summation order as the per-layer reduce kernels, so the conv
+    weight and bias gradients must be bit-identical to the undeferred schedule (and to themselves under the two-graph DP split)."""
+    N, W = 8, 88
+    x, labels, ll, sl = make_batch(N, W, 2, 4, 7)
+    names = ['conv%s/%s' % (l, k) for l in ('2', '3_1', '3_2', '4_1', '4_2') for k in ('weights', 'biases')]
+
+    def grads(defer, split):
+        monkeypatch.setenv('OCR_W9_DEFER', defer)
+        eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
+        assert eng.defer_w9 == (defer == '1')
+        sp = eng.plan(N, W)
+        eng._bind(sp, x, sl, labels, ll)
+        if split:
+            eng._run_split(sp)()
+        else:
+            eng._run(sp, 'fb')
+            eng._run(sp, 'fb')                       # the second call replays the captured graph
+        torch.cuda.synchronize()
+        assert not sp.w9_pending
+        if defer == '1':
+            assert len(sp.w9_tables) == (2 if split else 1) and all(k + '/w9ws' in sp.buf for k in ('conv2', 'conv4_2'))
+        return {n: eng.grad(n).clone() for n in names}
+
+    base = grads('0', False)
+    for split in (False, True):
+        g = grads('1', split)
+        for n in names:
+            assert float(base[n].abs().max()) > 0 and torch.equal(g[n], base[n]), (n, split)
+
+
 def test_training_reduces_loss_and_matches_oracle_update(engine):
     N, W = 8, 88
     x, labels, ll, sl = make_batch(N, W, 2, 4, 3)
