@@ -147,9 +147,13 @@ int ocr_colsum_bf16(const void* a, float* out, long M, int C, long lda, void* st
 int ocr_pack_transpose(const float* in, void* out, int R, int Cc, long ldin, int lstm_units, void* stream);
 int ocr_pack_conv_dgrad(const float* w, void* out, int Cin, int Cout, void* stream);
 /* all weight re-packs of a step in ONE launch.  jobs: device array of 64-byte records
- * {int type(0 transpose+perm,1 conv-dgrad flip,2 strided cast,3 flat cast); int R, Cc, lstm_units; long ldin, ldout;
+ * {int type(0 transpose+perm,1 conv-dgrad flip,2 strided cast,3 flat cast,4 LSTM bias [4*lstm_units] fp32 -> packed gate order, fp32 dst);
+ *  int R, Cc, lstm_units; long ldin, ldout;
  *  const float* src; bf16* dst; long n; int block_start, nblocks;}  with block_start ascending */
 int ocr_pack_jobs(const void* jobs, int njobs, int total_blocks, void* stream);
+/* several fills in one launch: `jobs` = DEVICE table of njobs 32-byte records {void* ptr (16-byte aligned); long nwords (32-bit words);
+ * unsigned value; int block_start; int nblocks; int pad}, block_start = running sum of the preceding nblocks, total_blocks = their sum */
+int ocr_fill_jobs(const void* jobs, int njobs, int total_blocks, void* stream);
 int ocr_cast_f32_bf16(const float* in, void* out, long n, void* stream);
 /* uint8 pixels -> fp32 in [0, 1] (= u8 / 255, correctly rounded: identical to the host's `astype(float32) / 255.`, gen.py:59-65); n % 4 == 0 */
 int ocr_u8_to_unit_f32(const void* in, float* out, long n, void* stream);
@@ -205,6 +209,12 @@ int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, const int* seq_
                      float* cell, int Nb, int T, int U, float forget_bias, void* sync, void* stream);
 int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
                      const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync, void* stream);
+/* the same without the call's own fill launch: since the last use of the buffers the caller has stored 0xFFFF into every 16-bit element of
+ * the hand-off tensor (hout [Nb*T][2U] / dz [Nb*T][8U]) and zero into all ocr_lstm_seq_sync_words(Nb) words of sync — e.g. with ocr_fill_jobs */
+int ocr_lstm_fwd_seq_prefilled(const float* xproj, const void* whT_packed, const int* seq_len, void* hout, float* gates,
+                               float* cell, int Nb, int T, int U, float forget_bias, void* sync, void* stream);
+int ocr_lstm_bwd_seq_prefilled(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
+                               const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync, void* stream);
 /* hand-off protocol of the persistent kernels: 2 (default) = data-as-flag inside one XCD's L2 — needs workgroups with equal
  * (id & 7) on one XCD, see ocr_probe_xcc; 1 = data-as-flag through memory (sc1), 0 = counters (sc1): placement independent */
 int ocr_set_lstm_proto(int proto);

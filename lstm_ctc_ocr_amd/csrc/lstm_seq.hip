@@ -414,16 +414,17 @@ extern "C" int ocr_lstm_seq_supported(int Nb, int U) { return U == 256 && seq_ro
 // int32 words the caller must provide in `sync` (group counters + error word)
 extern "C" int ocr_lstm_seq_sync_words(int Nb) { return (2 * ceil_div(Nb, 16) + 1) * CNT_STRIDE; }
 
-extern "C" int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, const int* seq_len, void* hout,
-                                float* gates, float* cell, int Nb, int T, int U, float forget_bias, void* sync,
-                                void* stream_) {
+static int lstm_fwd_seq_(const float* xproj, const void* whT_packed, const int* seq_len, void* hout,
+                         float* gates, float* cell, int Nb, int T, int U, float forget_bias, void* sync,
+                         void* stream_, bool prefilled) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!xproj || !whT_packed || !seq_len || !hout || !gates || !cell || !sync) return OCR_ERR_INVALID;
     if (Nb <= 0 || T <= 0 || !ocr_lstm_seq_supported(Nb, U)) return OCR_ERR_INVALID;
     const int rows = seq_rows_per_wg(Nb, U);
     const int nz = ceil_div(Nb, rows), words = ocr_lstm_seq_sync_words(Nb);
     const int proto = seq_proto();
-    if (proto == 0) zero_words_kernel<<<1, 256, 0, stream>>>((unsigned*)sync, words);
+    if (prefilled) {}                                   // the caller's own fill pass did both (ocr_fill_jobs)
+    else if (proto == 0) zero_words_kernel<<<1, 256, 0, stream>>>((unsigned*)sync, words);
     else fill_words_kernel<<<256, 256, 0, stream>>>((unsigned*)hout, (long)Nb * T * 2 * U / 2, 0xFFFFFFFFu, (unsigned*)sync, words);
     OCR_CHECK_LAUNCH();
     LstmSeqFwdArgs a = {xproj, (const bf16_t*)whT_packed, seq_len, (bf16_t*)hout, gates, cell, (unsigned*)sync,
@@ -440,17 +441,31 @@ extern "C" int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, cons
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
+extern "C" int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, const int* seq_len, void* hout,
+                                float* gates, float* cell, int Nb, int T, int U, float forget_bias, void* sync,
+                                void* stream) {
+    return lstm_fwd_seq_(xproj, whT_packed, seq_len, hout, gates, cell, Nb, T, U, forget_bias, sync, stream, false);
+}
+// The same without the call's own fill launch: the caller has, since the last use of these buffers, stored 0xFFFF into every 16-bit
+// element of hout [Nb*T][2U] and zero into all ocr_lstm_seq_sync_words(Nb) words of sync (a training step does all its fills — this
+// one, the backward one, the gradient buffer — in ONE launch at its start: ocr_fill_jobs)
+extern "C" int ocr_lstm_fwd_seq_prefilled(const float* xproj, const void* whT_packed, const int* seq_len, void* hout,
+                                          float* gates, float* cell, int Nb, int T, int U, float forget_bias, void* sync,
+                                          void* stream) {
+    return lstm_fwd_seq_(xproj, whT_packed, seq_len, hout, gates, cell, Nb, T, U, forget_bias, sync, stream, true);
+}
 
-extern "C" int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
-                                const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync,
-                                void* stream_) {
+static int lstm_bwd_seq_(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
+                         const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync,
+                         void* stream_, bool prefilled) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!wh || !seq_len || !dhout || !gates || !cell || !dz || !sync) return OCR_ERR_INVALID;
     if (Nb <= 0 || T <= 0 || !ocr_lstm_seq_supported(Nb, U)) return OCR_ERR_INVALID;
     const int rows = seq_rows_per_wg(Nb, U);
     const int nz = ceil_div(Nb, rows), words = ocr_lstm_seq_sync_words(Nb);
     const int proto = seq_proto();
-    if (proto == 0) zero_words_kernel<<<1, 256, 0, stream>>>((unsigned*)sync, words);
+    if (prefilled) {}
+    else if (proto == 0) zero_words_kernel<<<1, 256, 0, stream>>>((unsigned*)sync, words);
     else fill_words_kernel<<<256, 256, 0, stream>>>((unsigned*)dz, (long)Nb * T * 8 * U / 2, 0xFFFFFFFFu, (unsigned*)sync, words);
     OCR_CHECK_LAUNCH();
     LstmSeqBwdArgs a = {(const bf16_t*)wh, ldw, w_dir_stride, seq_len, (const bf16_t*)dhout, gates, cell, (bf16_t*)dz,
@@ -466,4 +481,15 @@ extern "C" int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, con
 #undef LAUNCH_BWD
     OCR_CHECK_LAUNCH();
     return OCR_OK;
+}
+extern "C" int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
+                                const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync,
+                                void* stream) {
+    return lstm_bwd_seq_(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, Nb, T, U, sync, stream, false);
+}
+// as ocr_lstm_fwd_seq_prefilled: the caller has stored 0xFFFF into every 16-bit element of dz [Nb*T][8U] and zero into all sync words
+extern "C" int ocr_lstm_bwd_seq_prefilled(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
+                                          const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync,
+                                          void* stream) {
+    return lstm_bwd_seq_(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, Nb, T, U, sync, stream, true);
 }

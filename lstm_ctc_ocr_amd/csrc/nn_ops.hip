@@ -683,7 +683,7 @@ __global__ void conv5_col2im_kernel(const bf16_t* __restrict__ col, bf16_t* __re
 // ~4.5 us each as separate launches - 15 of them per step were ~90 us of pure launch latency)
 // ============================================================================================
 struct PackJob {            // 64 bytes, mirrored by lstm_ctc_ocr_amd/engine.py (numpy structured dtype)
-    int type;               // 0 transpose(+lstm perm), 1 conv dgrad flip, 2 strided cast, 3 flat cast
+    int type;               // 0 transpose(+lstm perm), 1 conv dgrad flip, 2 strided cast, 3 flat cast, 4 LSTM bias permutation (fp32 -> fp32)
     int R, Cc;              // type 0/2: rows, cols of the fp32 source ; type 1: Cin, Cout ; type 3: unused
     int lstm_units;         // type 0
     long ldin, ldout;       // type 0: ldin ; type 2: ldin, ldout
@@ -758,6 +758,15 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
             u32x2 pk = {pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
             *(u32x2*)(jb.dst + r * jb.ldout + c) = pk;
         }
+    } else if (jb.type == 4) {
+        // LSTM bias of one direction, fp32 [4U] gate-major -> fp32 in the packed gate-column order of the forward operands
+        // ((u / 16) * 64 + g * 16 + u % 16, as lstm_pack_bias_kernel); dst is a float address
+        float* out = (float*)jb.dst;
+        const int U = jb.lstm_units;
+        for (long i = (long)b * 256 + threadIdx.x; i < jb.n; i += (long)jb.nblocks * 256) {
+            const int g = (int)(i / U), u = (int)(i % U);
+            out[(u >> 4) * 64 + g * 16 + (u & 15)] = jb.src[i];
+        }
     } else {
         for (long i = ((long)b * 256 + threadIdx.x) * 4; i + 3 < jb.n; i += (long)jb.nblocks * 256 * 4) {
             f32x4 v = *(const f32x4*)(jb.src + i);
@@ -765,6 +774,35 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
             *(u32x2*)(jb.dst + i) = pk;
         }
     }
+}
+
+// ============================================================================================
+// Several buffer fills in ONE launch (the fills a training step needs before its first real kernel: the gradient buffer := 0, the
+// persistent LSTM's hand-off tensors := 0xFFFF and its counters := 0 — three separate launches of 5-7 us each otherwise, every one
+// of them bound by its launch and not by its bytes).
+// ============================================================================================
+struct FillJob {            // 32 bytes, mirrored by lstm_ctc_ocr_amd/engine.py
+    unsigned* ptr;          // 16-byte aligned
+    long nwords;            // 32-bit words to set
+    unsigned value;
+    int block_start, nblocks, pad_;
+};
+__global__ __launch_bounds__(256) void fill_jobs_kernel(const FillJob* __restrict__ jobs, int njobs) {
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block_start) ++j;
+    const FillJob jb = jobs[j];
+    const int b = blockIdx.x - jb.block_start;
+    const u32x4 v = {jb.value, jb.value, jb.value, jb.value};
+    const long n4 = jb.nwords >> 2;
+    for (long i = (long)b * 256 + threadIdx.x; i < n4; i += (long)jb.nblocks * 256) ((u32x4*)jb.ptr)[i] = v;
+    if (b == 0 && threadIdx.x < (int)(jb.nwords & 3)) jb.ptr[(n4 << 2) + threadIdx.x] = jb.value;
+}
+extern "C" int ocr_fill_jobs(const void* jobs, int njobs, int total_blocks, void* stream) {
+    static_assert(sizeof(FillJob) == 32, "FillJob is mirrored by engine.py");
+    if (!jobs || njobs <= 0 || total_blocks <= 0) return OCR_ERR_INVALID;
+    fill_jobs_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>((const FillJob*)jobs, njobs);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
 }
 
 // ============================================================================================

@@ -717,6 +717,12 @@ class _BiLstmOp(_Op):
             b[self.key + '/sync_f'] = torch.zeros(ops.lstm_seq_sync_words(N), dtype=I32, device=dev)
             b[self.key + '/sync_b'] = torch.zeros(ops.lstm_seq_sync_words(N), dtype=I32, device=dev)
             sp.lstm_sync = getattr(sp, 'lstm_sync', ()) + (b[self.key + '/sync_f'], b[self.key + '/sync_b'])
+            if self.eng.fuse_fills and self._persistent(N):
+                # data-as-flag hand-off: the exchanged tensors start as 0xFFFF, the counters / error words as 0 — set by the step's
+                # prologue launch instead of one fill launch in front of each persistent kernel
+                sp.fills_fwd += [(b[self.key + '/hout'], 0xFFFFFFFF), (b[self.key + '/sync_f'], 0)]
+                sp.fills_bwd += [(b[self.key + '/dz'], 0xFFFFFFFF), (b[self.key + '/sync_b'], 0)]
+                sp.prefilled = getattr(sp, 'prefilled', set()) | {self.key}
 
     def shadow_params(self):
         return [c + '/weights' for c in self.cells] + ([self.fc + '/weights'] if self.with_fc else [])
@@ -732,10 +738,15 @@ class _BiLstmOp(_Op):
         if self.with_fc:
             wf = e.param(self.fc + '/weights')
             jobs.append(dict(type=0, R=wf.shape[0], Cc=wf.shape[1], ldin=wf.shape[1], src=wf, dst=self.wfcT))
+        if e.fuse_pack_bias:        # the biases' gate-order permutation rides in the same launch (was a launch of its own per LSTM layer)
+            for d, cell in enumerate(self.cells):
+                jobs.append(dict(type=4, lstm_units=U, n=4 * U, src=e.param(cell + '/biases'), dst=self.bias[d * 4 * U:(d + 1) * 4 * U]))
         return jobs
 
     def refresh(self):
         e = self.eng
+        if e.fuse_pack_bias:
+            return
         ops.lstm_pack_bias(e.param(self.cells[0] + '/biases'), e.param(self.cells[1] + '/biases') if self.ND == 2 else None,
                            self.bias, self.U, self.ND)
 
@@ -748,7 +759,8 @@ class _BiLstmOp(_Op):
         ops.gemm_nt(x, self.wxT, out=b[self.key + '/xproj'], bias=self.bias)
         if self._persistent(N):
             ops.lstm_fwd_seq(b[self.key + '/xproj'], self.whT, sp.seq_len, b[self.key + '/hout'], b[self.key + '/gates'],
-                             b[self.key + '/cell'], N, T, U, b[self.key + '/sync_f'], 1.0)
+                             b[self.key + '/cell'], N, T, U, b[self.key + '/sync_f'], 1.0,
+                             prefilled=self.key in getattr(sp, 'prefilled', ()))
         else:
             for s in range(T):
                 ops.lstm_fwd_step(b[self.key + '/xproj'], self.whT, sp.seq_len, b[self.key + '/hout'],
@@ -774,7 +786,8 @@ class _BiLstmOp(_Op):
         stride = e.offset(self.cells[1] + '/weights') - e.offset(self.cells[0] + '/weights') if ND == 2 else 0
         if self._persistent(N):
             ops.lstm_bwd_seq(wsh[D:], 4 * U, stride, sp.seq_len, b[self.key + '/dhout'], b[self.key + '/gates'],
-                             b[self.key + '/cell'], b[self.key + '/dz'], N, T, U, b[self.key + '/sync_b'])
+                             b[self.key + '/cell'], b[self.key + '/dz'], N, T, U, b[self.key + '/sync_b'],
+                             prefilled=self.key in getattr(sp, 'prefilled', ()))
         else:
             b[self.key + '/dc'].zero_()
             for s in range(T - 1, -1, -1):
@@ -821,6 +834,7 @@ class ShapePlan(object):
         self.oshape = {'data': (N, W, eng.num_features)}       # output shape per op key (multi-input ops look their inputs up here)
         self.scratch = {}
         self.dy_done = set()
+        self.fills_fwd, self.fills_bwd, self.fill_tables = [], [], {}    # (tensor, 32-bit value) set by the one-launch prologue of a step
         self.w9_pending, self.w9_tables = [], {}    # deferred weight-gradient reductions of the running backward pass / their device tables
         for op in eng.ops:
             s = self.oshape[op.prev.key]
@@ -875,6 +889,10 @@ class Engine(object):
         # OCR_W9_DEFER=0: every 3x3 weight gradient reduces its slabs right behind its own kernel (five reduce launches per step
         # for the CRNN); default: one merged reduction per backward body (bit-identical sums)
         self.defer_w9 = os.environ.get('OCR_W9_DEFER', '1') != '0'
+        # OCR_FUSE_FILLS=0: the gradient buffer is zeroed by its own fill kernel and each persistent LSTM launch fills its hand-off
+        # tensor itself (three ~6 us launches per training step); default: ONE fill launch at the start of the step (_prologue)
+        self.fuse_fills = os.environ.get('OCR_FUSE_FILLS', '1') != '0'
+        self.fuse_pack_bias = os.environ.get('OCR_FUSE_PACK_BIAS', '1') != '0'     # LSTM bias permutation as a job of the re-pack launch
         self.comm_stream = torch.cuda.Stream(device=self.device)
         self._lower(net)                                 # operators first: the parameter layout follows their EXECUTION order
         self._layout(net)
@@ -990,6 +1008,8 @@ class Engine(object):
                 nb = min((j['n'] + 255) // 256, 512)
             elif t == 2:
                 nb = min((j['R'] * j['Cc'] // 4 + 255) // 256, 512)
+            elif t == 4:
+                nb = min((j['n'] + 255) // 256, 512)
             else:
                 nb = min((j['n'] // 4 + 255) // 256, 2048)
             tab[i] = (t, j.get('R', 0), j.get('Cc', 0), j.get('lstm_units', 0), j.get('ldin', 0), j.get('ldout', 0),
@@ -1163,8 +1183,40 @@ class Engine(object):
         """Device double counting the completed optimiser steps (scalars[6]) — the per-step salt of the dropout masks."""
         return self.scalars[6:7] if self.opt_ready else self._zero_step
 
+    FILL_JOB_DTYPE = np.dtype([('ptr', '<u8'), ('nwords', '<i8'), ('value', '<u4'), ('block_start', '<i4'), ('nblocks', '<i4'),
+                               ('pad', '<i4')])        # == struct FillJob in csrc/nn_ops.hip (32 bytes)
+
+    def _prologue(self, sp, training):
+        """Every fill a step needs before its first real kernel in ONE launch: the flat gradient buffer := 0 (training), the
+        persistent LSTMs' hand-off tensors := 0xFFFF and their counter / error words := 0 (the backward ones only in training).
+        With OCR_FUSE_FILLS=0 only the gradient buffer is zeroed here, by torch's fill kernel, as before."""
+        if not self.fuse_fills:
+            if training:
+                self.grads.zero_()
+            return
+        ent = sp.fill_tables.get(training)
+        if ent is None:
+            items = ([(self.grads, 0)] if training else []) + sp.fills_fwd + (sp.fills_bwd if training else [])
+            if not items:
+                sp.fill_tables[training] = ent = ()
+            else:
+                tab = np.zeros(len(items), self.FILL_JOB_DTYPE)
+                assert tab.itemsize == 32
+                start = 0
+                for i, (t, value) in enumerate(items):
+                    nbytes = t.numel() * t.element_size()
+                    assert t.is_contiguous() and t.data_ptr() % 16 == 0 and nbytes % 4 == 0, (tuple(t.shape), t.dtype)
+                    nblk = max(1, min(1024, (nbytes // 16 + 1023) // 1024))       # >= four 16-byte stores per thread
+                    tab[i] = (t.data_ptr(), nbytes // 4, value, start, nblk, 0)
+                    start += nblk
+                dev = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)   # uploaded on the eager run that precedes a capture
+                sp.fill_tables[training] = ent = (dev, len(items), start)
+        if ent:
+            ops.fill_jobs(*ent)
+
     def _forward(self, sp, training=False):
         self.training = training
+        self._prologue(sp, training)
         for op in self.ops:
             op.fwd(sp)
 
@@ -1256,8 +1308,7 @@ class Engine(object):
         """forward + loss + backward of the late layers as one graph, backward of the early layers as a second one (data-
         parallel runs: the exchange of the late gradients is issued between the two)."""
         def body1():
-            self.grads.zero_()
-            self._forward(sp, training=True)
+            self._forward(sp, training=True)            # starts with the step's fills (_prologue): gradient buffer := 0, ...
             self._loss_and_backward(sp)
 
         def body2():
@@ -1280,8 +1331,7 @@ class Engine(object):
             self.setup_optimizer()
 
         def fb():
-            self.grads.zero_()
-            self._forward(sp, training=True)
+            self._forward(sp, training=True)            # starts with the step's fills (_prologue): gradient buffer := 0, ...
             self._loss_and_backward(sp, flush=False)      # one merged weight-gradient reduction at the end of the whole backward
             self._backward_early(sp)
 
@@ -1299,9 +1349,7 @@ class Engine(object):
         attr = 'graph_fb' if which == 'fb' else 'graph_fwd'
 
         def body():
-            if which == 'fb':
-                self.grads.zero_()
-            self._forward(sp, training=(which == 'fb'))
+            self._forward(sp, training=(which == 'fb'))     # starts with the step's fills (_prologue)
             if which == 'fb':
                 self._loss_and_backward(sp, flush=False)
                 self._backward_early(sp)
