@@ -775,12 +775,18 @@ class _BiLstmOp(_Op):
         R = N * T
         b = sp.buf
         hout = b[self.key + '/hout']
+        x = self.prev.y(sp).view(R, D)
+        batched = (D + U) % 128 == 0 and (4 * U) % 128 == 0
+        aux = e.aux_side if (e.aux_stream is not None and self._persistent(N)) else None     # beside the persistent recurrence
         if self.with_fc:
             dl = b[self.key + '/dy']
             # FC: dW += H^T dL, db += colsum dL, dH = dL Wfc^T
-            with e.wgrad_side():
+            with (aux or e.wgrad_side)():
                 ops.gemm_tn(hout, dl, e.grad(self.fc + '/weights'), colsum=e.grad(self.fc + '/biases'))
             ops.gemm_nt(dl, e.shadow(self.fc + '/weights'), out=b[self.key + '/dhout'])
+        if aux is not None and batched:
+            with aux():
+                ops.lstm_xh(x, hout, sp.seq_len, b[self.key + '/xh'], N, T, D, U, ND)
         # BPTT, all directions per launch
         wsh = e.shadow(self.cells[0] + '/weights')
         stride = e.offset(self.cells[1] + '/weights') - e.offset(self.cells[0] + '/weights') if ND == 2 else 0
@@ -793,16 +799,17 @@ class _BiLstmOp(_Op):
             for s in range(T - 1, -1, -1):
                 ops.lstm_bwd_step(wsh[D:], 4 * U, stride, sp.seq_len, b[self.key + '/dhout'], b[self.key + '/gates'],
                                   b[self.key + '/cell'], b[self.key + '/dz'], b[self.key + '/dc'], N, T, U, s, ND)
+        e.join_aux()                 # the FC weight gradient and the [x | h_prev] operand are complete
         dz = b[self.key + '/dz']
-        x = self.prev.y(sp).view(R, D)
         gw = [e.grad(cell + '/weights') for cell in self.cells]
         gb = [e.grad(cell + '/biases') for cell in self.cells]
         with e.wgrad_side():
-            if (D + U) % 128 == 0 and (4 * U) % 128 == 0:
+            if batched:
                 # dW_d[D+U, 4U] = [x | h_prev,d]^T dz_d for all directions in ONE launch (the TF LSTMCell matrix is applied to
                 # concat([x_t, h_{t-1}]), network.py:104-107): 4 short-K weight-gradient launches become 1
                 xh = b[self.key + '/xh']
-                ops.lstm_xh(x, hout, sp.seq_len, xh, N, T, D, U, ND)
+                if aux is None:
+                    ops.lstm_xh(x, hout, sp.seq_len, xh, N, T, D, U, ND)
                 ops.gemm_tn_batched(xh, D + U, R * (D + U), dz, ND * 4 * U, 4 * U, gw[0], 4 * U, stride, R, D + U, 4 * U, ND,
                                     colsum=gb[0],
                                     strideColsum=(e.offset(self.cells[1] + '/biases') - e.offset(self.cells[0] + '/biases')) if ND == 2 else 0)
@@ -893,6 +900,12 @@ class Engine(object):
         # tensor itself (three ~6 us launches per training step); default: ONE fill launch at the start of the step (_prologue)
         self.fuse_fills = os.environ.get('OCR_FUSE_FILLS', '1') != '0'
         self.fuse_pack_bias = os.environ.get('OCR_FUSE_PACK_BIAS', '1') != '0'     # LSTM bias permutation as a job of the re-pack launch
+        # OCR_LSTM_AUX=0: everything of the BiLSTM backward on one stream.  Default: the two small kernels that do not depend on the
+        # backward recurrence (FC weight gradient, the [x | h_prev] operand of the LSTM weight gradient; ~7 us each, both bound by
+        # their launch) run on an auxiliary stream BESIDE the persistent recurrence kernel, whose 128 one-wave workgroups leave most
+        # of the chip idle for ~160 us (measured in round 2: a concurrent kernel hides under it, tools/side_stream_probe.py)
+        self.aux_stream = (torch.cuda.Stream(self.device) if os.environ.get('OCR_LSTM_AUX', '1') != '0' else None)
+        self._aux_used = False
         self.comm_stream = torch.cuda.Stream(device=self.device)
         self._lower(net)                                 # operators first: the parameter layout follows their EXECUTION order
         self._layout(net)
@@ -1283,6 +1296,24 @@ class Engine(object):
         if self._side_used:
             torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
             self._side_used = False
+
+    @contextlib.contextmanager
+    def aux_side(self):
+        """Launches inside run on the auxiliary stream, ordered after everything issued on the current stream so far; join_aux()
+        orders the current stream after them (fork / join become parallel branches of a captured hipGraph)."""
+        if self.aux_stream is None:
+            yield
+            return
+        if not self._aux_used:
+            self.aux_stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._aux_used = True
+        with torch.cuda.stream(self.aux_stream):
+            yield
+
+    def join_aux(self):
+        if self._aux_used:
+            torch.cuda.current_stream(self.device).wait_stream(self.aux_stream)
+            self._aux_used = False
 
     def _capture(self, fn):
         """hipGraph capture of fn() with Python's cyclic garbage collector paused: a collection that frees device tensors of
