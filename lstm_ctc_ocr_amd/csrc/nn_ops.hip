@@ -3,6 +3,7 @@
 // bias-gradient column sums, weight (re)packing.  Everything moves 16 B per lane (8 bf16 / 4 f32),
 // coalesced along the channel axis of the reference layout [N, W, H, C].
 #include "common.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ void unpack8(u32x4 p, float* f) {
     f[0] = bf_lo(p.x); f[1] = bf_hi(p.x); f[2] = bf_lo(p.y); f[3] = bf_hi(p.y);
@@ -151,6 +152,185 @@ __device__ __forceinline__ void conv1_window(const float* __restrict__ xn, int W
             for (int c = 0; c < 8; ++c) o[e][c] = fmaf(patch[a + t / 3][b + t % 3], wr[t][c], o[e][c]);
 #pragma unroll
         for (int c = 0; c < 8; ++c) o[e][c] = fmaxf(o[e][c] + br[c], 0.f);
+    }
+}
+
+// Second generation of the two fused kernels (round 2; the first one stays behind OCR_CONV1_V1=1).  The ISA of the first showed, per
+// loop iteration, two 64-bit integer divisions (~130 instructions each, half of them scalar with readfirstlane round trips), 16 patch
+// loads each in its own exec-masked branch, and the loads placed right in front of their first use — so every iteration exposed a
+// whole memory round trip.  Here: 32-bit index arithmetic, branch-free patch loads (clamped address, then a select: rows 1-2 and
+// columns 1-2 of the 4 x 4 patch are always inside the image), and the NEXT iteration's patch (and gradient row) requested before
+// the current iteration's ~300 FMAs.  The arithmetic on the loaded values is unchanged, hence bit-identical results.
+struct Conv1Patch { float v[4][4]; };
+struct Conv1Raw { float t[4][4]; unsigned ok; };     // as loaded (clamped addresses) + which border rows / columns exist; selected later
+__device__ __forceinline__ void conv1_patch_load(const float* __restrict__ x, int W, int H, int Wo, int Ho, unsigned op, Conv1Raw& raw) {
+    const unsigned ho = op % (unsigned)Ho, q = op / (unsigned)Ho;
+    const unsigned wo = q % (unsigned)Wo, n = q / (unsigned)Wo;
+    const float* xn = x + (long)n * W * H;
+    const int w0 = (int)wo * 2, h0 = (int)ho * 2;
+    // rows w0 - 1 .. w0 + 2: only the first can be < 0, only the last can be >= W (likewise the columns)
+    const bool r0 = w0 > 0, r3 = w0 + 2 < W, c0 = h0 > 0, c3 = h0 + 2 < H;
+    const int wi[4] = {r0 ? w0 - 1 : 0, w0, w0 + 1, r3 ? w0 + 2 : w0 + 1};
+    const int hj[4] = {c0 ? h0 - 1 : 0, h0, h0 + 1, c3 ? h0 + 2 : h0 + 1};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) raw.t[i][j] = xn[wi[i] * H + hj[j]];
+    raw.ok = (r0 ? 1u : 0u) | (r3 ? 2u : 0u) | (c0 ? 4u : 0u) | (c3 ? 8u : 0u);
+}
+// the zero padding is applied when the patch is USED (one iteration after its loads were issued): a select right behind the loads
+// would make the wave wait for them before the current iteration's arithmetic
+__device__ __forceinline__ void conv1_patch_select(const Conv1Raw& raw, Conv1Patch& pt) {
+    const bool r0 = raw.ok & 1u, r3 = raw.ok & 2u, c0 = raw.ok & 4u, c3 = raw.ok & 8u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = (i != 0 || r0) && (i != 3 || r3) && (j != 0 || c0) && (j != 3 || c3);
+            pt.v[i][j] = ok ? raw.t[i][j] : 0.f;
+        }
+}
+// The 80 weight / bias registers are made "arrived" before the loop: the memory counter is in-order, so as long as the compiler has to
+// assume that a weight load may still be outstanding, its counted waits inside the loop also drain the NEXT iteration's prefetch.
+__device__ __forceinline__ void conv1_pin_weights(float (&wr)[9][8], float (&br)[8]) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(wr[t][c]));
+#pragma unroll
+    for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(br[c]));
+}
+__device__ __forceinline__ void conv1_window_compute(const Conv1Patch& pt, const float (&wr)[9][8], const float (&br)[8], float (&o)[4][8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int a = e >> 1, b = e & 1;               // window element (a over W, b over H) = TF scan order
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[e][c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[e][c] = fmaf(pt.v[a + t / 3][b + t % 3], wr[t][c], o[e][c]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[e][c] = fmaxf(o[e][c] + br[c], 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void conv1_pool_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, bf16_t* __restrict__ p,
+                                                              int Nb, int W, int H, int Cout) {
+    const int groups = Cout >> 3, gq = threadIdx.x % groups, plane = threadIdx.x / groups, planes = 256 / groups;
+    float wr[9][8], br[8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) wr[t][c] = w[t * Cout + gq * 8 + c];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) br[c] = bias[gq * 8 + c];
+    conv1_pin_weights(wr, br);
+    const int Wo = W >> 1, Ho = H >> 1;
+    const unsigned npix = (unsigned)Nb * Wo * Ho, stride = gridDim.x * planes;      // npix < 2^31 (checked by the host)
+    unsigned op = blockIdx.x * planes + plane;
+    Conv1Raw nxt;
+    if (op < npix) conv1_patch_load(x, W, H, Wo, Ho, op, nxt);
+    for (; op < npix; op += stride) {
+        Conv1Patch cur;
+        conv1_patch_select(nxt, cur);
+        if (op + stride < npix) conv1_patch_load(x, W, H, Wo, Ho, op + stride, nxt);     // in flight during the FMAs below
+        float o[4][8];
+        conv1_window_compute(cur, wr, br, o);
+        float m[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) m[c] = fmaxf(fmaxf(o[0][c], o[1][c]), fmaxf(o[2][c], o[3][c]));   // rounding is monotone: max then round
+        u32x4 pk = {pack_bf2(m[0], m[1]), pack_bf2(m[2], m[3]), pack_bf2(m[4], m[5]), pack_bf2(m[6], m[7])};
+        *(u32x4*)(p + (long)op * Cout + gq * 8) = pk;
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv1_pool_bwd2_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                            const bf16_t* __restrict__ dp, float* __restrict__ dw, float* __restrict__ db, int Nb, int W,
+                            int H, int Cout, int pix_per_block) {
+    // Cout == 64: 8 channel groups x 32 pixel lanes
+    const int gq = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    float wr[9][8], br[8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) wr[t][c] = w[t * Cout + gq * 8 + c];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) br[c] = bias[gq * 8 + c];
+    conv1_pin_weights(wr, br);
+    const int Wo = W >> 1, Ho = H >> 1;
+    const unsigned npix = (unsigned)Nb * Wo * Ho;
+    const unsigned p0 = blockIdx.x * (unsigned)pix_per_block, p1 = min(npix, p0 + (unsigned)pix_per_block);
+    float acc[10][8];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[t][c] = 0.f;
+    unsigned op = p0 + pl;
+    Conv1Raw nxt;
+    u32x4 gnxt = {0u, 0u, 0u, 0u};
+    if (op < p1) {
+        conv1_patch_load(x, W, H, Wo, Ho, op, nxt);
+        gnxt = *(const u32x4*)(dp + (long)op * Cout + gq * 8);
+    }
+    for (; op < p1; op += 32) {
+        Conv1Patch cur;
+        conv1_patch_select(nxt, cur);
+        const u32x4 gcur = gnxt;
+        if (op + 32 < p1) {                                 // the next iteration's operands, in flight during this one's arithmetic
+            conv1_patch_load(x, W, H, Wo, Ho, op + 32, nxt);
+            gnxt = *(const u32x4*)(dp + (long)(op + 32) * Cout + gq * 8);
+        }
+        float o[4][8];
+        conv1_window_compute(cur, wr, br, o);
+        float g[8];
+        unpack8(gcur, g);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            // the forward stored bf16(max); compare on the same rounded values so ties resolve exactly like the unfused path
+            float r[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = bf_lo(pack_bf2(o[e][c], 0.f));
+            int best = 0; float bvv = r[0];
+#pragma unroll
+            for (int e = 1; e < 4; ++e) if (r[e] > bvv) { bvv = r[e]; best = e; }
+            const float gv = (bvv > 0.f) ? g[c] : 0.f;             // ReLU mask of the winning element
+            acc[9][c] += gv;
+            const int a = best >> 1, b = best & 1;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int i = t / 3, j = t % 3;
+                const float xv = (a == 0) ? ((b == 0) ? cur.v[i][j] : cur.v[i][j + 1]) : ((b == 0) ? cur.v[i + 1][j] : cur.v[i + 1][j + 1]);
+                acc[t][c] = fmaf(xv, gv, acc[t][c]);
+            }
+        }
+    }
+    __shared__ float red[4][10][64];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float v = acc[t][c];
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[t][c] = v;
+        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 8) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) red[wave][t][lane * 8 + c] = acc[t][c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 10 * 64; i += 256) {
+        int t = i / 64, c = i % 64;
+        float v = red[0][t][c] + red[1][t][c] + red[2][t][c] + red[3][t][c];
+        if (t < 9) atomicAdd(dw + t * Cout + c, v);
+        else atomicAdd(db + c, v);
     }
 }
 
@@ -833,6 +1013,12 @@ __global__ __launch_bounds__(256) void eltwise_bf16_kernel(int op, const bf16_t*
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
+// A/B knob OCR_CONV1_V1=1: the first generation of the fused conv1 + pool kernels (read once)
+static bool conv1_v1() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OCR_CONV1_V1"); v = (e && atoi(e) != 0) ? 1 : 0; }
+    return v == 1;
+}
 static inline int grid_for(long total, int cap = 4096) {
     long b = (total + 255) / 256;
     if (b > cap) b = cap;
@@ -869,7 +1055,10 @@ extern "C" int ocr_conv1_pool_fwd(const float* x, const float* w, const float* b
                                   void* stream) {
     if (!x || !w || !bias || !p || (Cout & 7) || Cout > 1024 || 256 % (Cout >> 3) || (W & 1) || (H & 1)) return OCR_ERR_INVALID;
     long total = (long)Nb * (W / 2) * (H / 2) * (Cout >> 3);
-    conv1_pool_fwd_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout);
+    if (!conv1_v1() && (long)Nb * (W / 2) * (H / 2) < 0x7fffffffL && (long)Nb * W * H < 0x7fffffffL && (long)W * H < 0x7fffffffL)
+        conv1_pool_fwd2_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout);
+    else
+        conv1_pool_fwd_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
@@ -878,8 +1067,12 @@ extern "C" int ocr_conv1_pool_bwd(const float* x, const float* w, const float* b
     if (!x || !w || !bias || !dp || !dw || !db || Cout != 64 || (W & 1) || (H & 1)) return OCR_ERR_INVALID;
     long npix = (long)Nb * (W / 2) * (H / 2);
     int ppb = 256;
-    conv1_pool_bwd_kernel<<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, w, bias, (const bf16_t*)dp, dw, db, Nb, W, H,
-                                                                                Cout, ppb);
+    if (!conv1_v1() && npix < 0x7fffffffL - 512 && (long)Nb * W * H < 0x7fffffffL)
+        conv1_pool_bwd2_kernel<<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, w, bias, (const bf16_t*)dp, dw, db, Nb, W, H,
+                                                                                     Cout, ppb);
+    else
+        conv1_pool_bwd_kernel<<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, w, bias, (const bf16_t*)dp, dw, db, Nb, W, H,
+                                                                                    Cout, ppb);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }

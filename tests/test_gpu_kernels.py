@@ -373,8 +373,11 @@ def test_conv1(dev):
     assert relerr(dw.cpu(), wr.grad) < 1e-4 and relerr(db.cpu(), br.grad) < 1e-4
 
 
-def test_conv1_pool_fused_equals_unfused(dev):
-    Nb, W, H, Co = 5, 24, 32, 64
+@pytest.mark.parametrize("Nb,W,H", [(5, 24, 32), (40, 250, 32), (3, 30, 12)])
+def test_conv1_pool_fused_equals_unfused(dev, Nb, W, H):
+    """(40, 250, 32): more pooled pixels than one sweep of the forward grid, so the kernels' next-iteration prefetch runs; W / 2 = 125
+    and H / 2 = 6 are not powers of two (32-bit index arithmetic)."""
+    Co = 64
     x = gen((Nb, W, H), 1).abs().to(dev); w = gen((3, 3, 1, Co), 2, 0.3).to(dev); b = gen((Co,), 3, 0.1).to(dev)
     y = ops.conv1_fwd(x, w, b)
     p_ref = ops.maxpool_fwd(y, 2, 2)
