@@ -518,6 +518,11 @@ def test_small_ops(dev):
     c = col.reshape(3, 8, 2, 64); ref = torch.zeros(3, 9, 64)
     ref[:, :8] += c[:, :, 0]; ref[:, 1:] += c[:, :, 1]
     assert maxerr(dx.float().cpu(), bf(ref)) == 0.0
+    col = bf(gen((7 * 32, 2, 1024), 7)); dx = torch.empty((7, 33, 1024), dtype=BF, device=dev)     # the headline row length (H * C = 2 * 512)
+    ops.conv5_col2im(col.to(dev).to(BF), dx, 7, 33, 1024)
+    c = col.reshape(7, 32, 2, 1024); ref = torch.zeros(7, 33, 1024)
+    ref[:, :32] += c[:, :, 0]; ref[:, 1:] += c[:, :, 1]
+    assert maxerr(dx.float().cpu(), bf(ref)) == 0.0
 
 
 # ------------------------------------------------------------------------------------------- LSTM
