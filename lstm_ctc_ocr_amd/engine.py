@@ -777,7 +777,7 @@ class _BiLstmOp(_Op):
         hout = b[self.key + '/hout']
         x = self.prev.y(sp).view(R, D)
         batched = (D + U) % 128 == 0 and (4 * U) % 128 == 0
-        aux = e.aux_side if (e.aux_stream is not None and self._persistent(N)) else None     # beside the persistent recurrence
+        aux = e.aux_side if (e.lstm_aux and self._persistent(N)) else None     # beside the persistent recurrence
         if self.with_fc:
             dl = b[self.key + '/dy']
             # FC: dW += H^T dL, db += colsum dL, dH = dL Wfc^T
@@ -904,7 +904,12 @@ class Engine(object):
         # backward recurrence (FC weight gradient, the [x | h_prev] operand of the LSTM weight gradient; ~7 us each, both bound by
         # their launch) run on an auxiliary stream BESIDE the persistent recurrence kernel, whose 128 one-wave workgroups leave most
         # of the chip idle for ~160 us (measured in round 2: a concurrent kernel hides under it, tools/side_stream_probe.py)
-        self.aux_stream = (torch.cuda.Stream(self.device) if os.environ.get('OCR_LSTM_AUX', '1') != '0' else None)
+        self.lstm_aux = os.environ.get('OCR_LSTM_AUX', '1') != '0'
+        # OCR_W9_OVERLAP=0: the merged weight-gradient reduction runs after the last backward kernel.  Default: it starts on the
+        # auxiliary stream as soon as the last 3x3 weight-gradient kernel of the body has been issued, beside what is left of the
+        # backward chain — for the CRNN the recomputing conv1 + pool backward, a VALU-bound kernel next to an HBM-bound one
+        self.w9_overlap = os.environ.get('OCR_W9_OVERLAP', '1') != '0'
+        self.aux_stream = torch.cuda.Stream(self.device) if (self.lstm_aux or self.w9_overlap) else None
         self._aux_used = False
         self.comm_stream = torch.cuda.Stream(device=self.device)
         self._lower(net)                                 # operators first: the parameter layout follows their EXECUTION order
@@ -1253,10 +1258,18 @@ class Engine(object):
             self._flush_w9(sp)
 
     def _backward_early(self, sp):
-        for op in reversed(self.ops[:self.split_op]):
+        rev = list(reversed(self.ops[:self.split_op]))
+        # after the last op that leaves a weight-gradient reduction pending, the merged reduction can run beside the rest of the chain
+        last = max([i for i, op in enumerate(rev) if isinstance(op, _ConvOp) and op.kind == '3x3'], default=-1)
+        for i, op in enumerate(rev):
             op.bwd(sp)
+            if i == last and self.w9_overlap and self.defer_w9 and sp.w9_pending and i + 1 < len(rev):
+                self._join_side()
+                with self.aux_side():
+                    self._flush_w9(sp)
         self._join_side()
         self._flush_w9(sp)
+        self.join_aux()
 
     W9_JOB_DTYPE = np.dtype([('dw', '<u8'), ('part', '<u8'), ('dbias', '<u8'), ('cs_part', '<u8'), ('n4', '<i8'), ('slab4', '<i8'),
                              ('S', '<i4'), ('rows', '<i4'), ('Cout', '<i4'), ('block_start', '<i4')])   # == struct W9ReduceJob (wgrad9.hip)

@@ -233,15 +233,17 @@ def test_step_prologue_and_bias_job_are_bit_identical(dev, monkeypatch):
 
 def test_lstm_backward_aux_stream_changes_nothing(dev, monkeypatch):
     """OCR_LSTM_AUX (default on): the FC weight gradient and the [x | h_prev] operand of the LSTM weight gradient run on an
-    auxiliary stream beside the persistent backward recurrence (parallel branches of the captured graph).  Same kernels, same
-    inputs: every gradient must agree with the one-stream schedule (bit for bit where no atomics are involved)."""
+    auxiliary stream beside the persistent backward recurrence (parallel branches of the captured graph); OCR_W9_OVERLAP (default
+    on): the merged slab reduction runs there beside the conv1 + pool backward.  Same kernels, same inputs: every gradient must
+    agree with the one-stream schedule (bit for bit where no atomics are involved)."""
     N, W = 8, 88
     x, labels, ll, sl = make_batch(N, W, 2, 4, 13, varlen=True)
 
     def run(flag):
         monkeypatch.setenv('OCR_LSTM_AUX', flag)
+        monkeypatch.setenv('OCR_W9_OVERLAP', flag)       # likewise: the merged slab reduction beside the conv1 + pool backward
         eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
-        assert (eng.aux_stream is not None) == (flag == '1')
+        assert (eng.aux_stream is not None) == (flag == '1') and eng.lstm_aux == eng.w9_overlap == (flag == '1')
         sp = eng.plan(N, W)
         eng._bind(sp, x, sl, labels, ll)
         for _ in range(3):                               # eager warm-up, capture, replay
@@ -254,7 +256,7 @@ def test_lstm_backward_aux_stream_changes_nothing(dev, monkeypatch):
     g1, eng = run('1')
     scale = float(g0.abs().max())
     assert float((g1 - g0).abs().max()) < 1e-4 * scale                 # fp32-atomics order noise of the plain GEMM weight gradients only
-    for name in ('conv2/weights', 'conv4_2/weights', 'conv4_1/conv4_1/gamma'):
+    for name in ('conv2/weights', 'conv2/biases', 'conv3_1/weights', 'conv4_2/weights', 'conv4_1/conv4_1/gamma'):
         o, n = eng.offset(name), int(np.prod(eng.specs[name].shape))
         assert torch.equal(g1[o:o + n], g0[o:o + n]), name
 

@@ -6,7 +6,7 @@
 TAG=${1:-r02i}
 O=gpurun_out; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-OLD="OCR_W9_DEFER=0 OCR_FUSE_FILLS=0 OCR_FUSE_PACK_BIAS=0 OCR_LSTM_AUX=0"
+OLD="OCR_W9_DEFER=0 OCR_FUSE_FILLS=0 OCR_FUSE_PACK_BIAS=0 OCR_LSTM_AUX=0 OCR_W9_OVERLAP=0 OCR_CONV1_V1=1"
 date +%s > $O/${TAG}_t0
 ( timeout 420 python -m pytest tests -m gpu -q 2>&1 | tail -120 ) > $O/${TAG}_pytest.log
 tail -3 $O/${TAG}_pytest.log
@@ -23,15 +23,16 @@ except Exception as e:
 E
 done
 timeout 200 bash tools/prof_bench.sh $TAG > $O/${TAG}_prof.log 2>&1
-for k in OCR_W9_DEFER OCR_FUSE_FILLS OCR_FUSE_PACK_BIAS OCR_LSTM_AUX; do
-    env $k=0 timeout 150 python bench.py --no-cpu-baseline --steps 200 > $O/${TAG}_bench_no_$k.json 2> /dev/null
+for k in OCR_W9_DEFER OCR_FUSE_FILLS OCR_FUSE_PACK_BIAS OCR_LSTM_AUX OCR_W9_OVERLAP OCR_CONV1_V1; do
+    v=0; [ $k = OCR_CONV1_V1 ] && v=1
+    env $k=$v timeout 150 python bench.py --no-cpu-baseline --steps 200 > $O/${TAG}_bench_no_$k.json 2> /dev/null
     python - <<E
 import json
 try:
     d = json.loads(open('$O/${TAG}_bench_no_$k.json').read().strip().splitlines()[-1])
-    print('$k=0', round(d['value']), 'img/s', round(d['ms_per_step'], 4), 'ms')
+    print('$k=$v', round(d['value']), 'img/s', round(d['ms_per_step'], 4), 'ms')
 except Exception as e:
-    print('$k=0', 'no line', e)
+    print('$k=$v', 'no line', e)
 E
 done
 timeout 200 python bench.py --workload deep --no-cpu-baseline > $O/${TAG}_deep_new.json 2> $O/${TAG}_deep_new.err
