@@ -155,7 +155,7 @@ __device__ __forceinline__ void conv1_window(const float* __restrict__ xn, int W
     }
 }
 
-// Second generation of the two fused kernels (round 2; the first one stays behind OCR_CONV1_V1=1).  The ISA of the first showed, per
+// Second generation of the two fused kernels (round 2; behind OCR_CONV1_V2=1 — measured slightly SLOWER than the first, see conv1_v1()).  The ISA of the first showed, per
 // loop iteration, two 64-bit integer divisions (~130 instructions each, half of them scalar with readfirstlane round trips), 16 patch
 // loads each in its own exec-masked branch, and the loads placed right in front of their first use — so every iteration exposed a
 // whole memory round trip.  Here: 32-bit index arithmetic, branch-free patch loads (clamped address, then a select: rows 1-2 and
@@ -1036,12 +1036,17 @@ __global__ __launch_bounds__(256) void eltwise_bf16_kernel(int op, const bf16_t*
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
-// A/B knob OCR_CONV1_V1=1: the first generation of the fused conv1 + pool kernels (read once)
-static bool conv1_v1() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OCR_CONV1_V1"); v = (e && atoi(e) != 0) ? 1 : 0; }
-    return v == 1;
+// A/B knobs, read once.  OCR_CONV1_V2=1: the second generation of the fused conv1 + pool kernels (32-bit index arithmetic, branch-free
+// patch loads, next-iteration prefetch).  Measured on MI355X (profiles/r02i_*) and REJECTED as default: forward 19.8 us against 17.3
+// (145 registers = 3 waves per SIMD instead of 4), backward 40 us against 38.6 — the first generation's 64-bit divisions and branchy
+// loads are hidden by its occupancy.  OCR_COL2IM_V1=1: the scalar col2im (13.3 us against 5.9 for the 16-byte one).
+static bool nn_knob(const char* name, int slot) {
+    static int v[2] = {-1, -1};
+    if (v[slot] < 0) { const char* e = getenv(name); v[slot] = (e && atoi(e) != 0) ? 1 : 0; }
+    return v[slot] == 1;
 }
+static bool conv1_v1() { return !nn_knob("OCR_CONV1_V2", 0); }
+static bool col2im_v1() { return nn_knob("OCR_COL2IM_V1", 1); }
 static inline int grid_for(long total, int cap = 4096) {
     long b = (total + 255) / 256;
     if (b > cap) b = cap;
@@ -1297,7 +1302,7 @@ extern "C" int ocr_tnc_to_ntc_bf16(const float* in, void* out, int T, int N, int
 }
 extern "C" int ocr_conv5_col2im(const void* col, void* dx, int Nb, int W, int HC, void* stream) {
     if (!col || !dx) return OCR_ERR_INVALID;
-    if (!conv1_v1() && (HC & 7) == 0 && (long)Nb * W * (HC >> 3) < 0x7fffffffL && ((size_t)col & 15) == 0 && ((size_t)dx & 15) == 0)
+    if (!col2im_v1() && (HC & 7) == 0 && (long)Nb * W * (HC >> 3) < 0x7fffffffL && ((size_t)col & 15) == 0 && ((size_t)dx & 15) == 0)
         conv5_col2im8_kernel<<<grid_for((long)Nb * W * (HC >> 3), 2048), 256, 0, (hipStream_t)stream>>>((const bf16_t*)col, (bf16_t*)dx, Nb, W, HC);
     else
         conv5_col2im_kernel<<<grid_for((long)Nb * W * HC), 256, 0, (hipStream_t)stream>>>((const bf16_t*)col, (bf16_t*)dx, Nb, W, HC);

@@ -896,15 +896,19 @@ class Engine(object):
         # OCR_W9_DEFER=0: every 3x3 weight gradient reduces its slabs right behind its own kernel (five reduce launches per step
         # for the CRNN); default: one merged reduction per backward body (bit-identical sums)
         self.defer_w9 = os.environ.get('OCR_W9_DEFER', '1') != '0'
-        # OCR_FUSE_FILLS=0: the gradient buffer is zeroed by its own fill kernel and each persistent LSTM launch fills its hand-off
-        # tensor itself (three ~6 us launches per training step); default: ONE fill launch at the start of the step (_prologue)
-        self.fuse_fills = os.environ.get('OCR_FUSE_FILLS', '1') != '0'
+        # OCR_FUSE_FILLS=1: ONE fill launch at the start of a step (gradient buffer := 0, persistent-LSTM hand-off tensors := 0xFFFF,
+        # counters := 0) instead of torch's zero fill + one fill in front of each persistent kernel.  Measured and REJECTED
+        # (profiles/r02i_*: 41.7 k -> 40.3 k images/s, lstm_fwd_seq 139 -> 155 us, lstm_bwd_seq 164 -> ~200 us): the data-as-flag
+        # protocol's first poll of every hand-off row misses the XCD's L2 by construction; filled just before the kernel the row
+        # comes from the Infinity Cache, filled ~0.3 ms and ~0.3 GB of traffic earlier it comes from HBM.  Default stays off.
+        self.fuse_fills = os.environ.get('OCR_FUSE_FILLS', '0') == '1'
         self.fuse_pack_bias = os.environ.get('OCR_FUSE_PACK_BIAS', '1') != '0'     # LSTM bias permutation as a job of the re-pack launch
-        # OCR_LSTM_AUX=0: everything of the BiLSTM backward on one stream.  Default: the two small kernels that do not depend on the
-        # backward recurrence (FC weight gradient, the [x | h_prev] operand of the LSTM weight gradient; ~7 us each, both bound by
-        # their launch) run on an auxiliary stream BESIDE the persistent recurrence kernel, whose 128 one-wave workgroups leave most
-        # of the chip idle for ~160 us (measured in round 2: a concurrent kernel hides under it, tools/side_stream_probe.py)
-        self.lstm_aux = os.environ.get('OCR_LSTM_AUX', '1') != '0'
+        # OCR_LSTM_AUX=1: the two small kernels of the BiLSTM backward that do not depend on the recurrence (FC weight gradient, the
+        # [x | h_prev] operand of the LSTM weight gradient; ~7 us each) on an auxiliary stream BESIDE the persistent recurrence
+        # kernel, whose 128 one-wave workgroups leave most of the chip idle for ~160 us.  Measured and REJECTED (profiles/r02i_*: 40.36 k
+        # images/s with it, 40.62 k without, same box and call): the 14 us that disappear from the chain come back as a slower recurrence
+        # (its hand-off rows share the L2s with the side kernels' traffic).  Default off.
+        self.lstm_aux = os.environ.get('OCR_LSTM_AUX', '0') == '1'
         # OCR_W9_OVERLAP=0: the merged weight-gradient reduction runs after the last backward kernel.  Default: it starts on the
         # auxiliary stream as soon as the last 3x3 weight-gradient kernel of the body has been issued, beside what is left of the
         # backward chain — for the CRNN the recomputing conv1 + pool backward, a VALU-bound kernel next to an HBM-bound one

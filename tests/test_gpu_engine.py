@@ -157,7 +157,7 @@ def test_deferred_weight_gradient_reduction_is_bit_identical(dev, monkeypatch):
         torch.cuda.synchronize()
         assert not sp.w9_pending
         if defer == '1':
-            assert len(sp.w9_tables) == (2 if split else 1) and all(k + '/w9ws' in sp.buf for k in ('conv2', 'conv4_2'))
+            assert len(sp.w9_tables) == (2 if split else 1) and sum(k.endswith('/w9ws') for k in sp.buf) == 5
         return {n: eng.grad(n).clone() for n in names}
 
     base = grads('0', False)
@@ -186,7 +186,7 @@ def test_fill_jobs_kernel(dev):
 
 
 def test_step_prologue_and_bias_job_are_bit_identical(dev, monkeypatch):
-    """OCR_FUSE_FILLS / OCR_FUSE_PACK_BIAS (defaults on) only move work between launches: one fill launch at the start of a step
+    """OCR_FUSE_FILLS (default off: measured slower, the LSTM's flag rows go cold) / OCR_FUSE_PACK_BIAS (default on) only move work between launches: one fill launch at the start of a step
     instead of torch's zero fill + one fill in front of each persistent LSTM kernel, the LSTM bias permutation as a job of the
     re-pack launch.  Logits, costs and the deterministic gradients must not change by a bit, over eager runs and graph replays,
     for training and inference bodies, and the optimiser step must leave identical parameters."""
@@ -232,7 +232,7 @@ def test_step_prologue_and_bias_job_are_bit_identical(dev, monkeypatch):
 
 
 def test_lstm_backward_aux_stream_changes_nothing(dev, monkeypatch):
-    """OCR_LSTM_AUX (default on): the FC weight gradient and the [x | h_prev] operand of the LSTM weight gradient run on an
+    """OCR_LSTM_AUX (default off: measured 0.7 % slower): the FC weight gradient and the [x | h_prev] operand of the LSTM weight gradient run on an
     auxiliary stream beside the persistent backward recurrence (parallel branches of the captured graph); OCR_W9_OVERLAP (default
     on): the merged slab reduction runs there beside the conv1 + pool backward.  Same kernels, same inputs: every gradient must
     agree with the one-stream schedule (bit for bit where no atomics are involved)."""

@@ -375,6 +375,21 @@ def test_conv1(dev):
 
 @pytest.mark.parametrize("Nb,W,H", [(5, 24, 32), (40, 250, 32), (3, 30, 12)])
 def test_conv1_pool_fused_equals_unfused(dev, Nb, W, H):
+    _conv1_pool_fused_equals_unfused(dev, Nb, W, H)
+
+
+def test_conv1_pool_second_generation_kernels(dev):
+    """OCR_CONV1_V2=1 (default off: measured slightly slower) — the knob is read once per process, so the variant runs in a child."""
+    import os, subprocess, sys
+    env = dict(os.environ, OCR_CONV1_V2='1')
+    code = ("import sys; sys.path.insert(0, %r); import torch; from tests import test_gpu_kernels as t; "
+            "[t._conv1_pool_fused_equals_unfused(torch.device('cuda', 0), *s) for s in ((5, 24, 32), (40, 250, 32), (3, 30, 12))]; print('V2_OK')"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'V2_OK' in out.stdout, out.stderr[-2000:]
+
+
+def _conv1_pool_fused_equals_unfused(dev, Nb, W, H):
     """(40, 250, 32): more pooled pixels than one sweep of the forward grid, so the kernels' next-iteration prefetch runs; W / 2 = 125
     and H / 2 = 6 are not powers of two (32-bit index arithmetic)."""
     Co = 64

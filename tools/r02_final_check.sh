@@ -6,14 +6,14 @@
 TAG=${1:-r02i}
 O=gpurun_out; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-OLD="OCR_W9_DEFER=0 OCR_FUSE_FILLS=0 OCR_FUSE_PACK_BIAS=0 OCR_LSTM_AUX=0 OCR_W9_OVERLAP=0 OCR_CONV1_V1=1"
+OLD="OCR_W9_DEFER=0 OCR_FUSE_FILLS=0 OCR_FUSE_PACK_BIAS=0 OCR_LSTM_AUX=0 OCR_W9_OVERLAP=0 OCR_COL2IM_V1=1"
 date +%s > $O/${TAG}_t0
 ( timeout 420 python -m pytest tests -m gpu -q 2>&1 | tail -120 ) > $O/${TAG}_pytest.log
 tail -3 $O/${TAG}_pytest.log
 FAILED=$(grep -E "^(FAILED|ERROR) " $O/${TAG}_pytest.log | awk '{print $2}' | sort -u | head -12 | tr '\n' ' ')
 if [ -n "$FAILED" ]; then          # which knob is it?  the failing tests again with each new default switched off, then with all of them off
-    for k in OCR_W9_DEFER OCR_FUSE_FILLS OCR_FUSE_PACK_BIAS OCR_LSTM_AUX OCR_W9_OVERLAP OCR_CONV1_V1 ALL; do
-        v=0; [ $k = OCR_CONV1_V1 ] && v=1
+    for k in OCR_W9_DEFER OCR_FUSE_PACK_BIAS OCR_W9_OVERLAP OCR_COL2IM_V1 ALL; do
+        v=0; [ $k = OCR_COL2IM_V1 ] && v=1
         E="$k=$v"; [ $k = ALL ] && E="$OLD"
         ( env $E timeout 200 python -m pytest $FAILED -q 2>&1 | tail -6 ) > $O/${TAG}_pytest_no_$k.log
         echo "$k off: $(tail -1 $O/${TAG}_pytest_no_$k.log)"
@@ -32,8 +32,9 @@ except Exception as e:
 E
 done
 timeout 200 bash tools/prof_bench.sh $TAG > $O/${TAG}_prof.log 2>&1
-for k in OCR_W9_DEFER OCR_FUSE_FILLS OCR_FUSE_PACK_BIAS OCR_LSTM_AUX OCR_W9_OVERLAP OCR_CONV1_V1; do
-    v=0; [ $k = OCR_CONV1_V1 ] && v=1
+for k in OCR_W9_DEFER OCR_FUSE_PACK_BIAS OCR_W9_OVERLAP OCR_COL2IM_V1; do
+    [ -n "$SHORT" ] && break
+    v=0; [ $k = OCR_COL2IM_V1 ] && v=1
     env $k=$v timeout 150 python bench.py --no-cpu-baseline --steps 200 > $O/${TAG}_bench_no_$k.json 2> /dev/null
     python - <<E
 import json
