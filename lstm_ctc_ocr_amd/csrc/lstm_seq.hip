@@ -99,7 +99,7 @@ template <int PROTO> __device__ __forceinline__ void store_pub(void* p, u32x2 v)
 template <int PROTO> __device__ __forceinline__ bf16x8 load_pub(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
     // `nt` loads are not kept in the L1 (every poll re-reads the XCD's L2) but, unlike sc1 loads, are served by that L2.
     // Tried and rejected on gfx950: sc0 loads and `buffer_inv sc0` + plain loads both kept hitting the stale L1 line.
-    if (PROTO == 2) return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, /*nt*/ 2));
+    if (PROTO >= 2) return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, /*nt*/ 2));
     return load_sc1(rsrc, byte_off);
 }
 // workgroup -> (unit block, direction, batch tile); PROTO >= 2: 1-D grid, id = ((g >> 3) * 16 + ub) * 8 + (g & 7), g = zb * 2 + d
@@ -109,6 +109,43 @@ template <int PROTO> __device__ __forceinline__ bool seq_decode(int ngroups, int
     const int g = (r >> 4) * 8 + (id & 7);
     ub = r & 15; d = g & 1; zb = g >> 1;
     return g < ngroups;
+}
+
+// ---- in-kernel fill (PROTO 3, experimental: OCR_LSTM_PROTO=3) -------------------------------------------------------------
+// As PROTO 2, but no fill kernel in front: every lane stores the fill pattern into the 8 bytes it will publish FILL_AHEAD steps
+// later (and, before the first step, into those of steps 0 .. FILL_AHEAD - 1, followed by ONE rendezvous of the group's 16
+// workgroups, so that nobody can poll a row that still holds the previous launch's values).  Why: a fill kernel leaves the rows
+// in memory (at best the Infinity Cache), so the first poll of every row is an L2 miss and every producer's 32-byte store lands
+// in a line the L2 has to complete from memory; filled from inside the XCD a few microseconds ahead, the row is a fully valid L2
+// line when producers and consumers touch it (measured background: filling ~0.3 ms EARLIER than the fill kernel does costs
+// 16 us forward / 40 us backward — OCR_FUSE_FILLS).  Safety of the running fill: a consumer polls the row of step s - 1
+// only after it has seen every producer's row of step s - 2, which that producer stored after (program order) its fill for step
+// s - 1 — issued FILL_AHEAD - 1 steps earlier still; same-address stores of one wave stay ordered, so the real row always
+// overwrites the fill.
+#define FILL_AHEAD 2
+// self-resetting rendezvous of `group` workgroups on two words {count, generation}; bounded
+__device__ __forceinline__ bool group_rendezvous(unsigned* words, unsigned group, int* err) {
+    __shared__ int ok_s;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's fill stores have reached the L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        const unsigned gen = __hip_atomic_load(words + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = __hip_atomic_fetch_add(words, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == group - 1) {
+            __hip_atomic_store(words, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(words + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            unsigned spins = 0;
+            while (__hip_atomic_load(words + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > SPIN_LIMIT) { atomicExch(err, 1); ok = 0; break; }
+            }
+        }
+        ok_s = ok;
+    }
+    __syncthreads();
+    return ok_s != 0;
 }
 
 struct LstmSeqFwdArgs {
@@ -146,6 +183,16 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
     int presleep = a.presleep, streak = 0;
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.hout, 0, (int)(R * 2 * U * 2), 0x00020000);
+    auto fill_step = [&](int s2) {                     // the 8 bytes this lane publishes at step s2 := fill pattern
+        if (!nvalid || s2 >= T) return;
+        const int t2 = (s2 < len) ? (d == 0 ? s2 : len - 1 - s2) : s2;
+        const u32x2 f = {0xFFFFFFFFu, 0xFFFFFFFFu};
+        *(u32x2*)(a.hout + ((long)nn * T + t2) * (2L * U) + (long)d * U + ub * 16 + ul0) = f;
+    };
+    if (PROTO == 3) {
+        for (int s2 = 0; s2 < FILL_AHEAD; ++s2) fill_step(s2);
+        if (!group_rendezvous(counter, group, a.err)) return;
+    }
     for (int s = 0; s < T; ++s) {
         const int dbgi = s;
         DBG_STAMP(0);
@@ -222,6 +269,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
                 *(f32x4*)(a.cell + ((long)d * R + row) * U + ub * 16 + ul0) = c;
             }
         }
+        if (PROTO == 3) fill_step(s + FILL_AHEAD);
         // ... so the arrive only has to wait for IT: stores retire in issue order, the five 16-byte saves for the backward
         // pass (gates, cell) may still be in flight when the counter is bumped
         if (PROTO == 0 && s + 1 < T) group_arrive_after(counter, 5);
@@ -261,6 +309,18 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
     f32x4 dcs = {0.f, 0.f, 0.f, 0.f};
     int presleep = a.presleep, streak = 0;
     const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, (int)(R * 8 * U * 2), 0x00020000);
+    auto fill_step = [&](int s2) {                     // the 4 x 8 bytes this lane publishes at step s2 := fill pattern
+        if (!nvalid || s2 < 0) return;
+        const int t2 = (s2 < len) ? (d == 0 ? s2 : len - 1 - s2) : s2;
+        const u32x2 f = {0xFFFFFFFFu, 0xFFFFFFFFu};
+        bf16_t* p = a.dz + ((long)nn * T + t2) * (8L * U) + (long)d * 4 * U + u0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *(u32x2*)(p + (long)g * U) = f;
+    };
+    if (PROTO == 3) {
+        for (int k = 0; k < FILL_AHEAD; ++k) fill_step(T - 1 - k);
+        if (!group_rendezvous(counter, group, a.err)) return;
+    }
     for (int s = T - 1, it = 0; s >= 0; --s, ++it) {
         const int dbgi = it;
         DBG_STAMP(0);
@@ -349,6 +409,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))
                 p.x = pack_bf2(dov[0], dov[1]); p.y = pack_bf2(dov[2], dov[3]); store_pub<PROTO>(zdst + 3L * U, p);
             }
         }
+        if (PROTO == 3) fill_step(s - FILL_AHEAD);
         if (PROTO == 0 && s > 0) group_arrive(counter);
         DBG_STAMP(3);
     }
@@ -400,13 +461,13 @@ static int g_seq_proto = -1;
 // OCR_LSTM_PROTO (A/B) wins over the setter, which the host uses to fall back to 1 when the device does not co-locate
 // workgroups with equal (id & 7) on one XCD (checked once with ocr_probe_xcc).
 extern "C" int ocr_set_lstm_proto(int proto) {
-    if (proto < 0 || proto > 2) return OCR_ERR_INVALID;
+    if (proto < 0 || proto > 3) return OCR_ERR_INVALID;
     g_seq_proto = proto;
     return OCR_OK;
 }
 static int seq_proto() {
     static int env = -2;
-    if (env == -2) { const char* e = getenv("OCR_LSTM_PROTO"); env = e ? atoi(e) : -1; if (env < -1 || env > 2) env = -1; }
+    if (env == -2) { const char* e = getenv("OCR_LSTM_PROTO"); env = e ? atoi(e) : -1; if (env < -1 || env > 3) env = -1; }
     if (env >= 0) return env;
     return g_seq_proto >= 0 ? g_seq_proto : 2;
 }
@@ -423,7 +484,7 @@ static int lstm_fwd_seq_(const float* xproj, const void* whT_packed, const int* 
     const int rows = seq_rows_per_wg(Nb, U);
     const int nz = ceil_div(Nb, rows), words = ocr_lstm_seq_sync_words(Nb);
     const int proto = seq_proto();
-    if (prefilled) {}                                   // the caller's own fill pass did both (ocr_fill_jobs)
+    if (prefilled || proto == 3) {}                     // the caller's own fill pass did both (ocr_fill_jobs) / the kernel fills as it goes
     else if (proto == 0) zero_words_kernel<<<1, 256, 0, stream>>>((unsigned*)sync, words);
     else fill_words_kernel<<<256, 256, 0, stream>>>((unsigned*)hout, (long)Nb * T * 2 * U / 2, 0xFFFFFFFFu, (unsigned*)sync, words);
     OCR_CHECK_LAUNCH();
@@ -436,6 +497,7 @@ static int lstm_fwd_seq_(const float* xproj, const void* whT_packed, const int* 
         else lstm_fwd_seq_kernel<8, 4, P><<<G, 256, 0, stream>>>(a); } while (0)
     if (proto == 0) LAUNCH_FWD(0, grid);
     else if (proto == 1) LAUNCH_FWD(1, grid);
+    else if (proto == 3) LAUNCH_FWD(3, g1);
     else LAUNCH_FWD(2, g1);
 #undef LAUNCH_FWD
     OCR_CHECK_LAUNCH();
@@ -464,7 +526,7 @@ static int lstm_bwd_seq_(const void* wh, long ldw, long w_dir_stride, const int*
     const int rows = seq_rows_per_wg(Nb, U);
     const int nz = ceil_div(Nb, rows), words = ocr_lstm_seq_sync_words(Nb);
     const int proto = seq_proto();
-    if (prefilled) {}
+    if (prefilled || proto == 3) {}
     else if (proto == 0) zero_words_kernel<<<1, 256, 0, stream>>>((unsigned*)sync, words);
     else fill_words_kernel<<<256, 256, 0, stream>>>((unsigned*)dz, (long)Nb * T * 8 * U / 2, 0xFFFFFFFFu, (unsigned*)sync, words);
     OCR_CHECK_LAUNCH();
@@ -477,6 +539,7 @@ static int lstm_bwd_seq_(const void* wh, long ldw, long w_dir_stride, const int*
         else lstm_bwd_seq_kernel<32, 4, P><<<G, 256, 0, stream>>>(a); } while (0)
     if (proto == 0) LAUNCH_BWD(0, grid);
     else if (proto == 1) LAUNCH_BWD(1, grid);
+    else if (proto == 3) LAUNCH_BWD(3, g1);
     else LAUNCH_BWD(2, g1);
 #undef LAUNCH_BWD
     OCR_CHECK_LAUNCH();

@@ -847,6 +847,16 @@ class ShapePlan(object):
             s = self.oshape[op.prev.key]
             op.alloc(self, s)
             self.oshape[op.key] = op.out_shape(s)
+        # deferred weight-gradient reductions keep every layer's slabs until the end of the backward body: that pays while the slabs
+        # still sit in the Infinity Cache when the merged reduction reads them (5 x 19 MB for the CRNN).  A deep graph (configs[4]:
+        # 32 layers, ~0.4 GB of slabs) would read them back from HBM — measured 3 % slower than reducing behind each layer — so
+        # such a plan falls back to ONE shared workspace and immediate reductions.
+        own = [k for k in self.buf if k.endswith('/w9ws')]
+        if own and sum(self.buf[k].numel() for k in own) > eng.W9_DEFER_MAX_BYTES:
+            need = max(self.buf[k].numel() for k in own)
+            for k in own:
+                del self.buf[k]
+            self.buf['wgrad_ws'] = torch.empty(need, dtype=torch.uint8, device=dev)
         self.T, _, self.C = self.oshape[eng.ops[-1].key]
         self.costs = torch.zeros(N, dtype=F32, device=dev)
         self.ctc_grad = torch.empty((self.T, N, self.C), dtype=F32, device=dev)
@@ -909,10 +919,12 @@ class Engine(object):
         # images/s with it, 40.62 k without, same box and call): the 14 us that disappear from the chain come back as a slower recurrence
         # (its hand-off rows share the L2s with the side kernels' traffic).  Default off.
         self.lstm_aux = os.environ.get('OCR_LSTM_AUX', '0') == '1'
-        # OCR_W9_OVERLAP=0: the merged weight-gradient reduction runs after the last backward kernel.  Default: it starts on the
-        # auxiliary stream as soon as the last 3x3 weight-gradient kernel of the body has been issued, beside what is left of the
-        # backward chain — for the CRNN the recomputing conv1 + pool backward, a VALU-bound kernel next to an HBM-bound one
-        self.w9_overlap = os.environ.get('OCR_W9_OVERLAP', '1') != '0'
+        # OCR_W9_OVERLAP=1: the merged weight-gradient reduction starts on the auxiliary stream as soon as the last 3x3 weight-gradient
+        # kernel of the body has been issued, beside what is left of the backward chain — for the CRNN the recomputing conv1 + pool
+        # backward, a VALU-bound kernel next to an HBM-bound one.  Measured (profiles/r02j_*): the two kernels do overlap (76 us
+        # together against 39 + 45 apart), but the fork / join inside the captured graph costs about what the overlap returns
+        # (kernel time per step -24 us, step time +7 us against the previous schedule).  Default off: one stream, no fork.
+        self.w9_overlap = os.environ.get('OCR_W9_OVERLAP', '0') == '1'
         self.aux_stream = torch.cuda.Stream(self.device) if (self.lstm_aux or self.w9_overlap) else None
         self._aux_used = False
         self.comm_stream = torch.cuda.Stream(device=self.device)
@@ -1275,6 +1287,7 @@ class Engine(object):
         self._flush_w9(sp)
         self.join_aux()
 
+    W9_DEFER_MAX_BYTES = 160 << 20       # total slab bytes of a plan up to which the reductions are deferred (Infinity Cache: 256 MB)
     W9_JOB_DTYPE = np.dtype([('dw', '<u8'), ('part', '<u8'), ('dbias', '<u8'), ('cs_part', '<u8'), ('n4', '<i8'), ('slab4', '<i8'),
                              ('S', '<i4'), ('rows', '<i4'), ('Cout', '<i4'), ('block_start', '<i4')])   # == struct W9ReduceJob (wgrad9.hip)
 

@@ -145,6 +145,7 @@ def test_deferred_weight_gradient_reduction_is_bit_identical(dev, monkeypatch):
 
     def grads(defer, split):
         monkeypatch.setenv('OCR_W9_DEFER', defer)
+        monkeypatch.setenv('OCR_W9_OVERLAP', '1' if split else '0')      # the reduction beside the rest of the chain, too
         eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
         assert eng.defer_w9 == (defer == '1')
         sp = eng.plan(N, W)
@@ -234,7 +235,7 @@ def test_step_prologue_and_bias_job_are_bit_identical(dev, monkeypatch):
 def test_lstm_backward_aux_stream_changes_nothing(dev, monkeypatch):
     """OCR_LSTM_AUX (default off: measured 0.7 % slower): the FC weight gradient and the [x | h_prev] operand of the LSTM weight gradient run on an
     auxiliary stream beside the persistent backward recurrence (parallel branches of the captured graph); OCR_W9_OVERLAP (default
-    on): the merged slab reduction runs there beside the conv1 + pool backward.  Same kernels, same inputs: every gradient must
+    off: the fork / join costs what the overlap returns): the merged slab reduction runs there beside the conv1 + pool backward.  Same kernels, same inputs: every gradient must
     agree with the one-stream schedule (bit for bit where no atomics are involved)."""
     N, W = 8, 88
     x, labels, ll, sl = make_batch(N, W, 2, 4, 13, varlen=True)
