@@ -852,7 +852,7 @@ class ShapePlan(object):
         # 32 layers, ~0.4 GB of slabs) would read them back from HBM — measured 3 % slower than reducing behind each layer — so
         # such a plan falls back to ONE shared workspace and immediate reductions.
         own = [k for k in self.buf if k.endswith('/w9ws')]
-        if own and sum(self.buf[k].numel() for k in own) > eng.W9_DEFER_MAX_BYTES:
+        if own and sum(self.buf[k].numel() for k in own) > eng.w9_defer_max_bytes:
             need = max(self.buf[k].numel() for k in own)
             for k in own:
                 del self.buf[k]
@@ -906,6 +906,7 @@ class Engine(object):
         # OCR_W9_DEFER=0: every 3x3 weight gradient reduces its slabs right behind its own kernel (five reduce launches per step
         # for the CRNN); default: one merged reduction per backward body (bit-identical sums)
         self.defer_w9 = os.environ.get('OCR_W9_DEFER', '1') != '0'
+        self.w9_defer_max_bytes = int(os.environ.get('OCR_W9_DEFER_MAX_MB', self.W9_DEFER_MAX_BYTES >> 20)) << 20
         # OCR_FUSE_FILLS=1: ONE fill launch at the start of a step (gradient buffer := 0, persistent-LSTM hand-off tensors := 0xFFFF,
         # counters := 0) instead of torch's zero fill + one fill in front of each persistent kernel.  Measured and REJECTED
         # (profiles/r02i_*: 41.7 k -> 40.3 k images/s, lstm_fwd_seq 139 -> 155 us, lstm_bwd_seq 164 -> ~200 us): the data-as-flag
