@@ -848,7 +848,7 @@ class ShapePlan(object):
             op.alloc(self, s)
             self.oshape[op.key] = op.out_shape(s)
         # deferred weight-gradient reductions keep every layer's slabs until the end of the backward body: that pays while the slabs
-        # still sit in the Infinity Cache when the merged reduction reads them (5 x 19 MB for the CRNN).  A deep graph (configs[4]:
+        # still sit in the Infinity Cache when the merged reduction reads them (162 MB for the CRNN at 64 x 256: 18 + 4 x 36 MB).  A deep graph (configs[4]:
         # 32 layers, ~0.4 GB of slabs) would read them back from HBM — measured 3 % slower than reducing behind each layer — so
         # such a plan falls back to ONE shared workspace and immediate reductions.
         own = [k for k in self.buf if k.endswith('/w9ws')]
@@ -1288,7 +1288,8 @@ class Engine(object):
         self._flush_w9(sp)
         self.join_aux()
 
-    W9_DEFER_MAX_BYTES = 160 << 20       # total slab bytes of a plan up to which the reductions are deferred (Infinity Cache: 256 MB)
+    W9_DEFER_MAX_BYTES = 192 << 20       # total slab bytes of a plan up to which the reductions are deferred (Infinity Cache: 256 MB;
+                                         # the headline plan has 162 MB); OCR_W9_DEFER_MAX_MB overrides
     W9_JOB_DTYPE = np.dtype([('dw', '<u8'), ('part', '<u8'), ('dbias', '<u8'), ('cs_part', '<u8'), ('n4', '<i8'), ('slab4', '<i8'),
                              ('S', '<i4'), ('rows', '<i4'), ('Cout', '<i4'), ('block_start', '<i4')])   # == struct W9ReduceJob (wgrad9.hip)
 

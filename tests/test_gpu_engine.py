@@ -135,11 +135,11 @@ def test_train_step_parity(engine):
     assert not bad, bad
 
 
-def test_deferred_weight_gradient_reduction_is_bit_identical(dev, monkeypatch):
+@pytest.mark.parametrize("N,W", [(8, 88), (64, 256)])
+def test_deferred_weight_gradient_reduction_is_bit_identical(dev, monkeypatch, N, W):
     """OCR_W9_DEFER (default on): the 3x3 weight-gradient slab kernels leave their reductions pending and ONE launch at the end of
     the backward body adds all layers' slabs — same per-element summation order as the per-layer reduce kernels, so the conv
     weight and bias gradients must be bit-identical to the undeferred schedule (and to themselves under the two-graph DP split)."""
-    N, W = 8, 88
     x, labels, ll, sl = make_batch(N, W, 2, 4, 7)
     names = ['conv%s/%s' % (l, k) for l in ('2', '3_1', '3_2', '4_1', '4_2') for k in ('weights', 'biases')]
 
