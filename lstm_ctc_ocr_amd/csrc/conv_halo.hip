@@ -15,6 +15,7 @@
 // tap 0 AFTER the weight DMA so the counted wait of tap 1 does not have to drain it), raw s_barrier per step.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 enum { IGH_BIAS = 1, IGH_RELU = 2, IGH_MASK = 16, IGH_ACCUM = 64 /* out (bf16) += value: a data gradient added to what another consumer already delivered */ };
 
@@ -24,6 +25,7 @@ struct HaloArgs {
     int cW, cH;
     bf16_t* out; const float* bias; const bf16_t* mask; int flags;
     bf16_t* pool; int pool_kind;          // max-pool of the (ReLU'd) output written by the same epilogue: 0 none, 1 feature pairs (1 x 2), 2 2 x 2
+    int stagger, stagger_bit;             // experiment OCR_HALO_STAGGER=units,bit: workgroups whose in-XCD index has `bit` set start `units` x 64 clocks late
 };
 
 __device__ u32x4 igh_zero_page[4];
@@ -56,6 +58,10 @@ void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 8 * NW */
     const int H = g.cH, C = g.C;
     long long* const clk = g_halo_clk;
     if (clk && blockIdx.x == 0 && tid == 0) { clk[0] = (long long)__builtin_amdgcn_s_memtime(); clk[1] = (long long)wall_clock64(); }
+    // co-resident workgroups of a launch start in phase (their prologue DMA, K steps and epilogue stores coincide instead of
+    // overlapping — the short-K layers run at half their MFMA-only rate): optional start offset for every other workgroup of a CU
+    if (g.stagger > 0 && ((blockIdx.x >> 3) & g.stagger_bit))
+        for (int i = 0; i < g.stagger; i += 16) __builtin_amdgcn_s_sleep(16);
     const int NR = BM + 2 * H + 2;                     // halo rows actually needed
     const int PI = NRpad / (8 * NW);                   // halo DMA instructions per wave (8 rows each)
 
@@ -321,7 +327,9 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
     // has two workgroups for every CU).  Otherwise 256-pixel workgroups of 8 waves, one per CU.
     static int nw = -1;                                  // A/B knob OCR_HALO_NW: 8 / 4 force one kind, unset = by grid size
     if (nw < 0) { const char* e = getenv("OCR_HALO_NW"); nw = e ? atoi(e) : 0; }
-    HaloArgs g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind};
+    static int stag = -1, stag_bit = 32;                 // experiment knob OCR_HALO_STAGGER=units[,bit] (units of 64 clocks; default off)
+    if (stag < 0) { const char* e = getenv("OCR_HALO_STAGGER"); stag = e ? atoi(e) : 0; const char* c = e ? strchr(e, ',') : nullptr; if (c) stag_bit = atoi(c + 1); if (stag < 0) stag = 0; }
+    HaloArgs g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, stag, stag_bit};
     static int dense = -1;                               // A/B knob OCR_HALO_DENSE=1: 8 waves per 128-pixel tile (4 waves per SIMD with two workgroups per CU)
     if (dense < 0) { const char* e = getenv("OCR_HALO_DENSE"); dense = e ? atoi(e) : 0; }
     if (dense && nw != 8) {
