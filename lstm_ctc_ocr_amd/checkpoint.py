@@ -6,7 +6,8 @@ here, so a snapshot is a single `.npz` holding every variable under its TF name 
 logits/{weights,biases}) plus the optimiser slots and step counters, and a text file `checkpoint` naming the
 latest one — the same naming (`lstm_ctc[_infix]_iter_<n>.ckpt`), resume rule (iteration parsed from the file
 name) and retention as the reference.  A dict of arrays converted from a real TF checkpoint loads through
-Engine.load_arrays unchanged.
+Engine.load_arrays unchanged; `python -m lstm_ctc_ocr_amd.tf_bundle <prefix> <out.npz>` converts a TensorFlow V2 checkpoint
+(weights, Adam slots, step count) into such a snapshot without TensorFlow (format unpinned offline: see that module).
 """
 import os
 
@@ -84,6 +85,10 @@ def restore(engine, path, with_optimizer=True):
         sc = torch.from_numpy(data['opt/scalars'])          # the first 8 doubles are state, the rest per-step scratch
         n = min(sc.numel(), engine.scalars.numel())
         engine.scalars[:n].copy_(sc[:n])
-        engine.lr = float(data['opt/scalars'][2])           # host mirror of the device learning rate (console line, scale_lr)
+        if float(data['opt/scalars'][2]) > 0:
+            engine.lr = float(data['opt/scalars'][2])       # host mirror of the device learning rate (console line, scale_lr)
+        else:                                               # a snapshot converted from a TensorFlow checkpoint (tf_bundle.convert) carries no
+            from . import ops                               # learning rate: keep the one the driver configured
+            ops.optim_set_lr(engine.scalars, engine.lr)
     engine.iteration = int(data['meta/iteration']) if 'meta/iteration' in data.files else 0
     return engine

@@ -1,0 +1,156 @@
+"""CPU: the TensorFlow-free reader of tensor-bundle checkpoints (lstm_ctc_ocr_amd/tf_bundle.py) on bundles written by its own writer —
+multi-block index with prefix-compressed keys, scalars, several dtypes — on hand-encoded snappy streams, and the conversion to this
+package's .npz snapshots (variable-name normalisation, Adam slots, step counters).  No TensorFlow-written file exists offline: the
+format itself stays unpinned (see the module docstring)."""
+import struct
+
+import numpy as np
+import pytest
+
+from lstm_ctc_ocr_amd import tf_bundle as tb
+
+
+def _arrays(seed=0):
+    rng = np.random.RandomState(seed)
+    return {
+        'conv1/weights': rng.randn(3, 3, 1, 64).astype(np.float32),
+        'conv1/biases': rng.randn(64).astype(np.float32),
+        'conv4_1/conv4_1/beta': rng.randn(512).astype(np.float32),
+        'conv4_1/conv4_1/gamma': rng.randn(512).astype(np.float32),
+        'conv4_1/conv4_1/moving_mean': np.zeros(512, np.float32),
+        'logits/bidirectional_rnn/fw/lstm_cell/weights': rng.randn(768, 1024).astype(np.float32),
+        'logits/bidirectional_rnn/fw/lstm_cell/biases': rng.randn(1024).astype(np.float32),
+        'logits/bidirectional_rnn/fw/lstm_cell/weights/Adam': rng.randn(768, 1024).astype(np.float32),
+        'logits/bidirectional_rnn/fw/lstm_cell/weights/Adam_1': rng.rand(768, 1024).astype(np.float32),
+        'logits/weights': rng.randn(512, 64).astype(np.float32),
+        'beta1_power': np.float32(0.9 ** 1234),
+        'beta2_power': np.float32(0.999 ** 1234),
+        'global_step': np.int64(1234),
+        'some/int32': np.arange(7, dtype=np.int32),
+    }
+
+
+@pytest.mark.parametrize("per_block", [1, 3, 100])
+def test_round_trip_through_the_table_format(tmp_path, per_block):
+    arrays = _arrays()
+    prefix = str(tmp_path / 'LSTM_ctc_iter_2000.ckpt')
+    tb.write_bundle(prefix, arrays, per_block=per_block)
+    got = tb.read_bundle(prefix)
+    assert sorted(got) == sorted(arrays)
+    for k, v in arrays.items():
+        assert got[k].dtype == np.asarray(v).dtype and got[k].shape == np.asarray(v).shape and np.array_equal(got[k], v), k
+    listed = {n: (dt, sh) for n, dt, sh in tb.list_bundle(prefix)}
+    assert listed['conv1/weights'] == (np.float32, (3, 3, 1, 64)) and listed['beta1_power'][1] == ()
+    only = tb.read_bundle(prefix, names={'conv1/biases'})
+    assert list(only) == ['conv1/biases']
+
+
+def test_rejects_files_that_are_not_tables(tmp_path):
+    p = tmp_path / 'x.index'
+    p.write_bytes(b'\x00' * 100)
+    with pytest.raises(ValueError):
+        tb.read_table(str(p))
+
+
+def test_snappy_block_decoder():
+    raw = b'abcdefgh' * 5 + b'XYZ'
+    # literal 'abcdefgh' (tag (8-1)<<2), copy-2 of 32 bytes from offset 8 (tag ((32-1)<<2)|2 + uint16 offset), literal 'XYZ'
+    stream = tb._put_varint(len(raw)) + bytes([(8 - 1) << 2]) + b'abcdefgh' + bytes([((32 - 1) << 2) | 2]) + struct.pack('<H', 8) \
+        + bytes([(3 - 1) << 2]) + b'XYZ'
+    assert tb._snappy_decompress(stream) == raw
+    # copy-1: length 4..11, 11-bit offset
+    raw2 = b'0123' + b'0123'
+    stream2 = tb._put_varint(8) + bytes([(4 - 1) << 2]) + b'0123' + bytes([((4 - 4) << 2) | 1 | (0 << 5)]) + bytes([4])
+    assert tb._snappy_decompress(stream2) == raw2
+    with pytest.raises(ValueError):
+        tb._snappy_decompress(tb._put_varint(9) + bytes([(4 - 1) << 2]) + b'0123')          # length mismatch
+
+
+def test_compressed_blocks_are_read(tmp_path):
+    """An index whose data block is stored snappy-compressed (type byte 1): literal-only stream of the same block bytes."""
+    arrays = {'a/weights': np.arange(12, dtype=np.float32).reshape(3, 4)}
+    prefix = str(tmp_path / 'c.ckpt')
+    tb.write_bundle(prefix, arrays, per_block=100)
+    data = bytearray(open(prefix + '.index', 'rb').read())
+    footer = bytes(data[-48:])
+    moff, p = tb._varint(footer, 0); msize, p = tb._varint(footer, p)
+    blk = bytes(data[:moff - 5])                                   # the single data block (without its trailer)
+    assert len(blk) < 60 * 256
+    lit = bytearray(tb._put_varint(len(blk)))
+    for i in range(0, len(blk), 60):                               # literals of <= 60 bytes: tag = (len - 1) << 2
+        piece = blk[i:i + 60]
+        lit += bytes([(len(piece) - 1) << 2]) + piece
+    comp = bytes(lit)
+    meta = tb._build_block([])
+    out = bytearray(comp + b'\x01' + b'\x00' * 4)
+    meta_handle = tb._put_varint(len(out)) + tb._put_varint(len(meta))
+    out += meta + b'\x00' * 5
+    idx = tb._build_block([(b'a/weights', tb._put_varint(0) + tb._put_varint(len(comp)))], restart_interval=1)
+    idx_handle = tb._put_varint(len(out)) + tb._put_varint(len(idx))
+    out += idx + b'\x00' * 5
+    foot = meta_handle + idx_handle
+    foot += b'\x00' * (40 - len(foot)) + struct.pack('<Q', tb.TABLE_MAGIC)
+    open(prefix + '.index', 'wb').write(bytes(out) + foot)
+    got = tb.read_bundle(prefix)
+    assert np.array_equal(got['a/weights'], arrays['a/weights'])
+
+
+def test_conversion_to_a_snapshot(tmp_path):
+    arrays = _arrays(1)
+    prefix = str(tmp_path / 'LSTM_ctc_iter_2000.ckpt')
+    tb.write_bundle(prefix, arrays)
+    wanted = ['conv1/weights', 'conv1/biases', 'conv4_1/conv4_1/beta', 'conv4_1/conv4_1/gamma', 'logits/fw/weights', 'logits/fw/biases',
+              'logits/weights', 'logits/biases']
+    out = str(tmp_path / 'snap.npz')
+    matched, rest = tb.convert(prefix, out, wanted)
+    assert matched == sorted(set(wanted) - {'logits/biases'})                        # not in the checkpoint: reported by its absence
+    assert 'global_step' not in rest and 'some/int32' in rest and not any('moving_' in r for r in rest)
+    snap = np.load(out)
+    assert np.array_equal(snap['var/logits/fw/weights'], arrays['logits/bidirectional_rnn/fw/lstm_cell/weights'])
+    assert np.array_equal(snap['slot1/logits/fw/weights'], arrays['logits/bidirectional_rnn/fw/lstm_cell/weights/Adam'])
+    assert np.array_equal(snap['slot2/logits/fw/weights'], arrays['logits/bidirectional_rnn/fw/lstm_cell/weights/Adam_1'])
+    sc = snap['opt/scalars']
+    assert sc[6] == 1234 and sc[4] == 0.9 ** 1234 and sc[5] == 0.999 ** 1234 and int(snap['meta/iteration']) == 2000
+    # without global_step the count comes from beta2^t (beta1^t = 0.9^1234 is 0 in float32)
+    del arrays['global_step']
+    tb.write_bundle(prefix, arrays)
+    tb.convert(prefix, out, wanted)
+    assert np.load(out)['opt/scalars'][6] == 1234
+    assert tb.normalise_name('logits/bidirectional_rnn/bw/lstm_cell/biases') == 'logits/bw/biases'
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(__import__('os').environ.get('OCR_TEST_EXPERIMENTAL') != '1', reason='not yet run on hardware: set OCR_TEST_EXPERIMENTAL=1')
+def test_converted_checkpoint_restores_into_an_engine(dev, tmp_path):
+    """Engine -> TF-named bundle (helper scopes of bidirectional_dynamic_rnn / LSTMCell put back) -> convert -> restore: parameters and
+    Adam slots bit-equal, step count kept, learning rate taken from the driver's configuration (a TF checkpoint stores none)."""
+    import torch
+    from lstm_ctc_ocr_amd import checkpoint
+    from lstm_ctc_ocr_amd.engine import Engine
+    from lstm_ctc_ocr_amd.models import get_network
+    eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=11)
+    eng.setup_optimizer('Adam', 3e-4)
+    tf_name = lambda n: n.replace('logits/fw/', 'logits/bidirectional_rnn/fw/lstm_cell/').replace('logits/bw/', 'logits/bidirectional_rnn/bw/lstm_cell/')
+    arrays = {}
+    rng = np.random.RandomState(0)
+    slots = {}
+    for name, a in eng.state_arrays().items():
+        arrays[tf_name(name)] = a
+        slots[name] = (rng.randn(*a.shape).astype(np.float32), rng.rand(*a.shape).astype(np.float32))
+        arrays[tf_name(name) + '/Adam'], arrays[tf_name(name) + '/Adam_1'] = slots[name]
+    arrays['beta1_power'], arrays['beta2_power'], arrays['global_step'] = np.float32(0.9 ** 77), np.float32(0.999 ** 77), np.int64(77)
+    prefix = str(tmp_path / 'LSTM_ctc_iter_78.ckpt')
+    tb.write_bundle(prefix, arrays, per_block=4)
+    out = str(tmp_path / 'LSTM_ctc_iter_78.npz')
+    matched, rest = tb.convert(prefix, out, list(eng.specs))
+    assert matched == sorted(eng.specs) and rest == []
+    eng2 = Engine(get_network('LSTM_train'), device='cuda:0', seed=12)
+    eng2.setup_optimizer('Adam', 3e-4)
+    checkpoint.restore(eng2, out)
+    assert torch.equal(eng2.params, eng.params) and eng2.iteration == 78 and eng2.lr == 3e-4
+    sc = eng2.scalars.cpu().numpy()
+    assert sc[6] == 77 and sc[2] == 3e-4
+    for name in ('conv2/weights', 'logits/bw/weights'):
+        o, n = eng2.offsets[name], slots[name][0].size
+        assert np.array_equal(eng2.state1[o:o + n].cpu().numpy(), slots[name][0].reshape(-1))
+        assert np.array_equal(eng2.state2[o:o + n].cpu().numpy(), slots[name][1].reshape(-1))
