@@ -117,8 +117,10 @@ def max_pool(x, kw, kh):
     return y.permute(0, 2, 3, 1)
 
 
-def lstm_direction(x, seq_len, W, b, reverse, sim, forget_bias=1.0):
-    """x [N, T, D] (already bf16-rounded when sim); W [D+U, 4U] (TF LSTMCell), gate order i, j, f, o."""
+def lstm_direction(x, seq_len, W, b, reverse, sim, forget_bias=1.0, state0=None, return_state=False):
+    """x [N, T, D] (already bf16-rounded when sim); W [D+U, 4U] (TF LSTMCell), gate order i, j, f, o.
+    state0 = (c0, h0) and return_state exist for the TensorFlow known-answer test of the cell equations
+    (tests/test_oracle_graph.py::test_lstm_cell_equations_on_tensorflows_own_test_vector); the graph uses a zero state."""
     N, T, D = x.shape
     U = W.shape[1] // 4
     Wx, Wh = q(W[:D], sim), q(W[D:], sim)
@@ -126,6 +128,8 @@ def lstm_direction(x, seq_len, W, b, reverse, sim, forget_bias=1.0):
     xproj = xproj.reshape(N, T, 4 * U)
     h = torch.zeros(N, U)
     c = torch.zeros(N, U)
+    if state0 is not None:
+        c, h = state0
     outs = [None] * T
     lens = torch.as_tensor(seq_len)
     for s in range(T):
@@ -151,6 +155,8 @@ def lstm_direction(x, seq_len, W, b, reverse, sim, forget_bias=1.0):
             if bool(active[n]):
                 frames[int(t_idx[n])] = hn[n]
         rows.append(torch.stack([fr if fr is not None else torch.zeros(U) for fr in frames]))
+    if return_state:
+        return torch.stack(rows), (c, h)
     return torch.stack(rows)
 
 

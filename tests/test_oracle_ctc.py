@@ -98,6 +98,32 @@ def test_decoders_on_hand_cases_and_enumeration():
         assert abs(np.exp(scores[0]) - best[1]) < 1e-9
 
 
+def test_tensorflow_ctc_loss_known_answers():
+    """TensorFlow's own CTC loss vectors (tensorflow/python/kernel_tests/ctc_loss_op_test.py::testBasic, 1.0 line): two sequences of 5
+    steps over depth 6 (blank = class 5, TF's convention), targets [0, 1, 2, 1, 0] and [0, 1, 1, 0], expected
+    -log p = 3.34211 and 5.42262.  Both oracle implementations (numpy and the fp64 C one) must give them; the second target has a
+    repeated label, i.e. a mandatory blank between the two 1s.  With the beam-search vector below and the LSTM cell vector in
+    test_oracle_graph.py these are the TensorFlow-held numbers the oracle is pinned on."""
+    m0 = np.array([[0.633766, 0.221185, 0.0917319, 0.0129757, 0.0142857, 0.0260553],
+                   [0.111121, 0.588392, 0.278779, 0.0055756, 0.00569609, 0.010436],
+                   [0.0357786, 0.633813, 0.321418, 0.00249248, 0.00272882, 0.0037688],
+                   [0.0663296, 0.643849, 0.280111, 0.00283995, 0.0035545, 0.00331533],
+                   [0.458235, 0.396634, 0.123377, 0.00648837, 0.00903441, 0.00623107]])
+    m1 = np.array([[0.30176, 0.28562, 0.0831517, 0.0862751, 0.0816851, 0.161508],
+                   [0.24082, 0.397533, 0.0557226, 0.0546814, 0.0557528, 0.19549],
+                   [0.230246, 0.450868, 0.0389607, 0.038309, 0.0391602, 0.202456],
+                   [0.280884, 0.429522, 0.0326593, 0.0339046, 0.0326856, 0.190345],
+                   [0.423286, 0.315517, 0.0338439, 0.0393744, 0.0339315, 0.154046]])
+    act = np.stack([np.log(m0), np.log(m1)], 1).astype(np.float32)          # [T = 5, N = 2, C = 6]
+    labels = np.array([0, 1, 2, 1, 0, 0, 1, 1, 0], np.int32)
+    ll, il = np.array([5, 4], np.int32), np.array([5, 5], np.int32)
+    for fn in (octc.ctc_loss_numpy, octc.ctc_loss_c):
+        costs, grads = fn(act, labels, ll, il, blank=5)
+        assert abs(costs[0] - 3.34211) < 2e-5 and abs(costs[1] - 5.42262) < 2e-5, (fn.__name__, costs)
+        # d cost / d activation of a softmax input = softmax - posterior: every frame's gradient sums to zero
+        assert np.abs(np.asarray(grads).sum(-1)).max() < 1e-5
+
+
 def test_tensorflow_beam_search_known_answer():
     """The only external vector that exists for tf.nn.ctc_beam_search_decoder (network.py:656): TensorFlow's own
     ctc_decoder_ops_test.py::testCTCDecoderBeamSearch — depth 6 (blank = class 5), 5 time steps, beam_width = 2,

@@ -24,6 +24,45 @@ def test_lstm_cell_matches_repacked_torch_lstm():
     assert float((out - exp).abs().max()) < 1e-5
 
 
+def test_lstm_cell_equations_on_tensorflows_own_test_vector():
+    """TensorFlow's rnn_cell test `testBasicLSTMCell` (tensorflow/contrib/rnn/python/kernel_tests/core_rnn_cell_test.py in the 1.0
+    line): two stacked BasicLSTMCell(2) under constant_initializer(0.5) (biases 0), input [[1, 1]], every state entry 0.1 ->
+    output [[0.24024698, 0.24024698]] and state [c1 c1 h1 h1 c2 c2 h2 h2] = [0.68967271 x2, 0.44848421 x2, 0.39897051 x2, 0.24024698 x2].
+    A vector TensorFlow itself holds for the cell the reference builds (network.py:104-107: LSTMCell without peepholes or projection
+    computes the same equations): it pins forget_bias = 1 added to f, c' = sigmoid(f + 1) c + sigmoid(i) tanh(j), h' = sigmoid(o) tanh(c')
+    and the [x, h] operand order of this oracle.  (All weights are equal, so it does not distinguish the gate ORDER — that one is
+    pinned on the re-packed torch.nn.LSTM above.)"""
+    U = 2
+    W = torch.full((2 + U, 4 * U), 0.5)
+    b = torch.zeros(4 * U)
+    s0 = (torch.full((1, U), 0.1), torch.full((1, U), 0.1))
+    h1, (c1, hs1) = og.lstm_direction(torch.tensor([[[1.0, 1.0]]]), [1], W, b, False, False, state0=s0, return_state=True)
+    h2, (c2, hs2) = og.lstm_direction(h1, [1], W, b, False, False, state0=s0, return_state=True)
+    got = torch.cat([c1, hs1, c2, hs2], 1)[0]
+    want = torch.tensor([0.68967271, 0.68967271, 0.44848421, 0.44848421, 0.39897051, 0.39897051, 0.24024698, 0.24024698])
+    assert float((got - want).abs().max()) < 2e-7, got
+    assert float((h2[0, 0] - torch.tensor([0.24024698, 0.24024698])).abs().max()) < 2e-7
+
+
+def test_conv_pool_clip_on_tensorflows_own_test_vectors():
+    """Vectors TensorFlow's unit tests hold for the ops the reference graph is built from (1.0 line):
+    conv_ops_test.py testConv2D2x2Filter (input 1..18 as [1,2,3,3] NHWC, filter 1..36 as [2,2,3,3] HWIO, VALID — the shape class of
+    conv5) and testConv2D1x1Filter; pooling_ops_test.py max-pool VALID 2x2 / stride 2 on 1..27 as [1,3,3,3]; clip_ops_test.py
+    testClipByGlobalNormClipped (train.py:79-83 clips by global norm).  They pin the oracle's tensor layout conventions (NHWC x HWIO,
+    cross-correlation, channel contraction order) and the clip formula on TensorFlow's own numbers."""
+    x = torch.arange(1, 19, dtype=torch.float32).reshape(1, 2, 3, 3)
+    w22 = torch.arange(1, 37, dtype=torch.float32).reshape(2, 2, 3, 3)
+    assert og.conv_single(x, w22, torch.zeros(3), 'VALID', False).flatten().tolist() == [2271.0, 2367.0, 2463.0, 2901.0, 3033.0, 3165.0]
+    w11 = torch.arange(1, 10, dtype=torch.float32).reshape(1, 1, 3, 3)
+    assert og.conv_single(x, w11, torch.zeros(3), 'VALID', False).flatten().tolist() == [
+        30.0, 36.0, 42.0, 66.0, 81.0, 96.0, 102.0, 126.0, 150.0, 138.0, 171.0, 204.0, 174.0, 216.0, 258.0, 210.0, 261.0, 312.0]
+    xp = torch.arange(1, 28, dtype=torch.float32).reshape(1, 3, 3, 3)
+    assert og.max_pool(xp[:, :2, :2], 2, 2).flatten().tolist() == [13.0, 14.0, 15.0]
+    clipped, norm = og.clip_by_global_norm({'x0': torch.tensor([[-2.0, 0.0, 0.0], [4.0, 0.0, 0.0]]), 'x1': torch.tensor([1.0, -2.0])}, clip=4.0)
+    assert norm == 5.0
+    assert torch.allclose(clipped['x0'], torch.tensor([[-1.6, 0.0, 0.0], [3.2, 0.0, 0.0]])) and torch.allclose(clipped['x1'], torch.tensor([0.8, -1.6]))
+
+
 def test_bidirectional_sequence_length_semantics():
     torch.manual_seed(1)
     N, T, D, U = 2, 6, 5, 4
