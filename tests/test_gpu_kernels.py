@@ -115,6 +115,31 @@ def test_ctc_known_answer(dev):
     assert np.abs(g - exp).max() < 1e-5
 
 
+@pytest.mark.skipif(__import__('os').environ.get('OCR_TEST_EXPERIMENTAL') != '1', reason='added without a GPU at the end of round 2: set OCR_TEST_EXPERIMENTAL=1')
+def test_ctc_tensorflow_known_answers(dev):
+    """The device kernels on TensorFlow's own ctc_loss vectors (ctc_loss_op_test.py::testBasic; blank = C - 1 = 5): -log p = 3.34211 and
+    5.42262, gradients = prob - onehot(the single alignment) — the CPU oracle is pinned on the same numbers in tests/test_oracle_ctc.py."""
+    m0 = np.array([[0.633766, 0.221185, 0.0917319, 0.0129757, 0.0142857, 0.0260553], [0.111121, 0.588392, 0.278779, 0.0055756, 0.00569609, 0.010436],
+                   [0.0357786, 0.633813, 0.321418, 0.00249248, 0.00272882, 0.0037688], [0.0663296, 0.643849, 0.280111, 0.00283995, 0.0035545, 0.00331533],
+                   [0.458235, 0.396634, 0.123377, 0.00648837, 0.00903441, 0.00623107]])
+    m1 = np.array([[0.30176, 0.28562, 0.0831517, 0.0862751, 0.0816851, 0.161508], [0.24082, 0.397533, 0.0557226, 0.0546814, 0.0557528, 0.19549],
+                   [0.230246, 0.450868, 0.0389607, 0.038309, 0.0391602, 0.202456], [0.280884, 0.429522, 0.0326593, 0.0339046, 0.0326856, 0.190345],
+                   [0.423286, 0.315517, 0.0338439, 0.0393744, 0.0339315, 0.154046]])
+    acts = torch.from_numpy(np.stack([np.log(m0), np.log(m1)], 1).astype(np.float32)).to(dev)
+    lab = torch.tensor([0, 1, 2, 1, 0, 0, 1, 1, 0], dtype=torch.int32, device=dev)
+    ll = torch.tensor([5, 4], dtype=torch.int32, device=dev); il = torch.tensor([5, 5], dtype=torch.int32, device=dev)
+    from lstm_ctc_ocr_amd import _native as nat
+    for engine in (0, 1):
+        nat.call("ocr_set_ctc_engine", engine)
+        costs, grads = ops.ctc_loss(acts, lab, ll, il, 5, 5)
+        c = costs.cpu().numpy(); g = grads.cpu().numpy()
+        assert abs(c[0] - 3.34211) < 5e-5 and abs(c[1] - 5.42262) < 5e-5, (engine, c)
+        for n, (m, path) in enumerate(((m0, [0, 1, 2, 1, 0]), (m1, [0, 1, 5, 1, 0]))):
+            want = m.copy(); want[np.arange(5), path] -= 1.0
+            assert np.abs(g[:, n, :] - want).max() < 2e-5, (engine, n)
+    nat.call("ocr_set_ctc_engine", 1)
+
+
 def test_warpctc_abi_compute_ctc_loss(dev):
     """warp-ctc's own entry points (include/warpctc_abi.h: host labels / lengths / costs, ctcOptions by value) — the call
     warpctc_tensorflow.ctc makes (network.py:653-654): published known-answer vector, a ragged batch against the fp64 oracle

@@ -122,6 +122,14 @@ def test_tensorflow_ctc_loss_known_answers():
         assert abs(costs[0] - 3.34211) < 2e-5 and abs(costs[1] - 5.42262) < 2e-5, (fn.__name__, costs)
         # d cost / d activation of a softmax input = softmax - posterior: every frame's gradient sums to zero
         assert np.abs(np.asarray(grads).sum(-1)).max() < 1e-5
+        # TensorFlow lists the gradients too (gradient_log_prob_0 / _1 of the same test).  Both targets leave exactly ONE alignment
+        # (5 frames for 5 labels; 5 frames for 4 labels with a mandatory blank between the repeated 1s), so the posterior is one-hot
+        # and the listed rows are prob - onehot: e.g. TF's -0.366234 = 0.633766 - 1, -0.797544 = 0.202456 - 1 (blank column, frame 2)
+        for n, (m, path) in enumerate(((m0, [0, 1, 2, 1, 0]), (m1, [0, 1, 5, 1, 0]))):
+            want = m.copy()
+            want[np.arange(5), path] -= 1.0
+            assert np.abs(np.asarray(grads)[:, n, :] - want).max() < 2e-6, (fn.__name__, n)
+        assert abs(np.asarray(grads)[0, 0, 0] - (-0.366234)) < 2e-6 and abs(np.asarray(grads)[2, 1, 5] - (-0.797544)) < 2e-6
 
 
 def test_tensorflow_beam_search_known_answer():
