@@ -132,6 +132,15 @@ def test_tensorflow_ctc_loss_known_answers():
         assert abs(np.asarray(grads)[0, 0, 0] - (-0.366234)) < 2e-6 and abs(np.asarray(grads)[2, 1, 5] - (-0.797544)) < 2e-6
 
 
+def test_tensorflow_greedy_decoder_known_answer():
+    """ctc_decoder_ops_test.py::testCTCGreedyDecoder (depth 4, blank = class 3, sequence lengths 4 and 5 of 6 steps): TF expects
+    [0, 1] and [1, 1, 0] — repeats merged, blanks dropped, a repeat separated by a blank kept, frames past seq_len ignored."""
+    m0 = [[1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.4, 0.6], [0.0, 0.0, 0.4, 0.6], [0.0, 0.9, 0.1, 0.0], [0.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0]]
+    m1 = [[0.1, 0.9, 0.0, 0.0], [0.0, 0.9, 0.1, 0.0], [0.0, 0.0, 0.1, 0.9], [0.0, 0.9, 0.1, 0.1], [0.9, 0.1, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0]]
+    x = np.stack([np.array(m0), np.array(m1)], 1)
+    assert odec.greedy_decode(x, [4, 5], blank=3) == [[0, 1], [1, 1, 0]]
+
+
 def test_tensorflow_beam_search_known_answer():
     """The only external vector that exists for tf.nn.ctc_beam_search_decoder (network.py:656): TensorFlow's own
     ctc_decoder_ops_test.py::testCTCDecoderBeamSearch — depth 6 (blank = class 5), 5 time steps, beam_width = 2,
