@@ -240,6 +240,25 @@ def adam_step(params, grads, state, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     return params
 
 
+def momentum_step(params, grads, state, lr, momentum=0.9):
+    """TF-1.0 MomentumOptimizer (train.py:76, the reference's fallback solver): acc = momentum * acc + g; w -= lr * acc."""
+    for k in params:
+        acc = state.setdefault("acc/" + k, torch.zeros_like(params[k]))
+        acc.mul_(momentum).add_(grads[k])
+        params[k] = params[k] - lr * acc
+    return params
+
+
+def rmsprop_step(params, grads, state, lr, decay=0.9, eps=1e-10):
+    """TF-1.0 RMSPropOptimizer with momentum 0 (train.py:75): the `rms` slot starts at ONES; ms = decay * ms + (1 - decay) g^2;
+    w -= lr * g / sqrt(ms + eps) (epsilon INSIDE the root)."""
+    for k in params:
+        ms = state.setdefault("rms/" + k, torch.ones_like(params[k]))
+        ms.mul_(decay).addcmul_(grads[k], grads[k], value=1 - decay)
+        params[k] = params[k] - lr * grads[k] / (ms + eps).sqrt()
+    return params
+
+
 def train_step(params, state, batch, lr, weight_decay, clip=10.0, sim_bf16=False):
     x, labels, label_len, seq_len = batch
     leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}

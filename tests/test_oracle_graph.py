@@ -63,6 +63,32 @@ def test_conv_pool_clip_on_tensorflows_own_test_vectors():
     assert torch.allclose(clipped['x0'], torch.tensor([[-1.6, 0.0, 0.0], [3.2, 0.0, 0.0]])) and torch.allclose(clipped['x1'], torch.tensor([0.8, -1.6]))
 
 
+def test_optimizer_formulas_on_tensorflows_own_test_vectors():
+    """momentum_test.py::testBasic and rmsprop_test.py::testWithoutMomentum of the 1.0 line (learning rate 2.0; RMSProp decay 0.9,
+    epsilon 1.0): the accumulator / mean-square values TF lists after each step — 0.1 then 0.9 * 0.1 + 0.1; rms 0.901 then
+    0.901 * 0.9 + 0.001 (the slot starts at ONE) — and the variables that follow from them."""
+    v = {'v0': torch.tensor([1.0, 2.0], dtype=torch.float64), 'v1': torch.tensor([3.0, 4.0], dtype=torch.float64)}
+    g = {'v0': torch.tensor([0.1, 0.1], dtype=torch.float64), 'v1': torch.tensor([0.01, 0.01], dtype=torch.float64)}
+    st = {}
+    p = og.momentum_step(dict(v), g, st, lr=2.0, momentum=0.9)
+    assert torch.allclose(st['acc/v0'], torch.tensor([0.1, 0.1], dtype=torch.float64)) and torch.allclose(p['v0'], torch.tensor([1.0 - 0.1 * 2.0, 2.0 - 0.1 * 2.0], dtype=torch.float64))
+    p = og.momentum_step(p, g, st, lr=2.0, momentum=0.9)
+    a2 = 0.9 * 0.1 + 0.1
+    assert torch.allclose(st['acc/v0'], torch.tensor([a2, a2], dtype=torch.float64))
+    assert torch.allclose(p['v0'], torch.tensor([1.0 - 0.1 * 2.0 - a2 * 2.0, 2.0 - 0.1 * 2.0 - a2 * 2.0], dtype=torch.float64))
+    assert torch.allclose(p['v1'], torch.tensor([2.98 - (0.9 * 0.01 + 0.01) * 2.0, 3.98 - (0.9 * 0.01 + 0.01) * 2.0], dtype=torch.float64))
+    st = {}
+    p = og.rmsprop_step(dict(v), g, st, lr=2.0, decay=0.9, eps=1.0)
+    assert torch.allclose(st['rms/v0'], torch.tensor([0.901, 0.901], dtype=torch.float64)) and torch.allclose(st['rms/v1'], torch.tensor([0.90001, 0.90001], dtype=torch.float64))
+    s1 = 0.1 * 2.0 / (0.901 + 1.0) ** 0.5
+    assert torch.allclose(p['v0'], torch.tensor([1.0 - s1, 2.0 - s1], dtype=torch.float64))
+    p = og.rmsprop_step(p, g, st, lr=2.0, decay=0.9, eps=1.0)
+    r2 = 0.901 * 0.9 + 0.001
+    assert torch.allclose(st['rms/v0'], torch.tensor([r2, r2], dtype=torch.float64))
+    s2 = 0.1 * 2.0 / (r2 + 1.0) ** 0.5
+    assert torch.allclose(p['v0'], torch.tensor([1.0 - s1 - s2, 2.0 - s1 - s2], dtype=torch.float64))
+
+
 def test_bidirectional_sequence_length_semantics():
     torch.manual_seed(1)
     N, T, D, U = 2, 6, 5, 4
