@@ -283,9 +283,17 @@ def main():
         if args.workload != "fixed":
             line["metric"] = "captcha images/sec training (%s workload)" % args.workload
             line.pop("model_tflops_per_gpu")
-        line["roofline"] = conv_roofline(eng, device)
+        # the timed number above is complete at this point: a failure in the two side measurements must not cost the line (it is
+        # reported inside the line instead of being swallowed)
+        try:
+            line["roofline"] = conv_roofline(eng, device)
+        except Exception as e:              # noqa: BLE001
+            line["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as e:          # noqa: BLE001
+                line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
