@@ -52,6 +52,32 @@ def _put_varint(v):
             return bytes(out)
 
 
+_CRC_TABLE = None
+
+
+def crc32c(data, crc=0):
+    """CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) — the checksum of the table blocks and of every tensor."""
+    global _CRC_TABLE
+    if _CRC_TABLE is None:
+        tab = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+            tab.append(c)
+        _CRC_TABLE = tab
+    tab, c = _CRC_TABLE, crc ^ 0xFFFFFFFF
+    for b in bytes(data):
+        c = tab[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def masked_crc(data):
+    """leveldb / TensorFlow store crc32c rotated right by 15 bits plus a constant."""
+    c = crc32c(data)
+    return (((c >> 15) | (c << 17)) + 0xa282ead8) & 0xFFFFFFFF
+
+
 def _proto_fields(buf):
     """Generic protobuf wire parser: yields (field number, wire type, value) — value is an int or a bytes object."""
     pos, n = 0, len(buf)
@@ -108,7 +134,10 @@ def _snappy_decompress(buf):
 # ------------------------------------------------------------------------------------------------ table reader
 def _read_block(data, offset, size):
     raw = data[offset:offset + size]
-    ctype = data[offset + size]                         # trailer: type byte + 4 bytes of masked crc32c (not verified)
+    ctype = data[offset + size]                         # trailer: type byte + 4 bytes of masked crc32c over contents + type byte
+    stored = struct.unpack_from('<I', data, offset + size + 1)[0]
+    if stored != 0 and stored != masked_crc(data[offset:offset + size + 1]):      # (0: written without checksums)
+        raise ValueError('table block at %d: checksum mismatch — not a table file, or a misread handle' % offset)
     if ctype == 1:
         raw = _snappy_decompress(raw)
     elif ctype != 0:
@@ -146,12 +175,13 @@ def read_table(path):
 
 # ------------------------------------------------------------------------------------------------ bundle reader
 class BundleEntry(object):
-    def __init__(self, name, dtype, shape, shard, offset, size, sliced):
+    def __init__(self, name, dtype, shape, shard, offset, size, sliced, crc=0):
         self.name, self.dtype, self.shape, self.shard, self.offset, self.size, self.sliced = name, dtype, shape, shard, offset, size, sliced
+        self.crc = crc
 
 
 def _parse_entry(name, value):
-    dtype, shape, shard, offset, size, sliced = 0, [], 0, 0, 0, False
+    dtype, shape, shard, offset, size, sliced, crc = 0, [], 0, 0, 0, False, 0
     for f, wt, v in _proto_fields(value):
         if f == 1: dtype = v
         elif f == 2:
@@ -164,12 +194,14 @@ def _parse_entry(name, value):
         elif f == 3: shard = v
         elif f == 4: offset = v
         elif f == 5: size = v
+        elif f == 6: crc = v
         elif f == 7: sliced = True
-    return BundleEntry(name, dtype, tuple(shape), shard, offset, size, sliced)
+    return BundleEntry(name, dtype, tuple(shape), shard, offset, size, sliced, crc)
 
 
-def read_bundle(prefix, names=None):
-    """{variable name: numpy array} of the checkpoint `prefix` (the path WITHOUT .index / .data-...)."""
+def read_bundle(prefix, names=None, verify=False):
+    """{variable name: numpy array} of the checkpoint `prefix` (the path WITHOUT .index / .data-...).  verify=True checks every tensor's
+    stored crc32c (pure Python: ~1 s per MB) — on a TensorFlow-written file a full pass without a mismatch proves the offsets were read right."""
     table = read_table(prefix + '.index')
     num_shards = 1
     entries = []
@@ -195,6 +227,8 @@ def read_bundle(prefix, names=None):
         if n * dt.itemsize != e.size:
             raise ValueError('%s: size %d does not match shape %s of %s' % (e.name, e.size, e.shape, dt))
         raw = np.asarray(files[e.shard][e.offset:e.offset + e.size])
+        if verify and e.crc != 0 and e.crc != masked_crc(raw.tobytes()):
+            raise ValueError('%s: tensor checksum mismatch' % e.name)
         out[e.name] = raw.view(dt).reshape(e.shape).copy()
     return out
 
@@ -205,8 +239,8 @@ def list_bundle(prefix):
 
 
 # ------------------------------------------------------------------------------------------------ writer (tests; same format, one block per `per_block` keys)
-def _crc_placeholder():
-    return b'\x00\x00\x00\x00'
+def _trailer(block, ctype=0):
+    return bytes([ctype]) + struct.pack('<I', masked_crc(block + bytes([ctype])))
 
 
 def _build_block(items, restart_interval=16):
@@ -238,15 +272,15 @@ def _proto(fields):
     return bytes(out)
 
 
-def write_bundle(prefix, arrays, per_block=3):
-    """Writes {name: array} as a one-shard bundle (uncompressed blocks, checksums zeroed).  Test infrastructure for the reader."""
+def write_bundle(prefix, arrays, per_block=3, tensor_crc=True):
+    """Writes {name: array} as a one-shard bundle (uncompressed blocks, real checksums).  Test infrastructure for the reader."""
     enum = {np.dtype(v): k for k, v in DTYPES.items()}
     data, items = bytearray(), [(b'', _proto([(1, 0, 1), (2, 0, 0), (3, 2, _proto([(1, 0, 1)]))]))]
     for name in sorted(arrays):
         a = np.asarray(arrays[name])
         a = np.ascontiguousarray(a) if a.ndim else a          # (ascontiguousarray would turn a scalar into shape (1,))
         shape = _proto([(2, 2, _proto([(1, 0, int(d))])) for d in a.shape])
-        items.append((name.encode('utf-8'), _proto([(1, 0, enum[a.dtype]), (2, 2, shape), (3, 0, 0), (4, 0, len(data)), (5, 0, a.nbytes), (6, 5, 0)])))
+        items.append((name.encode('utf-8'), _proto([(1, 0, enum[a.dtype]), (2, 2, shape), (3, 0, 0), (4, 0, len(data)), (5, 0, a.nbytes), (6, 5, masked_crc(a.tobytes()) if tensor_crc else 0)])))
         data += a.tobytes()
     with open('%s.data-00000-of-00001' % prefix, 'wb') as f:
         f.write(bytes(data))
@@ -254,13 +288,13 @@ def write_bundle(prefix, arrays, per_block=3):
     for i in range(0, len(items), per_block):
         blk = _build_block(items[i:i + per_block], restart_interval=2)
         index_items.append((items[min(i + per_block, len(items)) - 1][0], _put_varint(len(out)) + _put_varint(len(blk))))
-        out += blk + b'\x00' + _crc_placeholder()
+        out += blk + _trailer(blk)
     meta = _build_block([])
     meta_handle = _put_varint(len(out)) + _put_varint(len(meta))
-    out += meta + b'\x00' + _crc_placeholder()
+    out += meta + _trailer(meta)
     idx = _build_block(index_items, restart_interval=1)
     idx_handle = _put_varint(len(out)) + _put_varint(len(idx))
-    out += idx + b'\x00' + _crc_placeholder()
+    out += idx + _trailer(idx)
     footer = meta_handle + idx_handle
     footer += b'\x00' * (40 - len(footer)) + struct.pack('<Q', TABLE_MAGIC)
     with open(prefix + '.index', 'wb') as f:
@@ -279,12 +313,12 @@ def normalise_name(name):
     return name
 
 
-def convert(prefix, out_path, wanted=None, iteration=None):
+def convert(prefix, out_path, wanted=None, iteration=None, verify=False):
     """TensorFlow checkpoint `prefix` -> `.npz` snapshot for checkpoint.restore().  `wanted` = the engine's variable names (Engine.specs);
     variables are matched by exact name, then by name with the RNN helper scopes removed.  Adam slots (`<var>/Adam`, `<var>/Adam_1`,
     `beta1_power`, `beta2_power`) become slot1 / slot2 / optimiser scalars; batch-norm moving averages are dropped (the reference never
     uses them: network.py:176-178 runs batch norm with is_training=True everywhere).  Returns (matched, unmatched TF names)."""
-    tf_vars = read_bundle(prefix)
+    tf_vars = read_bundle(prefix, verify=verify)
     by_norm = {}
     for k in tf_vars:
         by_norm.setdefault(normalise_name(k), k)
@@ -333,13 +367,14 @@ def main(argv=None):
     ap.add_argument('prefix', help='checkpoint path without .index / .data-*, e.g. output/lstm_ctc/LSTM_ctc_iter_40000.ckpt')
     ap.add_argument('out', nargs='?', help='snapshot to write (default: only list the variables)')
     ap.add_argument('--network', default='LSTM_train', help='match against this network\'s variable names')
+    ap.add_argument('--verify', action='store_true', help='check every tensor\'s stored crc32c (pure Python, ~1 s per MB)')
     args = ap.parse_args(argv)
     for name, dt, shape in list_bundle(args.prefix):
         print('%-60s %-10s %s' % (name, getattr(dt, '__name__', dt), shape))
     if args.out:
         from .models import get_network
         wanted = list(get_network(args.network).param_specs)
-        matched, rest = convert(args.prefix, args.out, wanted)
+        matched, rest = convert(args.prefix, args.out, wanted, verify=args.verify)
         print('matched %d of %d variables of %s; unmatched in the network: %s; unused in the checkpoint: %s'
               % (len(matched), len(wanted), args.network, sorted(set(wanted) - set(matched)), rest))
 
