@@ -115,7 +115,6 @@ def test_ctc_known_answer(dev):
     assert np.abs(g - exp).max() < 1e-5
 
 
-@pytest.mark.skipif(__import__('os').environ.get('OCR_TEST_EXPERIMENTAL') != '1', reason='added without a GPU at the end of round 2: set OCR_TEST_EXPERIMENTAL=1')
 def test_ctc_tensorflow_known_answers(dev):
     """The device kernels on TensorFlow's own ctc_loss vectors (ctc_loss_op_test.py::testBasic; blank = C - 1 = 5): -log p = 3.34211 and
     5.42262, gradients = prob - onehot(the single alignment) — the CPU oracle is pinned on the same numbers in tests/test_oracle_ctc.py."""

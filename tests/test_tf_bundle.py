@@ -139,7 +139,6 @@ def test_conversion_to_a_snapshot(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(__import__('os').environ.get('OCR_TEST_EXPERIMENTAL') != '1', reason='not yet run on hardware: set OCR_TEST_EXPERIMENTAL=1')
 def test_converted_checkpoint_restores_into_an_engine(dev, tmp_path):
     """Engine -> TF-named bundle (helper scopes of bidirectional_dynamic_rnn / LSTMCell put back) -> convert -> restore: parameters and
     Adam slots bit-equal, step count kept, learning rate taken from the driver's configuration (a TF checkpoint stores none)."""
