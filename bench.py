@@ -175,7 +175,7 @@ def main():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--workload", choices=["fixed", "varwidth", "deep"], default="fixed",
                     help="fixed = BASELINE configs[1] (the headline metric); varwidth = configs[3] (W in [80,320] padded per "
-                         "batch); deep = configs[4] (ResNet-34-style extractor + 2 x BiLSTM(512), 96 classes, bs=32/GPU)")
+                         "batch); deep = configs[4] (ResNet-34-style extractor + 2 x BiLSTM(512 per direction), 96 classes, bs=32/GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -197,7 +197,8 @@ def main():
     global BATCH
     net_name = 'LSTM_train'
     if args.workload == 'deep':
-        cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, BATCH, net_name = 96, 2, 32, 'RESNET_train'
+        # "2 x BiLSTM(512)" = 512 units per direction = TRAIN.NUM_HID 1024 (the reference's bi_lstm halves it: network.py:104-105)
+        cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, cfg.TRAIN.NUM_HID, BATCH, net_name = 96, 2, 1024, 32, 'RESNET_train'
     eng = Engine(get_network(net_name), device=device, seed=cfg.RNG_SEED, use_graphs=not args.no_graphs)
     eng.setup_optimizer()
     # fixed and deep: W = 256 for every batch (what their config strings say); varwidth: W in [80, 320] padded per batch
@@ -271,8 +272,8 @@ def main():
                                     "(BASELINE.json configs[1]), Adam lr 1e-4 wd 1e-5 clip 10") if args.workload == "fixed" else
                                    ("VGG-7 + BiLSTM(256) + CTC train step, H=32, W in [80,320] padded per batch, masked CTC, "
                                     "bs=64/GPU (BASELINE.json configs[3])") if args.workload == "varwidth" else
-                                   ("ResNet-34-style extractor + 2 x BiLSTM(512) + CTC, 96 classes, H=32 W=256, bs=32/GPU "
-                                    "(BASELINE.json configs[4])"),
+                                   ("ResNet-34-style extractor + 2 x BiLSTM(512 units per direction, NUM_HID=1024) + CTC, 96 classes, H=32 W=256, "
+                                    "bs=32/GPU (BASELINE.json configs[4]; bf16 MFMA operands where BASELINE says fp16: same MFMA rate, fp32 accumulation)"),
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world, "hipgraph": not args.no_graphs},
             "final_loss": loss,
             "dp_check": dp_check,

@@ -151,9 +151,6 @@ int ocr_pack_conv_dgrad(const float* w, void* out, int Cin, int Cout, void* stre
  *  int R, Cc, lstm_units; long ldin, ldout;
  *  const float* src; bf16* dst; long n; int block_start, nblocks;}  with block_start ascending */
 int ocr_pack_jobs(const void* jobs, int njobs, int total_blocks, void* stream);
-/* several fills in one launch: `jobs` = DEVICE table of njobs 32-byte records {void* ptr (16-byte aligned); long nwords (32-bit words);
- * unsigned value; int block_start; int nblocks; int pad}, block_start = running sum of the preceding nblocks, total_blocks = their sum */
-int ocr_fill_jobs(const void* jobs, int njobs, int total_blocks, void* stream);
 int ocr_cast_f32_bf16(const float* in, void* out, long n, void* stream);
 /* uint8 pixels -> fp32 in [0, 1] (= u8 / 255, correctly rounded: identical to the host's `astype(float32) / 255.`, gen.py:59-65); n % 4 == 0 */
 int ocr_u8_to_unit_f32(const void* in, float* out, long n, void* stream);
@@ -196,27 +193,23 @@ int ocr_lstm_fwd_step(const float* xproj, const void* whT_packed, const int* seq
 int ocr_lstm_bwd_step(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
                       const float* gates, const float* cell, void* dz, float* dc_state, int Nb, int T, int U,
                       int step, int ndir, void* stream);
-/* whole-sequence (persistent) variants: one launch for all T steps; the 16 workgroups of a (direction, 16-row batch tile)
- * group exchange h_t / dz_t through the output tensor itself (hout / dz), which the call first fills with the bf16 pattern
- * 0xFFFF ("not written yet") — see ocr_set_lstm_proto for the hand-off protocols.  `sync`: ocr_lstm_seq_sync_words(Nb) int32
- * words of scratch (cleared by the call; last word = spin-timeout error flag, non-zero => results invalid).
- * ocr_lstm_seq_supported() tells whether the shape is covered (two directions, U == 256 and the grid fits one workgroup per
- * CU); otherwise use the step entry points. */
+/* whole-sequence (persistent) variants: one launch for all T steps.  The U/16 workgroups of a (direction, batch tile) group
+ * exchange h_t / dz_t either through a small ring that stays in one XCD's L2 (protocol 4, default), through the output tensor
+ * itself (protocol 2; the call first fills it with the bf16 pattern 0xFFFF = "not written yet") or behind counters (protocol 0) —
+ * see ocr_set_lstm_proto.  `sync`: ocr_lstm_seq_sync_words(Nb, U) int32 words of scratch (group counters | ring | tail; what the
+ * protocol needs is initialised by the call; LAST word = spin-timeout error flag, non-zero => results invalid).
+ * ocr_lstm_seq_supported() tells whether the shape is covered (two directions, U == 256 or 512 — the latter with the contraction
+ * axis split over two waves — and a grid of at most one workgroup per CU); otherwise use the step entry points. */
 int ocr_lstm_seq_supported(int Nb, int U);
-int ocr_lstm_seq_sync_words(int Nb);
+long ocr_lstm_seq_sync_words(int Nb, int U);
 int ocr_lstm_seq_debug(void* dbg /* device int64[4*T] phase stamps of workgroup 0, NULL = off */);
 int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, const int* seq_len, void* hout, float* gates,
                      float* cell, int Nb, int T, int U, float forget_bias, void* sync, void* stream);
 int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
                      const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync, void* stream);
-/* the same without the call's own fill launch: since the last use of the buffers the caller has stored 0xFFFF into every 16-bit element of
- * the hand-off tensor (hout [Nb*T][2U] / dz [Nb*T][8U]) and zero into all ocr_lstm_seq_sync_words(Nb) words of sync — e.g. with ocr_fill_jobs */
-int ocr_lstm_fwd_seq_prefilled(const float* xproj, const void* whT_packed, const int* seq_len, void* hout, float* gates,
-                               float* cell, int Nb, int T, int U, float forget_bias, void* sync, void* stream);
-int ocr_lstm_bwd_seq_prefilled(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
-                               const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync, void* stream);
-/* hand-off protocol of the persistent kernels: 2 (default) = data-as-flag inside one XCD's L2 — needs workgroups with equal
- * (id & 7) on one XCD, see ocr_probe_xcc; 1 = data-as-flag through memory (sc1), 0 = counters (sc1): placement independent */
+/* hand-off protocol of the persistent kernels: 4 (default) = data-as-flag through a ring inside one XCD's L2, 2 = data-as-flag
+ * through the output tensor inside one XCD's L2 — both need workgroups with equal (id & 7) on one XCD, see ocr_probe_xcc;
+ * 0 = counters (sc1): placement independent */
 int ocr_set_lstm_proto(int proto);
 int ocr_lstm_hprev(const void* hout, const int* seq_len, void* hprev, int Nb, int T, int U, int ndir, void* stream);
 /* xh [ndir][Nb*T][D+U] = [x | h_{t-1} in direction order]: operand of the LSTMCell-matrix weight gradient (one GEMM per direction) */

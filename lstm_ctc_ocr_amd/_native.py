@@ -76,12 +76,9 @@ _SIGS = {
     "ocr_lstm_bwd_step": ([_P, _L, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "ocr_lstm_seq_supported": ([_I, _I], _I),
     "ocr_lstm_seq_debug": ([_P], _I),
-    "ocr_lstm_seq_sync_words": ([_I], _I),
+    "ocr_lstm_seq_sync_words": ([_I, _I], _L),
     "ocr_lstm_fwd_seq": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P], _I),
     "ocr_lstm_bwd_seq": ([_P, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
-    "ocr_lstm_fwd_seq_prefilled": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P], _I),
-    "ocr_lstm_bwd_seq_prefilled": ([_P, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
-    "ocr_fill_jobs": ([_P, _I, _I, _P], _I),
     "ocr_lstm_hprev": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "ocr_lstm_pack_bias": ([_P, _P, _P, _I, _I, _P], _I),
     "ocr_optim_scalar_count": ([], _I),

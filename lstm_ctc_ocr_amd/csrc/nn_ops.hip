@@ -980,35 +980,6 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
 }
 
 // ============================================================================================
-// Several buffer fills in ONE launch (the fills a training step needs before its first real kernel: the gradient buffer := 0, the
-// persistent LSTM's hand-off tensors := 0xFFFF and its counters := 0 — three separate launches of 5-7 us each otherwise, every one
-// of them bound by its launch and not by its bytes).
-// ============================================================================================
-struct FillJob {            // 32 bytes, mirrored by lstm_ctc_ocr_amd/engine.py
-    unsigned* ptr;          // 16-byte aligned
-    long nwords;            // 32-bit words to set
-    unsigned value;
-    int block_start, nblocks, pad_;
-};
-__global__ __launch_bounds__(256) void fill_jobs_kernel(const FillJob* __restrict__ jobs, int njobs) {
-    int j = 0;
-    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block_start) ++j;
-    const FillJob jb = jobs[j];
-    const int b = blockIdx.x - jb.block_start;
-    const u32x4 v = {jb.value, jb.value, jb.value, jb.value};
-    const long n4 = jb.nwords >> 2;
-    for (long i = (long)b * 256 + threadIdx.x; i < n4; i += (long)jb.nblocks * 256) ((u32x4*)jb.ptr)[i] = v;
-    if (b == 0 && threadIdx.x < (int)(jb.nwords & 3)) jb.ptr[(n4 << 2) + threadIdx.x] = jb.value;
-}
-extern "C" int ocr_fill_jobs(const void* jobs, int njobs, int total_blocks, void* stream) {
-    static_assert(sizeof(FillJob) == 32, "FillJob is mirrored by engine.py");
-    if (!jobs || njobs <= 0 || total_blocks <= 0) return OCR_ERR_INVALID;
-    fill_jobs_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>((const FillJob*)jobs, njobs);
-    OCR_CHECK_LAUNCH();
-    return OCR_OK;
-}
-
-// ============================================================================================
 // element-wise bf16 helpers for residual graphs (Network.add network.py:461-463, Network.relu :340-341)
 //   op 0: out = a + b        op 1: out = max(a, 0)        op 2: out = (b > 0) ? a : 0   (ReLU backward: a = dy, b = y)
 //   op 3: out = max(a + b, 0)  (residual add + ReLU)        op 4: out += (b > 0) ? a : 0   (ReLU backward accumulated into out)

@@ -17,7 +17,6 @@ optimiser math.  oracle/graph.py(sim_bf16=True) rounds at the same points.
 """
 import math
 
-import contextlib
 import os
 
 import numpy as np
@@ -257,13 +256,12 @@ class _ConvOp(_Op):
         pmask = self.prev.y(sp) if self.prev.mask_in_consumer else None
         if self.kind == '3x3':
             own_ws = sp.buf.get(self.key + '/w9ws')
-            with e.wgrad_side():
-                if own_ws is not None:      # slab kernel now, the reduction with the other layers' at the end of the pass
-                    job, nblk = ops.conv3x3_wgrad_deferred(x, dz, dw, db, own_ws)
-                    if job is not None:
-                        sp.w9_pending.append((job, nblk))
-                else:
-                    ops.conv3x3_wgrad(x, dz, dw, dbias=db, workspace=sp.buf.get('wgrad_ws'))   # bias gradient rides on the same pass
+            if own_ws is not None:      # slab kernel now, the reduction with the other layers' at the end of the pass
+                job, nblk = ops.conv3x3_wgrad_deferred(x, dz, dw, db, own_ws)
+                if job is not None:
+                    sp.w9_pending.append((job, nblk))
+            else:
+                ops.conv3x3_wgrad(x, dz, dw, dbias=db, workspace=sp.buf.get('wgrad_ws'))   # bias gradient rides on the same pass
             # a producer with several consumers (residual graphs): where the halo kernel runs, its epilogue adds to what was already
             # delivered instead of writing a scratch tensor that a second pass adds
             pdy, finish, acc = e.grad_dst_acc(sp, self.prev, ops.conv3x3_accum_supported(o[0], o[1], o[2], self.co, self.ci))
@@ -273,8 +271,7 @@ class _ConvOp(_Op):
             return
         pdy, finish = e.grad_dst(sp, self.prev)
         if self.kind == '1x1':
-            with e.wgrad_side():
-                ops.gemm_tn(x.view(M, self.ci), dz.view(M, self.co), dw.view(self.ci, self.co), colsum=db)
+            ops.gemm_tn(x.view(M, self.ci), dz.view(M, self.co), dw.view(self.ci, self.co), colsum=db)
             if pdy is not None:
                 wsh = e.shadow(self.name + '/weights').view(self.ci, self.co)      # Q[n = ci][k = co]
                 ops.gemm_nt(dz.view(M, self.co), wsh, out=pdy.view(M, self.ci),
@@ -284,9 +281,8 @@ class _ConvOp(_Op):
             N, W, H, C = s
             Wo = o[1]
             K = self.kh * H * C
-            with e.wgrad_side():
-                ops.gemm_tn(x, dz.view(M, self.co), dw.view(K, self.co), Mk=M, I=K, J=self.co, lda=H * C, ldb=self.co,
-                            ldo=self.co, row_group=Wo, row_skip=self.kh - 1, colsum=db)
+            ops.gemm_tn(x, dz.view(M, self.co), dw.view(K, self.co), Mk=M, I=K, J=self.co, lda=H * C, ldb=self.co,
+                        ldo=self.co, row_group=Wo, row_skip=self.kh - 1, colsum=db)
             if pdy is not None:
                 if pmask is not None or self.kh != 2:
                     raise NotImplementedError('%s: data gradient of a full-height VALID conv is lowered for k_h = 2 '
@@ -714,15 +710,10 @@ class _BiLstmOp(_Op):
         b[self.key + '/hprev'] = torch.empty((ND, R, U), dtype=BF16, device=dev)
         b[self.key + '/xh'] = torch.empty((ND, R, self.D + U), dtype=BF16, device=dev)
         if self.ND == 2:
-            b[self.key + '/sync_f'] = torch.zeros(ops.lstm_seq_sync_words(N), dtype=I32, device=dev)
-            b[self.key + '/sync_b'] = torch.zeros(ops.lstm_seq_sync_words(N), dtype=I32, device=dev)
+            words = max(ops.lstm_seq_sync_words(N, U), 64) if self._persistent(N) else 64
+            b[self.key + '/sync_f'] = torch.zeros(words, dtype=I32, device=dev)
+            b[self.key + '/sync_b'] = torch.zeros(words, dtype=I32, device=dev)
             sp.lstm_sync = getattr(sp, 'lstm_sync', ()) + (b[self.key + '/sync_f'], b[self.key + '/sync_b'])
-            if self.eng.fuse_fills and self._persistent(N):
-                # data-as-flag hand-off: the exchanged tensors start as 0xFFFF, the counters / error words as 0 — set by the step's
-                # prologue launch instead of one fill launch in front of each persistent kernel
-                sp.fills_fwd += [(b[self.key + '/hout'], 0xFFFFFFFF), (b[self.key + '/sync_f'], 0)]
-                sp.fills_bwd += [(b[self.key + '/dz'], 0xFFFFFFFF), (b[self.key + '/sync_b'], 0)]
-                sp.prefilled = getattr(sp, 'prefilled', set()) | {self.key}
 
     def shadow_params(self):
         return [c + '/weights' for c in self.cells] + ([self.fc + '/weights'] if self.with_fc else [])
@@ -738,17 +729,9 @@ class _BiLstmOp(_Op):
         if self.with_fc:
             wf = e.param(self.fc + '/weights')
             jobs.append(dict(type=0, R=wf.shape[0], Cc=wf.shape[1], ldin=wf.shape[1], src=wf, dst=self.wfcT))
-        if e.fuse_pack_bias:        # the biases' gate-order permutation rides in the same launch (was a launch of its own per LSTM layer)
-            for d, cell in enumerate(self.cells):
-                jobs.append(dict(type=4, lstm_units=U, n=4 * U, src=e.param(cell + '/biases'), dst=self.bias[d * 4 * U:(d + 1) * 4 * U]))
+        for d, cell in enumerate(self.cells):      # the biases' gate-order permutation rides in the same launch
+            jobs.append(dict(type=4, lstm_units=U, n=4 * U, src=e.param(cell + '/biases'), dst=self.bias[d * 4 * U:(d + 1) * 4 * U]))
         return jobs
-
-    def refresh(self):
-        e = self.eng
-        if e.fuse_pack_bias:
-            return
-        ops.lstm_pack_bias(e.param(self.cells[0] + '/biases'), e.param(self.cells[1] + '/biases') if self.ND == 2 else None,
-                           self.bias, self.U, self.ND)
 
     def fwd(self, sp):
         e, U, C, ND = self.eng, self.U, self.C, self.ND
@@ -759,8 +742,7 @@ class _BiLstmOp(_Op):
         ops.gemm_nt(x, self.wxT, out=b[self.key + '/xproj'], bias=self.bias)
         if self._persistent(N):
             ops.lstm_fwd_seq(b[self.key + '/xproj'], self.whT, sp.seq_len, b[self.key + '/hout'], b[self.key + '/gates'],
-                             b[self.key + '/cell'], N, T, U, b[self.key + '/sync_f'], 1.0,
-                             prefilled=self.key in getattr(sp, 'prefilled', ()))
+                             b[self.key + '/cell'], N, T, U, b[self.key + '/sync_f'], 1.0)
         else:
             for s in range(T):
                 ops.lstm_fwd_step(b[self.key + '/xproj'], self.whT, sp.seq_len, b[self.key + '/hout'],
@@ -777,48 +759,39 @@ class _BiLstmOp(_Op):
         hout = b[self.key + '/hout']
         x = self.prev.y(sp).view(R, D)
         batched = (D + U) % 128 == 0 and (4 * U) % 128 == 0
-        aux = e.aux_side if (e.lstm_aux and self._persistent(N)) else None     # beside the persistent recurrence
         if self.with_fc:
             dl = b[self.key + '/dy']
             # FC: dW += H^T dL, db += colsum dL, dH = dL Wfc^T
-            with (aux or e.wgrad_side)():
-                ops.gemm_tn(hout, dl, e.grad(self.fc + '/weights'), colsum=e.grad(self.fc + '/biases'))
+            ops.gemm_tn(hout, dl, e.grad(self.fc + '/weights'), colsum=e.grad(self.fc + '/biases'))
             ops.gemm_nt(dl, e.shadow(self.fc + '/weights'), out=b[self.key + '/dhout'])
-        if aux is not None and batched:
-            with aux():
-                ops.lstm_xh(x, hout, sp.seq_len, b[self.key + '/xh'], N, T, D, U, ND)
         # BPTT, all directions per launch
         wsh = e.shadow(self.cells[0] + '/weights')
         stride = e.offset(self.cells[1] + '/weights') - e.offset(self.cells[0] + '/weights') if ND == 2 else 0
         if self._persistent(N):
             ops.lstm_bwd_seq(wsh[D:], 4 * U, stride, sp.seq_len, b[self.key + '/dhout'], b[self.key + '/gates'],
-                             b[self.key + '/cell'], b[self.key + '/dz'], N, T, U, b[self.key + '/sync_b'],
-                             prefilled=self.key in getattr(sp, 'prefilled', ()))
+                             b[self.key + '/cell'], b[self.key + '/dz'], N, T, U, b[self.key + '/sync_b'])
         else:
             b[self.key + '/dc'].zero_()
             for s in range(T - 1, -1, -1):
                 ops.lstm_bwd_step(wsh[D:], 4 * U, stride, sp.seq_len, b[self.key + '/dhout'], b[self.key + '/gates'],
                                   b[self.key + '/cell'], b[self.key + '/dz'], b[self.key + '/dc'], N, T, U, s, ND)
-        e.join_aux()                 # the FC weight gradient and the [x | h_prev] operand are complete
         dz = b[self.key + '/dz']
         gw = [e.grad(cell + '/weights') for cell in self.cells]
         gb = [e.grad(cell + '/biases') for cell in self.cells]
-        with e.wgrad_side():
-            if batched:
-                # dW_d[D+U, 4U] = [x | h_prev,d]^T dz_d for all directions in ONE launch (the TF LSTMCell matrix is applied to
-                # concat([x_t, h_{t-1}]), network.py:104-107): 4 short-K weight-gradient launches become 1
-                xh = b[self.key + '/xh']
-                if aux is None:
-                    ops.lstm_xh(x, hout, sp.seq_len, xh, N, T, D, U, ND)
-                ops.gemm_tn_batched(xh, D + U, R * (D + U), dz, ND * 4 * U, 4 * U, gw[0], 4 * U, stride, R, D + U, 4 * U, ND,
-                                    colsum=gb[0],
-                                    strideColsum=(e.offset(self.cells[1] + '/biases') - e.offset(self.cells[0] + '/biases')) if ND == 2 else 0)
-            else:
-                ops.lstm_hprev(hout, sp.seq_len, b[self.key + '/hprev'], N, T, U, ND)
-                for d in range(ND):
-                    dzd = dz[:, d * 4 * U:(d + 1) * 4 * U]
-                    ops.gemm_tn(x, dzd, gw[d][:D], Mk=R, I=D, J=4 * U, lda=D, ldb=ND * 4 * U, ldo=4 * U, colsum=gb[d])
-                    ops.gemm_tn(b[self.key + '/hprev'][d], dzd, gw[d][D:], Mk=R, I=U, J=4 * U, lda=U, ldb=ND * 4 * U, ldo=4 * U)
+        if batched:
+            # dW_d[D+U, 4U] = [x | h_prev,d]^T dz_d for all directions in ONE launch (the TF LSTMCell matrix is applied to
+            # concat([x_t, h_{t-1}]), network.py:104-107): 4 short-K weight-gradient launches become 1
+            xh = b[self.key + '/xh']
+            ops.lstm_xh(x, hout, sp.seq_len, xh, N, T, D, U, ND)
+            ops.gemm_tn_batched(xh, D + U, R * (D + U), dz, ND * 4 * U, 4 * U, gw[0], 4 * U, stride, R, D + U, 4 * U, ND,
+                                colsum=gb[0],
+                                strideColsum=(e.offset(self.cells[1] + '/biases') - e.offset(self.cells[0] + '/biases')) if ND == 2 else 0)
+        else:
+            ops.lstm_hprev(hout, sp.seq_len, b[self.key + '/hprev'], N, T, U, ND)
+            for d in range(ND):
+                dzd = dz[:, d * 4 * U:(d + 1) * 4 * U]
+                ops.gemm_tn(x, dzd, gw[d][:D], Mk=R, I=D, J=4 * U, lda=D, ldb=ND * 4 * U, ldo=4 * U, colsum=gb[d])
+                ops.gemm_tn(b[self.key + '/hprev'][d], dzd, gw[d][D:], Mk=R, I=U, J=4 * U, lda=U, ldb=ND * 4 * U, ldo=4 * U)
         pdy, finish = e.grad_dst(sp, self.prev)
         if pdy is not None:
             pmask = self.prev.y(sp).view(R, D) if self.prev.mask_in_consumer else None
@@ -841,7 +814,6 @@ class ShapePlan(object):
         self.oshape = {'data': (N, W, eng.num_features)}       # output shape per op key (multi-input ops look their inputs up here)
         self.scratch = {}
         self.dy_done = set()
-        self.fills_fwd, self.fills_bwd, self.fill_tables = [], [], {}    # (tensor, 32-bit value) set by the one-launch prologue of a step
         self.w9_pending, self.w9_tables = [], {}    # deferred weight-gradient reductions of the running backward pass / their device tables
         for op in eng.ops:
             s = self.oshape[op.prev.key]
@@ -895,39 +867,10 @@ class Engine(object):
             self.world = int(os.environ['OCR_FAKE_WORLD'])
             self.force_allreduce = True
         self.overlap_allreduce = os.environ.get('OCR_OVERLAP_ALLREDUCE', '1') != '0'
-        # OCR_WGRAD_STREAM=1: weight gradients on a side stream (forked after the producer of dz, joined at the end of each
-        # backward body; parallel branches of the hipGraph).  Measured (tools/side_stream_probe.py, A/B of the whole step): two
-        # convolution kernels do not overlap at all (wgrad2 + dgrad2: 89.6 us sequential, 91.6 us on two streams) and the step
-        # time is unchanged (1.513 vs 1.507 ms), so the default stays one stream.  Only the persistent LSTM kernels (128 one-wave
-        # workgroups) hide a concurrent kernel (wgrad2 + lstm_fwd: 197 -> 155 us) — and nothing in the step is independent of them.
-        self.wgrad_stream = (torch.cuda.Stream(self.device) if self.device.type == 'cuda' and
-                             os.environ.get('OCR_WGRAD_STREAM', '0') == '1' else None)
-        self._side_used = False
         # OCR_W9_DEFER=0: every 3x3 weight gradient reduces its slabs right behind its own kernel (five reduce launches per step
         # for the CRNN); default: one merged reduction per backward body (bit-identical sums)
         self.defer_w9 = os.environ.get('OCR_W9_DEFER', '1') != '0'
         self.w9_defer_max_bytes = int(os.environ.get('OCR_W9_DEFER_MAX_MB', self.W9_DEFER_MAX_BYTES >> 20)) << 20
-        # OCR_FUSE_FILLS=1: ONE fill launch at the start of a step (gradient buffer := 0, persistent-LSTM hand-off tensors := 0xFFFF,
-        # counters := 0) instead of torch's zero fill + one fill in front of each persistent kernel.  Measured and REJECTED
-        # (profiles/r02i_*: 41.7 k -> 40.3 k images/s, lstm_fwd_seq 139 -> 155 us, lstm_bwd_seq 164 -> ~200 us): the data-as-flag
-        # protocol's first poll of every hand-off row misses the XCD's L2 by construction; filled just before the kernel the row
-        # comes from the Infinity Cache, filled ~0.3 ms and ~0.3 GB of traffic earlier it comes from HBM.  Default stays off.
-        self.fuse_fills = os.environ.get('OCR_FUSE_FILLS', '0') == '1'
-        self.fuse_pack_bias = os.environ.get('OCR_FUSE_PACK_BIAS', '1') != '0'     # LSTM bias permutation as a job of the re-pack launch
-        # OCR_LSTM_AUX=1: the two small kernels of the BiLSTM backward that do not depend on the recurrence (FC weight gradient, the
-        # [x | h_prev] operand of the LSTM weight gradient; ~7 us each) on an auxiliary stream BESIDE the persistent recurrence
-        # kernel, whose 128 one-wave workgroups leave most of the chip idle for ~160 us.  Measured and REJECTED (profiles/r02i_*: 40.36 k
-        # images/s with it, 40.62 k without, same box and call): the 14 us that disappear from the chain come back as a slower recurrence
-        # (its hand-off rows share the L2s with the side kernels' traffic).  Default off.
-        self.lstm_aux = os.environ.get('OCR_LSTM_AUX', '0') == '1'
-        # OCR_W9_OVERLAP=1: the merged weight-gradient reduction starts on the auxiliary stream as soon as the last 3x3 weight-gradient
-        # kernel of the body has been issued, beside what is left of the backward chain — for the CRNN the recomputing conv1 + pool
-        # backward, a VALU-bound kernel next to an HBM-bound one.  Measured (profiles/r02j_*): the two kernels do overlap (76 us
-        # together against 39 + 45 apart), but the fork / join inside the captured graph costs about what the overlap returns
-        # (kernel time per step -24 us, step time +7 us against the previous schedule).  Default off: one stream, no fork.
-        self.w9_overlap = os.environ.get('OCR_W9_OVERLAP', '0') == '1'
-        self.aux_stream = torch.cuda.Stream(self.device) if (self.lstm_aux or self.w9_overlap) else None
-        self._aux_used = False
         self.comm_stream = torch.cuda.Stream(device=self.device)
         self._lower(net)                                 # operators first: the parameter layout follows their EXECUTION order
         self._layout(net)
@@ -972,7 +915,7 @@ class Engine(object):
         xcc = out[:n].cpu().numpy()
         colocated = all(len(set(xcc[r::8].tolist())) == 1 for r in range(8))
         if not colocated:
-            nat_call('ocr_set_lstm_proto', 1)
+            nat_call('ocr_set_lstm_proto', 0)
 
     def _layout(self, net):
         """Flat parameter / gradient layout [early rest | early regularised | late regularised | late rest] — layout.py."""
@@ -1218,40 +1161,10 @@ class Engine(object):
         """Device double counting the completed optimiser steps (scalars[6]) — the per-step salt of the dropout masks."""
         return self.scalars[6:7] if self.opt_ready else self._zero_step
 
-    FILL_JOB_DTYPE = np.dtype([('ptr', '<u8'), ('nwords', '<i8'), ('value', '<u4'), ('block_start', '<i4'), ('nblocks', '<i4'),
-                               ('pad', '<i4')])        # == struct FillJob in csrc/nn_ops.hip (32 bytes)
-
-    def _prologue(self, sp, training):
-        """Every fill a step needs before its first real kernel in ONE launch: the flat gradient buffer := 0 (training), the
-        persistent LSTMs' hand-off tensors := 0xFFFF and their counter / error words := 0 (the backward ones only in training).
-        With OCR_FUSE_FILLS=0 only the gradient buffer is zeroed here, by torch's fill kernel, as before."""
-        if not self.fuse_fills:
-            if training:
-                self.grads.zero_()
-            return
-        ent = sp.fill_tables.get(training)
-        if ent is None:
-            items = ([(self.grads, 0)] if training else []) + sp.fills_fwd + (sp.fills_bwd if training else [])
-            if not items:
-                sp.fill_tables[training] = ent = ()
-            else:
-                tab = np.zeros(len(items), self.FILL_JOB_DTYPE)
-                assert tab.itemsize == 32
-                start = 0
-                for i, (t, value) in enumerate(items):
-                    nbytes = t.numel() * t.element_size()
-                    assert t.is_contiguous() and t.data_ptr() % 16 == 0 and nbytes % 4 == 0, (tuple(t.shape), t.dtype)
-                    nblk = max(1, min(1024, (nbytes // 16 + 1023) // 1024))       # >= four 16-byte stores per thread
-                    tab[i] = (t.data_ptr(), nbytes // 4, value, start, nblk, 0)
-                    start += nblk
-                dev = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)   # uploaded on the eager run that precedes a capture
-                sp.fill_tables[training] = ent = (dev, len(items), start)
-        if ent:
-            ops.fill_jobs(*ent)
-
     def _forward(self, sp, training=False):
         self.training = training
-        self._prologue(sp, training)
+        if training:
+            self.grads.zero_()
         for op in self.ops:
             op.fwd(sp)
 
@@ -1270,23 +1183,13 @@ class Engine(object):
             ops.tnc_to_ntc_bf16(sp.ctc_grad, self.ops[-1].dy(sp), scale)
         for op in reversed(self.ops[self.split_op:]):
             op.bwd(sp)
-        self._join_side()
         if flush:
             self._flush_w9(sp)
 
     def _backward_early(self, sp):
-        rev = list(reversed(self.ops[:self.split_op]))
-        # after the last op that leaves a weight-gradient reduction pending, the merged reduction can run beside the rest of the chain
-        last = max([i for i, op in enumerate(rev) if isinstance(op, _ConvOp) and op.kind == '3x3'], default=-1)
-        for i, op in enumerate(rev):
+        for op in reversed(self.ops[:self.split_op]):
             op.bwd(sp)
-            if i == last and self.w9_overlap and self.defer_w9 and sp.w9_pending and i + 1 < len(rev):
-                self._join_side()
-                with self.aux_side():
-                    self._flush_w9(sp)
-        self._join_side()
         self._flush_w9(sp)
-        self.join_aux()
 
     W9_DEFER_MAX_BYTES = 192 << 20       # total slab bytes of a plan up to which the reductions are deferred (Infinity Cache: 256 MB;
                                          # the headline plan has 162 MB); OCR_W9_DEFER_MAX_MB overrides
@@ -1313,40 +1216,6 @@ class Engine(object):
             ent = sp.w9_tables[raw] = (dev, len(pend), start)
         ops.wgrad9_reduce_jobs(*ent)
 
-    @contextlib.contextmanager
-    def wgrad_side(self):
-        """Launches inside run on the weight-gradient stream, ordered after everything issued on the current stream so far."""
-        if self.wgrad_stream is None:
-            yield
-            return
-        self.wgrad_stream.wait_stream(torch.cuda.current_stream(self.device))
-        self._side_used = True
-        with torch.cuda.stream(self.wgrad_stream):
-            yield
-
-    def _join_side(self):
-        if self._side_used:
-            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
-            self._side_used = False
-
-    @contextlib.contextmanager
-    def aux_side(self):
-        """Launches inside run on the auxiliary stream, ordered after everything issued on the current stream so far; join_aux()
-        orders the current stream after them (fork / join become parallel branches of a captured hipGraph)."""
-        if self.aux_stream is None:
-            yield
-            return
-        if not self._aux_used:
-            self.aux_stream.wait_stream(torch.cuda.current_stream(self.device))
-            self._aux_used = True
-        with torch.cuda.stream(self.aux_stream):
-            yield
-
-    def join_aux(self):
-        if self._aux_used:
-            torch.cuda.current_stream(self.device).wait_stream(self.aux_stream)
-            self._aux_used = False
-
     def _capture(self, fn):
         """hipGraph capture of fn() with Python's cyclic garbage collector paused: a collection that frees device tensors of
         an unreferenced engine (engine <-> op cycles) in the middle of a capture aborts the process."""
@@ -1371,7 +1240,7 @@ class Engine(object):
         """forward + loss + backward of the late layers as one graph, backward of the early layers as a second one (data-
         parallel runs: the exchange of the late gradients is issued between the two)."""
         def body1():
-            self._forward(sp, training=True)            # starts with the step's fills (_prologue): gradient buffer := 0, ...
+            self._forward(sp, training=True)
             self._loss_and_backward(sp)
 
         def body2():
@@ -1394,7 +1263,7 @@ class Engine(object):
             self.setup_optimizer()
 
         def fb():
-            self._forward(sp, training=True)            # starts with the step's fills (_prologue): gradient buffer := 0, ...
+            self._forward(sp, training=True)
             self._loss_and_backward(sp, flush=False)      # one merged weight-gradient reduction at the end of the whole backward
             self._backward_early(sp)
 
@@ -1412,7 +1281,7 @@ class Engine(object):
         attr = 'graph_fb' if which == 'fb' else 'graph_fwd'
 
         def body():
-            self._forward(sp, training=(which == 'fb'))     # starts with the step's fills (_prologue)
+            self._forward(sp, training=(which == 'fb'))
             if which == 'fb':
                 self._loss_and_backward(sp, flush=False)
                 self._backward_early(sp)
@@ -1534,37 +1403,60 @@ class Engine(object):
         if fetch_loss:
             return self.last_loss()
         if self.iteration % 64 == 0:          # even when nobody reads the loss: look at the persistent LSTM's time-out words
-            self.last_loss()                  # every 64 steps (one host sync per ~100 ms of device work)
+            self._watchdog()                  # every 64 steps — WITHOUT a host sync (the report of 64 steps ago is read if it has landed)
         return None
+
+    def _watchdog(self):
+        """Queue a report of this step into the watchdog's OWN slot and evaluate the one queued 64 steps ago (an event query, no wait):
+        a persistent-LSTM time-out raises at most 64 steps late instead of costing a pipeline drain every 64 steps."""
+        pending = getattr(self, '_watch_pending', None)
+        if pending is not None and pending[1].query():
+            self.report_wait(pending)
+        self._watch_pending = self.report_async(_slot='watch')
 
     def last_loss(self):
         """Loss of the last step: mean CTC cost of the local batch + L2 term.  ONE tiny kernel gathers the mean cost, the
         optimiser's scalars and the persistent-LSTM time-out words into 4 doubles, ONE 32-byte D2H copy into pinned memory and ONE
         stream wait follow (four blocking .cpu() / .item() round trips cost ~0.1 ms per iteration of the training loop, which
         fetches the loss every step like the reference: train.py:130,139; four async copies were four blit kernels)."""
-        return self.report_wait(self.report_async())
+        return self.report_wait(self.report_async(_slot='sync'))
 
-    def report_async(self):
+    REPORT_SLOTS = 4       # handles that may be outstanding at once (the training loop keeps one, OCR_LOSS_LAG = 1)
+
+    def report_async(self, _slot=None):
         """Queue the report of the step that was just issued (kernel + 32-byte copy + event) and return a handle for report_wait().
-        The training loop waits for it one iteration LATER, so the host never drains the queue between two steps."""
+        The training loop waits for it one iteration LATER, so the host never drains the queue between two steps.
+        Slot ownership (a two-slot ring shared with the engine's own every-64-steps check let that check take the slot
+        a pending handle still pointed at — one logged loss in 64 was the NEXT step's): handles rotate over REPORT_SLOTS slots that
+        only this function hands out, a slot is reused only after REPORT_SLOTS - 1 further handles were issued and its previous
+        handle was waited for (checked), and the synchronous last_loss() and the watchdog each have a slot of their own."""
         sp = self.last_plan
         words = getattr(sp, 'lstm_sync', ())
         ring = getattr(sp, '_report', None)
         if ring is None:
             addrs = torch.tensor([w[-1:].data_ptr() for w in words], dtype=torch.int64, device=self.device) if words else None
-            ring = sp._report = dict(addrs=addrs, i=0, slots=[(torch.zeros(4, dtype=torch.float64, device=self.device),
-                                                               torch.zeros(4, dtype=torch.float64).pin_memory(), torch.cuda.Event())
-                                                              for _ in range(2)])
-        ring['i'] ^= 1
-        dev, host, ev = ring['slots'][ring['i']]
+            mk = lambda: [torch.zeros(4, dtype=torch.float64, device=self.device), torch.zeros(4, dtype=torch.float64).pin_memory(),
+                          torch.cuda.Event(), False]                      # [device block, pinned host block, event, handle outstanding]
+            ring = sp._report = dict(addrs=addrs, i=0, slots=[mk() for _ in range(self.REPORT_SLOTS)], sync=mk(), watch=mk())
+        if _slot is None:
+            ring['i'] = (ring['i'] + 1) % self.REPORT_SLOTS
+            slot = ring['slots'][ring['i']]
+            if slot[3]:
+                raise RuntimeError('report_async: %d reports are outstanding — call report_wait() on the older handles first'
+                                   % self.REPORT_SLOTS)
+        else:
+            slot = ring[_slot]
+        slot[3] = True
+        dev, host, ev = slot[0], slot[1], slot[2]
         ops.step_report(sp.costs, self.scalars if self.opt_ready else None, ring['addrs'], dev)
         host.copy_(dev, non_blocking=True)
         ev.record(torch.cuda.current_stream(self.device))
-        return (host, ev, words, self.opt_ready)
+        return (host, ev, words, self.opt_ready, slot)
 
     def report_wait(self, handle):
-        host, ev, words, opt_ready = handle
+        host, ev, words, opt_ready, slot = handle
         ev.synchronize()
+        slot[3] = False
         ctc, reg2, gnorm, bits = (float(v) for v in host.numpy())
         reg = 0.5 * float(self.cfg.TRAIN.WEIGHT_DECAY) * reg2 if (self.cfg.TRAIN.WEIGHT_DECAY > 0 and opt_ready) else 0.0
         self.last_ctc, self.last_reg, self.last_gnorm = ctc, reg, gnorm if opt_ready else 0.0

@@ -401,24 +401,19 @@ def lstm_seq_supported(Nb, U):
     return bool(nat.lib().ocr_lstm_seq_supported(Nb, U))
 
 
-def lstm_seq_sync_words(Nb):
-    return int(nat.lib().ocr_lstm_seq_sync_words(Nb))
+def lstm_seq_sync_words(Nb, U):
+    """int32 words of the persistent kernels' scratch block (group counters | hand-off ring | tail with the error word LAST)."""
+    return int(nat.lib().ocr_lstm_seq_sync_words(Nb, U))
 
 
-def lstm_fwd_seq(xproj, whT, seq_len, hout, gates, cell, Nb, T, U, sync, forget_bias=1.0, prefilled=False):
-    """prefilled: the caller's own fill pass (fill_jobs) has set hout to 0xFFFF and sync to 0 since their last use."""
-    call("ocr_lstm_fwd_seq_prefilled" if prefilled else "ocr_lstm_fwd_seq", ptr(_dev(xproj)), ptr(whT), ptr(seq_len), ptr(hout),
+def lstm_fwd_seq(xproj, whT, seq_len, hout, gates, cell, Nb, T, U, sync, forget_bias=1.0):
+    call("ocr_lstm_fwd_seq", ptr(_dev(xproj)), ptr(whT), ptr(seq_len), ptr(hout),
          ptr(gates), ptr(cell), Nb, T, U, float(forget_bias), ptr(sync), _st())
 
 
-def lstm_bwd_seq(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, Nb, T, U, sync, prefilled=False):
-    call("ocr_lstm_bwd_seq_prefilled" if prefilled else "ocr_lstm_bwd_seq", ptr(_dev(wh)), ldw, w_dir_stride, ptr(seq_len),
+def lstm_bwd_seq(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, Nb, T, U, sync):
+    call("ocr_lstm_bwd_seq", ptr(_dev(wh)), ldw, w_dir_stride, ptr(seq_len),
          ptr(dhout), ptr(gates), ptr(cell), ptr(dz), Nb, T, U, ptr(sync), _st())
-
-
-def fill_jobs(table, njobs, total_blocks):
-    """Several buffer fills in one launch; `table` = device bytes of njobs 32-byte FillJob records (csrc/nn_ops.hip)."""
-    call("ocr_fill_jobs", ptr(_dev(table)), njobs, total_blocks, _st())
 
 
 def lstm_hprev(hout, seq_len, hprev, Nb, T, U, ndir=2):

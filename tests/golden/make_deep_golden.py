@@ -2,7 +2,14 @@
 over a 96-class alphabet, batch 32, W = 256 — not in the reference, expressed through its DSL (lstm_ctc_ocr_amd/models.py) and
 evaluated by the plan-walking CPU oracle (oracle/plan_exec.py) on seeded parameters (lstm_ctc_ocr_amd.layout.host_parameters:
 the same draw Engine(seed) makes) and a seeded batch.     python tests/golden/make_deep_golden.py   -> tests/golden/deep_c4.npz
-"""
+
+"BiLSTM(512)" = 512 units PER DIRECTION, as BASELINE's own naming has it (configs[1] calls the reference's 256-per-direction layer
+"BiLSTM(256)"): TRAIN.NUM_HID = 1024, because the reference's bi_lstm gives each direction LSTMCell(num_hids // 2)
+(lib/networks/network.py:104-105, lib/lstm/config.py:48); the second layer's input is 1024 wide.  (Round 2 generated this file with
+NUM_HID = 512, i.e. 256 per direction — VERDICT r2.)
+
+Besides logits / costs the file holds the oracle's GRADIENT of the mean CTC cost (autograd through the bf16-simulating plan walk):
+per parameter tensor its L2 norm and a seeded sample of GRAD_SAMPLE entries — the full gradient would be 140 MB."""
 import os
 import sys
 import time
@@ -19,6 +26,7 @@ from oracle import graph as og  # noqa: E402
 from oracle import plan_exec  # noqa: E402
 
 SEED, N, W, L = 5, 32, 256, 6
+GRAD_SAMPLE = 2048
 
 
 def inputs():
@@ -33,9 +41,16 @@ def inputs():
     return x, labels, ll, sl
 
 
+def sample_index(name, numel):
+    """The entries of a parameter tensor's flat gradient that the golden file keeps (seeded by the tensor's name)."""
+    import zlib
+    r = np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff)
+    return np.sort(r.choice(numel, size=min(GRAD_SAMPLE, numel), replace=False)).astype(np.int64)
+
+
 def build():
     from lstm_ctc_ocr_amd import models
-    cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, cfg.TRAIN.NUM_HID = 96, 2, 512
+    cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, cfg.TRAIN.NUM_HID = 96, 2, 1024
     return models.RESNET_train()
 
 
@@ -54,6 +69,20 @@ def main():
             out['costs_' + tag] = costs.astype(np.float64)
             print(tag, 'forward %.1f s, mean cost %.5f' % (time.time() - t0, costs.mean()))
     out['greedy_bf16sim'] = odec.dense(odec.greedy_decode(out['logits_bf16sim'], sl))
+    # gradient of the mean cost w.r.t. every parameter tensor (bf16-simulating walk: the device's storage points)
+    t0 = time.time()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    lg = plan_exec.forward(net, leaves, torch.from_numpy(x), sl.tolist(), sim_bf16=True)
+    og._CTC.apply(lg, labels, ll, sl).mean().backward()
+    names = sorted(leaves)
+    out['grad_names'] = np.array(names)
+    out['grad_norm'] = np.array([float(leaves[k].grad.double().norm()) for k in names])
+    out['grad_absmax'] = np.array([float(leaves[k].grad.abs().max()) for k in names])
+    for k in names:
+        g = leaves[k].grad.reshape(-1)
+        idx = sample_index(k, g.numel())
+        out['grad_sample/' + k] = g[torch.from_numpy(idx)].numpy().astype(np.float32)
+    print('backward %.1f s' % (time.time() - t0))
     out['param_checksum'] = np.float64(sum(float(v.double().abs().sum()) for v in params.values()))
     out['x_checksum'] = np.float64(np.abs(x.astype(np.float64)).sum())
     np.savez_compressed(os.path.join(HERE, 'deep_c4.npz'), **out)

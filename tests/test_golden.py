@@ -144,16 +144,17 @@ def test_deep_fixture_parameters_are_reproducible():
         assert abs(chk - float(d['param_checksum'])) < 1e-9 * chk
         x, labels, ll, sl = mdg.inputs()
         assert abs(float(np.abs(x.astype(np.float64)).sum()) - float(d['x_checksum'])) < 1e-9 * float(d['x_checksum'])
-        assert d['logits_fp32'].shape == (63, 32, 96) and sum(v.numel() for v in params.values()) == 25532384
+        assert d['logits_fp32'].shape == (63, 32, 96) and sum(v.numel() for v in params.values()) == 32925664
     finally:
         cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, cfg.TRAIN.NUM_HID = old
 
 
 @pytest.mark.gpu
 def test_device_matches_deep_fixture(dev):
-    """BASELINE configs[4] at FULL size (ResNet-34-style [3,4,6,3] + 2 x BiLSTM(512), 96 classes, batch 32, W = 256, ragged
-    lengths) against the committed oracle outputs: logits, per-sample CTC costs (bar 1e-3 relative, against the pure-fp32
-    oracle too), and both decoders on the device's own logits."""
+    """BASELINE configs[4] at FULL size (ResNet-34-style [3,4,6,3] + 2 x BiLSTM(512 units per direction: NUM_HID = 1024), 96 classes,
+    batch 32, W = 256, ragged lengths) against the committed oracle outputs: logits, per-sample CTC costs (bar 1e-3 relative, against
+    the pure-fp32 oracle too), both decoders on the device's own logits, and the GRADIENT of the mean cost for every parameter tensor
+    (norm + a seeded sample of 2048 entries per tensor from the bf16-simulating oracle's autograd)."""
     import sys
     sys.path.insert(0, G)
     import make_deep_golden as mdg
@@ -182,6 +183,29 @@ def test_device_matches_deep_fixture(dev):
               % (e_sim, e_f32, scale, r_sim, r_f32))
         assert e_sim < 2e-2 * max(scale, 1.0) and e_f32 < 5e-2 * max(scale, 1.0)
         assert r_sim < 1e-3 and r_f32 < 1e-3
+        # ---- gradients (the 'fb' run above left them in eng.grads): per tensor, relative L2 distance and cosine on the sample, and the
+        #      ratio of the full norms.  Bars as for the miniature (tests/test_gpu_engine.py: bf16 activation gradients through 33
+        #      batch-norm backward passes): L2 < 15 %, cosine > 0.99; tensors whose gradient is mathematically zero (biases in
+        #      front of a batch norm) are compared on absolute size only.
+        gmax = float(d['grad_absmax'].max())
+        bad, worst = [], (0.0, None)
+        for i, name in enumerate(d['grad_names'].tolist()):
+            g = eng.grad(name).reshape(-1)
+            idx = torch.from_numpy(mdg.sample_index(name, g.numel())).to(g.device)
+            got, ref = g[idx].double().cpu().numpy(), d['grad_sample/' + name].astype(np.float64)
+            if float(d['grad_absmax'][i]) < 1e-5 * gmax:
+                if np.abs(got).max() > 1e-3 * gmax:
+                    bad.append((name, 'zero-gradient tensor', float(np.abs(got).max())))
+                continue
+            e2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref)))
+            nr = float(g.double().norm().cpu()) / float(d['grad_norm'][i])
+            if e2 > worst[0]:
+                worst = (e2, name)
+            if not (e2 < 0.15 and cos > 0.99 and 0.9 < nr < 1.1):
+                bad.append((name, e2, cos, nr))
+        print('deep fixture gradients: %d tensors, worst relative L2 %.3f (%s)' % (len(d['grad_names']), worst[0], worst[1]))
+        assert not bad, bad[:8]
         assert eng.decode(x, sl, method='greedy') == odec.greedy_decode(logits, sl)
         assert eng.decode(x, sl, method='beam')[:4] == odec.reference_decode(logits[:, :4], sl[:4], beam_width=100)   # (pure-Python search: 4 samples)
     finally:

@@ -168,98 +168,60 @@ def test_deferred_weight_gradient_reduction_is_bit_identical(dev, monkeypatch, N
             assert float(base[n].abs().max()) > 0 and torch.equal(g[n], base[n]), (n, split)
 
 
-def test_fill_jobs_kernel(dev):
-    """ocr_fill_jobs: several fills in one launch (word counts that are not multiples of four, a one-block and a many-block job)."""
-    from lstm_ctc_ocr_amd import ops
-    sizes = [(4099, 0xFFFFFFFF), (64, 0), (1 << 20, 0x3F803F80), (3, 7)]
-    bufs = [torch.full((n + 8,), 0x12345678, dtype=torch.int32, device='cuda') for n, _ in sizes]
-    tab = np.zeros(len(sizes), Engine.FILL_JOB_DTYPE)
-    start = 0
-    for i, ((n, v), b) in enumerate(zip(sizes, bufs)):
-        nblk = max(1, min(1024, (n // 4 + 1023) // 1024))
-        tab[i] = (b.data_ptr(), n, v, start, nblk, 0)
-        start += nblk
-    ops.fill_jobs(torch.from_numpy(tab.view(np.uint8).copy()).cuda(), len(sizes), start)
-    torch.cuda.synchronize()
-    for (n, v), b in zip(sizes, bufs):
-        h = b.cpu().numpy().view(np.uint32)
-        assert (h[:n] == v).all() and (h[n:] == 0x12345678).all(), (n, v)
-
-
-def test_step_prologue_and_bias_job_are_bit_identical(dev, monkeypatch):
-    """OCR_FUSE_FILLS (default off: measured slower, the LSTM's flag rows go cold) / OCR_FUSE_PACK_BIAS (default on) only move work between launches: one fill launch at the start of a step
-    instead of torch's zero fill + one fill in front of each persistent LSTM kernel, the LSTM bias permutation as a job of the
-    re-pack launch.  Logits, costs and the deterministic gradients must not change by a bit, over eager runs and graph replays,
-    for training and inference bodies, and the optimiser step must leave identical parameters."""
+def test_lstm_bias_job_follows_the_updated_parameter(dev):
+    """The LSTM bias permutation is a job of the re-pack launch behind the optimiser: after training steps the packed bias is the
+    permutation (u / 16) * 64 + g * 16 + u % 16 of the UPDATED gate-major TF vector."""
     N, W = 8, 88
     x, labels, ll, sl = make_batch(N, W, 2, 4, 11, varlen=True)
-    det = ['conv%s/%s' % (l, k) for l in ('2', '3_1', '3_2', '4_1', '4_2') for k in ('weights', 'biases')]
-
-    def run(flag):
-        for k in ('OCR_FUSE_FILLS', 'OCR_FUSE_PACK_BIAS'):
-            monkeypatch.setenv(k, flag)
-        eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
-        assert eng.fuse_fills == (flag == '1') and eng.fuse_pack_bias == (flag == '1')
-        lstm = [op for op in eng.ops if hasattr(op, 'whT')][0]
-        bias0 = lstm.bias.clone()
-        inf = eng.forward(x, sl).clone()                 # inference body: eager warm-up + capture + replay
-        inf2 = eng.forward(x, sl).clone()
-        assert torch.equal(inf, inf2)
-        sp = eng.plan(N, W)
-        assert bool(sp.fills_fwd) == (flag == '1') and (flag == '0' or len(sp.fill_tables) >= 1)
-        eng._bind(sp, x, sl, labels, ll)
-        eng._run(sp, 'fb'); eng._run(sp, 'fb')
-        torch.cuda.synchronize()
-        out = dict(inf=inf, logits=eng.ops[-1].y(sp).clone(), costs=sp.costs.clone(), bias0=bias0,
-                   grads={n: eng.grad(n).clone() for n in det})
-        eng.setup_optimizer('Adam', 1e-3)
-        losses = [eng.train_step(x, labels, ll, sl) for _ in range(3)]
-        out['bias3'] = lstm.bias.clone()
-        out['lstm_b'] = eng.param('logits/fw/biases').clone()
-        return out, losses
-
-    a, la = run('0')
-    b, lb = run('1')
-    for k in ('inf', 'logits', 'costs', 'bias0'):
-        assert torch.equal(a[k], b[k]), k
-    for n in det:
-        assert torch.equal(a['grads'][n], b['grads'][n]), n
-    assert np.allclose(la, lb, rtol=2e-3), (la, lb)          # the other weight gradients use fp32 atomics: order noise only
-    assert float((a['bias3'] - b['bias3']).abs().max()) < 1e-2 and not torch.equal(b['bias3'], b['bias0'])
-    # the packed bias follows the updated parameter: permutation (u / 16) * 64 + g * 16 + u % 16 of the gate-major TF vector
+    eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
+    lstm = [op for op in eng.ops if hasattr(op, 'whT')][0]
+    bias0 = lstm.bias.clone()
+    eng.setup_optimizer('Adam', 1e-3)
+    for _ in range(3):
+        eng.train_step(x, labels, ll, sl)
     U = 256
-    want = b['lstm_b'].view(4, U // 16, 16).permute(1, 0, 2).reshape(-1)
-    assert torch.equal(b['bias3'][:4 * U], want)
+    want = eng.param('logits/fw/biases').view(4, U // 16, 16).permute(1, 0, 2).reshape(-1)
+    assert torch.equal(lstm.bias[:4 * U], want) and not torch.equal(lstm.bias, bias0)
 
 
-def test_lstm_backward_aux_stream_changes_nothing(dev, monkeypatch):
-    """OCR_LSTM_AUX (default off: measured 0.7 % slower): the FC weight gradient and the [x | h_prev] operand of the LSTM weight gradient run on an
-    auxiliary stream beside the persistent backward recurrence (parallel branches of the captured graph); OCR_W9_OVERLAP (default
-    off: the fork / join costs what the overlap returns): the merged slab reduction runs there beside the conv1 + pool backward.  Same kernels, same inputs: every gradient must
-    agree with the one-stream schedule (bit for bit where no atomics are involved)."""
-    N, W = 8, 88
-    x, labels, ll, sl = make_batch(N, W, 2, 4, 13, varlen=True)
+def test_lagged_loss_reports_are_the_right_iterations(dev):
+    """with the loss of iteration k read while k + 1 runs (report_async / report_wait, the training loop's default) the
+    engine's own every-64-steps time-out check used to take the ring slot a pending handle still pointed at, so one logged loss in 64
+    was the next step's.  More than 64 lagged iterations must give exactly the losses of the loop that waits at once."""
+    N, W, steps = 8, 88, 70
+    batches = [make_batch(N, W, 2, 4, 100 + i, varlen=True) for i in range(4)]
 
-    def run(flag):
-        monkeypatch.setenv('OCR_LSTM_AUX', flag)
-        monkeypatch.setenv('OCR_W9_OVERLAP', flag)       # likewise: the merged slab reduction beside the conv1 + pool backward
+    def run(lagged):
         eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
-        assert (eng.aux_stream is not None) == (flag == '1') and eng.lstm_aux == eng.w9_overlap == (flag == '1')
-        sp = eng.plan(N, W)
-        eng._bind(sp, x, sl, labels, ll)
-        for _ in range(3):                               # eager warm-up, capture, replay
-            eng._run(sp, 'fb')
-        torch.cuda.synchronize()
-        assert not eng._aux_used
-        return eng.grads.clone(), eng
+        eng.setup_optimizer('Momentum', 1e-3)           # (no atomics-order dependence worth mentioning over 70 steps at this lr)
+        out, pending = [], None
+        for it in range(steps):
+            x, labels, ll, sl = batches[it % len(batches)]
+            if not lagged:
+                out.append(eng.train_step(x, labels, ll, sl, fetch_loss=True))
+                continue
+            eng.train_step(x, labels, ll, sl, fetch_loss=False)
+            h = eng.report_async()
+            if pending is not None:
+                out.append(eng.report_wait(pending))
+            pending = h
+        if pending is not None:
+            out.append(eng.report_wait(pending))
+        return np.array(out)
 
-    g0, _ = run('0')
-    g1, eng = run('1')
-    scale = float(g0.abs().max())
-    assert float((g1 - g0).abs().max()) < 1e-4 * scale                 # fp32-atomics order noise of the plain GEMM weight gradients only
-    for name in ('conv2/weights', 'conv2/biases', 'conv3_1/weights', 'conv4_2/weights', 'conv4_1/conv4_1/gamma'):
-        o, n = eng.offset(name), int(np.prod(eng.specs[name].shape))
-        assert torch.equal(g1[o:o + n], g0[o:o + n]), name
+    a, b = run(False), run(True)
+    assert len(a) == len(b) == steps
+    # same kernels, same order: the two loops differ only in WHEN the host reads; fp32-atomics order noise of the plain GEMM weight
+    # gradients is far below the step-to-step change of the loss
+    assert np.allclose(a, b, rtol=2e-3), np.abs(a - b).max()
+    step_change = np.abs(np.diff(a)).min()
+    assert np.abs(a - b).max() < 0.25 * step_change + 1e-6 or np.allclose(a, b, rtol=1e-4)
+    with pytest.raises(RuntimeError):                    # slot ownership is enforced: a fifth outstanding handle is refused
+        eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
+        x, labels, ll, sl = batches[0]
+        eng.train_step(x, labels, ll, sl, fetch_loss=False)
+        for _ in range(Engine.REPORT_SLOTS + 1):
+            eng.report_async()
 
 
 def test_training_reduces_loss_and_matches_oracle_update(engine):

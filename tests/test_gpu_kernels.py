@@ -584,7 +584,7 @@ def _lstm_device_forward(dev, x, seq_len, Ws, bs, U, persistent=False):
     gates = torch.zeros((2, R, 4 * U), device=dev); cell = torch.zeros((2, R, U), device=dev)
     if persistent:
         assert ops.lstm_seq_supported(N, U)
-        sync = torch.zeros(ops.lstm_seq_sync_words(N), dtype=torch.int32, device=dev)
+        sync = torch.zeros(ops.lstm_seq_sync_words(N, U), dtype=torch.int32, device=dev)
         ops.lstm_fwd_seq(xproj, whT, sl, hout, gates, cell, N, T, U, sync)
         torch.cuda.synchronize()
         assert int(sync[-1]) == 0, "persistent LSTM forward: spin timeout"
@@ -596,7 +596,10 @@ def _lstm_device_forward(dev, x, seq_len, Ws, bs, U, persistent=False):
 
 @pytest.mark.parametrize("N,T,D,U,lens,persistent", [(64, 21, 512, 256, None, False), (5, 9, 64, 32, [9, 4, 1, 7, 9], False),
                                                         (70, 6, 64, 32, None, False), (64, 63, 512, 256, None, True),
-                                                        (100, 12, 64, 256, None, True), (3, 5, 64, 256, [5, 1, 3], True), (200, 4, 64, 256, None, True), (8, 21, 512, 256, None, True)])
+                                                        (100, 12, 64, 256, None, True), (3, 5, 64, 256, [5, 1, 3], True), (200, 4, 64, 256, None, True), (8, 21, 512, 256, None, True),
+                                                        # BASELINE configs[4]: 512 units per direction (contraction axis split over two waves); layer-2 input 1024
+                                                        (8, 9, 64, 512, None, False), (64, 63, 512, 512, None, True), (32, 21, 1024, 512, None, True),
+                                                        (100, 12, 64, 512, None, True), (3, 5, 64, 512, [5, 1, 3], True)])
 def test_lstm_fwd_bwd(dev, N, T, D, U, lens, persistent):
     rng = np.random.RandomState(1)
     seq_len = lens if lens is not None else rng.randint(max(1, T // 2), T + 1, N).tolist()
@@ -624,7 +627,7 @@ def test_lstm_fwd_bwd(dev, N, T, D, U, lens, persistent):
     dc = torch.zeros((2, N, U), device=dev)
     dhd = dh.to(dev).to(BF).reshape(R, 2 * U)
     if persistent:
-        sync = torch.zeros(ops.lstm_seq_sync_words(N), dtype=torch.int32, device=dev)
+        sync = torch.zeros(ops.lstm_seq_sync_words(N, U), dtype=torch.int32, device=dev)
         ops.lstm_bwd_seq(whb[:, D:], 4 * U, (D + U) * 4 * U, st["sl"], dhd, st["gates"], st["cell"], dz, N, T, U, sync)
         torch.cuda.synchronize()
         assert int(sync[-1]) == 0, "persistent LSTM backward: spin timeout"
@@ -646,6 +649,17 @@ def test_lstm_fwd_bwd(dev, N, T, D, U, lens, persistent):
         ops.cast2d_bf16(Ws[d].to(dev), 4 * U, wcat[:, d * 4 * U:], 8 * U, D, 4 * U)
     dx = ops.gemm_nt(dz, wcat)
     assert relerr(dx.float().cpu().reshape(N, T, D), xr.grad) < 1e-2
+
+
+@pytest.mark.parametrize("env", [dict(OCR_LSTM_PROTO='0'), dict(OCR_LSTM_PROTO='2'), dict(OCR_LSTM_ROWS='8'), dict(OCR_LSTM_PROTO='2', OCR_LSTM_ROWS='8')])
+def test_lstm_persistent_other_protocols_and_tiles(dev, env):
+    """The persistent kernels' other hand-off protocols (0 = counters, the placement-independent fallback; 2 = data-as-flag through the
+    output tensor) and the 8-row batch tiles, through the same parity cases (the knobs are read once per process: own interpreter)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_kernels.py'), '-q', '-k', 'test_lstm_fwd_bwd and True'],
+                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:]
 
 
 # ------------------------------------------------------------------------------------------- optimiser

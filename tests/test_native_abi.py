@@ -28,6 +28,9 @@ def test_status_codes_and_host_side_validation():
     assert lib.ocr_gemm_nt_bf16(None, 0, None, 0, None, 0, 8, 8, 8, None, None, 0, 0, 1, 0, 0, 0, 0, None) == 2
     assert lib.ocr_lstm_seq_supported(64, 256) == 1 and lib.ocr_lstm_seq_supported(64, 128) == 0
     assert lib.ocr_lstm_seq_supported(64 * 9, 256) == 0                            # would not be one workgroup per CU
+    assert lib.ocr_lstm_seq_supported(64, 512) == 1 and lib.ocr_lstm_seq_supported(128, 512) == 1      # configs[4]: 512 units per direction
+    assert lib.ocr_lstm_seq_supported(129, 512) == 0
+    assert lib.ocr_lstm_seq_sync_words(64, 256) > 2 * 8 * 64 and lib.ocr_lstm_seq_sync_words(0, 256) == 0
 
 
 def test_warpctc_abi_is_exported_with_its_own_prototypes():
@@ -73,17 +76,15 @@ def test_hot_path_has_no_cpu_fallback():
 
 def test_job_table_records_match_the_c_structs():
     """The engine hands three kinds of job tables to one-launch kernels (re-packs, fills, weight-gradient slab reductions); their numpy
-    record layouts must be the C structs' (csrc/nn_ops.hip PackJob / FillJob, csrc/wgrad9.hip W9ReduceJob; the .hip side
+    record layouts must be the C structs' (csrc/nn_ops.hip PackJob, csrc/wgrad9.hip W9ReduceJob; the .hip side
     static_asserts the sizes), and host-side argument checks of the new entry points reject NULL tables before any launch."""
     from lstm_ctc_ocr_amd.engine import Engine
     off = lambda dt: {n: dt.fields[n][1] for n in dt.names}
     assert Engine.PACK_DTYPE.itemsize == 64
-    assert Engine.FILL_JOB_DTYPE.itemsize == 32
-    assert off(Engine.FILL_JOB_DTYPE) == dict(ptr=0, nwords=8, value=16, block_start=20, nblocks=24, pad=28)
     assert Engine.W9_JOB_DTYPE.itemsize == 64
     assert off(Engine.W9_JOB_DTYPE) == dict(dw=0, part=8, dbias=16, cs_part=24, n4=32, slab4=40, S=48, rows=52, Cout=56, block_start=60)
     lib = nat.lib()
-    assert lib.ocr_fill_jobs(None, 1, 1, None) == 2 and lib.ocr_wgrad9_reduce_jobs(None, 1, 1, None) == 2
+    assert lib.ocr_wgrad9_reduce_jobs(None, 1, 1, None) == 2
     job = (ctypes.c_ubyte * 64)()
     nb, deferred = ctypes.c_int(0), ctypes.c_int(0)
     assert lib.ocr_conv3x3_wgrad_defer_bf16(None, None, None, None, 8, 8, 8, 64, 64, None, 0, ctypes.cast(job, ctypes.c_void_p),

@@ -96,7 +96,7 @@ def main():
         for s in range(T - 1, -1, -1):
             ops.lstm_bwd_step(whb[:, 512:], 4 * U, 768 * 4 * U, sl, dh, gates, cell, dzb, dc, Nb, T, U, s)
     rec("lstm.bwd_63steps", timeit(lstm_bwd, iters=5))
-    syn = torch.zeros(ops.lstm_seq_sync_words(Nb), dtype=torch.int32, device=dev)
+    syn = torch.zeros(ops.lstm_seq_sync_words(Nb, U), dtype=torch.int32, device=dev)
     rec("lstm.fwd_seq_persistent", timeit(lambda: ops.lstm_fwd_seq(xproj, whT, sl, hout, gates, cell, Nb, T, U, syn), iters=10))
     rec("lstm.bwd_seq_persistent", timeit(lambda: ops.lstm_bwd_seq(whb[:, 512:], 4 * U, 768 * 4 * U, sl, dh, gates, cell, dzb, Nb, T, U, syn), iters=10))
     print("persistent spin-timeout flag:", int(syn[-1]))
