@@ -26,6 +26,7 @@ struct HaloArgs {
     bf16_t* out; const float* bias; const bf16_t* mask; int flags;
     bf16_t* pool; int pool_kind;          // max-pool of the (ReLU'd) output written by the same epilogue: 0 none, 1 feature pairs (1 x 2), 2 2 x 2
     int stagger, stagger_bit;             // experiment OCR_HALO_STAGGER=units,bit: workgroups whose in-XCD index has `bit` set start `units` x 64 clocks late
+    int prio;                             // experiment OCR_HALO_PRIO=1: s_setprio 1 around the MFMA clusters (guide T5)
 };
 
 __device__ u32x4 igh_zero_page[4];
@@ -203,12 +204,14 @@ void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 8 * NW */
             if (kk == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FN + FM) : "memory");     // the second half's reads may stay in flight
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            if (g.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int a = 0; a < FN; ++a)
 #pragma unroll
                 for (int b = 0; b < FM; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[kk][a]),
                                                                         __builtin_bit_cast(bf16x8, bfr[kk][b]), acc[a][b], 0, 0, 0);
+            if (g.prio && kk == 1) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -548,6 +551,10 @@ static int launch_halo(const HaloArgs& g, hipStream_t stream) {
     return launch_halo_<BN, NW, 0>(g, stream);
 }
 
+int k2_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
+                    const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind);
+#define K2_DEFAULT 0            // until measured faster on hardware (round 3)
+
 // -1 = shape not covered (caller falls back to igemm.hip / gemm.hip)
 int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
                       const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind) {
@@ -559,6 +566,14 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
         if (pool_kind != 1 && pool_kind != 2) return -1;
         if (M % (pool_kind == 2 ? 2 * H : 2)) return -1;
     }
+    // fifth generation (conv_k2.hip: 128 x 64 wave tiles through an in-workgroup K split, ping-pong K halves) where its tiles fill the
+    // chip; A/B knob OCR_CONV_K2 = 0 keeps every shape on this file's kernels
+    static int k2 = -1;
+    if (k2 < 0) { const char* e = getenv("OCR_CONV_K2"); k2 = e ? atoi(e) : K2_DEFAULT; }
+    if (k2) {
+        const int rc = k2_try_dispatch(x, wpack, y, M, W, H, Cin, Cout, bias, mask, flags, stream, pool, pool_kind);
+        if (rc >= 0) return rc;
+    }
     // Tile choice.  128-pixel workgroups of 4 waves leave room for TWO workgroups per CU (80 KiB of LDS each): they drift out
     // of phase, so one's MFMA burst covers the other's barrier / DMA-issue / LDS-read phase (+5-7 % where the grid then still
     // has two workgroups for every CU).  Otherwise 256-pixel workgroups of 8 waves, one per CU.
@@ -566,7 +581,9 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
     if (nw < 0) { const char* e = getenv("OCR_HALO_NW"); nw = e ? atoi(e) : 0; }
     static int stag = -1, stag_bit = 32;                 // experiment knob OCR_HALO_STAGGER=units[,bit] (units of 64 clocks; default off)
     if (stag < 0) { const char* e = getenv("OCR_HALO_STAGGER"); stag = e ? atoi(e) : 0; const char* c = e ? strchr(e, ',') : nullptr; if (c) stag_bit = atoi(c + 1); if (stag < 0) stag = 0; }
-    HaloArgs g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, stag, stag_bit};
+    static int prio = -1;
+    if (prio < 0) { const char* e = getenv("OCR_HALO_PRIO"); prio = e ? atoi(e) : 0; }
+    HaloArgs g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, stag, stag_bit, prio};
     static int dense = -1;                               // A/B knob OCR_HALO_DENSE=1: 8 waves per 128-pixel tile (4 waves per SIMD with two workgroups per CU)
     if (dense < 0) { const char* e = getenv("OCR_HALO_DENSE"); dense = e ? atoi(e) : 0; }
     if (dense && nw != 8) {

@@ -1,0 +1,362 @@
+// 3x3 SAME implicit-GEMM convolution for gfx950, fifth generation: 128 x 64 WAVE TILES through an IN-WORKGROUP K SPLIT,
+// ping-pong between the two K halves (same contract as ocr_conv3x3_bf16 — reference lib/networks/network.py:160-191 forward, and
+// its data gradient; same halo-tile / tap-reuse idea as conv_halo.hip).
+//
+// Why (round 3): conv_halo's 64 x 64 wave tiles read 0.5 LDS fragments per MFMA and its 128-pixel
+// workgroups re-stream a 16 KiB weight tile per 2.1 MFLOP; with two such workgroups per CU the LDS carries 128 ds_read_b128 +
+// 36 KiB of DMA per K step against 1024 MFMA cycles per SIMD — the LDS is as busy as the matrix pipe, which is why removing
+// either the reads or the DMA returned the same ~20 % and nothing overlapped (r02 ablations).  Larger wave tiles need more
+// accumulators than two independent workgroups per CU can hold, and larger workgroup tiles leave half the chip idle at batch 64
+// (128 tiles of 256 x 256).  So: ONE workgroup of 8 waves per CU on a 256-pixel x 128-channel tile, waves = 2 (pixels) x 2
+// (channels) x 2 (K halves): the waves w and w + 4 own the SAME 128 x 64 output block, w the channels 0-31 of every 64-channel
+// K chunk and w + 4 the channels 32-63.  Per K step (tap, chunk) a wave reads 4 weight + 8 pixel fragments for 32 MFMAs (0.375
+// per MFMA), the workgroup DMAs 16 KiB of weights + 1/9 of a 40 KiB halo tile for 4.2 MFLOP (half of conv_halo's bytes per flop),
+// and 256 tiles still fill the chip for every layer of the headline step but two (those take the 128-pixel form, FM = 4).
+// The two K halves meet once, after the last step: each wave hands half of its accumulators to its partner through LDS
+// (16 KiB per wave, the stages are dead by then) and finishes the other half (bias / ReLU / mask / accumulate / fused max-pool
+// epilogue as in conv_halo).
+//
+// Schedule: the two waves of a SIMD (w, w + 4) run half a step apart, separated by workgroup barriers (two per step):
+//     segment 2s     : waves 0-3  LOAD(s) = DMA issue for step s + 2, fragment addresses, the 12 fragment reads of step s
+//                      waves 4-7  COMP(s - 1) = 32 MFMAs (s_setprio 1) on the fragments they read in segment 2s - 1
+//     segment 2s + 1 : waves 0-3  COMP(s),  waves 4-7  LOAD(s)
+// so every SIMD has one wave on the matrix pipe and one on the LDS / DMA / VALU pipes at all times, and nothing a wave waits
+// for was issued less than a segment ago:
+//   * weight tiles: FOUR stages, tile s + 2 is streamed while tiles s and s + 1 are read; its stage held tile s - 2, whose last
+//     readers (waves 4-7, segment 2s - 3) completed their reads before segment 2s - 2 began — no read is ever in flight on a
+//     stage that is being overwritten, although the reads of a LOAD segment are only waited for AFTER the barrier that ends it;
+//   * halo tiles: two stages, the PI pieces per wave of chunk c + 1 are issued one per step at taps 1 .. PI of chunk c (never at
+//     tap 0: the previous chunk's last reads may still be in flight then);
+//   * every wave retires, at the end of segment 2s + 1, everything it issued before its LOAD(s) (counted vmcnt = the pieces of
+//     LOAD(s)); the barrier there publishes tile s + 1 and any halo piece one step after its issue.
+// DMA addressing: buffer_load ... lds through a buffer descriptor — per piece a loop-invariant 32-bit lane offset and a scalar
+// offset that advances per step, no per-step vector arithmetic (the flat-pointer form cost 150-260 issue cycles per piece in
+// conv_halo); rows that do not exist (n >= N, pixels outside [0, M), the zero rows behind the halo) carry an out-of-range lane
+// offset and arrive as zeros.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+enum { K2_BIAS = 1, K2_RELU = 2, K2_MASK = 16, K2_ACCUM = 64 };
+
+struct K2Args {
+    const bf16_t* P; const bf16_t* Q;     // P [M pixels][C] ; Q [N][9*C]
+    int M, N, C;                          // C % 64 == 0
+    int cW, cH;
+    bf16_t* out; const float* bias; const bf16_t* mask; int flags;
+    bf16_t* pool; int pool_kind;          // as conv_halo: 0 none, 1 feature pairs (1 x 2), 2 2 x 2
+};
+
+__device__ long long* k2_dbg;             // diagnostic: s_memtime stamps of workgroup 0 (ocr_conv_k2_debug)
+typedef __attribute__((address_space(3))) void* lptr_t;
+#define K2_OOB 0x80000000u                // lane offset of a row that does not exist: beyond any descriptor's range
+
+#define K2_VMWAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <int FM /* 16-pixel fragments per wave: 8 (256-pixel tiles) or 4 (128-pixel tiles) */, bool DBG>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_k2_kernel(K2Args g) {
+    constexpr int NW = 8, FN = 4, BN = 128;
+    constexpr int WM = FM * 16, BM = 2 * WM;
+    constexpr int NRpad = (BM == 256) ? 320 : 192;      // halo rows incl. >= 2 zero rows, a multiple of 8 rows x 8 waves
+    constexpr int PI = NRpad / (8 * NW);                // halo DMA pieces per wave and chunk (5 / 3)
+    constexpr int QI = BN / (8 * NW);                   // weight DMA pieces per wave and step (2)
+    constexpr int PBYTES = NRpad * 128, QB = BN * 128, QOFF = 2 * PBYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int H = g.cH, C = g.C;
+    const int NR = BM + 2 * H + 2;                      // halo rows actually needed; rows NR, NR + 1 are the zero rows
+
+    const int mtiles = (g.M + BM - 1) / BM, ntiles = (g.N + BN - 1) / BN;
+    const int nblk = mtiles * ntiles;
+    int Lb = blockIdx.x;
+    if ((nblk & 7) == 0) Lb = (Lb & 7) * (nblk >> 3) + (Lb >> 3);        // XCD-aware: each XCD gets a contiguous run of tiles
+    const int m0 = (Lb / ntiles) * BM, n0 = (Lb % ntiles) * BN;
+
+    const int rsub = lane >> 3;
+    const int csrc = ((lane & 7) ^ rsub) * 8;           // LDS position lane&7 of row r holds source chunk (lane&7)^(r&7)
+    const long mfirst = (long)m0 - H - 1;               // flat pixel of halo row 0
+
+    const __amdgpu_buffer_rsrc_t psrd = __builtin_amdgcn_make_buffer_rsrc((void*)g.P, 0, (int)((long)g.M * C * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t qsrd = __builtin_amdgcn_make_buffer_rsrc((void*)g.Q, 0, (int)((long)g.N * 9 * C * 2), 0x00020000);
+    unsigned voffQ[QI], voffP[PI];
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+        const int n = n0 + (wave * QI + j) * 8 + rsub;
+        voffQ[j] = n < g.N ? (unsigned)(((long)n * 9 * C + csrc) * 2) : K2_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < PI; ++j) {
+        const int r = (wave * PI + j) * 8 + rsub;
+        const long m = mfirst + r;
+        voffP[j] = (r < NR && m >= 0 && m < g.M) ? (unsigned)((m * C + csrc) * 2) : K2_OOB;
+    }
+    auto load_q = [&](int k0 /* tap*C + chunk*64 */, int stage) {
+#pragma unroll
+        for (int j = 0; j < QI; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qsrd, (lptr_t)(smem + QOFF + stage * QB + (wave * QI + j) * 1024), 16, (int)voffQ[j], k0 * 2, 0, 0);
+    };
+    auto load_p1 = [&](int chunk, int buf, int j, unsigned voff) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(psrd, (lptr_t)(smem + buf * PBYTES + (wave * PI + j) * 1024), 16, (int)voff, chunk * 128, 0, 0);
+    };
+
+    // per pixel-fragment validity of the nine taps (bit t set <=> tap t of this lane's pixel is inside the image)
+    unsigned vmask[FM];
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+        const int m = m0 + wm * WM + b * 16 + (lane & 15);
+        unsigned bits = 0;
+        if (m < g.M) {
+            const int h = m % H, w = (m / H) % g.cW;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ww = w + t / 3 - 1, hh = h + t % 3 - 1;
+                if ((unsigned)ww < (unsigned)g.cW && (unsigned)hh < (unsigned)H) bits |= 1u << t;
+            }
+        }
+        vmask[b] = bits;
+    }
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
+    const int nchunks = C / 64;
+    const int nsteps = nchunks * 9;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    // this wave's K half: 16-byte chunks kh*4 + fq of a 128-byte row, at position (kh*4 + fq) ^ (row & 7)
+    const unsigned qfrag0 = lds0 + QOFF + (wn * 64 + frow) * 128 + ((((kh << 2) | fq) ^ fx) << 4);       // + stage*QB, + a*2048
+    const unsigned prow0 = lds0 + (wm * WM + frow) * 128;                                                 // + stage, + shift*128 + swizzle
+
+    // ---- prologue: weight tiles of steps 0 and 1, the whole halo of chunk 0; everything has landed before barrier 0
+    load_q(0, 0);
+    if (nsteps > 1) load_q(C, 1);
+#pragma unroll
+    for (int j = 0; j < PI; ++j) load_p1(0, 0, j, voffP[j]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kh == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }        // segment 0: waves 4-7 have nothing to multiply yet
+
+    int tap = 0, chunk = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        long long st[6] = {0, 0, 0, 0, 0, 0};
+        if (DBG) st[0] = __builtin_amdgcn_s_memtime();
+        // ================================================================ LOAD(s)
+        const bool more_q = s + 2 < nsteps;
+        const bool halo_now = tap >= 1 && tap <= PI && chunk + 1 < nchunks;
+        {
+            int t2 = tap + 2, c2 = chunk;
+            if (t2 >= 9) { t2 -= 9; ++c2; }
+            if (more_q) load_q(t2 * C + c2 * 64, (s + 2) & 3);
+            if (halo_now) {                     // one halo piece of the next chunk per step (static register index)
+                const int nb = (chunk + 1) & 1;
+                switch (tap) {
+                    case 1: load_p1(chunk + 1, nb, 0, voffP[0]); break;
+                    case 2: load_p1(chunk + 1, nb, 1, voffP[1]); break;
+                    case 3: load_p1(chunk + 1, nb, 2, voffP[2]); break;
+                    case 4: if (PI > 3) load_p1(chunk + 1, nb, 3, voffP[PI > 3 ? 3 : 0]); break;
+                    default: if (PI > 4) load_p1(chunk + 1, nb, 4, voffP[PI > 4 ? 4 : 0]); break;
+                }
+            }
+        }
+        if (DBG) st[1] = __builtin_amdgcn_s_memtime();
+        const int shift = (H + 1) + (tap / 3 - 1) * H + (tap % 3 - 1);       // halo row of local pixel 0 for this tap
+        const unsigned qa = qfrag0 + (s & 3) * QB;
+        // pixel fragments: row (wm*WM + b*16 + frow + shift), chunk position ((kh*4 + fq) ^ (row & 7)); lanes whose tap falls outside
+        // the image read a zero row (NR / NR + 1: the one with the real row's parity, at the real row's position in its 256 bytes, so
+        // the redirected lanes keep the banks the swizzle gave them)
+        const unsigned psw = ((((unsigned)kh << 2) | (unsigned)fq) ^ (unsigned)((frow + shift) & 7)) << 4;
+        const unsigned pbase = prow0 + (chunk & 1) * PBYTES + shift * 128 + psw;
+        const unsigned zoff = lds0 + (chunk & 1) * PBYTES + NR * 128 + (((frow + shift) & 1) << 7) + psw;
+        u32x4 afr[FN], bfr[FM];
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[a]) : "v"(qa), "n"(a * 2048));
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+            const unsigned pa = ((vmask[b] >> tap) & 1u) ? pbase + b * 2048 : zoff;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[b]) : "v"(pa));
+        }
+        // pieces of this wave younger than tile s + 1 = what LOAD(s) issued
+        const int younger = (more_q ? QI : 0) + (halo_now ? 1 : 0);
+        auto vmwait = [&]() {
+            switch (younger) {
+                case 0: K2_VMWAIT(0); break; case 1: K2_VMWAIT(1); break; case 2: K2_VMWAIT(2); break;
+                default: K2_VMWAIT(3); break;
+            }
+        };
+        if (DBG) st[2] = __builtin_amdgcn_s_memtime();
+        if (kh == 1) vmwait();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (DBG) st[3] = __builtin_amdgcn_s_memtime();
+        // ================================================================ COMP(s)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int b = 0; b < FM; ++b)
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[a]), __builtin_bit_cast(bf16x8, bfr[b]),
+                                                                    acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (DBG) st[4] = __builtin_amdgcn_s_memtime();
+        if (kh == 0) vmwait();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (DBG && blockIdx.x == 0 && lane == 0 && k2_dbg != nullptr && s < 80) {
+            st[5] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int i = 0; i < 6; ++i) k2_dbg[(wave * 80 + s) * 6 + i] = st[i];
+        }
+        if (++tap == 9) { tap = 0; ++chunk; }
+    }
+    if (kh == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }      // matches the extra barrier waves 4-7 took at the start
+
+    // ---- the two K halves meet: a wave keeps the pixel fragments [kh*FM/2, (kh+1)*FM/2) and hands the others to its partner
+    // (every MFMA and every fragment read of the workgroup is complete: all waves have passed the last barrier).
+    // kh is wave-uniform but not a compile-time constant; the tail is instantiated for both halves and branched on, so that every
+    // accumulator index stays static (a select between two elements of acc[][] sent the whole array to scratch memory).
+    constexpr int FH = FM / 2;
+    auto tail = [&](auto half_c) {
+        constexpr int KH = decltype(half_c)::value;
+        {
+            f32x4* mine = (f32x4*)smem + (size_t)wave * (FN * FH * 64);
+            const f32x4* theirs = (const f32x4*)smem + (size_t)(wave ^ 4) * (FN * FH * 64);
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int b = 0; b < FH; ++b) mine[(a * FH + b) * 64 + lane] = acc[a][(1 - KH) * FH + b];      // what the partner finishes
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int b = 0; b < FH; ++b) acc[a][KH * FH + b] += theirs[(a * FH + b) * 64 + lane];
+        }
+        // epilogue for this wave's FH pixel fragments (m-block outer, n-fragment inner: the stores completing a 128-B run of a pixel
+        // row are adjacent)
+        const int flags = g.flags;
+        f32x4 bv[FN];
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+            bv[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if ((flags & K2_BIAS) && n < g.N) bv[a] = *(const f32x4*)(g.bias + n);
+        }
+#pragma unroll
+        for (int bb = 0; bb < FH; ++bb) {
+            const int m = m0 + wm * WM + (KH * FH + bb) * 16 + (lane & 15);
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+                const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+                if (n >= g.N) continue;
+                f32x4 v = acc[a][KH * FH + bb] + bv[a];
+                if (flags & K2_RELU) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                if (flags & K2_MASK) {
+                    u32x2 mk = *(const u32x2*)(g.mask + (long)m * g.N + n);
+                    if (!(bf_lo(mk.x) > 0.f)) v.x = 0.f;
+                    if (!(bf_hi(mk.x) > 0.f)) v.y = 0.f;
+                    if (!(bf_lo(mk.y) > 0.f)) v.z = 0.f;
+                    if (!(bf_hi(mk.y) > 0.f)) v.w = 0.f;
+                }
+                if (flags & K2_ACCUM) {
+                    const u32x2 old = *(const u32x2*)(g.out + (long)m * g.N + n);
+                    v.x += bf_lo(old.x); v.y += bf_hi(old.x); v.z += bf_lo(old.y); v.w += bf_hi(old.y);
+                }
+                u32x2 pk;
+                pk.x = pack_bf2(v.x, v.y);
+                pk.y = pack_bf2(v.z, v.w);
+                *(u32x2*)(g.out + (long)m * g.N + n) = pk;
+                if (g.pool_kind) {
+                    // max-pool window of this pixel, as in conv_halo: feature-axis neighbour = lane ^ 1; time-axis neighbour = lane ^ H
+                    // for H = 4, 8, the same lane of fragment b ^ 1 for H = 16 (b ^ 1 stays inside this wave's half: FH is even)
+                    f32x4 mx = v;
+                    if (g.pool_kind == 2) {
+                        if (H == 16) {
+                            f32x4 u = acc[a][KH * FH + (bb ^ 1)] + bv[a];
+                            u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
+                            mx.x = fmaxf(mx.x, u.x); mx.y = fmaxf(mx.y, u.y); mx.z = fmaxf(mx.z, u.z); mx.w = fmaxf(mx.w, u.w);
+                        } else {
+                            mx.x = fmaxf(mx.x, __shfl_xor(mx.x, H, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, H, 64));
+                            mx.z = fmaxf(mx.z, __shfl_xor(mx.z, H, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, H, 64));
+                        }
+                    }
+                    mx.x = fmaxf(mx.x, __shfl_xor(mx.x, 1, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, 1, 64));
+                    mx.z = fmaxf(mx.z, __shfl_xor(mx.z, 1, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, 1, 64));
+                    const int h = m % H, col = m / H;
+                    const bool writer = !(h & 1) && (g.pool_kind == 1 || !(col & 1));
+                    if (writer) {
+                        const long pidx = g.pool_kind == 1 ? (long)(m >> 1) : (long)(col >> 1) * (H >> 1) + (h >> 1);
+                        u32x2 pp;
+                        pp.x = pack_bf2(mx.x, mx.y);
+                        pp.y = pack_bf2(mx.z, mx.w);
+                        *(u32x2*)(g.pool + pidx * g.N + n) = pp;
+                    }
+                }
+            }
+        }
+    };
+    if (kh) tail(std::integral_constant<int, 1>{}); else tail(std::integral_constant<int, 0>{});
+}
+
+static bool g_k2_dbg = false;
+extern "C" int ocr_conv_k2_debug(void* dbg /* device int64[8 waves][80 steps][6] or NULL */) {
+    long long* q = (long long*)dbg;
+    g_k2_dbg = q != nullptr;
+    return hipMemcpyToSymbol(HIP_SYMBOL(k2_dbg), &q, sizeof(q)) == hipSuccess ? OCR_OK : OCR_ERR_MEMOPS;
+}
+
+template <int FM, bool DBG>
+static int launch_k2_(const K2Args& g, hipStream_t stream) {
+    constexpr int BM = 32 * FM, NRpad = (BM == 256) ? 320 : 192;
+    const int lds = 2 * NRpad * 128 + 4 * 128 * 128;               // halo stages, weight stages (the K-half exchange reuses them)
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv_k2_kernel<FM, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC;
+        attr = true;
+    }
+    const int mt = (g.M + BM - 1) / BM, nt = (g.N + 127) / 128;
+    conv_k2_kernel<FM, DBG><<<mt * nt, 512, lds, stream>>>(g);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+template <int FM>
+static int launch_k2(const K2Args& g, hipStream_t stream) { return g_k2_dbg ? launch_k2_<FM, true>(g, stream) : launch_k2_<FM, false>(g, stream); }
+
+// does this kernel take the shape, and with which tile?  0 = no (caller uses conv_halo), else FM
+int k2_tile(long M, int W, int H, int Cin, int Cout) {
+    if ((Cin & 63) || (Cout & 127) || M < 4096 || H > 16 || H < 1) return 0;        // channel tiles of 128; zero rows need NR + 2 <= NRpad
+    if (M * Cin * 2 >= 0x7fffffffL || (long)Cout * 9 * Cin * 2 >= 0x7fffffffL) return 0;   // 32-bit descriptor offsets
+    static int force = -1;                               // A/B knob OCR_K2_FM: 8 / 4 force one tile, unset = by grid size
+    if (force < 0) { const char* e = getenv("OCR_K2_FM"); force = e ? atoi(e) : 0; }
+    const long nt = Cout / 128;
+    const long t8 = (M + 255) / 256 * nt, t4 = (M + 127) / 128 * nt;
+    if (force == 8 || force == 4) return force;
+    if (t8 >= 224) return 8;                            // (almost) every CU gets a 256-pixel tile
+    if (t4 >= 224) return 4;
+    return 0;
+}
+
+// -1 = shape not covered (caller falls back to conv_halo.hip)
+int k2_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
+                    const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind) {
+    if (flags & ~(K2_BIAS | K2_RELU | K2_MASK | K2_ACCUM)) return -1;
+    const int fm = k2_tile(M, W, H, Cin, Cout);
+    if (!fm) return -1;
+    K2Args g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind};
+    return fm == 8 ? launch_k2<8>(g, stream) : launch_k2<4>(g, stream);
+}

@@ -12,9 +12,10 @@
 //     of a (direction, batch-tile) group exchange.  Hand-off protocols (ocr_set_lstm_proto / OCR_LSTM_PROTO):
 //       0  counters (placement independent, MI355X guide G16/R1): write-through (sc1) payload stores -> every wave drains
 //          vmcnt -> __syncthreads -> one lane bumps a monotonic agent-scope counter; consumers poll it relaxed, then read the
-//          rows with sc1 loads.  Used when the device does not co-locate workgroups as 2 / 4 assume (ocr_probe_xcc).
-//       2  data-as-flag inside one XCD's L2, exchanged through the output tensor itself (hout / dz pre-filled with 0xFFFF).
-//       4  (round 3) data-as-flag through a small RING in the XCD's L2: see below.
+//          rows with sc1 loads.  Used when the device does not co-locate workgroups as protocol 4 assumes (ocr_probe_xcc).
+//       4  (default, round 3) data-as-flag through a small RING in one XCD's L2: see below.  (Round 2's protocol 2 exchanged through
+//          the output tensor itself: 141 / 170 us forward / backward at N = 64, U = 256 against 138 / 133 with the ring, 158 / 262
+//          against 150 / 162 at U = 512 — removed.)
 //   * residency: the grid is (U/16) x 2 x ceil(N/rows) workgroups, at most one per CU (the C entry point refuses larger grids;
 //     the caller then uses the per-step kernels).  Spins are bounded and report through an error word instead of hanging.
 #include "common.h"
@@ -54,7 +55,7 @@ __device__ __forceinline__ void group_wait(unsigned* counter, unsigned target, i
     __syncthreads();
 }
 
-// ---- data-as-flag hand-off (PROTO 2, 4) ---------------------------------------------------------------------------------
+// ---- data-as-flag hand-off (PROTO 4) ------------------------------------------------------------------------------------
 // The exchanged rows themselves carry the "ready" information: they start as the bf16 bit pattern 0xFFFF (a NaN that
 // sigma(.)*tanh(.) and the gate gradients never produce; a diverged run yields the canonical quiet NaN 0x7FC0/0xFFC0),
 // producers publish with plain stores and move on WITHOUT draining them or bumping a counter, and consumers re-issue their
@@ -68,12 +69,11 @@ __device__ __forceinline__ void group_wait(unsigned* counter, unsigned target, i
 // A failed poll costs a whole extra round trip (and its traffic), so each wave sleeps `presleep` x 64 clocks before its first
 // poll and adapts that to what it sees: a miss adds two units, eight first-try hits in a row remove one.
 //
-// PROTO 2 exchanges through the layer's own output tensor: every step touches rows nobody has touched since the fill kernel
-// (4 MB of 0xFFFF per launch at N = 64, T = 63), the first poll of every row comes from the Infinity Cache at best, and the
-// 32-byte pieces of the 16 producers land in cache lines that the L2 has to complete (round 2: filling 0.3 ms earlier, i.e.
-// rows in HBM instead of the Infinity Cache, costs 16 us forward / 40 us backward — the recurrence is that sensitive to where
-// its flag rows live).
-// PROTO 4 exchanges through a ring of RING = 4 step slots per group instead, [slot][unit block][batch sub-tile]([gate])[16 rows][16 units]:
+// Round 2 exchanged through the layer's own output tensor: every step touched rows nobody had touched since the fill kernel
+// (4 MB of 0xFFFF per launch at N = 64, T = 63), the first poll of every row came from the Infinity Cache at best, and the
+// 32-byte pieces of the 16 producers landed in cache lines that the L2 had to complete (filling 0.3 ms earlier, i.e. rows in HBM
+// instead of the Infinity Cache, cost 16 us forward / 40 us backward — the recurrence is that sensitive to where its flag rows live).
+// Now the exchange goes through a ring of RING = 4 step slots per group, [slot][unit block][batch sub-tile]([gate])[16 rows][16 units]:
 //   * a producer wave's piece is 512 B (forward) / 2 KB (backward) of whole cache lines, written by nobody else;
 //   * the ring (32 KB forward / 128 KB backward per group at U = 256) never leaves the XCD's L2: every poll is an L2 hit;
 //   * slots are recycled by their producers: at step s, after its own poll for step s has succeeded — every workgroup of the group
@@ -97,10 +97,6 @@ __global__ void fill_words_kernel(unsigned* p, long n, unsigned v, unsigned* zer
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero[i] = 0u;
 }
 #define POLL_ADAPT() do { if (spins > 0) { presleep += 2; streak = 0; } else if (++streak >= 8) { streak = 0; if (presleep > 0) --presleep; } } while (0)
-template <int PROTO> __device__ __forceinline__ void store_pub(void* p, u32x2 v) {
-    if (PROTO >= 2) *(u32x2*)p = v;
-    else store_wt8(p, v);
-}
 template <int PROTO> __device__ __forceinline__ bf16x8 load_pub(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, unsigned uniform_off = 0) {
     if (PROTO >= 2) return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, (int)uniform_off, /*nt*/ 2));
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, (int)uniform_off, /*sc1*/ 16));
@@ -122,11 +118,11 @@ struct LstmSeqFwdArgs {
 };
 
 // U: hidden units per direction; WPB: batch sub-tiles (waves) per workgroup; KSP: waves that share the contraction axis of one
-// sub-tile (1, or 2 at U = 512); RPW: batch rows per sub-tile (16, or 8: the upper half of the MFMA's 16 columns is idle, twice the
-// groups on otherwise idle CUs and half the hand-off payload per CU)
-template <int U, int WPB, int KSP, int RPW, int PROTO>
+// sub-tile (1, or 2 at U = 512).  (8-row sub-tiles — twice the groups, half the hand-off payload per CU — were measured and dropped:
+// 146 / 154 us against 138 / 133 at N = 64, U = 256.)
+template <int U, int WPB, int KSP, int PROTO>
 __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_seq_kernel(LstmSeqFwdArgs a) {
-    constexpr int KS = U / 32 / KSP, UB = U / 16, ROWS = RPW * WPB;
+    constexpr int RPW = 16, KS = U / 32 / KSP, UB = U / 16, ROWS = RPW * WPB;
     constexpr unsigned SLOT = (unsigned)UB * WPB * 512u;                 // ring bytes per step and group
     __shared__ f32x4 red[KSP == 2 ? 2 : 1][WPB][4][64];
     const int lane = threadIdx.x & 63;
@@ -237,7 +233,7 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
             if (!active) {
                 u32x2 z = {0u, 0u};
                 if (PROTO == 4) { *rdst = z; *(u32x2*)hdst = z; }
-                else store_pub<PROTO>(hdst, z);
+                else store_wt8(hdst, z);
             } else {
                 f32x4 zi = xi + acc[0], zj = xj + acc[1], zf = xf + acc[2], zo = xo + acc[3];
                 f32x4 gi, gj, gf, go, hn;
@@ -252,7 +248,7 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
                 }
                 u32x2 hp = {pack_bf2(hn[0], hn[1]), pack_bf2(hn[2], hn[3])};
                 if (PROTO == 4) { *rdst = hp; asm volatile("" ::: "memory"); *(u32x2*)hdst = hp; }
-                else store_pub<PROTO>(hdst, hp);           // the hand-off payload goes out FIRST ...
+                else store_wt8(hdst, hp);                  // the hand-off payload goes out FIRST ...
                 asm volatile("" ::: "memory");
                 float* gdst = a.gates + ((long)d * R + row) * (4L * U) + (long)ub * 64 + ul0;
                 *(f32x4*)(gdst + 0) = gi; *(f32x4*)(gdst + 16) = gj; *(f32x4*)(gdst + 32) = gf; *(f32x4*)(gdst + 48) = go;
@@ -276,9 +272,9 @@ struct LstmSeqBwdArgs {
     int Nb, T; long long* dbg; int presleep;
 };
 
-template <int U, int WPB, int KSP, int RPW, int PROTO>
+template <int U, int WPB, int KSP, int PROTO>
 __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_seq_kernel(LstmSeqBwdArgs a) {
-    constexpr int KS = 4 * U / 32 / KSP, UB = U / 16, ROWS = RPW * WPB;
+    constexpr int RPW = 16, KS = 4 * U / 32 / KSP, UB = U / 16, ROWS = RPW * WPB;
     constexpr unsigned SLOT = (unsigned)UB * WPB * 2048u;                // ring bytes per step and group: [ub][bw][gate][16 rows][16 units]
     __shared__ f32x4 red[KSP == 2 ? 2 : 1][WPB][64];
     const int lane = threadIdx.x & 63;
@@ -346,8 +342,7 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
                     if (PROTO == 4) {
                         const int K0 = (kh * KS + kk) * 32;
                         z[kk] = load_pub<4>(rrsrc, roff, (unsigned)(((K0 % U) / 16) * WPB * 2048 + (K0 / U) * 512));
-                    } else if (PROTO == 0) z[kk] = load_pub<0>(zrsrc, zoff + kk * 64);
-                    else z[kk] = load_pub<2>(zrsrc, zoff + kk * 64);
+                    } else z[kk] = load_pub<0>(zrsrc, zoff + kk * 64);
                 }
             };
             if (PROTO == 0) {
@@ -401,7 +396,7 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
                     for (int g = 0; g < 4; ++g) *(u32x2*)(zdst + (long)g * U) = z;
                 } else {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) store_pub<PROTO>(zdst + (long)g * U, z);
+                    for (int g = 0; g < 4; ++g) store_wt8(zdst + (long)g * U, z);
                 }
             } else {
                 if (!has_next) dh = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -430,7 +425,7 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
                     for (int g = 0; g < 4; ++g) *(u32x2*)(zdst + (long)g * U) = p[g];
                 } else {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) store_pub<PROTO>(zdst + (long)g * U, p[g]);
+                    for (int g = 0; g < 4; ++g) store_wt8(zdst + (long)g * U, p[g]);
                 }
             }
             if (PROTO == 4 && it >= 2) {
@@ -469,38 +464,35 @@ static int seq_env_int(const char* name, int slot, int dflt) {
 }
 // batch rows per workgroup: the smallest tile whose grid still fits one workgroup per CU (measured at N = 64, U = 256, us per
 // step forward / backward: 16 rows 2.6 / 3.2, 32 rows 3.0 / 4.1, 64 rows 3.6 / 6.2 — the per-step cost is the hand-off payload a
-// CU has to pull plus a fixed part).  OCR_LSTM_ROWS forces 8 / 16 / 32 / 64 where that fits.
+// CU has to pull plus a fixed part).  OCR_LSTM_ROWS forces 16 / 32 / 64 where that fits.
 static int seq_rows_per_wg(int Nb, int U) {
     if (U != 256 && U != 512) return 0;
     const int want = seq_env_int("OCR_LSTM_ROWS", 2, 0);
-    const int cand[4] = {8, 16, 32, 64};
     for (int pass = 0; pass < 2; ++pass)
-        for (int i = 0; i < 4; ++i) {
-            const int rows = cand[i];
-            if (pass == 0 ? rows != want : rows == 8) continue;          // 8-row tiles only on request
+        for (int rows = 16; rows <= 64; rows *= 2) {
+            if (pass == 0 && rows != want) continue;
             if (U == 512 && rows == 64) continue;                        // 8 waves of 256 VGPRs: the backward kernel would spill
             if ((U / 16) * 2 * ceil_div(Nb, rows) <= 256) return rows;
         }
     return 0;
 }
 static int g_seq_proto = -1;
-// hand-off protocol: 0 counters (sc1), 2 data-as-flag through the output tensor inside one XCD, 4 data-as-flag through a ring inside
-// one XCD (default).  Environment OCR_LSTM_PROTO (A/B) wins over the setter, which the host uses to fall back to 0 when the device
+// hand-off protocol: 0 counters (sc1), 4 data-as-flag through a ring inside one XCD (default).  Environment OCR_LSTM_PROTO (A/B) wins over the setter, which the host uses to fall back to 0 when the device
 // does not co-locate workgroups with equal (id & 7) on one XCD (checked once with ocr_probe_xcc).
 extern "C" int ocr_set_lstm_proto(int proto) {
-    if (proto != 0 && proto != 2 && proto != 4) return OCR_ERR_INVALID;
+    if (proto != 0 && proto != 4) return OCR_ERR_INVALID;
     g_seq_proto = proto;
     return OCR_OK;
 }
 static int seq_proto() {
     const int env = seq_env_int("OCR_LSTM_PROTO", 3, -1);
-    if (env == 0 || env == 2 || env == 4) return env;
+    if (env == 0 || env == 4) return env;
     return g_seq_proto >= 0 ? g_seq_proto : 4;
 }
 extern "C" int ocr_lstm_seq_supported(int Nb, int U) { return Nb > 0 && seq_rows_per_wg(Nb, U) != 0; }
 // int32 words the caller must provide in `sync`: group counters | ring (sized for the backward pass and the smallest tile) | tail
-static long seq_counter_words(int Nb) { return 2L * ceil_div(Nb, 8) * CNT_STRIDE; }
-static long seq_ring_bytes_max(int Nb, int U) { return (long)RING * (2L * ceil_div(Nb, 8) * 16) * 4 * U * 2; }
+static long seq_counter_words(int Nb) { return 2L * ceil_div(Nb, 16) * CNT_STRIDE; }
+static long seq_ring_bytes_max(int Nb, int U) { return (long)RING * (2L * ceil_div(Nb, 16) * 16 + 96) * 4 * U * 2; }
 extern "C" long ocr_lstm_seq_sync_words(int Nb, int U) {
     if (Nb <= 0 || U <= 0) return 0;
     return seq_counter_words(Nb) + seq_ring_bytes_max(Nb, U) / 4 + CNT_STRIDE;
@@ -510,29 +502,25 @@ template <int U, int PROTO>
 static void launch_fwd(const LstmSeqFwdArgs& a, int rows, dim3 grid3, dim3 grid1, hipStream_t stream) {
     constexpr int KSP = U / 256;
     const dim3 G = PROTO < 2 ? grid3 : grid1;
-    if (rows == 8) lstm_fwd_seq_kernel<U, 1, KSP, 8, PROTO><<<G, 64 * KSP, 0, stream>>>(a);
-    else if (rows == 16) lstm_fwd_seq_kernel<U, 1, KSP, 16, PROTO><<<G, 64 * KSP, 0, stream>>>(a);
-    else if (rows == 32) lstm_fwd_seq_kernel<U, 2, KSP, 16, PROTO><<<G, 128 * KSP, 0, stream>>>(a);
-    else if constexpr (KSP == 1) lstm_fwd_seq_kernel<U, 4, KSP, 16, PROTO><<<G, 256 * KSP, 0, stream>>>(a);
+    if (rows == 16) lstm_fwd_seq_kernel<U, 1, KSP, PROTO><<<G, 64 * KSP, 0, stream>>>(a);
+    else if (rows == 32) lstm_fwd_seq_kernel<U, 2, KSP, PROTO><<<G, 128 * KSP, 0, stream>>>(a);
+    else if constexpr (KSP == 1) lstm_fwd_seq_kernel<U, 4, KSP, PROTO><<<G, 256 * KSP, 0, stream>>>(a);
 }
 template <int U, int PROTO>
 static void launch_bwd(const LstmSeqBwdArgs& a, int rows, dim3 grid3, dim3 grid1, hipStream_t stream) {
     constexpr int KSP = U / 256;
     const dim3 G = PROTO < 2 ? grid3 : grid1;
-    if (rows == 8) lstm_bwd_seq_kernel<U, 1, KSP, 8, PROTO><<<G, 64 * KSP, 0, stream>>>(a);
-    else if (rows == 16) lstm_bwd_seq_kernel<U, 1, KSP, 16, PROTO><<<G, 64 * KSP, 0, stream>>>(a);
-    else if (rows == 32) lstm_bwd_seq_kernel<U, 2, KSP, 16, PROTO><<<G, 128 * KSP, 0, stream>>>(a);
-    else if constexpr (KSP == 1) lstm_bwd_seq_kernel<U, 4, KSP, 16, PROTO><<<G, 256 * KSP, 0, stream>>>(a);
+    if (rows == 16) lstm_bwd_seq_kernel<U, 1, KSP, PROTO><<<G, 64 * KSP, 0, stream>>>(a);
+    else if (rows == 32) lstm_bwd_seq_kernel<U, 2, KSP, PROTO><<<G, 128 * KSP, 0, stream>>>(a);
+    else if constexpr (KSP == 1) lstm_bwd_seq_kernel<U, 4, KSP, PROTO><<<G, 256 * KSP, 0, stream>>>(a);
 }
 
-// the call's own fill launch: counters + error word := 0, then what the protocol polls := 0xFFFF
-static void seq_prepare(int proto, void* sync, long words, long cwords, void* tensor, long tensor_words, long ring_words, hipStream_t stream) {
+// the call's own fill launch: counters + error word := 0, the ring := 0xFFFF
+static void seq_prepare(int proto, void* sync, long words, long cwords, long ring_words, hipStream_t stream) {
     unsigned* s = (unsigned*)sync;
     if (proto == 0) {
         zero_words_kernel<<<1, 256, 0, stream>>>(s, (int)cwords);
         zero_words_kernel<<<1, 64, 0, stream>>>(s + words - CNT_STRIDE, CNT_STRIDE);
-    } else if (proto == 2) {
-        fill_words_kernel<<<256, 256, 0, stream>>>((unsigned*)tensor, tensor_words, 0xFFFFFFFFu, s + words - CNT_STRIDE, CNT_STRIDE);
     } else {
         fill_words_kernel<<<64, 256, 0, stream>>>(s + cwords, ring_words, 0xFFFFFFFFu, s + words - CNT_STRIDE, CNT_STRIDE);
     }
@@ -548,16 +536,15 @@ extern "C" int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, cons
     const int nz = ceil_div(Nb, rows);
     const long words = ocr_lstm_seq_sync_words(Nb, U), cwords = seq_counter_words(Nb);
     const int proto = seq_proto();
-    const int wpb = rows <= 16 ? 1 : rows / 16;
+    const int wpb = rows / 16;
     const long ring_words = (long)(2 * nz) * RING * ((long)(U / 16) * wpb * 512) / 4;
-    seq_prepare(proto, sync, words, cwords, hout, (long)Nb * T * 2 * U / 2, ring_words, stream);
+    seq_prepare(proto, sync, words, cwords, ring_words, stream);
     OCR_CHECK_LAUNCH();
     LstmSeqFwdArgs a = {xproj, (const bf16_t*)whT_packed, seq_len, (bf16_t*)hout, gates, cell, (unsigned*)sync,
                         (unsigned char*)((unsigned*)sync + cwords), (int*)sync + words - 1, Nb, T, forget_bias, g_lstm_dbg,
                         seq_env_int("OCR_LSTM_PRESLEEP_F", 0, 0)};
     const dim3 grid3(U / 16, 2, nz), grid1((U / 16) * 8 * ceil_div(2 * nz, 8));
-#define FWD(UU) do { if (proto == 0) launch_fwd<UU, 0>(a, rows, grid3, grid1, stream); else if (proto == 2) launch_fwd<UU, 2>(a, rows, grid3, grid1, stream); \
-        else launch_fwd<UU, 4>(a, rows, grid3, grid1, stream); } while (0)
+#define FWD(UU) do { if (proto == 0) launch_fwd<UU, 0>(a, rows, grid3, grid1, stream); else launch_fwd<UU, 4>(a, rows, grid3, grid1, stream); } while (0)
     if (U == 256) FWD(256); else FWD(512);
 #undef FWD
     OCR_CHECK_LAUNCH();
@@ -574,16 +561,15 @@ extern "C" int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, con
     const int nz = ceil_div(Nb, rows);
     const long words = ocr_lstm_seq_sync_words(Nb, U), cwords = seq_counter_words(Nb);
     const int proto = seq_proto();
-    const int wpb = rows <= 16 ? 1 : rows / 16;
+    const int wpb = rows / 16;
     const long ring_words = (long)(2 * nz) * RING * ((long)(U / 16) * wpb * 2048) / 4;
-    seq_prepare(proto, sync, words, cwords, dz, (long)Nb * T * 8 * U / 2, ring_words, stream);
+    seq_prepare(proto, sync, words, cwords, ring_words, stream);
     OCR_CHECK_LAUNCH();
     LstmSeqBwdArgs a = {(const bf16_t*)wh, ldw, w_dir_stride, seq_len, (const bf16_t*)dhout, gates, cell, (bf16_t*)dz,
                         (unsigned*)sync, (unsigned char*)((unsigned*)sync + cwords), (int*)sync + words - 1, Nb, T, g_lstm_dbg,
                         seq_env_int("OCR_LSTM_PRESLEEP", 1, 4)};
     const dim3 grid3(U / 16, 2, nz), grid1((U / 16) * 8 * ceil_div(2 * nz, 8));
-#define BWD(UU) do { if (proto == 0) launch_bwd<UU, 0>(a, rows, grid3, grid1, stream); else if (proto == 2) launch_bwd<UU, 2>(a, rows, grid3, grid1, stream); \
-        else launch_bwd<UU, 4>(a, rows, grid3, grid1, stream); } while (0)
+#define BWD(UU) do { if (proto == 0) launch_bwd<UU, 0>(a, rows, grid3, grid1, stream); else launch_bwd<UU, 4>(a, rows, grid3, grid1, stream); } while (0)
     if (U == 256) BWD(256); else BWD(512);
 #undef BWD
     OCR_CHECK_LAUNCH();

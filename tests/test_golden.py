@@ -183,28 +183,36 @@ def test_device_matches_deep_fixture(dev):
               % (e_sim, e_f32, scale, r_sim, r_f32))
         assert e_sim < 2e-2 * max(scale, 1.0) and e_f32 < 5e-2 * max(scale, 1.0)
         assert r_sim < 1e-3 and r_f32 < 1e-3
-        # ---- gradients (the 'fb' run above left them in eng.grads): per tensor, relative L2 distance and cosine on the sample, and the
-        #      ratio of the full norms.  Bars as for the miniature (tests/test_gpu_engine.py: bf16 activation gradients through 33
-        #      batch-norm backward passes): L2 < 15 %, cosine > 0.99; tensors whose gradient is mathematically zero (biases in
-        #      front of a batch norm) are compared on absolute size only.
-        gmax = float(d['grad_absmax'].max())
-        bad, worst = [], (0.0, None)
+        # ---- gradients (the 'fb' run above left them in eng.grads), per parameter tensor on the golden sample: relative L2 distance to
+        #      the bf16-simulating oracle's gradient and the ratio of the full norms.  The yardstick is the distance between the two
+        #      ORACLES (bf16-simulating vs pure fp32 forward, stored in the golden): 1 % near the loss, 0.6-0.9 from res3_0 down to
+        #      conv1 — the early layers' gradient of a randomly initialised 34-layer batch-norm ResNet is chaotic under bf16-level
+        #      forward differences (make_deep_golden.py).  Bar: the device is no farther from the bf16-simulating oracle than
+        #      max(15 %, the fp32 oracle's distance), and its norm is within 15 %; a structural error (missed residual contribution,
+        #      wrong mask / halo / K-split hand-off) shows as O(1) in the layers near the loss, where the bar is 15 %.
+        bad, table = [], []
         for i, name in enumerate(d['grad_names'].tolist()):
             g = eng.grad(name).reshape(-1)
             idx = torch.from_numpy(mdg.sample_index(name, g.numel())).to(g.device)
-            got, ref = g[idx].double().cpu().numpy(), d['grad_sample/' + name].astype(np.float64)
-            if float(d['grad_absmax'][i]) < 1e-5 * gmax:
-                if np.abs(got).max() > 1e-3 * gmax:
-                    bad.append((name, 'zero-gradient tensor', float(np.abs(got).max())))
+            got = g[idx].double().cpu().numpy()
+            ref, ref32 = d['grad_sample/' + name].astype(np.float64), d['grad32_sample/' + name].astype(np.float64)
+            e_ref = float(np.linalg.norm(ref32 - ref) / max(np.linalg.norm(ref), 1e-30))
+            nr = float(g.double().norm().cpu()) / max(float(d['grad_norm'][i]), 1e-30)
+            if e_ref > 0.95:          # the two oracles are uncorrelated here: a mathematically zero gradient (bias in front of a batch
+                if not nr < 4.0:      # norm), what is stored is summation noise — only its size is comparable
+                    bad.append((name, 'noise-only tensor', nr))
                 continue
             e2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
-            cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref)))
-            nr = float(g.double().norm().cpu()) / float(d['grad_norm'][i])
-            if e2 > worst[0]:
-                worst = (e2, name)
-            if not (e2 < 0.15 and cos > 0.99 and 0.9 < nr < 1.1):
-                bad.append((name, e2, cos, nr))
-        print('deep fixture gradients: %d tensors, worst relative L2 %.3f (%s)' % (len(d['grad_names']), worst[0], worst[1]))
+            table.append((name, e2, e_ref, nr))
+            if not (e2 < max(0.15, 1.05 * e_ref) and 0.85 < nr < 1.15):
+                bad.append((name, e2, e_ref, nr))
+        for name in ('logits/weights', 'logits/fw/weights', 'logits/stack0/fw/weights', 'conv5/weights', 'res4_2_b/weights', 'res4_0_a/weights',
+                     'res3_5_b/weights', 'res3_0_a/weights', 'res2_3_b/weights', 'res2_0_a/weights', 'res1_2_b/weights', 'res1_0_a/weights',
+                     'conv1/weights'):
+            row = [t for t in table if t[0] == name]
+            if row:
+                print('grad %-26s device-vs-oracle L2 %.3f   (fp32 oracle vs oracle %.3f)   norm ratio %.3f' % row[0])
+        print('deep fixture gradients: %d tensors compared' % len(table))
         assert not bad, bad[:8]
         assert eng.decode(x, sl, method='greedy') == odec.greedy_decode(logits, sl)
         assert eng.decode(x, sl, method='beam')[:4] == odec.reference_decode(logits[:, :4], sl[:4], beam_width=100)   # (pure-Python search: 4 samples)

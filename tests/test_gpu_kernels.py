@@ -284,7 +284,8 @@ def _conv_ref(x, w, b):   # x [N,W,H,C], w HWIO
 
 @pytest.mark.parametrize("Nb,W,H,Ci,Co", [(4, 16, 8, 64, 128), (2, 12, 4, 256, 512), (64, 64, 4, 256, 512), (3, 20, 16, 64, 128),
                                           (16, 32, 16, 64, 128), (64, 128, 8, 64, 256), (5, 52, 4, 128, 192), (32, 64, 4, 512, 512),
-                                          (7, 22, 8, 128, 256), (32, 64, 2, 512, 512), (3, 18, 2, 64, 128), (9, 64, 2, 128, 64)])
+                                          (7, 22, 8, 128, 256), (32, 64, 2, 512, 512), (3, 18, 2, 64, 128), (9, 64, 2, 128, 64),
+                                          (17, 62, 4, 128, 128), (9, 30, 16, 64, 256)])      # ragged last tiles of the 256- / 128-pixel kernels
 def test_conv3x3_fwd_dgrad_wgrad(dev, Nb, W, H, Ci, Co):
     x = bf(gen((Nb, W, H, Ci), 1)); w = bf(gen((3, 3, Ci, Co), 2, 0.05)); b = gen((Co,), 3)
     ref = _conv_ref(x, w, b)
@@ -327,6 +328,17 @@ def test_conv3x3_fwd_dgrad_wgrad(dev, Nb, W, H, Ci, Co):
     dw2 = torch.ones((3, 3, Ci, Co), dtype=torch.float32, device=dev)        # "+=" semantics like the atomics path
     ops.conv3x3_wgrad(x.to(dev).to(BF), dy.to(dev).to(BF), dw2, workspace=ws)
     assert relerr(dw2.cpu() - 1.0, wr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("env", [dict(OCR_CONV_K2='1', OCR_K2_FM='8'), dict(OCR_CONV_K2='1', OCR_K2_FM='4'), dict(OCR_CONV_K2='0')])
+def test_conv_kernel_generations_through_the_convolution_parity_tests(dev, env):
+    """conv_k2.hip (128 x 64 wave tiles, in-workgroup K split) with both tile heights forced onto every shape it covers, and the
+    conv_halo.hip kernels alone, through the same parity / fused-pool / accumulate tests (the knobs are read once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_kernels.py'), '-q', '-k', 'test_conv3x3'],
+                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=1200, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:]
 
 
 @pytest.mark.parametrize("Mk,I,J", [(4032, 512, 2048), (4032, 256, 1024), (4032, 512, 64), (100, 72, 136), (300, 128, 128), (1000, 256, 384)])
@@ -651,10 +663,10 @@ def test_lstm_fwd_bwd(dev, N, T, D, U, lens, persistent):
     assert relerr(dx.float().cpu().reshape(N, T, D), xr.grad) < 1e-2
 
 
-@pytest.mark.parametrize("env", [dict(OCR_LSTM_PROTO='0'), dict(OCR_LSTM_PROTO='2'), dict(OCR_LSTM_ROWS='8'), dict(OCR_LSTM_PROTO='2', OCR_LSTM_ROWS='8')])
+@pytest.mark.parametrize("env", [dict(OCR_LSTM_PROTO='0'), dict(OCR_LSTM_ROWS='32')])
 def test_lstm_persistent_other_protocols_and_tiles(dev, env):
-    """The persistent kernels' other hand-off protocols (0 = counters, the placement-independent fallback; 2 = data-as-flag through the
-    output tensor) and the 8-row batch tiles, through the same parity cases (the knobs are read once per process: own interpreter)."""
+    """The persistent kernels' counter protocol (0: the placement-independent fallback) and 32-row workgroups forced where 16 rows are
+    the default, through the same parity cases (the knobs are read once per process: own interpreter)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_kernels.py'), '-q', '-k', 'test_lstm_fwd_bwd and True'],

@@ -1,5 +1,5 @@
 """Persistent BiLSTM recurrence timings (forward / backward, one launch each) with the phase stamps of workgroup 0.
-    python tools/lstm_bench.py [--nb 64 --u 256 --t 63]      env: OCR_LSTM_PROTO (0 / 2 / 4), OCR_LSTM_ROWS (8 / 16 / 32 / 64)
+    python tools/lstm_bench.py [--nb 64 --u 256 --t 63]      env: OCR_LSTM_PROTO (0 / 4), OCR_LSTM_ROWS (16 / 32 / 64)
 One JSON line: us per launch, us per recurrent step, median phase times."""
 import argparse
 import json
