@@ -183,12 +183,28 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    # OCR_DIST_BACKEND=gloo is for the test-suite only (tests/test_gpu_bench_two_ranks.py: two ranks of this script sharing the one GPU
+    # of a test box, gradients staged through the host by lstm_ctc_ocr_amd.dist); the driver's runs use RCCL ("nccl")
+    backend = os.environ.get("OCR_DIST_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+
+    def reduce_(t, op):                 # small host-visible reductions of the line's own bookkeeping
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+            return t
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        return h.to(t.device)
 
     from lstm_ctc_ocr_amd.config import cfg
     from lstm_ctc_ocr_amd.engine import Engine
@@ -223,20 +239,16 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(reduce_(torch.tensor([dt], dtype=torch.float64, device=device), dist.ReduceOp.MAX).item())
     loss = eng.last_loss()
     dp_check = None
     if world > 1:
         # data-parallel self-check on the hardware the line was measured on: every rank applied the same all-reduced gradient, so
         # the replicas' parameters must be bit-identical; their data streams are rank-seeded, so their local losses must differ
         chk = torch.stack([eng.params.double().sum(), eng.params.double().abs().sum()])
-        lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        lo, hi = reduce_(chk.clone(), dist.ReduceOp.MIN), reduce_(chk.clone(), dist.ReduceOp.MAX)
         ls = torch.tensor([loss], dtype=torch.float64, device=device)
-        llo, lhi = ls.clone(), ls.clone()
-        dist.all_reduce(llo, op=dist.ReduceOp.MIN); dist.all_reduce(lhi, op=dist.ReduceOp.MAX)
+        llo, lhi = reduce_(ls.clone(), dist.ReduceOp.MIN), reduce_(ls.clone(), dist.ReduceOp.MAX)
         dp_check = {"replicas_bit_identical": bool(torch.equal(lo, hi)), "local_loss_min": float(llo.item()), "local_loss_max": float(lhi.item())}
     # the same loop the way lib/lstm/train.py:130,139 runs it — the loss is fetched (one host sync) after EVERY step; reported
     # beside `value`, never as `value`

@@ -36,6 +36,11 @@ def save(engine, path):
     tmp = path + '.tmp.npz'
     np.savez(tmp, **arrays)
     os.replace(tmp, path)
+    return register(path)
+
+
+def register(path):
+    """Append a snapshot to its directory's `checkpoint` index (newest last) and apply the Saver's retention."""
     out_dir = os.path.dirname(path)
     idx = _index_path(out_dir)
     kept = []

@@ -532,14 +532,22 @@ class _BatchNormOp(_Op):
 
 
 class _DropoutOp(_Op):
-    """Network.dropout = tf.nn.dropout(x, keep_prob) (network.py:626-628).  keep_prob is the value the driver feeds: 0.5 in
-    training steps (train.py:126), 1.0 otherwise (train.py:156, test.py:75) — Engine.train_keep_prob / inference = 1."""
+    """Network.dropout = tf.nn.dropout(x, keep_prob) (network.py:626-628).  keep_prob is the layer's own argument: the network's
+    keep_prob input slot (what the shipped graphs pass) takes the value the driver feeds — 0.5 in training steps (train.py:126), 1.0
+    otherwise (train.py:156, test.py:75): Engine.train_keep_prob / inference = 1 — and a NUMBER written in the graph is a constant of
+    the graph, applied in training and inference alike, as tf.nn.dropout does with a Python float (it used to be ignored).
+    The mask is a hash of (layer name, rank, completed optimiser steps, element index): data-parallel ranks draw different masks."""
 
     def __init__(self, eng, node, prev):
         super(_DropoutOp, self).__init__(eng, node, prev)
         self.mask_in_consumer = False
         import zlib
-        self.seed = zlib.crc32(self.name.encode()) ^ 0x5bd1e995
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank(eng.group)
+        self.seed = (zlib.crc32(self.name.encode()) ^ 0x5bd1e995 ^ (rank * 0x9E3779B1)) & 0xffffffff
+        kp = node.attrs.get('keep_prob')
+        self.const_keep_prob = float(kp) if isinstance(kp, (int, float)) and not isinstance(kp, bool) else None
 
     def dy_needed(self):
         return True
@@ -554,6 +562,8 @@ class _DropoutOp(_Op):
         sp.buf[self.key + '/dx'] = torch.empty(s, dtype=BF16, device=self.eng.device)
 
     def _kp(self):
+        if self.const_keep_prob is not None:
+            return self.const_keep_prob
         return float(self.eng.train_keep_prob) if self.eng.training else 1.0
 
     def fwd(self, sp):
@@ -890,7 +900,9 @@ class Engine(object):
         self.plans = {}
         self.training = False                            # set by the run bodies: dropout keeps everything outside training steps
         self.train_keep_prob = 0.5                       # what the reference feeds in training steps (train.py:126)
-        self._zero_step = torch.zeros(1, dtype=torch.float64, device=self.device)
+        # optimiser scalars live from the start (all zero until setup_optimizer): graphs captured before the optimiser exists read the
+        # step counter — the dropout masks' salt — through the same pointer afterwards (they kept a dummy zero for ever)
+        self.scalars = torch.zeros(ops.optim_scalar_count(), dtype=torch.float64, device=self.device)
         self.opt_ready = False
         self.graph_opt = None
         self.iteration = 0
@@ -1159,7 +1171,7 @@ class Engine(object):
     # ------------------------------------------------------------------ forward / backward bodies (capturable)
     def step_counter(self):
         """Device double counting the completed optimiser steps (scalars[6]) — the per-step salt of the dropout masks."""
-        return self.scalars[6:7] if self.opt_ready else self._zero_step
+        return self.scalars[6:7]
 
     def _forward(self, sp, training=False):
         self.training = training
@@ -1331,7 +1343,7 @@ class Engine(object):
         # (tf.train.RMSPropOptimizer: the first steps are ~ lr * g / sqrt(0.9 + 0.1 g^2), not lr * sign(g) / sqrt(0.1))
         self.state1 = torch.ones_like(self.params) if self.solver == 2 else torch.zeros_like(self.params)
         self.state2 = torch.zeros_like(self.params) if self.solver == 0 else None
-        self.scalars = torch.zeros(ops.optim_scalar_count(), dtype=torch.float64, device=self.device)
+        self.scalars.zero_()                             # in place: captured graphs keep pointing at it
         ops.optim_init(self.scalars, self.lr)
         self.opt_ready = True
         self.graph_opt = None                            # captured optimiser graphs hold the old slot tensors
@@ -1378,8 +1390,8 @@ class Engine(object):
         """One optimisation step on a batch laid out as gen.py:41-67 produces it.  Returns the total loss
         (mean CTC cost of the local batch + L2 term) as a Python float when fetch_loss, else None.
         Data-parallel schedule: graph 1 (forward, CTC, backward of the late layers) -> the late gradients (one contiguous
-        range, ~87 % of the bytes for the CRNN) are all-reduced on a side stream WHILE graph 2 (backward of the early layers) runs -> the early
-        gradients are all-reduced -> join -> graph 3 (clip + optimiser + re-pack)."""
+        range, ~87 % of the bytes for the CRNN) are all-reduced on the communication stream WHILE graph 2 (backward of the early layers)
+        runs -> the early gradients are all-reduced on the same stream -> join -> graph 3 (clip + optimiser + re-pack)."""
         sp = self.plan(data.shape[0], data.shape[1])
         self._bind(sp, data, seq_len, labels, labels_len)
         if (self.world > 1 or self.force_allreduce) and self.overlap_allreduce and self.split_op > 0:
@@ -1389,7 +1401,11 @@ class Engine(object):
             with torch.cuda.stream(self.comm_stream):
                 self.allreduce_grads(self.late_begin, self.n_total)
             rest()                                       # backward of the early layers, concurrent with the exchange above
-            self.allreduce_grads(0, self.late_begin)
+            # the early bucket goes out on the SAME stream as the late one: both collectives of a step are issued from one ordering
+            # domain, in the same order on every rank (two streams relied on ProcessGroupNCCL's internal ordering)
+            self.comm_stream.wait_stream(main)
+            with torch.cuda.stream(self.comm_stream):
+                self.allreduce_grads(0, self.late_begin)
             main.wait_stream(self.comm_stream)
             self.optimizer_step()
         elif self.world == 1 and not self.force_allreduce and self.use_graphs:

@@ -132,11 +132,15 @@ def _snappy_decompress(buf):
 
 
 # ------------------------------------------------------------------------------------------------ table reader
+ALLOW_UNCHECKED_BLOCKS = False
+
+
 def _read_block(data, offset, size):
     raw = data[offset:offset + size]
     ctype = data[offset + size]                         # trailer: type byte + 4 bytes of masked crc32c over contents + type byte
     stored = struct.unpack_from('<I', data, offset + size + 1)[0]
-    if stored != 0 and stored != masked_crc(data[offset:offset + size + 1]):      # (0: written without checksums)
+    # TensorFlow always writes block checksums: a zero trailer is corruption too (ALLOW_UNCHECKED_BLOCKS is for hand-built test tables)
+    if not (ALLOW_UNCHECKED_BLOCKS and stored == 0) and stored != masked_crc(data[offset:offset + size + 1]):
         raise ValueError('table block at %d: checksum mismatch — not a table file, or a misread handle' % offset)
     if ctype == 1:
         raw = _snappy_decompress(raw)
@@ -313,11 +317,16 @@ def normalise_name(name):
     return name
 
 
-def convert(prefix, out_path, wanted=None, iteration=None, verify=False):
+def convert(prefix, out_path, wanted=None, iteration=None, verify=False, output_dir=None):
     """TensorFlow checkpoint `prefix` -> `.npz` snapshot for checkpoint.restore().  `wanted` = the engine's variable names (Engine.specs);
     variables are matched by exact name, then by name with the RNN helper scopes removed.  Adam slots (`<var>/Adam`, `<var>/Adam_1`,
     `beta1_power`, `beta2_power`) become slot1 / slot2 / optimiser scalars; batch-norm moving averages are dropped (the reference never
-    uses them: network.py:176-178 runs batch norm with is_training=True everywhere).  Returns (matched, unmatched TF names)."""
+    uses them: network.py:176-178 runs batch norm with is_training=True everywhere).  Returns (matched, unmatched TF names).
+    The reference creates its learning-rate and step variables UNNAMED (`lr = tf.Variable(...)`, `global_step = tf.Variable(0, ...)`:
+    lib/lstm/train.py:73,78), so a checkpoint it wrote holds them as `Variable` (float scalar, the possibly decayed learning rate) and
+    `Variable_1` (integer scalar, the step count); `global_step` is accepted too.
+    output_dir: write the snapshot as `<output_dir>/<basename>_iter_<n>.ckpt` instead of `out_path` and register it in that
+    directory's `checkpoint` index, so that test_net / train_net --restore find it (checkpoint.latest_checkpoint)."""
     tf_vars = read_bundle(prefix, verify=verify)
     by_norm = {}
     for k in tf_vars:
@@ -338,15 +347,23 @@ def convert(prefix, out_path, wanted=None, iteration=None, verify=False):
         # Adam's step count: the reference's global_step variable (train.py:71,85) if it was saved; else from the float32 powers —
         # beta2^t first (0.9^t underflows float32 after ~830 steps, 0.999^t after ~87 000).  The device keeps the powers in double.
         b1t, b2t = float(np.asarray(tf_vars['beta1_power']).reshape(-1)[0]), float(np.asarray(tf_vars['beta2_power']).reshape(-1)[0])
-        if 'global_step' in tf_vars:
-            step = int(np.asarray(tf_vars['global_step']).reshape(-1)[0])
-            used.add('global_step')
+        step_var = next((k for k in ('global_step', 'Variable_1') if k in tf_vars and np.asarray(tf_vars[k]).size == 1
+                         and np.issubdtype(np.asarray(tf_vars[k]).dtype, np.integer)), None)
+        if step_var is not None:
+            step = int(np.asarray(tf_vars[step_var]).reshape(-1)[0])
+            used.add(step_var)
+        elif re.search(r'_iter_(\d+)', os.path.basename(prefix)):        # the Saver's file name carries the iteration (train.py:27-36)
+            step = max(0, int(re.search(r'_iter_(\d+)', os.path.basename(prefix)).group(1)) - 1)
         elif 0 < b2t < 1:
             step = int(round(np.log(b2t) / np.log(0.999)))
         else:
             step = int(round(np.log(b1t) / np.log(0.9))) if 0 < b1t < 1 else 0
         sc = np.zeros(8, np.float64)                    # csrc/optim.hip: [2] lr (set by the driver), [4] beta1^t, [5] beta2^t, [6] step
         sc[4], sc[5], sc[6] = 0.9 ** step, 0.999 ** step, step
+        lr_var = tf_vars.get('Variable')                # the reference's unnamed learning-rate variable: restored like the reference does
+        if lr_var is not None and np.asarray(lr_var).size == 1 and np.issubdtype(np.asarray(lr_var).dtype, np.floating):
+            sc[2] = float(np.asarray(lr_var).reshape(-1)[0])
+            used.add('Variable')
         arrays['opt/scalars'] = sc
         arrays['opt/solver'] = np.int64(0)
         used.update(('beta1_power', 'beta2_power'))
@@ -354,9 +371,16 @@ def convert(prefix, out_path, wanted=None, iteration=None, verify=False):
         m = re.search(r'_iter_(\d+)', os.path.basename(prefix))
         iteration = int(m.group(1)) if m else 0
     arrays['meta/iteration'] = np.int64(iteration)
+    if output_dir is not None:
+        base = re.sub(r'(_iter_\d+)?(\.ckpt)?$', '', os.path.basename(prefix)) or 'converted'
+        os.makedirs(output_dir, exist_ok=True)
+        out_path = os.path.join(output_dir, '%s_iter_%d.ckpt' % (base, iteration))
     tmp = out_path + '.tmp.npz'
     np.savez(tmp, **arrays)
     os.replace(tmp, out_path)
+    if output_dir is not None:
+        from .checkpoint import register
+        register(out_path)
     matched = sorted(k[4:] for k in arrays if k.startswith('var/'))
     return matched, sorted(k for k in tf_vars if k not in used and not re.search(r'moving_(mean|variance)$', k))
 
@@ -368,13 +392,15 @@ def main(argv=None):
     ap.add_argument('out', nargs='?', help='snapshot to write (default: only list the variables)')
     ap.add_argument('--network', default='LSTM_train', help='match against this network\'s variable names')
     ap.add_argument('--verify', action='store_true', help='check every tensor\'s stored crc32c (pure Python, ~1 s per MB)')
+    ap.add_argument('--output-dir', default=None, help='write <output-dir>/<name>_iter_<n>.ckpt and register it in that directory\'s '
+                                                       '`checkpoint` index, so that test_net / train_net --restore load it')
     args = ap.parse_args(argv)
     for name, dt, shape in list_bundle(args.prefix):
         print('%-60s %-10s %s' % (name, getattr(dt, '__name__', dt), shape))
-    if args.out:
+    if args.out or args.output_dir:
         from .models import get_network
         wanted = list(get_network(args.network).param_specs)
-        matched, rest = convert(args.prefix, args.out, wanted, verify=args.verify)
+        matched, rest = convert(args.prefix, args.out, wanted, verify=args.verify, output_dir=args.output_dir)
         print('matched %d of %d variables of %s; unmatched in the network: %s; unused in the checkpoint: %s'
               % (len(matched), len(wanted), args.network, sorted(set(wanted) - set(matched)), rest))
 

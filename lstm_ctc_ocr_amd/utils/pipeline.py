@@ -109,6 +109,10 @@ def _worker(index, seed, layout, buf, free_q, ready_q, halt, gen_kwargs, once=Fa
             ready_q.put(slot)
     except KeyboardInterrupt:
         pass
+    except BaseException as e:                          # a batch that does not fit its slot, a PIL error, ...: tell the consumer
+        import traceback                                # instead of dying silently (the ring would then starve and the training
+        ready_q.put(('error', 'generator worker %d: %r\n%s' % (index, e, traceback.format_exc())))     # loop hang — ADVICE r2)
+        raise
 
 
 class SharedBatchRing(object):
@@ -148,9 +152,27 @@ class SharedBatchRing(object):
                 self._order = list(range(self.pool))
                 self._rng.shuffle(self._order)
             return self._order.pop()
-        i = self.ready_q.get(timeout=timeout)
+        try:
+            i = self.ready_q.get(timeout=timeout)
+        except queue.Empty:
+            self._check_workers()
+            raise
+        if isinstance(i, tuple):                        # ('error', text) from a worker
+            raise RuntimeError(i[1])
         self._seen += 1
         return i
+
+    def _check_workers(self):
+        """Called when no batch arrived in time: a worker that was killed (out of memory, a signal) cannot report itself."""
+        codes = [p.exitcode for p in self.procs]
+        dead = [(k, c) for k, c in enumerate(codes) if c not in (None, 0)]
+        if dead:
+            raise RuntimeError('generator worker(s) died: %s' % ', '.join('#%d exit code %s' % kc for kc in dead))
+        if self.procs and all(c is not None for c in codes) and self.ready_q.empty():
+            if self.pool and self._seen < self.pool:
+                raise RuntimeError('generator workers finished after %d of %d pool batches' % (self._seen, self.pool))
+            if not self.pool:
+                raise RuntimeError('all generator workers have exited')
 
     def release(self, i):
         if not self.pool:

@@ -81,8 +81,10 @@ def forward(net, params, x, seq_len, sim_bf16=False, keep=False, keep_prob=1.0, 
             out = h.reshape(h.shape[0], h.shape[1] * h.shape[2], h.shape[3])
         elif nd.op == 'dropout':
             h = ev(nd.inputs[0])
-            kp = float(np.float32(keep_prob))
-            out = og.qa(h * dropout_mask(tuple(h.shape), nd.name, step, keep_prob) * float(np.float32(1.0) / np.float32(kp)), sim)
+            own = nd.attrs.get('keep_prob')                   # a number in the graph is a constant of the graph (tf.nn.dropout(x, 0.8));
+            kp_in = float(own) if isinstance(own, (int, float)) and not isinstance(own, bool) else keep_prob     # else: what the driver feeds
+            kp = float(np.float32(kp_in))
+            out = og.qa(h * dropout_mask(tuple(h.shape), nd.name, step, kp_in) * float(np.float32(1.0) / np.float32(kp)), sim)
         elif nd.op == 'batch_norm':
             h = ev(nd.inputs[0])
             if nd.attrs['is_training']:

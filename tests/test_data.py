@@ -1,5 +1,6 @@
 """Input-layout contract of gen.py:41-67 (what the kernels receive) and the prefetcher."""
 import numpy as np
+import pytest
 
 from lstm_ctc_ocr_amd.config import cfg
 from lstm_ctc_ocr_amd.utils import gen
@@ -145,3 +146,32 @@ def test_width_bucketing_is_opt_in(monkeypatch):
     batch2, _, _, steps2 = gen.groupBatch([i.copy() for i in imgs], labels)
     assert batch2[0].shape[0] == 192 and steps2 == steps
     assert np.array_equal(batch2[2][:180], batch[2]) and float(np.abs(batch2[2][180:]).max()) == 0.0
+
+
+def test_a_dead_generator_worker_is_reported_not_waited_for():
+    """a worker that raises (here: a batch wider than its slot) or is killed used to leave the consumer polling an empty queue
+    forever.  The exception text travels through the ready queue; a killed worker is noticed by its exit code."""
+    import os
+    import queue
+    import signal
+    import time
+    from lstm_ctc_ocr_amd.utils.pipeline import SharedBatchRing
+    ring = SharedBatchRing(batch_size=4, workers=1, slots=2, seed=3, max_w=16)          # stock captchas are 88 columns wide
+    try:
+        with pytest.raises(RuntimeError, match='does not fit its slot'):
+            ring.get(timeout=120)
+    finally:
+        ring.close()
+    ring = SharedBatchRing(batch_size=4, workers=1, slots=1, seed=3)
+    try:
+        ring.get(timeout=120)                           # the only slot is out: the worker now waits for a free one
+        os.kill(ring.procs[0].pid, signal.SIGKILL)
+        t0 = time.time()
+        with pytest.raises(RuntimeError, match='died'):
+            while time.time() - t0 < 30:
+                try:
+                    ring.get(timeout=0.5)
+                except queue.Empty:
+                    continue
+    finally:
+        ring.close()

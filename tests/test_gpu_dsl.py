@@ -120,6 +120,34 @@ class UniLstmNet(WideDslNet):
         self.feed('rs', 'time_step_len').lstm(64, 2, name='logits')
 
 
+def test_dropout_with_a_constant_keep_prob_in_the_graph(dev):
+    """`.dropout(0.8, ...)` — a Python number instead of the keep_prob input slot — is a constant of the graph (tf.nn.dropout
+    applies it in every run); the engine used to ignore it.  Inference forward == the oracle with the same constant, and != keep-all."""
+    class ConstDrop(WideDslNet):
+        def setup(self):
+            self.keep_prob = 0.8
+            WideDslNet.setup(self)
+    old = cfg.TRAIN.WEIGHT_DECAY
+    cfg.TRAIN.WEIGHT_DECAY = 0.0
+    try:
+        net = ConstDrop()
+        eng = Engine(net, device='cuda:0', seed=7)
+        drop = [op for op in eng.ops if op.name == 'drop'][0]
+        assert drop.const_keep_prob == 0.8
+        params = {k: torch.from_numpy(v) for k, v in eng.state_arrays().items()}
+        rng = np.random.RandomState(3)
+        N, W = 8, 64
+        x = rng.rand(N, W, 32).astype(np.float32)
+        sl = np.full(N, W // 2 - 1, np.int32)
+        logits = eng.forward(x, sl).float().cpu()
+        ref = plan_exec.forward(net, params, torch.from_numpy(x), sl.tolist(), sim_bf16=True, keep_prob=1.0)       # the layer's own 0.8 wins
+        keep_all = plan_exec.forward(WideDslNet(), params, torch.from_numpy(x), sl.tolist(), sim_bf16=True, keep_prob=1.0)
+        assert float((logits - ref).abs().max()) < 1e-2
+        assert float((logits - keep_all).abs().max()) > 5 * float((logits - ref).abs().max())
+    finally:
+        cfg.TRAIN.WEIGHT_DECAY = old
+
+
 def test_unidirectional_stacked_lstm_matches_oracle(dev):
     old = cfg.TRAIN.WEIGHT_DECAY
     cfg.TRAIN.WEIGHT_DECAY = 0.0

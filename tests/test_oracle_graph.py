@@ -1,5 +1,7 @@
 """Pins the layer-level oracle (oracle/graph.py) on independent implementations: a re-packed torch.nn.LSTM for the
 TF-1.0 LSTMCell restatement, plain numpy loops for conv / pool / batch-norm, and TF's documented sequence-length rules."""
+import math
+
 import numpy as np
 import torch
 
@@ -157,3 +159,68 @@ def test_full_graph_shapes_loss_and_optimizer_formulas():
     st = {}
     new = og.adam_step({'a': torch.zeros(2)}, clipped, st, lr=0.1)
     assert torch.allclose(new['a'], torch.tensor([-0.1, -0.1]), atol=1e-6)   # first Adam step = -lr * sign(g)
+
+
+def test_batch_norm_train_against_torchs_own_batch_norm():
+    """The oracle's restatement of tf.contrib.layers.batch_norm(is_training=True, epsilon=1e-3, biased variance over N, W, H — network.py:176-178)
+    pinned on an INDEPENDENT implementation: torch.nn.functional.batch_norm(training=True, eps=1e-3) after the NHWC -> NCHW permute,
+    forward and all three gradients; including the reference's quirk Q2: batch-norm stays in training mode at inference,
+    so a batch of ONE image normalises with that image's own statistics, and zero-padded columns are part of the statistics."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    for shape, pad_from in (((6, 9, 4, 16), None), ((1, 12, 4, 8), None), ((3, 10, 2, 8), 6)):
+        z = torch.randn(shape, generator=g, dtype=torch.float64) * 1.7 + 0.3
+        if pad_from is not None:
+            z[:, pad_from:] = 0.25                       # what a padded column holds after conv + bias of an all-zero input: a constant
+        gamma = torch.rand(shape[3], generator=g, dtype=torch.float64) + 0.5
+        beta = torch.randn(shape[3], generator=g, dtype=torch.float64)
+        dy = torch.randn(shape, generator=g, dtype=torch.float64)
+        za, ga, ba = (t.clone().requires_grad_(True) for t in (z, gamma, beta))
+        ya = og.batch_norm_train(za, ga, ba)
+        ya.backward(dy)
+        zb, gb, bb = (t.clone().requires_grad_(True) for t in (z, gamma, beta))
+        yb = F.batch_norm(zb.permute(0, 3, 1, 2), None, None, gb, bb, training=True, momentum=0.0, eps=1e-3).permute(0, 2, 3, 1)
+        yb.backward(dy)
+        assert float((ya - yb).abs().max()) < 1e-12
+        for a, b in ((za.grad, zb.grad), (ga.grad, gb.grad), (ba.grad, bb.grad)):
+            assert float((a - b).abs().max()) < 1e-10 * max(1.0, float(b.abs().max()))
+        # the statistics really include the padded columns: normalising the unpadded part alone gives something else
+        if pad_from is not None:
+            alone = og.batch_norm_train(z[:, :pad_from], gamma, beta)
+            assert float((alone - ya.detach()[:, :pad_from]).abs().max()) > 1e-2
+    # epsilon is 1e-3 (contrib default), not torch's 1e-5: a low-variance channel tells them apart
+    z = torch.zeros(2, 3, 1, 1, dtype=torch.float64); z[0, 0, 0, 0] = 0.02
+    y = og.batch_norm_train(z, torch.ones(1, dtype=torch.float64), torch.zeros(1, dtype=torch.float64))
+    var = float(z.var(unbiased=False))
+    assert abs(float(y[0, 0, 0, 0]) - (0.02 - 0.02 / 6) / math.sqrt(var + 1e-3)) < 1e-12
+
+
+def test_adam_on_a_hand_derived_three_step_trajectory():
+    """TF-1.0 AdamOptimizer (train.py:74): m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; lr_t = lr sqrt(1 - b2^t) / (1 - b1^t);
+    w -= lr_t m / (sqrt(v) + eps) — epsilon OUTSIDE the bias correction ("epsilon hat" of the paper's section 2), unlike torch.optim.Adam.
+    Three steps of a scalar with constant gradient g = 2 and of one with gradients 1, -1, 3, worked out by hand in exact fractions:
+    constant g: m_t = g (1 - b1^t), v_t = g^2 (1 - b2^t)  =>  step = lr_t m_t / (sqrt(v_t) + eps) = lr g (.) / (|g| + eps / sqrt(1 - b2^t))."""
+    from fractions import Fraction as Fr
+    b1, b2, lr, eps = Fr(9, 10), Fr(999, 1000), Fr(1, 100), 1e-8
+    # (a) constant gradient: closed form
+    w, st = {'a': torch.tensor([1.0], dtype=torch.float64)}, {}
+    want = 1.0
+    for t in (1, 2, 3):
+        w = og.adam_step(w, {'a': torch.tensor([2.0], dtype=torch.float64)}, st, lr=float(lr))
+        want -= float(lr) * 2.0 / (2.0 + eps / math.sqrt(1.0 - float(b2) ** t))
+        assert abs(float(w['a']) - want) < 1e-13, t
+    # (b) gradients 1, -1, 3: moments as exact fractions
+    m = v = Fr(0)
+    w, st, want = {'a': torch.tensor([0.0], dtype=torch.float64)}, {}, 0.0
+    for t, g in enumerate((1, -1, 3), 1):
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        lr_t = float(lr) * math.sqrt(1.0 - float(b2 ** t)) / (1.0 - float(b1 ** t))
+        want -= lr_t * float(m) / (math.sqrt(float(v)) + eps)
+        w = og.adam_step(w, {'a': torch.tensor([float(g)], dtype=torch.float64)}, st, lr=float(lr))
+        assert abs(float(w['a']) - want) < 1e-13, t
+    assert m == Fr(1, 10) * 3 + Fr(9, 10) * (Fr(-1, 10) + Fr(9, 100)) and abs(want + 0.01 - 0.0 + 0.00329) < 5e-3       # sanity of the hand values
+    # the unit test TensorFlow itself ships (adam_test.py::testBasic: numpy reference with the same lr_t form, epsilon outside) moves
+    # var0 = [1, 2] with grads [0.1, 0.1], lr 0.001 by exactly lr * sign on the first step up to eps: 1 - 0.001 * (0.1 / (0.1 + eps'))
+    w = og.adam_step({'v': torch.tensor([1.0, 2.0], dtype=torch.float64)}, {'v': torch.tensor([0.1, 0.1], dtype=torch.float64)}, {}, lr=0.001)
+    assert torch.allclose(w['v'], torch.tensor([0.999, 1.999], dtype=torch.float64), atol=1e-9)

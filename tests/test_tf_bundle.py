@@ -4,6 +4,8 @@ package's .npz snapshots (variable-name normalisation, Adam slots, step counters
 format itself stays unpinned (see the module docstring)."""
 import struct
 
+import os
+
 import numpy as np
 import pytest
 
@@ -85,8 +87,11 @@ def test_snappy_block_decoder():
         tb._snappy_decompress(tb._put_varint(9) + bytes([(4 - 1) << 2]) + b'0123')          # length mismatch
 
 
-def test_compressed_blocks_are_read(tmp_path):
-    """An index whose data block is stored snappy-compressed (type byte 1): literal-only stream of the same block bytes."""
+def test_compressed_blocks_are_read(tmp_path, monkeypatch):
+    """An index whose data block is stored snappy-compressed (type byte 1): literal-only stream of the same block bytes.  The
+    hand-built table carries zero trailers: only the explicit test switch lets the reader accept them — on a real file a zeroed
+    trailer is corruption."""
+    monkeypatch.setattr(tb, 'ALLOW_UNCHECKED_BLOCKS', True)
     arrays = {'a/weights': np.arange(12, dtype=np.float32).reshape(3, 4)}
     prefix = str(tmp_path / 'c.ckpt')
     tb.write_bundle(prefix, arrays, per_block=100)
@@ -112,6 +117,9 @@ def test_compressed_blocks_are_read(tmp_path):
     open(prefix + '.index', 'wb').write(bytes(out) + foot)
     got = tb.read_bundle(prefix)
     assert np.array_equal(got['a/weights'], arrays['a/weights'])
+    monkeypatch.setattr(tb, 'ALLOW_UNCHECKED_BLOCKS', False)
+    with pytest.raises(ValueError):
+        tb.read_bundle(prefix)
 
 
 def test_conversion_to_a_snapshot(tmp_path):
@@ -130,12 +138,31 @@ def test_conversion_to_a_snapshot(tmp_path):
     assert np.array_equal(snap['slot2/logits/fw/weights'], arrays['logits/bidirectional_rnn/fw/lstm_cell/weights/Adam_1'])
     sc = snap['opt/scalars']
     assert sc[6] == 1234 and sc[4] == 0.9 ** 1234 and sc[5] == 0.999 ** 1234 and int(snap['meta/iteration']) == 2000
-    # without global_step the count comes from beta2^t (beta1^t = 0.9^1234 is 0 in float32)
+    # without a step variable the count comes from the Saver's file name (`_iter_2000` = 1999 completed steps: the reference's loop
+    # starts at 1 and names a snapshot iter + 1, train.py:27-36,111), and only then from beta2^t (beta1^t = 0.9^1234 is 0 in float32)
     del arrays['global_step']
     tb.write_bundle(prefix, arrays)
     tb.convert(prefix, out, wanted)
+    assert np.load(out)['opt/scalars'][6] == 1999
+    plain = str(tmp_path / 'weights_only_name.ckpt')
+    tb.write_bundle(plain, arrays)
+    tb.convert(plain, out, wanted)
     assert np.load(out)['opt/scalars'][6] == 1234
     assert tb.normalise_name('logits/bidirectional_rnn/bw/lstm_cell/biases') == 'logits/bw/biases'
+    # what the REFERENCE writes: its learning-rate and step variables are unnamed (train.py:73,78) -> `Variable` (float) / `Variable_1` (int);
+    # the decayed learning rate is restored like the reference restores it, the step comes from the integer, not from float32 beta powers
+    arrays['Variable'], arrays['Variable_1'] = np.float32(1e-5), np.int32(54321)
+    arrays['beta2_power'] = np.float32(0.0)                                      # denormal / flushed after ~87k steps: must not be used
+    tb.write_bundle(prefix, arrays)
+    matched, rest = tb.convert(prefix, out, wanted)
+    sc = np.load(out)['opt/scalars']
+    assert sc[6] == 54321 and abs(sc[2] - 1e-5) < 1e-12 and 'Variable' not in rest and 'Variable_1' not in rest
+    # --output-dir: written under the Saver's naming and registered in the directory's `checkpoint` index -> latest_checkpoint finds it
+    from lstm_ctc_ocr_amd import checkpoint
+    outdir = str(tmp_path / 'out')
+    tb.convert(prefix, None, wanted, output_dir=outdir)
+    latest = checkpoint.latest_checkpoint(outdir)
+    assert latest is not None and os.path.basename(latest) == 'LSTM_ctc_iter_2000.ckpt' and int(np.load(latest)['meta/iteration']) == 2000
 
 
 @pytest.mark.gpu

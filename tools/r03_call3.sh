@@ -17,3 +17,4 @@ done
 cat $O/r03c_conv.log
 OCR_CONV_K2=1 timeout 60 python tools/k2_stamps.py > $O/r03c_k2_stamps.log 2>&1; cat $O/r03c_k2_stamps.log | tail -20
 OCR_GEMM_ENGINE=4 timeout 60 python tools/pp_stamps.py > $O/r03c_pp_stamps.log 2>&1; cat $O/r03c_pp_stamps.log | tail -12
+( timeout 300 python -m pytest tests/test_golden.py tests/test_gpu_kernels.py -m gpu -q -k "deep_fixture or lstm" -s 2>&1 | grep -E "grad |deep fixture|passed|failed|Error" | tail -30 ) > $O/r03c_deep_lstm.log; cat $O/r03c_deep_lstm.log
