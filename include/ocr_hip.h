@@ -228,7 +228,6 @@ int ocr_optim_step(float* params, float* grads, float* state1, float* state2, lo
 
 /* diagnostics: s_memtime stamps of workgroup 0 (NULL = off); device int64 [8 waves][64 steps][8] / [8][80][8] */
 int ocr_wgrad9_debug(void* dbg);
-int ocr_conv_pp_debug(void* dbg);
 
 /* ---- device probes used by the test-suite (not part of the hot path) ------------------------------------------ */
 /* ds_read_b64_tr_b16 lane-semantics probe: LDS holds shorts 0..8191 (value = element index); lane l reads at

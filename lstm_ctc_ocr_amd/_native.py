@@ -9,7 +9,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libocrhip.so")
+# OCR_NATIVE_LIB: load another build of the same library — the `make EXPERIMENTS=1` flavour with the rejected variants, for the A/B tools
+LIB_PATH = os.environ.get("OCR_NATIVE_LIB") or os.path.join(_HERE, "libocrhip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ocr_hip.h")
 
 EPI_BIAS, EPI_RELU, EPI_OUT_F32, EPI_MASK, EPI_ROWSWAP, EPI_ACCUM = 1, 2, 4, 16, 32, 64
@@ -86,7 +87,6 @@ _SIGS = {
     "ocr_optim_set_lr": ([_P, _D, _I, _P], _I),
     "ocr_optim_step": ([_P, _P, _P, _P, _L, _L, _L, _F, _F, _I, _F, _F, _F, _P, _P], _I),
     "ocr_wgrad9_debug": ([_P], _I),
-    "ocr_conv_pp_debug": ([_P], _I),
     "ocr_conv_k2_debug": ([_P], _I),
     "ocr_probe_tr16": ([_P, _P, _P], _I),
     "ocr_set_lstm_proto": ([_I], _I),

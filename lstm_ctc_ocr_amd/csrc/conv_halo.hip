@@ -287,242 +287,8 @@ void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 8 * NW */
     if (clk && blockIdx.x == 0 && tid == 0) { clk[2] = (long long)__builtin_amdgcn_s_memtime(); clk[3] = (long long)wall_clock64(); }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// EXPERIMENTAL variant on v_mfma_f32_32x32x16_bf16 (OCR_HALO_MFMA32=1; written without a GPU at the end of round 2 — its index
-// arithmetic is replayed lane by lane by tools/halo_m32_model.py / tests/test_halo_m32_model.py, its numerics are NOT yet checked on
-// hardware; the GPU parity tests for it run only with OCR_TEST_EXPERIMENTAL=1).  Why try it: the 16x16x32 form issues at ~17 clocks per
-// 16 Ki flop against 32 clocks per 32 Ki flop for the 32x32x16 form (MI355X_MICROARCH.md, per-instruction constants), half as many
-// MFMA issues per K step, the same LDS bytes per flop (64 x 64 wave tiles either way).  Same tiling, pipeline, DMA geometry and
-// epilogue contract as conv_halo_kernel; what differs:
-//   * fragments are 32 rows x 16 k: lane l reads row (l & 31), 16-byte position (kq * 2 + (l >> 5)) for the four k quarters kq;
-//   * a 32-row fragment read with the (r & 7) swizzle puts rows r and r + 8 (or r + 24) of one ds_read_b128 lane group on the same
-//     banks; the row swizzle here is sw(r) = (r & 7) ^ ((r >> 3) & 1) — conflict free for every tap shift (model) — applied by the
-//     DMA to the source chunk (8-row groups with odd index swap neighbouring chunks) and by the reads;
-//   * the accumulator of a 32 x 32 block holds, per lane, pixel (l & 31) and channels 8 j + 4 (l >> 5) + 0..3 for j = 0..3: four
-//     8-byte stores per block, the lane pair (l, l + 32) completing 16 bytes of a pixel row.
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-template <int BN, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void conv_halo32_kernel(HaloArgs g, int NRpad) {
-    constexpr int BM = 32 * NW;
-    constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
-    constexpr int WM = BM / WAVES_M, FM32 = WM / 32;
-    constexpr int QB = BN * 128, QI = BN / (8 * NW);
-    constexpr int RD = 2 + FM32;                       // fragment reads per k quarter: two weight fragments + FM32 pixel fragments
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int PBYTES = NRpad * 128;
-    unsigned char* pbuf0 = smem;                       // 2 halo stages
-    unsigned char* qbuf0 = smem + 2 * PBYTES;          // 2 weight stages
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int H = g.cH, C = g.C;
-    const int NR = BM + 2 * H + 2;
-    const int PI = NRpad / (8 * NW);
-
-    const int mtiles = (g.M + BM - 1) / BM, ntiles = (g.N + BN - 1) / BN;
-    const int nblk = mtiles * ntiles;
-    int L = blockIdx.x;
-    if ((nblk & 7) == 0) L = (L & 7) * (nblk >> 3) + (L >> 3);
-    const int m0 = (L / ntiles) * BM, n0 = (L % ntiles) * BN;
-
-    const int rsub = lane >> 3;
-    const int csrc = ((lane & 7) ^ rsub) * 8;          // LDS position lane&7 of row r holds source chunk (lane&7) ^ sw(r): ^ 8 for odd 8-row groups
-    const bf16_t* zero = (const bf16_t*)igh_zero_page;
-    const long mfirst = (long)m0 - H - 1;
-
-    const bf16_t* qrow[QI];
-#pragma unroll
-    for (int j = 0; j < QI; ++j) {
-        const int grp = wave * QI + j;
-        const int n = n0 + grp * 8 + rsub;
-        qrow[j] = (n < g.N) ? g.Q + (long)n * 9 * C + (csrc ^ ((grp & 1) * 8)) : nullptr;
-    }
-    auto load_q = [&](int k0, int buf) {
-        unsigned char* sq = qbuf0 + buf * QB;
-#pragma unroll
-        for (int j = 0; j < QI; ++j) {
-            const bf16_t* src = qrow[j] ? qrow[j] + k0 : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sq + (wave * QI + j) * 1024), 16, 0, 0);
-        }
-    };
-    auto load_p = [&](int chunk, int buf) {
-        unsigned char* sp = pbuf0 + buf * PBYTES;
-        for (int j = 0; j < PI; ++j) {
-            const int grp = wave * PI + j;
-            const int r = grp * 8 + rsub;
-            const long m = mfirst + r;
-            const bf16_t* src = (r < NR && m >= 0 && m < g.M) ? g.P + m * C + chunk * 64 + (csrc ^ ((grp & 1) * 8)) : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sp + grp * 1024), 16, 0, 0);
-        }
-    };
-
-    const int r32 = lane & 31, half = lane >> 5;
-    unsigned vmask[FM32];
-#pragma unroll
-    for (int b = 0; b < FM32; ++b) {
-        const int m = m0 + wm * WM + b * 32 + r32;
-        unsigned bits = 0;
-        if (m < g.M) {
-            const int h = m % H, w = (m / H) % g.cW;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int ww = w + t / 3 - 1, hh = h + t % 3 - 1;
-                if ((unsigned)ww < (unsigned)g.cW && (unsigned)hh < (unsigned)H) bits |= 1u << t;
-            }
-        }
-        vmask[b] = bits;
-    }
-
-    f32x16 acc[2][FM32];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < FM32; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-    const int nchunks = C / 64;
-    const int nsteps = nchunks * 9;
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-    const unsigned swA = (unsigned)((lane & 7) ^ ((lane >> 3) & 1));                 // sw(row) of the weight fragment rows (tile rows are 32-aligned)
-    const unsigned qfrag0 = (unsigned)(qbuf0 - smem) + (wn * 64 + r32) * 128 + ((half ^ swA) << 4);    // + stage*QB, + a*4096, ^ (kq << 5)
-    const unsigned prow0 = (wm * WM + r32) * 128;
-    load_q(0, 0);
-    load_p(0, 0);
-    int tap = 0, chunk = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        if (tap == 1 && chunk + 1 < nchunks) {
-            if (PI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if (PI == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else if (PI == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        {
-            int ntap = tap + 1, nchunk = chunk;
-            if (ntap == 9) { ntap = 0; ++nchunk; }
-            if (s + 1 < nsteps) load_q(ntap * C + nchunk * 64, (s + 1) & 1);
-            if (tap == 0 && chunk + 1 < nchunks) load_p(chunk + 1, (chunk + 1) & 1);
-        }
-        const int shift = (H + 1) + (tap / 3 - 1) * H + (tap % 3 - 1);
-        const unsigned qa = qfrag0 + (s & 1) * QB;
-        const unsigned rs = (unsigned)(r32 + shift);
-        const unsigned psw = (half ^ ((rs & 7) ^ ((rs >> 3) & 1))) << 4;            // (half ^ sw(row)) << 4; the k quarter is XORed in below
-        const unsigned pbase = (chunk & 1) * PBYTES + prow0 + shift * 128 + psw;
-        const unsigned zoff = (chunk & 1) * PBYTES + NR * 128 + ((rs & 1) << 7) + psw;     // zero rows NR, NR + 1: same bank as the real row
-        unsigned pa[FM32];
-#pragma unroll
-        for (int b = 0; b < FM32; ++b) pa[b] = ((vmask[b] >> tap) & 1u) ? pbase + b * 4096 : zoff;
-        u32x4 afr[4][2], bfr[4][FM32];
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
-            const unsigned qk = qa ^ (kq << 5);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[kq][a]) : "v"(lds0 + qk), "n"(a * 4096));
-#pragma unroll
-            for (int b = 0; b < FM32; ++b)
-                asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[kq][b]) : "v"(lds0 + (pa[b] ^ (kq << 5))));
-        }
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
-            if (kq == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 * RD) : "memory");      // LDS returns in order: the younger quarters stay in flight
-            else if (kq == 1) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * RD) : "memory");
-            else if (kq == 2) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD) : "memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < FM32; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[kq][a]),
-                                                                        __builtin_bit_cast(bf16x8, bfr[kq][b]), acc[a][b], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (++tap == 9) { tap = 0; ++chunk; }
-    }
-
-    // ---- epilogue: block (a, b) of a lane = pixel (lane & 31) x channels a*32 + 8 j + 4 (lane >> 5) + 0..3, j = 0..3
-    const int flags = g.flags;
-#pragma unroll
-    for (int b = 0; b < FM32; ++b) {
-        const int m = m0 + wm * WM + b * 32 + r32;
-        if (m >= g.M) continue;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + a * 32 + j * 8 + half * 4;
-                if (n >= g.N) continue;
-                f32x4 v = {acc[a][b][4 * j], acc[a][b][4 * j + 1], acc[a][b][4 * j + 2], acc[a][b][4 * j + 3]};
-                if (flags & IGH_BIAS) v = v + *(const f32x4*)(g.bias + n);
-                if (flags & IGH_RELU) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-                if (flags & IGH_MASK) {
-                    u32x2 mk = *(const u32x2*)(g.mask + (long)m * g.N + n);
-                    if (!(bf_lo(mk.x) > 0.f)) v.x = 0.f;
-                    if (!(bf_hi(mk.x) > 0.f)) v.y = 0.f;
-                    if (!(bf_lo(mk.y) > 0.f)) v.z = 0.f;
-                    if (!(bf_hi(mk.y) > 0.f)) v.w = 0.f;
-                }
-                if (flags & IGH_ACCUM) {
-                    const u32x2 old = *(const u32x2*)(g.out + (long)m * g.N + n);
-                    v.x += bf_lo(old.x); v.y += bf_hi(old.x); v.z += bf_lo(old.y); v.w += bf_hi(old.y);
-                }
-                u32x2 pk;
-                pk.x = pack_bf2(v.x, v.y);
-                pk.y = pack_bf2(v.z, v.w);
-                *(u32x2*)(g.out + (long)m * g.N + n) = pk;
-                if (g.pool_kind) {
-                    // window neighbours of pixel m inside the 32-pixel fragment: feature axis m ^ 1 = lane ^ 1, time axis m +- H = lane ^ H
-                    // (H = 4, 8, 16 < 32; tiles and fragments start at multiples of 32 pixels, M is a multiple of 2 H)
-                    f32x4 mx = v;
-                    if (g.pool_kind == 2) {
-                        mx.x = fmaxf(mx.x, __shfl_xor(mx.x, H, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, H, 64));
-                        mx.z = fmaxf(mx.z, __shfl_xor(mx.z, H, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, H, 64));
-                    }
-                    mx.x = fmaxf(mx.x, __shfl_xor(mx.x, 1, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, 1, 64));
-                    mx.z = fmaxf(mx.z, __shfl_xor(mx.z, 1, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, 1, 64));
-                    const int h = m % H, col = m / H;
-                    const bool writer = !(h & 1) && (g.pool_kind == 1 || !(col & 1));
-                    if (writer) {
-                        const long pidx = g.pool_kind == 1 ? (long)(m >> 1) : (long)(col >> 1) * (H >> 1) + (h >> 1);
-                        u32x2 pp;
-                        pp.x = pack_bf2(mx.x, mx.y);
-                        pp.y = pack_bf2(mx.z, mx.w);
-                        *(u32x2*)(g.pool + pidx * g.N + n) = pp;
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int BN, int NW>
-static int launch_halo32(const HaloArgs& g, hipStream_t stream) {
-    constexpr int BM = 32 * NW;
-    const int NR = BM + 2 * g.cH + 2;
-    const int NRpad = (NR + 8 * NW) / (8 * NW) * (8 * NW);
-    const int lds = 2 * NRpad * 128 + 2 * BN * 128;
-    static int lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute((const void*)conv_halo32_kernel<BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return OCR_ERR_EXEC;
-        lds_set = lds;
-    }
-    int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
-    conv_halo32_kernel<BN, NW><<<mt * nt, 64 * NW, lds, stream>>>(g, NRpad);
-    OCR_CHECK_LAUNCH();
-    return OCR_OK;
-}
+// (A variant on v_mfma_f32_32x32x16_bf16 — same tiles, 32-row fragments, row swizzle (r & 7) ^ ((r >> 3) & 1) — was written in round 2,
+// passed the parity tests on hardware in round 3 and measured 10-15 % SLOWER on every layer (profiles/r03a_conv_32x32x16.log): removed.)
 
 template <int BN, int NW, int ABL = 0, int RPW = 32, int FNV = 4>
 static int launch_halo_(const HaloArgs& g, hipStream_t stream) {
@@ -543,11 +309,13 @@ static int launch_halo_(const HaloArgs& g, hipStream_t stream) {
 }
 template <int BN, int NW>
 static int launch_halo(const HaloArgs& g, hipStream_t stream) {
+#ifdef OCR_EXPERIMENTS
     static int abl = -1;                        // timing ablations for tools/halo_variants.py (OCR_HALO_ABL; results are wrong)
     if (abl < 0) { const char* e = getenv("OCR_HALO_ABL"); abl = e ? atoi(e) : 0; }
     if (abl == 1) return launch_halo_<BN, NW, 1>(g, stream);
     if (abl == 2) return launch_halo_<BN, NW, 2>(g, stream);
     if (abl == 5) return launch_halo_<BN, NW, 5>(g, stream);
+#endif
     return launch_halo_<BN, NW, 0>(g, stream);
 }
 
@@ -584,6 +352,7 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
     static int prio = -1;
     if (prio < 0) { const char* e = getenv("OCR_HALO_PRIO"); prio = e ? atoi(e) : 0; }
     HaloArgs g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, stag, stag_bit, prio};
+#ifdef OCR_EXPERIMENTS      // measured and rejected in round 2: dense = equal, wide = 27 % slower
     static int dense = -1;                               // A/B knob OCR_HALO_DENSE=1: 8 waves per 128-pixel tile (4 waves per SIMD with two workgroups per CU)
     if (dense < 0) { const char* e = getenv("OCR_HALO_DENSE"); dense = e ? atoi(e) : 0; }
     if (dense && nw != 8) {
@@ -601,24 +370,7 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
         if ((NRw / 32 == 5 || NRw / 32 == 6) && (long)((M + 127) / 128) * (Cout / 256) >= 224)
             return launch_halo_<256, 4, 0, 32, 8>(g, stream);
     }
-    static int m32 = -1;                                 // experiment knob OCR_HALO_MFMA32=1: the 32x32x16-MFMA variant (same tile choice)
-    if (m32 < 0) { const char* e = getenv("OCR_HALO_MFMA32"); m32 = e ? atoi(e) : 0; }
-    if (m32 && nw != 8) {
-        const int NR = 128 + 2 * H + 2, NRp = (NR + 32) / 32 * 32;
-        const long mt4 = (M + 127) / 128;
-        if (NRp / 32 == 5 || NRp / 32 == 6) {
-            if (Cout >= 128 && mt4 * ((Cout + 127) / 128) >= 448) return launch_halo32<128, 4>(g, stream);
-            return launch_halo32<64, 4>(g, stream);
-        }
-    }
-    if (m32) {
-        const int NRpad8 = (256 + 2 * H + 2 + 64) / 64 * 64;
-        if (NRpad8 / 64 == 5 || NRpad8 / 64 == 6) {
-            const int mt8 = (M + 255) / 256;
-            if (Cout >= 128 && ((long)mt8 * ((Cout + 127) / 128) >= 200 || (long)mt8 * ((Cout + 63) / 64) < 256)) return launch_halo32<128, 8>(g, stream);
-            return launch_halo32<64, 8>(g, stream);
-        }
-    }
+#endif
     if (nw != 8) {
         const int NR = 128 + 2 * H + 2, NRp = (NR + 32) / 32 * 32;
         const long mt4 = (M + 127) / 128;

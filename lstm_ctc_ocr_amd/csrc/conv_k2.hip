@@ -45,7 +45,8 @@ struct K2Args {
     int cW, cH;
     bf16_t* out; const float* bias; const bf16_t* mask; int flags;
     bf16_t* pool; int pool_kind;          // as conv_halo: 0 none, 1 feature pairs (1 x 2), 2 2 x 2
-};
+    int abl;                              // timing ablations (wrong results; only in `make EXPERIMENTS=1` builds, OCR_K2_ABL): 1 no DMA after the
+};                                        // prologue, 2 no fragment reads, 4 no MFMAs
 
 __device__ long long* k2_dbg;             // diagnostic: s_memtime stamps of workgroup 0 (ocr_conv_k2_debug)
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -53,21 +54,30 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 #define K2_VMWAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-template <int FM /* 16-pixel fragments per wave: 8 (256-pixel tiles) or 4 (128-pixel tiles) */, bool DBG>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_k2_kernel(K2Args g) {
-    constexpr int NW = 8, FN = 4, BN = 128;
-    constexpr int WM = FM * 16, BM = 2 * WM;
-    constexpr int NRpad = (BM == 256) ? 320 : 192;      // halo rows incl. >= 2 zero rows, a multiple of 8 rows x 8 waves
-    constexpr int PI = NRpad / (8 * NW);                // halo DMA pieces per wave and chunk (5 / 3)
-    constexpr int QI = BN / (8 * NW);                   // weight DMA pieces per wave and step (2)
-    constexpr int PBYTES = NRpad * 128, QB = BN * 128, QOFF = 2 * PBYTES;
+template <int FM /* 16-pixel fragments per wave: 8 or 4 */, int BN /* channels per tile: 128 (waves 2 pixel x 2 channel x 2 K) or 64
+                                                                          (4 pixel x 1 channel x 2 K: 512- / 256-pixel tiles) */,
+          int NST /* weight stages: 4, or 3 where the LDS is short (512-pixel tiles) */, bool DBG>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_k2_kernel(K2Args g, int NRpad /* halo rows incl. the zero rows, a multiple of 8 */) {
+    constexpr int NW = 8, FN = 4;
+    constexpr int WN = BN / 64, WMW = 4 / WN;           // waves along channels / pixels (per K half)
+    constexpr int WM = FM * 16, BM = WMW * WM;
+    constexpr int PIMAX = ((BM + 38 + 7) / 8 + NW - 1) / NW;      // halo DMA pieces (8 rows) per wave and chunk, at most (9 / 5 / 3)
+    constexpr int QI = BN / 64;                         // weight DMA pieces per wave and step (2 / 1)
+    constexpr int QB = BN * 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int PBYTES = NRpad * 128, QOFF = 2 * PBYTES;
 
+#ifdef OCR_EXPERIMENTS
+    const int abl = g.abl;
+#else
+    constexpr int abl = 0;
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int kh = wave >> 2, wm = (wave & 3) / WN, wn = (wave & 3) % WN;
     const int H = g.cH, C = g.C;
-    const int NR = BM + 2 * H + 2;                      // halo rows actually needed; rows NR, NR + 1 are the zero rows
+    const int NR = BM + 2 * H + 2;                      // halo rows actually needed; rows NR, NR + 1 are the zero rows (NR + 2 <= NRpad)
+    const int npieces = NRpad >> 3;
 
     const int mtiles = (g.M + BM - 1) / BM, ntiles = (g.N + BN - 1) / BN;
     const int nblk = mtiles * ntiles;
@@ -81,15 +91,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const __amdgpu_buffer_rsrc_t psrd = __builtin_amdgcn_make_buffer_rsrc((void*)g.P, 0, (int)((long)g.M * C * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t qsrd = __builtin_amdgcn_make_buffer_rsrc((void*)g.Q, 0, (int)((long)g.N * 9 * C * 2), 0x00020000);
-    unsigned voffQ[QI], voffP[PI];
+    unsigned voffQ[QI], voffP[PIMAX];
 #pragma unroll
     for (int j = 0; j < QI; ++j) {
         const int n = n0 + (wave * QI + j) * 8 + rsub;
         voffQ[j] = n < g.N ? (unsigned)(((long)n * 9 * C + csrc) * 2) : K2_OOB;
     }
 #pragma unroll
-    for (int j = 0; j < PI; ++j) {
-        const int r = (wave * PI + j) * 8 + rsub;
+    for (int j = 0; j < PIMAX; ++j) {                   // this wave's halo pieces are j * 8 + wave (those below npieces)
+        const int r = (j * NW + wave) * 8 + rsub;
         const long m = mfirst + r;
         voffP[j] = (r < NR && m >= 0 && m < g.M) ? (unsigned)((m * C + csrc) * 2) : K2_OOB;
     }
@@ -99,7 +109,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __builtin_amdgcn_raw_ptr_buffer_load_lds(qsrd, (lptr_t)(smem + QOFF + stage * QB + (wave * QI + j) * 1024), 16, (int)voffQ[j], k0 * 2, 0, 0);
     };
     auto load_p1 = [&](int chunk, int buf, int j, unsigned voff) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(psrd, (lptr_t)(smem + buf * PBYTES + (wave * PI + j) * 1024), 16, (int)voff, chunk * 128, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(psrd, (lptr_t)(smem + buf * PBYTES + (j * NW + wave) * 1024), 16, (int)voff, chunk * 128, 0, 0);
+    };
+    // piece j of the next chunk (static register index; pieces beyond npieces do not exist for this wave)
+    auto load_pj = [&](int chunk, int buf, int j) {
+        if ((j * NW + wave) >= npieces) return 0;
+        switch (j) {
+            case 0: load_p1(chunk, buf, 0, voffP[0]); break;
+            case 1: if (PIMAX > 1) load_p1(chunk, buf, 1, voffP[PIMAX > 1 ? 1 : 0]); break;
+            case 2: if (PIMAX > 2) load_p1(chunk, buf, 2, voffP[PIMAX > 2 ? 2 : 0]); break;
+            case 3: if (PIMAX > 3) load_p1(chunk, buf, 3, voffP[PIMAX > 3 ? 3 : 0]); break;
+            case 4: if (PIMAX > 4) load_p1(chunk, buf, 4, voffP[PIMAX > 4 ? 4 : 0]); break;
+            case 5: if (PIMAX > 5) load_p1(chunk, buf, 5, voffP[PIMAX > 5 ? 5 : 0]); break;
+            case 6: if (PIMAX > 6) load_p1(chunk, buf, 6, voffP[PIMAX > 6 ? 6 : 0]); break;
+            case 7: if (PIMAX > 7) load_p1(chunk, buf, 7, voffP[PIMAX > 7 ? 7 : 0]); break;
+            default: if (PIMAX > 8) load_p1(chunk, buf, 8, voffP[PIMAX > 8 ? 8 : 0]); break;
+        }
+        return 1;
     };
 
     // per pixel-fragment validity of the nine taps (bit t set <=> tap t of this lane's pixel is inside the image)
@@ -137,37 +163,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     load_q(0, 0);
     if (nsteps > 1) load_q(C, 1);
 #pragma unroll
-    for (int j = 0; j < PI; ++j) load_p1(0, 0, j, voffP[j]);
+    for (int j = 0; j < PIMAX; ++j) load_pj(0, 0, j);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kh == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }        // segment 0: waves 4-7 have nothing to multiply yet
 
-    int tap = 0, chunk = 0;
+    int tap = 0, chunk = 0, qs = 0 /* s % NST */;
     for (int s = 0; s < nsteps; ++s) {
         long long st[6] = {0, 0, 0, 0, 0, 0};
         if (DBG) st[0] = __builtin_amdgcn_s_memtime();
-        // ================================================================ LOAD(s)
-        const bool more_q = s + 2 < nsteps;
-        const bool halo_now = tap >= 1 && tap <= PI && chunk + 1 < nchunks;
-        {
-            int t2 = tap + 2, c2 = chunk;
-            if (t2 >= 9) { t2 -= 9; ++c2; }
-            if (more_q) load_q(t2 * C + c2 * 64, (s + 2) & 3);
-            if (halo_now) {                     // one halo piece of the next chunk per step (static register index)
-                const int nb = (chunk + 1) & 1;
-                switch (tap) {
-                    case 1: load_p1(chunk + 1, nb, 0, voffP[0]); break;
-                    case 2: load_p1(chunk + 1, nb, 1, voffP[1]); break;
-                    case 3: load_p1(chunk + 1, nb, 2, voffP[2]); break;
-                    case 4: if (PI > 3) load_p1(chunk + 1, nb, 3, voffP[PI > 3 ? 3 : 0]); break;
-                    default: if (PI > 4) load_p1(chunk + 1, nb, 4, voffP[PI > 4 ? 4 : 0]); break;
-                }
-            }
-        }
-        if (DBG) st[1] = __builtin_amdgcn_s_memtime();
+        // ================================================================ LOAD(s): fragment reads first (they complete under the DMA issue)
         const int shift = (H + 1) + (tap / 3 - 1) * H + (tap % 3 - 1);       // halo row of local pixel 0 for this tap
-        const unsigned qa = qfrag0 + (s & 3) * QB;
+        const unsigned qa = qfrag0 + qs * QB;
         // pixel fragments: row (wm*WM + b*16 + frow + shift), chunk position ((kh*4 + fq) ^ (row & 7)); lanes whose tap falls outside
         // the image read a zero row (NR / NR + 1: the one with the real row's parity, at the real row's position in its 256 bytes, so
         // the redirected lanes keep the banks the swizzle gave them)
@@ -175,23 +183,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const unsigned pbase = prow0 + (chunk & 1) * PBYTES + shift * 128 + psw;
         const unsigned zoff = lds0 + (chunk & 1) * PBYTES + NR * 128 + (((frow + shift) & 1) << 7) + psw;
         u32x4 afr[FN], bfr[FM];
+        if (abl & 2) {
 #pragma unroll
-        for (int a = 0; a < FN; ++a)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[a]) : "v"(qa), "n"(a * 2048));
+            for (int a = 0; a < FN; ++a) asm volatile("" : "=v"(afr[a]));
 #pragma unroll
-        for (int b = 0; b < FM; ++b) {
-            const unsigned pa = ((vmask[b] >> tap) & 1u) ? pbase + b * 2048 : zoff;
-            asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[b]) : "v"(pa));
+            for (int b = 0; b < FM; ++b) asm volatile("" : "=v"(bfr[b]));
+        } else {
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[a]) : "v"(qa), "n"(a * 2048));
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+                const unsigned pa = ((vmask[b] >> tap) & 1u) ? pbase + b * 2048 : zoff;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[b]) : "v"(pa));
+            }
         }
-        // pieces of this wave younger than tile s + 1 = what LOAD(s) issued
-        const int younger = (more_q ? QI : 0) + (halo_now ? 1 : 0);
+        if (DBG) st[1] = __builtin_amdgcn_s_memtime();
+        // DMA: the weight tile of step s + 2, and of the next chunk's halo piece tap - 1 (taps 1 .. 8; a ninth piece rides with the eighth)
+        const bool more_q = s + 2 < nsteps && !(abl & 1);
+        int younger = more_q ? QI : 0;
+        {
+            int t2 = tap + 2, c2 = chunk;
+            if (t2 >= 9) { t2 -= 9; ++c2; }
+            int q2 = qs + 2; if (q2 >= NST) q2 -= NST;
+            if (more_q) load_q(t2 * C + c2 * 64, q2);
+            if (tap >= 1 && tap <= PIMAX && chunk + 1 < nchunks && !(abl & 1)) {
+                younger += load_pj(chunk + 1, (chunk + 1) & 1, tap - 1);
+                if (PIMAX > 8 && tap == 8) younger += load_pj(chunk + 1, (chunk + 1) & 1, 8);
+            }
+        }
+        // pieces of this wave younger than tile s + 1 = what this LOAD issued
         auto vmwait = [&]() {
             switch (younger) {
-                case 0: K2_VMWAIT(0); break; case 1: K2_VMWAIT(1); break; case 2: K2_VMWAIT(2); break;
-                default: K2_VMWAIT(3); break;
+                case 0: K2_VMWAIT(0); break; case 1: K2_VMWAIT(1); break; case 2: K2_VMWAIT(2); break; case 3: K2_VMWAIT(3); break;
+                default: K2_VMWAIT(4); break;
             }
         };
         if (DBG) st[2] = __builtin_amdgcn_s_memtime();
+        // every fragment read is complete before the barrier: a stage is never overwritten while a read of it is in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (kh == 1) vmwait();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -199,15 +229,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_sched_barrier(0);
         if (DBG) st[3] = __builtin_amdgcn_s_memtime();
         // ================================================================ COMP(s)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
+        if (!(abl & 4)) {
 #pragma unroll
-        for (int b = 0; b < FM; ++b)
+            for (int b = 0; b < FM; ++b)
 #pragma unroll
-            for (int a = 0; a < FN; ++a)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[a]), __builtin_bit_cast(bf16x8, bfr[b]),
-                                                                    acc[a][b], 0, 0, 0);
+                for (int a = 0; a < FN; ++a)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[a]), __builtin_bit_cast(bf16x8, bfr[b]),
+                                                                        acc[a][b], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int a = 0; a < FN; ++a) asm volatile("" :: "v"(afr[a]));
+#pragma unroll
+            for (int b = 0; b < FM; ++b) asm volatile("" :: "v"(bfr[b]));
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (DBG) st[4] = __builtin_amdgcn_s_memtime();
@@ -221,6 +256,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int i = 0; i < 6; ++i) k2_dbg[(wave * 80 + s) * 6 + i] = st[i];
         }
         if (++tap == 9) { tap = 0; ++chunk; }
+        if (++qs == NST) qs = 0;
     }
     if (kh == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }      // matches the extra barrier waves 4-7 took at the start
 
@@ -320,34 +356,53 @@ extern "C" int ocr_conv_k2_debug(void* dbg /* device int64[8 waves][80 steps][6]
     return hipMemcpyToSymbol(HIP_SYMBOL(k2_dbg), &q, sizeof(q)) == hipSuccess ? OCR_OK : OCR_ERR_MEMOPS;
 }
 
-template <int FM, bool DBG>
+// tile configurations: A 256 x 128 (4 weight stages), B 128 x 128, C 512 x 64 (3 stages: the two 512-pixel halo stages take 135 KB),
+// D 256 x 64
+template <int FM, int BN, int NST, bool DBG>
 static int launch_k2_(const K2Args& g, hipStream_t stream) {
-    constexpr int BM = 32 * FM, NRpad = (BM == 256) ? 320 : 192;
-    const int lds = 2 * NRpad * 128 + 4 * 128 * 128;               // halo stages, weight stages (the K-half exchange reuses them)
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv_k2_kernel<FM, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC;
-        attr = true;
+    constexpr int BM = (4 / (BN / 64)) * FM * 16;
+    const int NRpad = (BM + 2 * g.cH + 4 + 7) / 8 * 8;             // needed rows + two zero rows, in 8-row DMA pieces
+    const int lds = 2 * NRpad * 128 + NST * BN * 128;               // halo stages, weight stages (the K-half exchange reuses them)
+    if (lds > 163840 || lds < 8 * FM * 2048) return -1;
+    static int attr = 0;
+    if (lds > attr) {
+        if (hipFuncSetAttribute((const void*)conv_k2_kernel<FM, BN, NST, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC;
+        attr = lds;
     }
-    const int mt = (g.M + BM - 1) / BM, nt = (g.N + 127) / 128;
-    conv_k2_kernel<FM, DBG><<<mt * nt, 512, lds, stream>>>(g);
+    const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
+    conv_k2_kernel<FM, BN, NST, DBG><<<mt * nt, 512, lds, stream>>>(g, NRpad);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
-template <int FM>
-static int launch_k2(const K2Args& g, hipStream_t stream) { return g_k2_dbg ? launch_k2_<FM, true>(g, stream) : launch_k2_<FM, false>(g, stream); }
+template <int FM, int BN, int NST>
+static int launch_k2(const K2Args& g, hipStream_t stream) {
+    return g_k2_dbg ? launch_k2_<FM, BN, NST, true>(g, stream) : launch_k2_<FM, BN, NST, false>(g, stream);
+}
 
-// does this kernel take the shape, and with which tile?  0 = no (caller uses conv_halo), else FM
-int k2_tile(long M, int W, int H, int Cin, int Cout) {
-    if ((Cin & 63) || (Cout & 127) || M < 4096 || H > 16 || H < 1) return 0;        // channel tiles of 128; zero rows need NR + 2 <= NRpad
+// Which tile, if any?  Every candidate moves (BN x 128 + (BM + 2H + 2) x 128 / 9) bytes from the L2 into the CU per K step of
+// 2 x BM x BN x 64 flop, and a CU takes ~10.5 B / clock whatever the source (tools/bin/dma_probe: profiles/r03d_dma_fill_probe.txt) —
+// that, not the matrix pipe, bounds these kernels — so the candidates are tried in the order of their bytes per flop: C (16.2 KB per
+// 4.2 MFLOP), A (20.5), D (24.2), B (36.6); a candidate must cover the shape, fit the LDS and fill the chip (>= 224 tiles).
+// Layers with fewer than OCR_K2_MINSTEPS K steps stay on conv_halo: with 9-18 steps a tile is mostly prologue and epilogue, and
+// conv_halo's two independent workgroups per CU overlap those (measured: conv2 33 against 42 us, conv3_1 27 against 30).
+static int k2_choose(long M, int H, int Cin, int Cout) {
+    if ((Cin & 63) || (Cout & 63) || M < 4096 || H > 16 || H < 1) return 0;
     if (M * Cin * 2 >= 0x7fffffffL || (long)Cout * 9 * Cin * 2 >= 0x7fffffffL) return 0;   // 32-bit descriptor offsets
-    static int force = -1;                               // A/B knob OCR_K2_FM: 8 / 4 force one tile, unset = by grid size
-    if (force < 0) { const char* e = getenv("OCR_K2_FM"); force = e ? atoi(e) : 0; }
-    const long nt = Cout / 128;
-    const long t8 = (M + 255) / 256 * nt, t4 = (M + 127) / 128 * nt;
-    if (force == 8 || force == 4) return force;
-    if (t8 >= 224) return 8;                            // (almost) every CU gets a 256-pixel tile
-    if (t4 >= 224) return 4;
+    static int force = -1, minsteps = -1;          // A/B knobs: OCR_K2_CFG = A / B / C / D forces one tile where it covers the shape
+    if (force < 0) { const char* e = getenv("OCR_K2_CFG"); force = (e && e[0] >= 'A' && e[0] <= 'D') ? e[0] : 0; }
+    if (minsteps < 0) { const char* e = getenv("OCR_K2_MINSTEPS"); minsteps = e ? atoi(e) : 36; }
+    const char order[4] = {'C', 'A', 'D', 'B'};
+    for (int i = 0; i < 4; ++i) {
+        const char c = order[i];
+        if (force && c != force) continue;
+        const int bm = c == 'C' ? 512 : (c == 'B' ? 128 : 256), bn = (c == 'A' || c == 'B') ? 128 : 64, nst = c == 'C' ? 3 : 4;
+        if (Cout % bn) continue;
+        const int nrpad = (bm + 2 * H + 4 + 7) / 8 * 8;
+        if (2 * nrpad * 128 + nst * bn * 128 > 163840) continue;
+        if (force) return c;
+        if (9 * (Cin / 64) < minsteps) return 0;
+        if ((M + bm - 1) / bm * (Cout / bn) >= 224) return c;
+    }
     return 0;
 }
 
@@ -355,8 +410,15 @@ int k2_tile(long M, int W, int H, int Cin, int Cout) {
 int k2_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
                     const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind) {
     if (flags & ~(K2_BIAS | K2_RELU | K2_MASK | K2_ACCUM)) return -1;
-    const int fm = k2_tile(M, W, H, Cin, Cout);
-    if (!fm) return -1;
-    K2Args g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind};
-    return fm == 8 ? launch_k2<8>(g, stream) : launch_k2<4>(g, stream);
+    const int c = k2_choose(M, H, Cin, Cout);
+    if (!c) return -1;
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("OCR_K2_ABL"); abl = e ? atoi(e) : 0; }
+    K2Args g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, abl};
+    switch (c) {
+        case 'A': return launch_k2<8, 128, 4>(g, stream);
+        case 'B': return launch_k2<4, 128, 4>(g, stream);
+        case 'C': return launch_k2<8, 64, 3>(g, stream);
+        default: return launch_k2<4, 64, 4>(g, stream);
+    }
 }

@@ -15,7 +15,7 @@
 // reading a zero row), but THREE weight stages: the tile of step s is read in segments 2s (waves 0-3) and 2s+1 (waves 4-7) and
 // the tile of step s+2 is streamed in during exactly those two segments into the buffer that step s-1 left in segment 2s-1.
 // Halo pieces of the next chunk are issued one per step (taps 0 .. PI-1), never as a block.
-#include "common.h"
+#include "../common.h"
 #include <stdlib.h>
 
 enum { PPF_BIAS = 1, PPF_RELU = 2, PPF_MASK = 16 };

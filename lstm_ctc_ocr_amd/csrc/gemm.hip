@@ -256,14 +256,16 @@ int ig_try_dispatch(const void* P, long ldp, const void* Q, long ldq, void* out,
                     int cH, int cC, int swap_inner, int swap_outer, hipStream_t stream);
 int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
                       const void* mask, int flags, hipStream_t stream, void* pool = nullptr, int pool_kind = 0);
+#ifdef OCR_EXPERIMENTS
 int pp_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
                     const void* mask, int flags, hipStream_t stream);
+#endif
 static int g_use_igemm = 1, g_use_halo = 1, g_use_pp = 0;
 extern int g_ig_stages;
 // A/B knob. 0 = 128x128 register-staged tiles only; 1 (default) = lock-step tap-reuse halo kernel (conv_halo.hip) for 3x3
 // convs + LDS-DMA 256-row tiles (three-stage) for plain GEMMs; 4 = ping-pong halo kernel (conv_pp.hip: measured 14 % SLOWER
 // than the lock-step kernel in round 2, kept for A/B), then as 1;
-// 2 = LDS-DMA tiles two-stage, no halo; 3 = LDS-DMA tiles three-stage, no halo
+// 2 = LDS-DMA tiles two-stage, no halo; 3 = LDS-DMA tiles three-stage, no halo   (4 only in builds with make EXPERIMENTS=1)
 extern "C" int ocr_set_gemm_engine(int mode) {
     g_use_igemm = mode != 0; g_use_halo = mode == 1 || mode == 4; g_use_pp = mode == 4; g_ig_stages = (mode == 2) ? 2 : 3;
     return OCR_OK;
@@ -311,10 +313,12 @@ extern "C" int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int N
     if ((flags & EPI_BIAS) && !bias) return OCR_ERR_INVALID;
     if ((flags & EPI_MASK) && !mask) return OCR_ERR_INVALID;
     if ((flags & EPI_ACCUM) && !ocr_conv3x3_accum_supported(Nb, W, H, Cin, Cout)) return OCR_ERR_INVALID;      // bf16 accumulate: halo epilogue only
+#ifdef OCR_EXPERIMENTS
     if (g_use_pp && x && wpack && y && g.M > 0 && Cout > 0 && Cin > 0) {
         int rc = pp_try_dispatch(x, wpack, y, g.M, W, H, Cin, Cout, bias, mask, g.flags, (hipStream_t)stream);
         if (rc >= 0) return rc;
     }
+#endif
     if (g_use_halo && x && wpack && y && g.M > 0 && Cout > 0 && Cin > 0) {
         int rc = halo_try_dispatch(x, wpack, y, g.M, W, H, Cin, Cout, bias, mask, g.flags, (hipStream_t)stream);
         if (rc >= 0) return rc;

@@ -758,6 +758,7 @@ int wgrad9_try_dispatch(const void* x, const void* dy, float* dw, float* dbias, 
         if (!attr) { if (hipFuncSetAttribute((const void*)wgrad9c_kernel<LA_, NS_, NB_, DBG_>, hipFuncAttributeMaxDynamicSharedMemorySize, W9_LDS) != hipSuccess) return OCR_ERR_EXEC; attr = true; } \
         wgrad9c_kernel<LA_, NS_, NB_, DBG_><<<grid, 512, W9_LDS, stream>>>(g); } while (0)
     switch (H == 2 ? 0 : variant) {             // H = 2 (a 4-row read block spans two image columns): only the redirecting default handles it
+#ifdef OCR_EXPERIMENTS      // timing variants / ablations of tools/w9_variants.py (round 2, all measured slower or equal)
         case 1: W9_LAUNCH(3, 0, false); break;
         case 2: W9_LAUNCH(4, 0, false); break;
         case 3: W9_LAUNCH(2, 3, false); break;
@@ -788,6 +789,7 @@ int wgrad9_try_dispatch(const void* x, const void* dy, float* dw, float* dbias, 
             if ((long)M * (Cin > Cout ? Cin : Cout) * 2 < 0x7fffffffL) W9_LAUNCH(2, 3, false, 0, 0, false, true, true);
             else W9_LAUNCH(2, 3, false, 0, 0, false, true);
             break;
+#endif
         default: W9_LAUNCH(2, 3, false, 0, 0, false, true); break;      // measured best (r2): look-ahead 2, DMA block before tap 3, zero-row padding
     }
 #undef W9_LAUNCH

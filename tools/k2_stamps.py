@@ -1,5 +1,6 @@
-"""s_memtime stamps of conv_k2_kernel (workgroup 0) per step and wave: LOAD = DMA issue | addresses + reads issue, wait + barrier,
-COMP = MFMA, wait + barrier.   OCR_CONV_K2=1 python tools/k2_stamps.py   (GPU box)"""
+"""s_memtime stamps of conv_k2_kernel (workgroup 0) per step and wave: LOAD = addresses + reads issue | DMA issue | waits + barrier,
+COMP = MFMA | wait + barrier.  (The stamped workgroup's own stores sit in its vmcnt queue: its waits are longer than the others'.)
+OCR_CONV_K2=1 [OCR_K2_CFG=C] python tools/k2_stamps.py   (GPU box)"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,6 +22,6 @@ for name, W, H, Ci, Co in [("conv4_2", 64, 4, 512, 512), ("conv3_2", 64, 8, 256,
         s = d[w, 2:n - 1]
         if not s[:, 0].any():
             print('  (no stamps: kernel not taken for this shape?)'); break
-        print('  wave %d: DMA issue %.0f | addr+reads issue %.0f | wait+barrier %.0f | lgkm+MFMA %.0f | vmwait+barrier %.0f | step %.0f' % (
+        print('  wave %d: addr+reads issue %.0f | DMA issue %.0f | waits+barrier %.0f | MFMA %.0f | vmwait+barrier %.0f | step %.0f' % (
             w, md(s[:, 1] - s[:, 0]), md(s[:, 2] - s[:, 1]), md(s[:, 3] - s[:, 2]), md(s[:, 4] - s[:, 3]), md(s[:, 5] - s[:, 4]),
             md(s[1:, 0] - s[:-1, 0])))
