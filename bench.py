@@ -105,24 +105,37 @@ def conv_roofline(eng, device):
     nat.call("ocr_conv_halo_clock_debug", None)
     ach = tot_fl / tot_t
     mhz = clk_cycles / clk_ticks * 100.0 if clk_ticks else None
-    # HBM bytes per launch and matrix-pipe occupancy from the separate rocprofv3 --pmc passes of the latest round
-    # (profiles/rNN_pmc_conv.json, made by tools/pmc_conv_summary.py; FETCH_SIZE doubled: the guide's gfx950 correction)
-    traffic, mfma_busy, src = None, None, None
+    # HBM bytes per launch and matrix-pipe occupancy of the same kernels from the separate rocprofv3 --pmc passes over THIS script
+    # (tools/prof_step_pmc.sh -> profiles/rNN_pmc_step.json; FETCH_SIZE doubled: the guide's gfx950 correction).  The file names the
+    # commit it was taken at and its kernel symbols: numbers whose symbols are not in the library loaded now are refused.
+    traffic, mfma_busy, src, pmc_commit, pmc_error = None, None, None, None, None
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv*.json")))
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step*.json")))
     if cands:
         src = os.path.basename(cands[-1])
         pm = json.load(open(cands[-1]))
-        traffic, mfma_busy = pm.get("hbm_bytes_per_launch"), pm.get("mfma_busy_frac")
-    return {"bound": "mfma", "kernel": "conv_halo_kernel<BN,NW> (implicit-GEMM 3x3 SAME conv, forward + data gradient: %d launches/step)" % n_launch,
+        pmc_commit = pm.get("commit")
+        conv = [k for k in pm.get("kernels", []) if k["symbol"].startswith(("_Z16conv_halo_kernel", "_Z14conv_k2_kernel"))]
+        lib = open(nat.LIB_PATH, "rb").read()
+        missing = [k["symbol"] for k in conv if k["symbol"].encode() not in lib]
+        if missing or not conv:
+            pmc_error = "kernel symbols of %s are not in the loaded library: %s" % (src, missing[:2]) if missing else "no convolution kernels in %s" % src
+        else:
+            nl = float(sum(k["launches"] for k in conv))
+            tm = float(sum(k["launches"] * k["avg_us"] for k in conv))
+            if all("read_mb" in k and "write_mb" in k for k in conv):
+                traffic = sum(k["launches"] * (k["read_mb"] + k["write_mb"]) for k in conv) / nl * 1e6
+            if all("mfma_busy_frac" in k for k in conv):
+                mfma_busy = sum(k["launches"] * k["avg_us"] * k["mfma_busy_frac"] for k in conv) / tm
+    return {"bound": "mfma", "kernel": "conv_halo_kernel / conv_k2_kernel (implicit-GEMM 3x3 SAME conv, forward + data gradient: %d launches/step)" % n_launch,
             "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK,
             "avg_launch_us": tot_t / n_launch * 1e6, "algorithmic_gflop_per_launch": tot_fl / n_launch / 1e9,
-            "traffic": traffic, "mfma_busy_frac": mfma_busy,
+            "traffic": traffic, "mfma_busy_frac": mfma_busy, "pmc_commit": pmc_commit, "pmc_error": pmc_error,
             "shader_clock_mhz": mhz, "frac_of_peak_at_that_clock": (ach / (MFMA_BF16_PEAK * mhz / PEAK_CLOCK_MHZ)) if mhz else None,
             "clock_note": "shader clock measured inside the kernel (s_memtime / s_memrealtime of workgroup 0, time-weighted over the launches); "
                           "`peak` is the guide's dense bf16 figure at %d MHz" % PEAK_CLOCK_MHZ,
             "traffic_note": "HBM bytes per launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) and SQ_VALU_MFMA_BUSY_CYCLES / "
-                            "available SIMD cycles, headline shapes, from profiles/%s" % src}
+                            "available SIMD cycles of the same kernels inside this script's train step, from profiles/%s" % src}
 
 
 def cpu_baseline(budget_s=12.0):
@@ -173,6 +186,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the live per-launch timing of the dominant kernel (profiling runs)")
     ap.add_argument("--workload", choices=["fixed", "varwidth", "deep"], default="fixed",
                     help="fixed = BASELINE configs[1] (the headline metric); varwidth = configs[3] (W in [80,320] padded per "
                          "batch); deep = configs[4] (ResNet-34-style extractor + 2 x BiLSTM(512 per direction), 96 classes, bs=32/GPU)")
@@ -298,10 +312,11 @@ def main():
             line.pop("model_tflops_per_gpu")
         # the timed number above is complete at this point: a failure in the two side measurements must not cost the line (it is
         # reported inside the line instead of being swallowed)
-        try:
-            line["roofline"] = conv_roofline(eng, device)
-        except Exception as e:              # noqa: BLE001
-            line["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if not args.no_roofline:
+            try:
+                line["roofline"] = conv_roofline(eng, device)
+            except Exception as e:              # noqa: BLE001
+                line["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()

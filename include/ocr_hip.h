@@ -79,8 +79,6 @@ int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int Nb, int W, i
 int ocr_conv3x3_accum_supported(int Nb, int W, int H, int Cin, int Cout);
 /* diagnostic: workgroup 0 of the halo convolution kernel stamps {shader clock counter, 100 MHz wall clock} at entry and exit into
  * dbg (device int64[4]; NULL = off) */
-/* diagnostic: s_memtime stamps of workgroup 0 of conv_k2_kernel (device int64 [8 waves][80 steps][6], NULL = off) */
-int ocr_conv_k2_debug(void* dbg);
 int ocr_conv_halo_clock_debug(void* dbg);
 /* conv3x3 + bias + ReLU AND the max-pool behind it from one epilogue (LSTM_train.py:26-33): y [Nb,W,H,Cout] and pooled
  * [Nb, W/kw, H/kh, Cout]; (kw, kh) = (1, 2) (feature axis) or (2, 2).  ocr_conv3x3_pool_supported() != 0 tells whether the shape is

@@ -16,19 +16,11 @@
 // (16 KiB per wave, the stages are dead by then) and finishes the other half (bias / ReLU / mask / accumulate / fused max-pool
 // epilogue as in conv_halo).
 //
-// Schedule: the two waves of a SIMD (w, w + 4) run half a step apart, separated by workgroup barriers (two per step):
-//     segment 2s     : waves 0-3  LOAD(s) = DMA issue for step s + 2, fragment addresses, the 12 fragment reads of step s
-//                      waves 4-7  COMP(s - 1) = 32 MFMAs (s_setprio 1) on the fragments they read in segment 2s - 1
-//     segment 2s + 1 : waves 0-3  COMP(s),  waves 4-7  LOAD(s)
-// so every SIMD has one wave on the matrix pipe and one on the LDS / DMA / VALU pipes at all times, and nothing a wave waits
-// for was issued less than a segment ago:
-//   * weight tiles: FOUR stages, tile s + 2 is streamed while tiles s and s + 1 are read; its stage held tile s - 2, whose last
-//     readers (waves 4-7, segment 2s - 3) completed their reads before segment 2s - 2 began — no read is ever in flight on a
-//     stage that is being overwritten, although the reads of a LOAD segment are only waited for AFTER the barrier that ends it;
-//   * halo tiles: two stages, the PI pieces per wave of chunk c + 1 are issued one per step at taps 1 .. PI of chunk c (never at
-//     tap 0: the previous chunk's last reads may still be in flight then);
-//   * every wave retires, at the end of segment 2s + 1, everything it issued before its LOAD(s) (counted vmcnt = the pieces of
-//     LOAD(s)); the barrier there publishes tile s + 1 and any halo piece one step after its issue.
+// Schedule (fourth version; what was measured on the way is in DESIGN section 3): the two waves of a SIMD (w, w + 4) run half a step
+// apart — waves 0-3 do LOAD(s) = 12 fragment reads + DMA issue for step s + 2, then COMP(s) = 32 MFMAs (s_setprio 1) with the NEXT
+// step's fragment addresses computed beside them; waves 4-7 do COMP(s - 1) on the fragments they read in the previous interval, then
+// LOAD(s) — with ONE workgroup barrier per step: see the comment at `interval` in the kernel.  Weight tiles have four stages (three
+// for the 512-pixel tiles), halo tiles two; DMA pieces are retired with counted vmcnt one interval after their issue.
 // DMA addressing: buffer_load ... lds through a buffer descriptor — per piece a loop-invariant 32-bit lane offset and a scalar
 // offset that advances per step, no per-step vector arithmetic (the flat-pointer form cost 150-260 issue cycles per piece in
 // conv_halo); rows that do not exist (n >= N, pixels outside [0, M), the zero rows behind the halo) carry an out-of-range lane
@@ -48,7 +40,6 @@ struct K2Args {
     int abl;                              // timing ablations (wrong results; only in `make EXPERIMENTS=1` builds, OCR_K2_ABL): 1 no DMA after the
 };                                        // prologue, 2 no fragment reads, 4 no MFMAs
 
-__device__ long long* k2_dbg;             // diagnostic: s_memtime stamps of workgroup 0 (ocr_conv_k2_debug)
 typedef __attribute__((address_space(3))) void* lptr_t;
 #define K2_OOB 0x80000000u                // lane offset of a row that does not exist: beyond any descriptor's range
 
@@ -56,7 +47,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int FM /* 16-pixel fragments per wave: 8 or 4 */, int BN /* channels per tile: 128 (waves 2 pixel x 2 channel x 2 K) or 64
                                                                           (4 pixel x 1 channel x 2 K: 512- / 256-pixel tiles) */,
-          int NST /* weight stages: 4, or 3 where the LDS is short (512-pixel tiles) */, bool DBG>
+          int NST /* weight stages: 4, or 3 where the LDS is short (512-pixel tiles) */>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_k2_kernel(K2Args g, int NRpad /* halo rows incl. the zero rows, a multiple of 8 */) {
     constexpr int NW = 8, FN = 4;
     constexpr int WN = BN / 64, WMW = 4 / WN;           // waves along channels / pixels (per K half)
@@ -167,68 +158,67 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kh == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }        // segment 0: waves 4-7 have nothing to multiply yet
 
-    int tap = 0, chunk = 0, qs = 0 /* s % NST */;
-    for (int s = 0; s < nsteps; ++s) {
-        long long st[6] = {0, 0, 0, 0, 0, 0};
-        if (DBG) st[0] = __builtin_amdgcn_s_memtime();
-        // ================================================================ LOAD(s): fragment reads first (they complete under the DMA issue)
-        const int shift = (H + 1) + (tap / 3 - 1) * H + (tap % 3 - 1);       // halo row of local pixel 0 for this tap
-        const unsigned qa = qfrag0 + qs * QB;
-        // pixel fragments: row (wm*WM + b*16 + frow + shift), chunk position ((kh*4 + fq) ^ (row & 7)); lanes whose tap falls outside
-        // the image read a zero row (NR / NR + 1: the one with the real row's parity, at the real row's position in its 256 bytes, so
-        // the redirected lanes keep the banks the swizzle gave them)
+    // Fragment addresses of a step are computed in the shadow of an MFMA segment (the vector ALU runs beside the matrix pipe, and the 40
+    // address instructions were a third of the load segment); the nine taps are unrolled, so everything that depends on the tap alone
+    // is an immediate or a scalar.
+    unsigned pa[FM];                                    // pixel-fragment addresses of the step about to be loaded
+    u32x4 afr[FN], bfr[FM];                             // fragments: waves 4-7 carry them across the barrier
+    auto gen_addr = [&](auto tapc, int chunk) {
+        constexpr int TAP = decltype(tapc)::value;
+        // halo row of local pixel 0 for this tap; pixel fragment b: row (wm*WM + b*16 + frow + shift), chunk position
+        // ((kh*4 + fq) ^ (row & 7)); lanes whose tap falls outside the image read a zero row (NR / NR + 1: the one with the real row's
+        // parity, at the real row's position in its 256 bytes, so the redirected lanes keep the banks the swizzle gave them)
+        const int shift = (H + 1) + (TAP / 3 - 1) * H + (TAP % 3 - 1);
         const unsigned psw = ((((unsigned)kh << 2) | (unsigned)fq) ^ (unsigned)((frow + shift) & 7)) << 4;
         const unsigned pbase = prow0 + (chunk & 1) * PBYTES + shift * 128 + psw;
         const unsigned zoff = lds0 + (chunk & 1) * PBYTES + NR * 128 + (((frow + shift) & 1) << 7) + psw;
-        u32x4 afr[FN], bfr[FM];
+#pragma unroll
+        for (int b = 0; b < FM; ++b) pa[b] = (vmask[b] & (1u << TAP)) ? pbase + b * 2048 : zoff;
+#pragma unroll
+        for (int b = 0; b < FM; ++b) asm volatile("" : "+v"(pa[b]));        // materialise them HERE (the compiler otherwise sinks them to their use)
+    };
+    int qs = 0 /* s % NST */, s = 0;
+    // LOAD(s): the 12 fragment reads of step s, then the DMA issue; returns the number of pieces issued
+    auto load = [&](auto tapc, int chunk) -> int {
+        constexpr int TAP = decltype(tapc)::value;
+        const unsigned qa = qfrag0 + qs * QB;
         if (abl & 2) {
 #pragma unroll
             for (int a = 0; a < FN; ++a) asm volatile("" : "=v"(afr[a]));
 #pragma unroll
-            for (int b = 0; b < FM; ++b) asm volatile("" : "=v"(bfr[b]));
+            for (int b = 0; b < FM; ++b) asm volatile("" : "=v"(bfr[b]) : "v"(pa[b]));
         } else {
 #pragma unroll
             for (int a = 0; a < FN; ++a)
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[a]) : "v"(qa), "n"(a * 2048));
 #pragma unroll
-            for (int b = 0; b < FM; ++b) {
-                const unsigned pa = ((vmask[b] >> tap) & 1u) ? pbase + b * 2048 : zoff;
-                asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[b]) : "v"(pa));
-            }
+            for (int b = 0; b < FM; ++b)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[b]) : "v"(pa[b]));
         }
-        if (DBG) st[1] = __builtin_amdgcn_s_memtime();
-        // DMA: the weight tile of step s + 2, and of the next chunk's halo piece tap - 1 (taps 1 .. 8; a ninth piece rides with the eighth)
+        // DMA: the weight tile of step s + 2, and this step's share of the next chunk's halo pieces
         const bool more_q = s + 2 < nsteps && !(abl & 1);
-        int younger = more_q ? QI : 0;
-        {
-            int t2 = tap + 2, c2 = chunk;
-            if (t2 >= 9) { t2 -= 9; ++c2; }
-            int q2 = qs + 2; if (q2 >= NST) q2 -= NST;
-            if (more_q) load_q(t2 * C + c2 * 64, q2);
-            if (tap >= 1 && tap <= PIMAX && chunk + 1 < nchunks && !(abl & 1)) {
-                younger += load_pj(chunk + 1, (chunk + 1) & 1, tap - 1);
-                if (PIMAX > 8 && tap == 8) younger += load_pj(chunk + 1, (chunk + 1) & 1, 8);
+        int issued = more_q ? QI : 0;
+        constexpr int T2 = (TAP + 2) % 9;
+        const int c2 = chunk + (TAP + 2 >= 9 ? 1 : 0);
+        int q2 = qs + 2; if (q2 >= NST) q2 -= NST;
+        if (more_q) load_q(T2 * C + c2 * 64, q2);
+        // PPT pieces per step at taps 1 .. 5: the last piece is issued four steps before tap 0 of the next chunk reads the tile (a piece
+        // is only known to have landed one step after its issue — the counted wait covers what was issued BEFORE the latest LOAD)
+        constexpr int PPT = (PIMAX + 4) / 5;
+        if (TAP >= 1 && TAP <= 5 && chunk + 1 < nchunks && !(abl & 1)) {
+#pragma unroll
+            for (int u = 0; u < PPT; ++u) {
+                constexpr int J0 = TAP >= 1 ? (TAP - 1) * PPT : 0;
+                if (J0 + u < PIMAX) issued += load_pj(chunk + 1, (chunk + 1) & 1, J0 + u);
             }
         }
-        // pieces of this wave younger than tile s + 1 = what this LOAD issued
-        auto vmwait = [&]() {
-            switch (younger) {
-                case 0: K2_VMWAIT(0); break; case 1: K2_VMWAIT(1); break; case 2: K2_VMWAIT(2); break; case 3: K2_VMWAIT(3); break;
-                default: K2_VMWAIT(4); break;
-            }
-        };
-        if (DBG) st[2] = __builtin_amdgcn_s_memtime();
-        // every fragment read is complete before the barrier: a stage is never overwritten while a read of it is in flight
+        return issued;
+    };
+    // COMP: 32 MFMAs on the fragments in registers, with the fragment addresses of step (TAP, chunk) generated in their shadow
+    auto comp = [&](auto tapc, int chunk) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (kh == 1) vmwait();
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (DBG) st[3] = __builtin_amdgcn_s_memtime();
-        // ================================================================ COMP(s)
         __builtin_amdgcn_s_setprio(1);
         if (!(abl & 4)) {
 #pragma unroll
@@ -243,22 +233,63 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int b = 0; b < FM; ++b) asm volatile("" :: "v"(bfr[b]));
         }
+        gen_addr(tapc, chunk);
+        // one MFMA, then up to two of the address instructions, and so on (the compiler otherwise puts all of them in front)
+#pragma unroll
+        for (int i = 0; i < FN * FM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (DBG) st[4] = __builtin_amdgcn_s_memtime();
-        if (kh == 0) vmwait();
+    };
+    auto vmwait = [&](int younger) {                    // retire everything this wave issued before its latest LOAD
+        switch (younger) {
+            case 0: K2_VMWAIT(0); break; case 1: K2_VMWAIT(1); break; case 2: K2_VMWAIT(2); break; case 3: K2_VMWAIT(3); break;
+            default: K2_VMWAIT(4); break;
+        }
+    };
+    // One interval = one K step, closed by ONE workgroup barrier.  Waves 0-3 run LOAD(s) then COMP(s); waves 4-7 run COMP(s - 1) (on
+    // the fragments they loaded in the previous interval) then LOAD(s): the two waves of a SIMD use the matrix pipe in opposite halves
+    // of the interval, and nothing forces a load segment and an MFMA segment to take equally long (the first versions had a second
+    // barrier in the middle: the interval then cost twice the LONGER segment, and the load segment is the longer one).
+    //   * tile s + 2 is streamed into the stage of tile s + 2 - NST: with four stages its last readers finished an interval ago; with
+    //     three (512-pixel tiles) waves 4-7 read it at the END of the previous interval, so they wait for those reads before the barrier;
+    //   * every wave retires, before the barrier of interval s, what it issued before this interval (counted vmcnt); the barrier
+    //     publishes tile s + 1 — issued during interval s - 1 — and any halo piece one interval after its issue.
+    auto interval = [&](auto khc, auto tapc, int chunk) {
+        constexpr int KH = decltype(khc)::value, TAP = decltype(tapc)::value;
+        int issued;
+        if (KH == 0) {
+            issued = load(tapc, chunk);
+            comp(std::integral_constant<int, (TAP + 1) % 9>{}, chunk + (TAP == 8 ? 1 : 0));       // addresses of step s + 1
+        } else {
+            if (s > 0) comp(tapc, chunk);                // step s - 1, and the addresses of step s
+            issued = load(tapc, chunk);
+            if (NST < 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        vmwait(issued);
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (DBG && blockIdx.x == 0 && lane == 0 && k2_dbg != nullptr && s < 80) {
-            st[5] = __builtin_amdgcn_s_memtime();
-#pragma unroll
-            for (int i = 0; i < 6; ++i) k2_dbg[(wave * 80 + s) * 6 + i] = st[i];
-        }
-        if (++tap == 9) { tap = 0; ++chunk; }
+        ++s;
         if (++qs == NST) qs = 0;
-    }
-    if (kh == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }      // matches the extra barrier waves 4-7 took at the start
+    };
+    // the two wave groups run separate copies of the loop (a per-interval branch on kh made the register allocator keep both groups'
+    // live ranges: a thousand spills); both copies execute the same number of barriers
+    auto run = [&](auto khc) {
+        gen_addr(std::integral_constant<int, 0>{}, 0);
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            interval(khc, std::integral_constant<int, 0>{}, chunk); interval(khc, std::integral_constant<int, 1>{}, chunk);
+            interval(khc, std::integral_constant<int, 2>{}, chunk); interval(khc, std::integral_constant<int, 3>{}, chunk);
+            interval(khc, std::integral_constant<int, 4>{}, chunk); interval(khc, std::integral_constant<int, 5>{}, chunk);
+            interval(khc, std::integral_constant<int, 6>{}, chunk); interval(khc, std::integral_constant<int, 7>{}, chunk);
+            interval(khc, std::integral_constant<int, 8>{}, chunk);
+        }
+        if (decltype(khc)::value == 1) comp(std::integral_constant<int, 0>{}, 0);      // the last step's MFMAs (the addresses generated beside them are unused)
+    };
+    if (kh == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
 
     // ---- the two K halves meet: a wave keeps the pixel fragments [kh*FM/2, (kh+1)*FM/2) and hands the others to its partner
     // (every MFMA and every fragment read of the workgroup is complete: all waves have passed the last barrier).
@@ -349,36 +380,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (kh) tail(std::integral_constant<int, 1>{}); else tail(std::integral_constant<int, 0>{});
 }
 
-static bool g_k2_dbg = false;
-extern "C" int ocr_conv_k2_debug(void* dbg /* device int64[8 waves][80 steps][6] or NULL */) {
-    long long* q = (long long*)dbg;
-    g_k2_dbg = q != nullptr;
-    return hipMemcpyToSymbol(HIP_SYMBOL(k2_dbg), &q, sizeof(q)) == hipSuccess ? OCR_OK : OCR_ERR_MEMOPS;
-}
-
 // tile configurations: A 256 x 128 (4 weight stages), B 128 x 128, C 512 x 64 (3 stages: the two 512-pixel halo stages take 135 KB),
 // D 256 x 64
-template <int FM, int BN, int NST, bool DBG>
-static int launch_k2_(const K2Args& g, hipStream_t stream) {
+template <int FM, int BN, int NST>
+static int launch_k2(const K2Args& g, hipStream_t stream) {
     constexpr int BM = (4 / (BN / 64)) * FM * 16;
     const int NRpad = (BM + 2 * g.cH + 4 + 7) / 8 * 8;             // needed rows + two zero rows, in 8-row DMA pieces
     const int lds = 2 * NRpad * 128 + NST * BN * 128;               // halo stages, weight stages (the K-half exchange reuses them)
     if (lds > 163840 || lds < 8 * FM * 2048) return -1;
     static int attr = 0;
     if (lds > attr) {
-        if (hipFuncSetAttribute((const void*)conv_k2_kernel<FM, BN, NST, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC;
+        if (hipFuncSetAttribute((const void*)conv_k2_kernel<FM, BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC;
         attr = lds;
     }
     const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
-    conv_k2_kernel<FM, BN, NST, DBG><<<mt * nt, 512, lds, stream>>>(g, NRpad);
+    conv_k2_kernel<FM, BN, NST><<<mt * nt, 512, lds, stream>>>(g, NRpad);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
-template <int FM, int BN, int NST>
-static int launch_k2(const K2Args& g, hipStream_t stream) {
-    return g_k2_dbg ? launch_k2_<FM, BN, NST, true>(g, stream) : launch_k2_<FM, BN, NST, false>(g, stream);
-}
-
 // Which tile, if any?  Every candidate moves (BN x 128 + (BM + 2H + 2) x 128 / 9) bytes from the L2 into the CU per K step of
 // 2 x BM x BN x 64 flop, and a CU takes ~10.5 B / clock whatever the source (tools/bin/dma_probe: profiles/r03d_dma_fill_probe.txt) —
 // that, not the matrix pipe, bounds these kernels — so the candidates are tried in the order of their bytes per flop: C (16.2 KB per

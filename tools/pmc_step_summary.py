@@ -1,0 +1,53 @@
+"""tools/rocpd_pmc.py text (per-kernel counter averages of the four --pmc passes over bench.py) -> profiles/rNN_pmc_step.json: per kernel
+HBM read bytes (FETCH_SIZE x 2: MI355X_MICROARCH.md — gfx950 reports half of wide coalesced reads; FETCH_SIZE / WRITE_SIZE are in KB),
+write bytes (as reported, uncalibrated), matrix-pipe occupancy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) with kernel
+cycles = GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs), L2 hit rate, LDS conflict share, VALU instructions per MFMA — together with
+the git commit and the kernel symbols, so that bench.py can refuse numbers taken from another build.
+usage: python tools/pmc_step_summary.py <txt> <repo root>"""
+import json
+import re
+import subprocess
+import sys
+
+
+def main():
+    kern, cur = {}, None
+    for line in open(sys.argv[1]):
+        m = re.match(r'(\S.*?)\s+launches=(\d+) avg_us=([\d.]+)', line)
+        if m:
+            cur = kern.setdefault(m.group(1), {'launches': int(m.group(2)), 'avg_us': float(m.group(3)), 'counters': {}})
+            continue
+        m = re.match(r'\s+(\S+)\s+avg ([\d.e+-]+)', line)
+        if m and cur is not None:
+            cur['counters'][m.group(1)] = float(m.group(2))
+    try:
+        commit = subprocess.check_output(['git', '-C', sys.argv[2], 'rev-parse', '--short', 'HEAD'], text=True).strip()
+    except Exception:
+        commit = None
+    try:      # the GPU box gets a snapshot without .git: the commit travels in a file written before the call
+        commit = commit or open(sys.argv[2] + '/gpurun_out/.commit').read().strip()
+    except Exception:
+        pass
+    rows = []
+    for name, k in kern.items():
+        c = k['counters']
+        g = lambda n: c.get(n)
+        row = {'symbol': name.replace('.kd', ''), 'short': re.sub(r'^_Z\d+', '', name)[:60], 'launches': k['launches'], 'avg_us': k['avg_us']}
+        if g('FETCH_SIZE') is not None: row['read_mb'] = 2.0 * g('FETCH_SIZE') * 1024 / 1e6
+        if g('WRITE_SIZE') is not None: row['write_mb'] = g('WRITE_SIZE') * 1024 / 1e6
+        if g('SQ_VALU_MFMA_BUSY_CYCLES') is not None and g('GRBM_GUI_ACTIVE'):
+            row['mfma_busy_frac'] = g('SQ_VALU_MFMA_BUSY_CYCLES') / (1024.0 * g('GRBM_GUI_ACTIVE') / 8.0)
+        if g('SQ_INSTS_MFMA'): row['valu_per_mfma'] = (g('SQ_INSTS_VALU') or 0.0) / g('SQ_INSTS_MFMA')
+        if g('SQ_WAVE_CYCLES'):
+            row['wait_any_frac'] = (g('SQ_WAIT_ANY') or 0.0) / g('SQ_WAVE_CYCLES'); row['wait_inst_frac'] = (g('SQ_WAIT_INST_ANY') or 0.0) / g('SQ_WAVE_CYCLES')
+        if g('TCC_HIT_sum') is not None: row['l2_hit_rate'] = g('TCC_HIT_sum') / max(1.0, g('TCC_HIT_sum') + (g('TCC_MISS_sum') or 0.0))
+        if g('SQ_LDS_IDX_ACTIVE'): row['lds_conflict_frac'] = (g('SQ_LDS_BANK_CONFLICT') or 0.0) / g('SQ_LDS_IDX_ACTIVE')
+        rows.append(row)
+    rows.sort(key=lambda r: -r['launches'] * r['avg_us'])
+    print(json.dumps({'source': 'rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* + GRBM_GUI_ACTIVE | LDS + TCC; --kernel-trace only) over '
+                                'bench.py --no-graphs --steps 3 --warmup 2 (5 eager train steps + the side loops of the line); FETCH_SIZE doubled '
+                                '(gfx950 correction of MI355X_MICROARCH.md), WRITE_SIZE uncalibrated', 'commit': commit, 'kernels': rows}, indent=1))
+
+
+if __name__ == '__main__':
+    main()
