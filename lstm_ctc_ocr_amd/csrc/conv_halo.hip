@@ -26,7 +26,7 @@ struct HaloArgs {
     bf16_t* out; const float* bias; const bf16_t* mask; int flags;
     bf16_t* pool; int pool_kind;          // max-pool of the (ReLU'd) output written by the same epilogue: 0 none, 1 feature pairs (1 x 2), 2 2 x 2
     int stagger, stagger_bit;             // experiment OCR_HALO_STAGGER=units,bit: workgroups whose in-XCD index has `bit` set start `units` x 64 clocks late
-    int prio;                             // experiment OCR_HALO_PRIO=1: s_setprio 1 around the MFMA clusters (guide T5)
+    int prio;                             // OCR_HALO_PRIO (default 1): s_setprio 1 around the MFMA clusters (guide T5)
 };
 
 __device__ u32x4 igh_zero_page[4];
@@ -321,7 +321,7 @@ static int launch_halo(const HaloArgs& g, hipStream_t stream) {
 
 int k2_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
                     const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind);
-#define K2_DEFAULT 0            // until measured faster on hardware (round 3)
+#define K2_DEFAULT 1            // measured (round 3, profiles/r03j_conv_k2_final.log): -8 % over the ten launches of the headline step
 
 // -1 = shape not covered (caller falls back to igemm.hip / gemm.hip)
 int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
@@ -350,7 +350,7 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
     static int stag = -1, stag_bit = 32;                 // experiment knob OCR_HALO_STAGGER=units[,bit] (units of 64 clocks; default off)
     if (stag < 0) { const char* e = getenv("OCR_HALO_STAGGER"); stag = e ? atoi(e) : 0; const char* c = e ? strchr(e, ',') : nullptr; if (c) stag_bit = atoi(c + 1); if (stag < 0) stag = 0; }
     static int prio = -1;
-    if (prio < 0) { const char* e = getenv("OCR_HALO_PRIO"); prio = e ? atoi(e) : 0; }
+    if (prio < 0) { const char* e = getenv("OCR_HALO_PRIO"); prio = e ? atoi(e) : 1; }      // measured: 451 against 458 us over the ten launches
     HaloArgs g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, stag, stag_bit, prio};
 #ifdef OCR_EXPERIMENTS      // measured and rejected in round 2: dense = equal, wide = 27 % slower
     static int dense = -1;                               // A/B knob OCR_HALO_DENSE=1: 8 waves per 128-pixel tile (4 waves per SIMD with two workgroups per CU)

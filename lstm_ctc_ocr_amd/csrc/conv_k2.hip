@@ -40,6 +40,20 @@ struct K2Args {
     int abl;                              // timing ablations (wrong results; only in `make EXPERIMENTS=1` builds, OCR_K2_ABL): 1 no DMA after the
 };                                        // prologue, 2 no fragment reads, 4 no MFMAs
 
+#ifdef OCR_EXPERIMENTS
+// diagnostic (experiments build, OCR_K2_ABL & 8): s_memtime stamps of workgroup 0, kept in spare LDS behind the stages (no global store
+// enters the vmcnt queue of the pipeline) and copied out at the end: dbg[(wave * 80 + interval) * 4 + {0 interval start, 1 MFMAs start,
+// 2 MFMAs done, 3 in front of the barrier}]
+__device__ unsigned* k2_dbg;
+extern "C" int ocr_conv_k2_debug(void* dbg) {
+    unsigned* q = (unsigned*)dbg;
+    return hipMemcpyToSymbol(HIP_SYMBOL(k2_dbg), &q, sizeof(q)) == hipSuccess ? OCR_OK : OCR_ERR_MEMOPS;
+}
+#define K2_STAMP(slot) do { if ((abl & 8) && blockIdx.x == 0 && s < 80) { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); \
+        if (lane == 0) ((unsigned*)(smem + 2 * PBYTES + NST * QB))[(wave * 80 + s) * 4 + (slot)] = t_; } } while (0)
+#else
+#define K2_STAMP(slot) do { } while (0)
+#endif
 typedef __attribute__((address_space(3))) void* lptr_t;
 #define K2_OOB 0x80000000u                // lane offset of a row that does not exist: beyond any descriptor's range
 
@@ -47,7 +61,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int FM /* 16-pixel fragments per wave: 8 or 4 */, int BN /* channels per tile: 128 (waves 2 pixel x 2 channel x 2 K) or 64
                                                                           (4 pixel x 1 channel x 2 K: 512- / 256-pixel tiles) */,
-          int NST /* weight stages: 4, or 3 where the LDS is short (512-pixel tiles) */>
+          int NST = 4 /* weight stages */>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_k2_kernel(K2Args g, int NRpad /* halo rows incl. the zero rows, a multiple of 8 */) {
     constexpr int NW = 8, FN = 4;
     constexpr int WN = BN / 64, WMW = 4 / WN;           // waves along channels / pixels (per K half)
@@ -159,10 +173,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    // Fragment addresses of a step are computed in the shadow of an MFMA segment (the vector ALU runs beside the matrix pipe, and the 40
-    // address instructions were a third of the load segment); the nine taps are unrolled, so everything that depends on the tap alone
-    // is an immediate or a scalar.
-    unsigned pa[FM];                                    // pixel-fragment addresses of the step about to be loaded
+    // The nine taps are unrolled, so everything that depends on the tap alone is an immediate, a scalar or a loop-invariant lane mask.
+    unsigned pa[FM];                                    // pixel-fragment addresses of the step being loaded
     u32x4 afr[FN], bfr[FM];                             // fragments: waves 4-7 carry them across the barrier
     auto gen_addr = [&](auto tapc, int chunk) {
         constexpr int TAP = decltype(tapc)::value;
@@ -175,13 +187,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const unsigned zoff = lds0 + (chunk & 1) * PBYTES + NR * 128 + (((frow + shift) & 1) << 7) + psw;
 #pragma unroll
         for (int b = 0; b < FM; ++b) pa[b] = (vmask[b] & (1u << TAP)) ? pbase + b * 2048 : zoff;
-#pragma unroll
-        for (int b = 0; b < FM; ++b) asm volatile("" : "+v"(pa[b]));        // materialise them HERE (the compiler otherwise sinks them to their use)
     };
     int qs = 0 /* s % NST */, s = 0;
     // LOAD(s): the 12 fragment reads of step s, then the DMA issue; returns the number of pieces issued
     auto load = [&](auto tapc, int chunk) -> int {
         constexpr int TAP = decltype(tapc)::value;
+        gen_addr(tapc, chunk);
         const unsigned qa = qfrag0 + qs * QB;
         if (abl & 2) {
 #pragma unroll
@@ -215,9 +226,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         return issued;
     };
-    // COMP: 32 MFMAs on the fragments in registers, with the fragment addresses of step (TAP, chunk) generated in their shadow
-    auto comp = [&](auto tapc, int chunk) {
+    // COMP: the MFMAs on the fragments in registers — nothing else: address arithmetic interleaved with them (third version) doubled the
+    // time of the MFMA burst (stamps: 32 MFMAs 950 instead of 516 clocks; the in-order wave waits on every s_nop / dependency in between)
+    auto comp = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        K2_STAMP(1);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
         if (!(abl & 4)) {
@@ -233,15 +246,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int b = 0; b < FM; ++b) asm volatile("" :: "v"(bfr[b]));
         }
-        gen_addr(tapc, chunk);
-        // one MFMA, then up to two of the address instructions, and so on (the compiler otherwise puts all of them in front)
-#pragma unroll
-        for (int i = 0; i < FN * FM; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        K2_STAMP(2);
     };
     auto vmwait = [&](int younger) {                    // retire everything this wave issued before its latest LOAD
         switch (younger) {
@@ -260,15 +267,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto interval = [&](auto khc, auto tapc, int chunk) {
         constexpr int KH = decltype(khc)::value, TAP = decltype(tapc)::value;
         int issued;
+        K2_STAMP(0);
         if (KH == 0) {
             issued = load(tapc, chunk);
-            comp(std::integral_constant<int, (TAP + 1) % 9>{}, chunk + (TAP == 8 ? 1 : 0));       // addresses of step s + 1
+            comp();
         } else {
-            if (s > 0) comp(tapc, chunk);                // step s - 1, and the addresses of step s
+            if (s > 0) comp();                           // step s - 1
             issued = load(tapc, chunk);
             if (NST < 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         vmwait(issued);
+        if (KH == 0) K2_STAMP(3);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -279,7 +288,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the two wave groups run separate copies of the loop (a per-interval branch on kh made the register allocator keep both groups'
     // live ranges: a thousand spills); both copies execute the same number of barriers
     auto run = [&](auto khc) {
-        gen_addr(std::integral_constant<int, 0>{}, 0);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             interval(khc, std::integral_constant<int, 0>{}, chunk); interval(khc, std::integral_constant<int, 1>{}, chunk);
             interval(khc, std::integral_constant<int, 2>{}, chunk); interval(khc, std::integral_constant<int, 3>{}, chunk);
@@ -287,9 +295,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             interval(khc, std::integral_constant<int, 6>{}, chunk); interval(khc, std::integral_constant<int, 7>{}, chunk);
             interval(khc, std::integral_constant<int, 8>{}, chunk);
         }
-        if (decltype(khc)::value == 1) comp(std::integral_constant<int, 0>{}, 0);      // the last step's MFMAs (the addresses generated beside them are unused)
+        if (decltype(khc)::value == 1) comp();          // the last step's MFMAs
     };
     if (kh == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
+#ifdef OCR_EXPERIMENTS
+    if ((abl & 8) && blockIdx.x == 0 && k2_dbg != nullptr) {
+        __syncthreads();
+        for (int i = tid; i < 8 * 80 * 4; i += 512) k2_dbg[i] = ((const unsigned*)(smem + 2 * PBYTES + NST * QB))[i];
+        __syncthreads();
+    }
+#endif
 
     // ---- the two K halves meet: a wave keeps the pixel fragments [kh*FM/2, (kh+1)*FM/2) and hands the others to its partner
     // (every MFMA and every fragment read of the workgroup is complete: all waves have passed the last barrier).
@@ -380,14 +395,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (kh) tail(std::integral_constant<int, 1>{}); else tail(std::integral_constant<int, 0>{});
 }
 
-// tile configurations: A 256 x 128 (4 weight stages), B 128 x 128, C 512 x 64 (3 stages: the two 512-pixel halo stages take 135 KB),
-// D 256 x 64
-template <int FM, int BN, int NST>
+// tile configurations: A = 256 pixels x 128 channels (waves 2 x 2 x 2 K), D = 256 x 64 (4 x 1 x 2 K: layers whose 256 x 128 tiles would not
+// fill the chip); 512 x 64 and 128 x 128 were built and measured too (profiles/r03e / r03h_conv*.log): never faster than these two
+template <int FM, int BN, int NST = 4>
 static int launch_k2(const K2Args& g, hipStream_t stream) {
     constexpr int BM = (4 / (BN / 64)) * FM * 16;
     const int NRpad = (BM + 2 * g.cH + 4 + 7) / 8 * 8;             // needed rows + two zero rows, in 8-row DMA pieces
-    const int lds = 2 * NRpad * 128 + NST * BN * 128;               // halo stages, weight stages (the K-half exchange reuses them)
+    int lds = 2 * NRpad * 128 + NST * BN * 128;                     // halo stages, weight stages (the K-half exchange reuses them)
     if (lds > 163840 || lds < 8 * FM * 2048) return -1;
+#ifdef OCR_EXPERIMENTS
+    if (lds + 10240 <= 163840) lds += 10240; else if (g.abl & 8) return -1;      // room for the stamps
+#endif
     static int attr = 0;
     if (lds > attr) {
         if (hipFuncSetAttribute((const void*)conv_k2_kernel<FM, BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC;
@@ -398,29 +416,24 @@ static int launch_k2(const K2Args& g, hipStream_t stream) {
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
-// Which tile, if any?  Every candidate moves (BN x 128 + (BM + 2H + 2) x 128 / 9) bytes from the L2 into the CU per K step of
-// 2 x BM x BN x 64 flop, and a CU takes ~10.5 B / clock whatever the source (tools/bin/dma_probe: profiles/r03d_dma_fill_probe.txt) —
-// that, not the matrix pipe, bounds these kernels — so the candidates are tried in the order of their bytes per flop: C (16.2 KB per
-// 4.2 MFLOP), A (20.5), D (24.2), B (36.6); a candidate must cover the shape, fit the LDS and fill the chip (>= 224 tiles).
-// Layers with fewer than OCR_K2_MINSTEPS K steps stay on conv_halo: with 9-18 steps a tile is mostly prologue and epilogue, and
-// conv_halo's two independent workgroups per CU overlap those (measured: conv2 33 against 42 us, conv3_1 27 against 30).
+// Which tile, if any?  A where its tiles fill the chip (>= 224), else D; layers with fewer than OCR_K2_MINSTEPS K steps (default 36)
+// stay on conv_halo: with 9-18 steps a tile is mostly prologue and epilogue, and conv_halo's two independent workgroups per CU overlap
+// those (measured: conv2 33 against 40 us, conv3_1 26.6 against 27.6).  OCR_K2_CFG = A / D forces one tile where it covers the shape.
 static int k2_choose(long M, int H, int Cin, int Cout) {
     if ((Cin & 63) || (Cout & 63) || M < 4096 || H > 16 || H < 1) return 0;
     if (M * Cin * 2 >= 0x7fffffffL || (long)Cout * 9 * Cin * 2 >= 0x7fffffffL) return 0;   // 32-bit descriptor offsets
-    static int force = -1, minsteps = -1;          // A/B knobs: OCR_K2_CFG = A / B / C / D forces one tile where it covers the shape
-    if (force < 0) { const char* e = getenv("OCR_K2_CFG"); force = (e && e[0] >= 'A' && e[0] <= 'D') ? e[0] : 0; }
+    static int force = -1, minsteps = -1;
+    if (force < 0) { const char* e = getenv("OCR_K2_CFG"); force = (e && (e[0] == 'A' || e[0] == 'D')) ? e[0] : 0; }
     if (minsteps < 0) { const char* e = getenv("OCR_K2_MINSTEPS"); minsteps = e ? atoi(e) : 36; }
-    const char order[4] = {'C', 'A', 'D', 'B'};
-    for (int i = 0; i < 4; ++i) {
+    const char order[2] = {'A', 'D'};
+    for (int i = 0; i < 2; ++i) {
         const char c = order[i];
         if (force && c != force) continue;
-        const int bm = c == 'C' ? 512 : (c == 'B' ? 128 : 256), bn = (c == 'A' || c == 'B') ? 128 : 64, nst = c == 'C' ? 3 : 4;
+        const int bn = c == 'A' ? 128 : 64;
         if (Cout % bn) continue;
-        const int nrpad = (bm + 2 * H + 4 + 7) / 8 * 8;
-        if (2 * nrpad * 128 + nst * bn * 128 > 163840) continue;
         if (force) return c;
         if (9 * (Cin / 64) < minsteps) return 0;
-        if ((M + bm - 1) / bm * (Cout / bn) >= 224) return c;
+        if ((M + 255) / 256 * (Cout / bn) >= 224) return c;
     }
     return 0;
 }
@@ -434,10 +447,5 @@ int k2_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("OCR_K2_ABL"); abl = e ? atoi(e) : 0; }
     K2Args g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, abl};
-    switch (c) {
-        case 'A': return launch_k2<8, 128, 4>(g, stream);
-        case 'B': return launch_k2<4, 128, 4>(g, stream);
-        case 'C': return launch_k2<8, 64, 3>(g, stream);
-        default: return launch_k2<4, 64, 4>(g, stream);
-    }
+    return c == 'A' ? launch_k2<8, 128>(g, stream) : launch_k2<4, 64>(g, stream);
 }

@@ -24,8 +24,8 @@ def main():
         commit = subprocess.check_output(['git', '-C', sys.argv[2], 'rev-parse', '--short', 'HEAD'], text=True).strip()
     except Exception:
         commit = None
-    try:      # the GPU box gets a snapshot without .git: the commit travels in a file written before the call
-        commit = commit or open(sys.argv[2] + '/gpurun_out/.commit').read().strip()
+    try:      # the GPU box gets a snapshot without .git: the commit travels in .build_commit (git rev-parse --short HEAD > .build_commit before the call)
+        commit = commit or open(sys.argv[2] + '/.build_commit').read().strip()
     except Exception:
         pass
     rows = []
