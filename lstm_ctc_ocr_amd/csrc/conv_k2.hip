@@ -422,13 +422,19 @@ static int launch_k2(const K2Args& g, hipStream_t stream) {
 static int k2_choose(long M, int H, int Cin, int Cout) {
     if ((Cin & 63) || (Cout & 63) || M < 4096 || H > 16 || H < 1) return 0;
     if (M * Cin * 2 >= 0x7fffffffL || (long)Cout * 9 * Cin * 2 >= 0x7fffffffL) return 0;   // 32-bit descriptor offsets
-    static int force = -1, minsteps = -1;
+    static int force = -1, minsteps = -1, allow_a = -1;
     if (force < 0) { const char* e = getenv("OCR_K2_CFG"); force = (e && (e[0] == 'A' || e[0] == 'D')) ? e[0] : 0; }
     if (minsteps < 0) { const char* e = getenv("OCR_K2_MINSTEPS"); minsteps = e ? atoi(e) : 36; }
+    // OCR_K2_TILES = AD lets the dispatcher take tile A too.  Default D only: inside the train step tile A is SLOWER than conv_halo (59 against
+    // ~51 us per launch over its five layers, profiles/r03k_bench_kernel_stats.md; the whole step 1.461 against 1.435 ms) although it is 6 %
+    // faster when the same launch is repeated back to back (tools/kernel_bench.py) — one 8-wave workgroup per CU in lock step has nothing
+    // to run while a DMA piece arrives late from a cold L2, two independent workgroups per CU do
+    if (allow_a < 0) { const char* e = getenv("OCR_K2_TILES"); allow_a = (e && e[0] == 'A') ? 1 : 0; }
     const char order[2] = {'A', 'D'};
     for (int i = 0; i < 2; ++i) {
         const char c = order[i];
         if (force && c != force) continue;
+        if (!force && c == 'A' && !allow_a) continue;
         const int bn = c == 'A' ? 128 : 64;
         if (Cout % bn) continue;
         if (force) return c;

@@ -164,7 +164,8 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
     for (int s = 0; s < T; ++s) {
         const int dbgi = s;
         DBG_STAMP(0);
-        if (PROTO == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // last step's stores (incl. the slot refill) have landed
+        // last step's slot refill (and everything older) has landed: stores retire in issue order, the six issued behind it may stay in flight
+        if (PROTO == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         const bool active = nvalid && s < len;
         const int t = active ? (d == 0 ? s : len - 1 - s) : s;
         const int tprev = (d == 0) ? t - 1 : t + 1;
@@ -230,10 +231,39 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
         if (nvalid && kh == 0) {
             bf16_t* hdst = a.hout + row * (2L * U) + (long)d * U + ub * 16 + ul0;
             u32x2* rdst = (u32x2*)(gring + (unsigned)(s & (RING - 1)) * SLOT + wr0);
-            if (!active) {
+            if (PROTO == 4) {
+                // One store sequence for every lane (rows past their length store zeros / throw-away gate values into rows nobody reads):
+                // ring piece, slot refill, output row, the five saves for the backward pass.  The wave then knows how many stores are
+                // younger than its refill, and the top of the next step waits for exactly the others (vmcnt(6)) instead of for all of them
+                // — the 16-byte saves took ~0.4 us of every step's critical path while it waited for vmcnt(0).
+                f32x4 zi = xi + acc[0], zj = xj + acc[1], zf = xf + acc[2], zo = xo + acc[3];
+                f32x4 gi, gj, gf, go, hn, cn;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gi[r] = sigmoidf_(zi[r]);
+                    gj[r] = tanhf_(zj[r]);
+                    gf[r] = sigmoidf_(zf[r] + a.forget_bias);
+                    go[r] = sigmoidf_(zo[r]);
+                    cn[r] = gf[r] * c[r] + gi[r] * gj[r];
+                    hn[r] = go[r] * tanhf_(cn[r]);
+                }
+                if (active) c = cn;
+                u32x2 hp = {pack_bf2(hn[0], hn[1]), pack_bf2(hn[2], hn[3])};
+                if (!active) hp = (u32x2){0u, 0u};
+                *rdst = hp;                                 // the hand-off payload goes out FIRST
+                asm volatile("" ::: "memory");
+                if (s >= 2) {                               // recycle this wave's piece of the slot that nobody reads any more
+                    const u32x2 f = {0xFFFFFFFFu, 0xFFFFFFFFu};
+                    *(u32x2*)(gring + (unsigned)((s - 2) & (RING - 1)) * SLOT + wr0) = f;
+                }
+                asm volatile("" ::: "memory");
+                *(u32x2*)hdst = hp;
+                float* gdst = a.gates + ((long)d * R + row) * (4L * U) + (long)ub * 64 + ul0;
+                *(f32x4*)(gdst + 0) = gi; *(f32x4*)(gdst + 16) = gj; *(f32x4*)(gdst + 32) = gf; *(f32x4*)(gdst + 48) = go;
+                *(f32x4*)(a.cell + ((long)d * R + row) * U + ub * 16 + ul0) = c;
+            } else if (!active) {
                 u32x2 z = {0u, 0u};
-                if (PROTO == 4) { *rdst = z; *(u32x2*)hdst = z; }
-                else store_wt8(hdst, z);
+                store_wt8(hdst, z);
             } else {
                 f32x4 zi = xi + acc[0], zj = xj + acc[1], zf = xf + acc[2], zo = xo + acc[3];
                 f32x4 gi, gj, gf, go, hn;
@@ -247,16 +277,11 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
                     hn[r] = go[r] * tanhf_(c[r]);
                 }
                 u32x2 hp = {pack_bf2(hn[0], hn[1]), pack_bf2(hn[2], hn[3])};
-                if (PROTO == 4) { *rdst = hp; asm volatile("" ::: "memory"); *(u32x2*)hdst = hp; }
-                else store_wt8(hdst, hp);                  // the hand-off payload goes out FIRST ...
+                store_wt8(hdst, hp);                       // the hand-off payload goes out FIRST ...
                 asm volatile("" ::: "memory");
                 float* gdst = a.gates + ((long)d * R + row) * (4L * U) + (long)ub * 64 + ul0;
                 *(f32x4*)(gdst + 0) = gi; *(f32x4*)(gdst + 16) = gj; *(f32x4*)(gdst + 32) = gf; *(f32x4*)(gdst + 48) = go;
                 *(f32x4*)(a.cell + ((long)d * R + row) * U + ub * 16 + ul0) = c;
-            }
-            if (PROTO == 4 && s >= 2) {             // recycle this wave's piece of the slot that nobody reads any more
-                const u32x2 f = {0xFFFFFFFFu, 0xFFFFFFFFu};
-                *(u32x2*)(gring + (unsigned)((s - 2) & (RING - 1)) * SLOT + wr0) = f;
             }
         }
         // ... so the arrive only has to wait for IT: stores retire in issue order, the five 16-byte saves for the backward
@@ -312,7 +337,7 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
     for (int s = T - 1, it = 0; s >= 0; --s, ++it) {
         const int dbgi = it;
         DBG_STAMP(0);
-        if (PROTO == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (PROTO == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // as in the forward kernel: the four dz stores sit behind the refill
         const bool active = nvalid && s < len;
         const bool has_next = nvalid && (s + 1 < len);
         const int t = active ? (d == 0 ? s : len - 1 - s) : s;
@@ -387,52 +412,47 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
         if (nvalid && kh == 0) {
             bf16_t* zdst = a.dz + row * (8L * U) + (long)d * 4 * U + u0;
             unsigned char* rdst = gring + (unsigned)(it & (RING - 1)) * SLOT + wr0;
-            if (!active) {
-                u32x2 z = {0u, 0u};
-                if (PROTO == 4) {
+            // one instruction sequence for every lane (rows past their length publish zeros and keep their state): ring pieces, slot
+            // refill, the dz rows — the top of the next step then waits for everything but the four stores behind the refill
+            if (!has_next) dh = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dh[0] += bf_lo(g2.x); dh[1] += bf_hi(g2.x); dh[2] += bf_lo(g2.y); dh[3] += bf_hi(g2.y);
+            f32x4 di, dj, df, dov, dcn;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) *(u32x2*)(rdst + g * 512) = z;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) *(u32x2*)(zdst + (long)g * U) = z;
-                } else {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) store_wt8(zdst + (long)g * U, z);
-                }
-            } else {
-                if (!has_next) dh = (f32x4){0.f, 0.f, 0.f, 0.f};
-                dh[0] += bf_lo(g2.x); dh[1] += bf_hi(g2.x); dh[2] += bf_lo(g2.y); dh[3] += bf_hi(g2.y);
-                f32x4 di, dj, df, dov;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float tc = tanhf_(c[r]);
-                    float dc = dcs[r] + dh[r] * go[r] * (1.f - tc * tc);
-                    dov[r] = dh[r] * tc * go[r] * (1.f - go[r]);
-                    di[r] = dc * gj[r] * gi[r] * (1.f - gi[r]);
-                    dj[r] = dc * gi[r] * (1.f - gj[r] * gj[r]);
-                    df[r] = dc * cprev[r] * gf[r] * (1.f - gf[r]);
-                    dcs[r] = dc * gf[r];
-                }
-                u32x2 p[4];
-                p[0].x = pack_bf2(di[0], di[1]); p[0].y = pack_bf2(di[2], di[3]);
-                p[1].x = pack_bf2(dj[0], dj[1]); p[1].y = pack_bf2(dj[2], dj[3]);
-                p[2].x = pack_bf2(df[0], df[1]); p[2].y = pack_bf2(df[2], df[3]);
-                p[3].x = pack_bf2(dov[0], dov[1]); p[3].y = pack_bf2(dov[2], dov[3]);
-                if (PROTO == 4) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) *(u32x2*)(rdst + g * 512) = p[g];
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) *(u32x2*)(zdst + (long)g * U) = p[g];
-                } else {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) store_wt8(zdst + (long)g * U, p[g]);
-                }
+            for (int r = 0; r < 4; ++r) {
+                float tc = tanhf_(c[r]);
+                float dc = dcs[r] + dh[r] * go[r] * (1.f - tc * tc);
+                dov[r] = dh[r] * tc * go[r] * (1.f - go[r]);
+                di[r] = dc * gj[r] * gi[r] * (1.f - gi[r]);
+                dj[r] = dc * gi[r] * (1.f - gj[r] * gj[r]);
+                df[r] = dc * cprev[r] * gf[r] * (1.f - gf[r]);
+                dcn[r] = dc * gf[r];
             }
-            if (PROTO == 4 && it >= 2) {
-                const u32x2 f = {0xFFFFFFFFu, 0xFFFFFFFFu};
-                unsigned char* old = gring + (unsigned)((it - 2) & (RING - 1)) * SLOT + wr0;
+            if (active) dcs = dcn;
+            u32x2 p[4];
+            p[0].x = pack_bf2(di[0], di[1]); p[0].y = pack_bf2(di[2], di[3]);
+            p[1].x = pack_bf2(dj[0], dj[1]); p[1].y = pack_bf2(dj[2], dj[3]);
+            p[2].x = pack_bf2(df[0], df[1]); p[2].y = pack_bf2(df[2], df[3]);
+            p[3].x = pack_bf2(dov[0], dov[1]); p[3].y = pack_bf2(dov[2], dov[3]);
+            if (!active) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) *(u32x2*)(old + g * 512) = f;
+                for (int g = 0; g < 4; ++g) p[g] = (u32x2){0u, 0u};
+            }
+            if (PROTO == 4) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *(u32x2*)(rdst + g * 512) = p[g];
+                asm volatile("" ::: "memory");
+                if (it >= 2) {
+                    const u32x2 f = {0xFFFFFFFFu, 0xFFFFFFFFu};
+                    unsigned char* old = gring + (unsigned)((it - 2) & (RING - 1)) * SLOT + wr0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) *(u32x2*)(old + g * 512) = f;
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *(u32x2*)(zdst + (long)g * U) = p[g];
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) store_wt8(zdst + (long)g * U, p[g]);
             }
         }
         if (PROTO == 0 && s > 0) group_arrive_after(counter, 0);
