@@ -321,9 +321,9 @@ static int launch_halo(const HaloArgs& g, hipStream_t stream) {
 
 int k2_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
                     const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind);
-#define K2_DEFAULT 0            // OPT-IN (OCR_CONV_K2=1): 8 % faster than this file's kernels over the ten launches of the headline step when each
-                                // launch is repeated back to back (profiles/r03j_conv_k2_final.log), but no faster (tile D) or 1.4 % slower (tiles A + D)
-                                // inside the train step (profiles/r03l_bench_conv_ab.log: 1.464 / 1.465 / 1.485 ms per step, three interleaved runs each)
+#define K2_DEFAULT 1            // on since the weight prefetch distance went from 2 to 3 steps (profiles/r03n: the step 1.415 against 1.440 ms, three
+                                // interleaved runs each; with distance 2 it was an opt-in: no faster (tile D) or 1.4 % slower (tiles A + D) in the step,
+                                // profiles/r03l_bench_conv_ab.log, although 8 % faster back to back, profiles/r03j_conv_k2_final.log)
 
 // -1 = shape not covered (caller falls back to igemm.hip / gemm.hip)
 int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,

@@ -61,7 +61,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int FM /* 16-pixel fragments per wave: 8 or 4 */, int BN /* channels per tile: 128 (waves 2 pixel x 2 channel x 2 K) or 64
                                                                           (4 pixel x 1 channel x 2 K: 512- / 256-pixel tiles) */,
-          int NST = 4 /* weight stages */>
+          int NST = 4 /* weight stages; tile s + NST - 2 is streamed during step s */>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_k2_kernel(K2Args g, int NRpad /* halo rows incl. the zero rows, a multiple of 8 */) {
     constexpr int NW = 8, FN = 4;
     constexpr int WN = BN / 64, WMW = 4 / WN;           // waves along channels / pixels (per K half)
@@ -165,8 +165,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned prow0 = lds0 + (wm * WM + frow) * 128;                                                 // + stage, + shift*128 + swizzle
 
     // ---- prologue: weight tiles of steps 0 and 1, the whole halo of chunk 0; everything has landed before barrier 0
+    constexpr int DEPTH = NST - 2;                      // prefetch distance of the weight tiles, in steps
     load_q(0, 0);
     if (nsteps > 1) load_q(C, 1);
+    if (DEPTH > 2 && nsteps > 2) load_q(2 * C, 2);
+    if (DEPTH > 3 && nsteps > 3) load_q(3 * C, 3);
 #pragma unroll
     for (int j = 0; j < PIMAX; ++j) load_pj(0, 0, j);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -208,11 +211,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[b]) : "v"(pa[b]));
         }
         // DMA: the weight tile of step s + 2, and this step's share of the next chunk's halo pieces
-        const bool more_q = s + 2 < nsteps && !(abl & 1);
+        const bool more_q = s + DEPTH < nsteps && !(abl & 1);
         int issued = more_q ? QI : 0;
-        constexpr int T2 = (TAP + 2) % 9;
-        const int c2 = chunk + (TAP + 2 >= 9 ? 1 : 0);
-        int q2 = qs + 2; if (q2 >= NST) q2 -= NST;
+        constexpr int T2 = (TAP + DEPTH) % 9;
+        const int c2 = chunk + (TAP + DEPTH >= 9 ? 1 : 0);
+        int q2 = qs + DEPTH; if (q2 >= NST) q2 -= NST;
         if (more_q) load_q(T2 * C + c2 * 64, q2);
         // PPT pieces per step at taps 1 .. 5: the last piece is issued four steps before tap 0 of the next chunk reads the tile (a piece
         // is only known to have landed one step after its issue — the counted wait covers what was issued BEFORE the latest LOAD)
@@ -250,20 +253,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_sched_barrier(0);
         K2_STAMP(2);
     };
-    auto vmwait = [&](int younger) {                    // retire everything this wave issued before its latest LOAD
+    auto vmwait = [&](int younger) {                    // retire everything but the `younger` most recent pieces of this wave
         switch (younger) {
             case 0: K2_VMWAIT(0); break; case 1: K2_VMWAIT(1); break; case 2: K2_VMWAIT(2); break; case 3: K2_VMWAIT(3); break;
-            default: K2_VMWAIT(4); break;
+            case 4: K2_VMWAIT(4); break; case 5: K2_VMWAIT(5); break; case 6: K2_VMWAIT(6); break; case 7: K2_VMWAIT(7); break;
+            case 8: K2_VMWAIT(8); break; case 9: K2_VMWAIT(9); break; case 10: K2_VMWAIT(10); break; case 11: K2_VMWAIT(11); break;
+            default: K2_VMWAIT(12); break;
         }
     };
+    int prev_issued = 0, prev2_issued = 0;              // DEPTH 3 (4): the pieces of the previous (two) interval(s) may stay in flight too
     // One interval = one K step, closed by ONE workgroup barrier.  Waves 0-3 run LOAD(s) then COMP(s); waves 4-7 run COMP(s - 1) (on
     // the fragments they loaded in the previous interval) then LOAD(s): the two waves of a SIMD use the matrix pipe in opposite halves
     // of the interval, and nothing forces a load segment and an MFMA segment to take equally long (the first versions had a second
     // barrier in the middle: the interval then cost twice the LONGER segment, and the load segment is the longer one).
     //   * tile s + 2 is streamed into the stage of tile s + 2 - NST: with four stages its last readers finished an interval ago; with
     //     three (512-pixel tiles) waves 4-7 read it at the END of the previous interval, so they wait for those reads before the barrier;
-    //   * every wave retires, before the barrier of interval s, what it issued before this interval (counted vmcnt); the barrier
-    //     publishes tile s + 1 — issued during interval s - 1 — and any halo piece one interval after its issue.
+    //   * every wave retires, before the barrier of interval s, what it issued before this interval (counted vmcnt) — with five stages
+    //     (tile A: prefetch distance 3) before the PREVIOUS interval: a piece then has two intervals (~1.8 us) to arrive, which is what
+    //     a first-touch miss to HBM needs under load (with one interval tile A lost 15-25 % behind a cache scrub, profiles/r03m);
+    //     the barrier publishes tile s + 1 and any halo piece one (two) intervals after its issue.
     auto interval = [&](auto khc, auto tapc, int chunk) {
         constexpr int KH = decltype(khc)::value, TAP = decltype(tapc)::value;
         int issued;
@@ -276,7 +284,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             issued = load(tapc, chunk);
             if (NST < 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        vmwait(issued);
+        vmwait(DEPTH > 3 ? issued + prev_issued + prev2_issued : DEPTH > 2 ? issued + prev_issued : issued);
+        prev2_issued = prev_issued;
+        prev_issued = issued;
         if (KH == 0) K2_STAMP(3);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -425,11 +435,12 @@ static int k2_choose(long M, int H, int Cin, int Cout) {
     static int force = -1, minsteps = -1, allow_a = -1;
     if (force < 0) { const char* e = getenv("OCR_K2_CFG"); force = (e && (e[0] == 'A' || e[0] == 'D')) ? e[0] : 0; }
     if (minsteps < 0) { const char* e = getenv("OCR_K2_MINSTEPS"); minsteps = e ? atoi(e) : 36; }
-    // OCR_K2_TILES = AD lets the dispatcher take tile A too.  Default D only: inside the train step tile A is SLOWER than conv_halo (59 against
-    // ~51 us per launch over its five layers, profiles/r03k_bench_kernel_stats.md; the whole step 1.461 against 1.435 ms) although it is 6 %
-    // faster when the same launch is repeated back to back (tools/kernel_bench.py) — one 8-wave workgroup per CU in lock step has nothing
-    // to run while a DMA piece arrives late from a cold L2, two independent workgroups per CU do
-    if (allow_a < 0) { const char* e = getenv("OCR_K2_TILES"); allow_a = (e && e[0] == 'A') ? 1 : 0; }
+    // OCR_K2_TILES = D keeps the dispatcher off tile A.  With prefetch distance 2 tile A was SLOWER than conv_halo inside the train step
+    // (1.461 against 1.435 ms, profiles/r03k) and 15-25 % slower behind a cache scrub (profiles/r03m) although 6 % faster when the same
+    // launch repeats back to back: one 8-wave workgroup per CU in lock step has nothing to run while a piece arrives late from HBM.
+    // With distance 3 (five weight stages) it is faster in all three settings (profiles/r03n: cold 474 against 504 us over the ten
+    // layers, hot 416 against 446, step 1.415 against 1.440 ms).
+    if (allow_a < 0) { const char* e = getenv("OCR_K2_TILES"); allow_a = (e && e[0] == 'D') ? 0 : 1; }
     const char order[2] = {'A', 'D'};
     for (int i = 0; i < 2; ++i) {
         const char c = order[i];
@@ -453,5 +464,14 @@ int k2_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("OCR_K2_ABL"); abl = e ? atoi(e) : 0; }
     K2Args g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, abl};
-    return c == 'A' ? launch_k2<8, 128>(g, stream) : launch_k2<4, 64>(g, stream);
+#ifdef OCR_EXPERIMENTS
+    static int nst = -1;                                 // A/B knob OCR_K2_NST: weight stages (prefetch distance + 2)
+    if (nst < 0) { const char* e = getenv("OCR_K2_NST"); nst = e ? atoi(e) : 0; }
+    if (c == 'A' && nst == 4) return launch_k2<8, 128, 4>(g, stream);
+    if (c == 'D' && nst == 5) return launch_k2<4, 64, 5>(g, stream);
+    if (c == 'D' && nst == 6) return launch_k2<4, 64, 6>(g, stream);
+#endif
+    // tile A: five weight stages = prefetch distance 3 (see k2_choose); tile D: four — five or six change nothing for it (profiles/r03o)
+    if (c == 'A') return launch_k2<8, 128, 5>(g, stream);
+    return launch_k2<4, 64, 4>(g, stream);
 }
