@@ -6,7 +6,7 @@ VGG-7 + BiLSTM(256) + CTC CRNN at H=32, W=256, 10-char labels, batch 64 per GPU 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-One JSON line on rank 0.  `roofline` is the dominant kernel (conv_halo_kernel: implicit-GEMM 3x3 convolution, MFMA-bound), timed
+One JSON line on rank 0.  `roofline` is the dominant kernel (conv_k3 / conv_k2 / conv_halo: implicit-GEMM 3x3 convolution, MFMA-bound), timed
 live with HIP events on the launch stream; `cpu_baseline` is the CPU oracle (a torch-CPU restatement of the
 reference TF1 graph — the TF reference itself cannot run here) on a bounded sample of the same workload.
 """
@@ -60,7 +60,7 @@ def synth_batches(n_batches, seed, device):
 
 
 def conv_roofline(eng, device):
-    """Every launch of the dominant kernel (conv_halo_kernel: the 3x3 SAME convolutions of the workload that was timed — forward
+    """Every launch of the dominant kernel (conv_k3 / conv_k2 / conv_halo, as the dispatcher picks them: the 3x3 SAME convolutions of the workload that was timed — forward
     and data gradient) timed with HIP events on the launch stream; achieved = sum(algorithmic flop) / sum(time).
     The layer shapes are read from the plan the timed steps ran (the widest one for variable-width batches)."""
     from lstm_ctc_ocr_amd import ops
@@ -115,7 +115,7 @@ def conv_roofline(eng, device):
         src = os.path.basename(cands[-1])
         pm = json.load(open(cands[-1]))
         pmc_commit = pm.get("commit")
-        conv = [k for k in pm.get("kernels", []) if k["symbol"].startswith(("_Z16conv_halo_kernel", "_Z14conv_k2_kernel"))]
+        conv = [k for k in pm.get("kernels", []) if k["symbol"].startswith(("_Z16conv_halo_kernel", "_Z14conv_k2_kernel", "_Z14conv_k3_kernel"))]
         lib = open(nat.LIB_PATH, "rb").read()
         missing = [k["symbol"] for k in conv if k["symbol"].encode() not in lib]
         if missing or not conv:
@@ -127,7 +127,7 @@ def conv_roofline(eng, device):
                 traffic = sum(k["launches"] * (k["read_mb"] + k["write_mb"]) for k in conv) / nl * 1e6
             if all("mfma_busy_frac" in k for k in conv):
                 mfma_busy = sum(k["launches"] * k["avg_us"] * k["mfma_busy_frac"] for k in conv) / tm
-    return {"bound": "mfma", "kernel": "conv_halo_kernel / conv_k2_kernel (implicit-GEMM 3x3 SAME conv, forward + data gradient: %d launches/step)" % n_launch,
+    return {"bound": "mfma", "kernel": "conv_k3_kernel / conv_k2_kernel / conv_halo_kernel (implicit-GEMM 3x3 SAME conv, forward + data gradient: %d launches/step)" % n_launch,
             "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK,
             "avg_launch_us": tot_t / n_launch * 1e6, "algorithmic_gflop_per_launch": tot_fl / n_launch / 1e9,
             "traffic": traffic, "mfma_busy_frac": mfma_busy, "pmc_commit": pmc_commit, "pmc_error": pmc_error,

@@ -426,15 +426,15 @@ static int launch_k2(const K2Args& g, hipStream_t stream) {
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
-// Which tile, if any?  A where its tiles fill the chip (>= 224), else D; layers with fewer than OCR_K2_MINSTEPS K steps (default 36)
-// stay on conv_halo: with 9-18 steps a tile is mostly prologue and epilogue, and conv_halo's two independent workgroups per CU overlap
-// those (measured: conv2 33 against 40 us, conv3_1 26.6 against 27.6).  OCR_K2_CFG = A / D forces one tile where it covers the shape.
+// Which tile, if any?  A where its tiles fill the chip (>= 224), else D; layers with fewer than OCR_K2_MINSTEPS K steps (default 18)
+// stay on conv_halo: with 9 steps a tile is mostly prologue and epilogue, and conv_halo's two independent workgroups per CU overlap
+// those (measured: conv2 33 against 40 us; conv3_1 forward, 18 steps: 26.9 on conv_halo, 27.6 on conv_k2, 24.0 on conv_k3 — profiles/r03q).  OCR_K2_CFG = A / D forces one tile where it covers the shape.
 static int k2_choose(long M, int H, int Cin, int Cout) {
     if ((Cin & 63) || (Cout & 63) || M < 4096 || H > 16 || H < 1) return 0;
     if (M * Cin * 2 >= 0x7fffffffL || (long)Cout * 9 * Cin * 2 >= 0x7fffffffL) return 0;   // 32-bit descriptor offsets
     static int force = -1, minsteps = -1, allow_a = -1;
     if (force < 0) { const char* e = getenv("OCR_K2_CFG"); force = (e && (e[0] == 'A' || e[0] == 'D')) ? e[0] : 0; }
-    if (minsteps < 0) { const char* e = getenv("OCR_K2_MINSTEPS"); minsteps = e ? atoi(e) : 36; }
+    if (minsteps < 0) { const char* e = getenv("OCR_K2_MINSTEPS"); minsteps = e ? atoi(e) : 18; }
     // OCR_K2_TILES = D keeps the dispatcher off tile A.  With prefetch distance 2 tile A was SLOWER than conv_halo inside the train step
     // (1.461 against 1.435 ms, profiles/r03k) and 15-25 % slower behind a cache scrub (profiles/r03m) although 6 % faster when the same
     // launch repeats back to back: one 8-wave workgroup per CU in lock step has nothing to run while a piece arrives late from HBM.
@@ -455,12 +455,22 @@ static int k2_choose(long M, int H, int Cin, int Cout) {
     return 0;
 }
 
+int k3_try_dispatch(int tile, const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
+                    const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind);
+
 // -1 = shape not covered (caller falls back to conv_halo.hip)
 int k2_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
                     const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind) {
     if (flags & ~(K2_BIAS | K2_RELU | K2_MASK | K2_ACCUM)) return -1;
     const int c = k2_choose(M, H, Cin, Cout);
     if (!c) return -1;
+    // sixth generation (conv_k3.hip: the same tiles with the halo stored as feature-row planes) where it covers the shape; A/B knob OCR_CONV_K3 = 0
+    static int k3 = -1;
+    if (k3 < 0) { const char* e = getenv("OCR_CONV_K3"); k3 = e ? atoi(e) : 1; }
+    if (k3) {
+        const int rc = k3_try_dispatch(c, x, wpack, y, M, W, H, Cin, Cout, bias, mask, flags, stream, pool, pool_kind);
+        if (rc >= 0) return rc;
+    }
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("OCR_K2_ABL"); abl = e ? atoi(e) : 0; }
     K2Args g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, abl};

@@ -1,0 +1,328 @@
+// 3x3 SAME implicit-GEMM convolution for gfx950, sixth generation: conv_k2.hip's tiles and schedule with the halo image stored as
+// FEATURE-ROW PLANES, so that the inner loop has no vector address arithmetic and multiplies no padding
+// (same contract as ocr_conv3x3_bf16 — reference lib/networks/network.py:160-191 forward, and its data gradient).
+//
+// Why (round 3, profiles/r03p_k2_stamps.log and the per-interval instruction mix of conv_k2): with DMA, fragment reads AND MFMAs removed
+// a K step of conv_k2 still took 1100 of its 2030 cycles.  Every step re-derived eight fragment addresses per wave — "is tap t of my
+// pixel inside the image" is a per-lane predicate when 16 consecutive pixels (several image columns) form a fragment, so each address
+// was a mask test + select, the compiler parked the 72 lane masks in spilled SGPR pairs (two v_readlane per fragment), and the counted
+// DMA waits were a branch tree on a runtime piece count.  VALU work does not hide behind the other wave's MFMAs on this SIMD.
+//
+// Here a 16-pixel fragment is 16 CONSECUTIVE IMAGE COLUMNS AT ONE FEATURE ROW h, and the halo tile of a chunk is laid out in LDS as
+// H planes of PS rows (PS = columns of the tile + 2, rounded up to 8): plane h, row c' <- pixel (column cbase - 1 + c', feature row h).
+//   * tap (dw, dh) of fragment (h, column block) is the same 16 rows shifted by dw rows in plane h + dh: the address is a
+//     loop-invariant lane register (one per dw: the XOR swizzle depends on (c' + dw) & 7 only, PS % 8 == 0) plus an IMMEDIATE;
+//   * SAME padding along the feature axis: plane h + dh does not exist -> the whole fragment contributes nothing for that tap -> its
+//     reads and MFMAs are not issued (H = 4: a sixth of all MFMAs, H = 8: a twelfth);
+//   * SAME padding along the time axis: a tile is NC = 256 / H whole columns of ONE image (W % NC == 0), image edges can only be the
+//     halo columns c' = 0 / NC + 1 — their DMA lanes carry an out-of-range offset and arrive as zeros;
+//   * every wave issues the same, compile-time number of DMA pieces per step (P buffers padded to 40 pieces, the pieces of a chunk that
+//     does not exist go through a zero-length descriptor): the counted vmcnt waits are immediates, the step is straight-line code.
+// Tiles, wave roles (2 x 2 x 2 K or 4 x 1 x 2 K), the ping-pong of the K halves with one barrier per step, weight stages / prefetch
+// distance, the K-half exchange and the epilogue (bias / ReLU / mask / accumulate / fused max-pool) are conv_k2.hip's.
+// Covered: H in {4, 8}, W % (256 / H) == 0 (hence M % 256 == 0), Cin % 64 == 0, Cout % 64 == 0; everything else stays on conv_k2 / conv_halo.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+enum { K3_BIAS = 1, K3_RELU = 2, K3_MASK = 16, K3_ACCUM = 64 };
+
+struct K3Args {
+    const bf16_t* P; const bf16_t* Q;     // P [M pixels][C] ; Q [N][9*C]
+    int M, N, C;                          // C % 64 == 0
+    int cW, cH;
+    bf16_t* out; const float* bias; const bf16_t* mask; int flags;
+    bf16_t* pool; int pool_kind;          // as conv_halo: 0 none, 1 feature pairs (1 x 2), 2 2 x 2
+};
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+#define K3_OOB 0x80000000u                // lane offset of a row that does not exist: beyond any descriptor's range
+#define K3_VMWAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <int FM /* 16-pixel fragments per wave: 8 or 4 */, int BN /* channels per tile: 128 (waves 2 pixel x 2 channel x 2 K) or 64 (4 x 1 x 2 K) */,
+          int NST /* weight stages; tile s + NST - 2 is streamed during step s */, int H /* feature rows: 4 or 8 */>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_k3_kernel(K3Args g) {
+    constexpr int NW = 8, FN = 4, BM = 256;
+    constexpr int WN = BN / 64, WMW = 4 / WN;           // waves along channels / pixels (per K half)
+    static_assert(FM * WMW == 16, "256-pixel tiles");
+    constexpr int NC = BM / H, NCB = NC / 16;           // image columns per tile; 16-column blocks
+    constexpr int PS = (NC + 2 + 7) / 8 * 8;            // rows per plane
+    constexpr int PPIECES = 40, PBYTES = PPIECES * 1024, PI = PPIECES / NW;     // every wave streams PI = 5 pieces (8 rows) per chunk
+    static_assert(H * PS <= PPIECES * 8, "planes fit the padded buffer");
+    constexpr int CBW = NCB / WMW > 0 ? NCB / WMW : 1;  // column blocks per wave group
+    constexpr int HW = FM / CBW;                        // planes per wave group
+    constexpr int WGC = NCB / CBW;                      // wave groups along the columns
+    constexpr bool STATIC_H = HW == H;                  // else (256 x 64 tiles at H = 8) a wave group owns the upper or the lower four planes
+    constexpr int QI = BN / 64;                         // weight DMA pieces per wave and step (2 / 1)
+    constexpr int QB = BN * 128, QTOT = NST * QB;
+    constexpr int DEPTH = NST - 2;                      // prefetch distance of the weight tiles, in steps
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];        // [NST weight stages][2 halo buffers]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave >> 2, wm = (wave & 3) / WN, wn = (wave & 3) % WN;
+    const int C = g.C;
+    const int cb0 = (wm % WGC) * CBW, hbase = (wm / WGC) * HW;
+    const bool top = STATIC_H || hbase == 0, bot = STATIC_H || hbase + HW == H;
+
+    const int mtiles = g.M / BM, ntiles = (g.N + BN - 1) / BN;
+    const int nblk = mtiles * ntiles;
+    int Lb = blockIdx.x;
+    if ((nblk & 7) == 0) Lb = (Lb & 7) * (nblk >> 3) + (Lb >> 3);        // XCD-aware: each XCD gets a contiguous run of tiles
+    const int m0 = (Lb / ntiles) * BM, n0 = (Lb % ntiles) * BN;
+    const int col0 = m0 / H;                            // first column of the tile, counted over the whole batch (image = col / W)
+    const bool edge_l = col0 % g.cW == 0, edge_r = (col0 + NC) % g.cW == 0;
+
+    const int rsub = lane >> 3;
+    const int csrc = ((lane & 7) ^ rsub) * 8;           // LDS position lane&7 of row r holds source chunk (lane&7)^(r&7)
+
+    const int pbytes_all = (int)((long)g.M * C * 2);
+    const __amdgpu_buffer_rsrc_t qsrd = __builtin_amdgcn_make_buffer_rsrc((void*)g.Q, 0, (int)((long)g.N * 9 * C * 2), 0x00020000);
+    unsigned voffQ[QI], voffP[PI];
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+        const int n = n0 + (wave * QI + j) * 8 + rsub;
+        voffQ[j] = n < g.N ? (unsigned)(((long)n * 9 * C + csrc) * 2) : K3_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < PI; ++j) {                      // this wave's halo pieces are j * 8 + wave
+        const int r = (j * NW + wave) * 8 + rsub;       // buffer row: plane r / PS, plane row r % PS (r & 7 == rsub == plane row & 7)
+        const int h = r / PS, cp = r % PS;
+        const bool ok = h < H && cp < NC + 2 && !(cp == 0 && edge_l) && !(cp == NC + 1 && edge_r);
+        const long m = (long)(col0 - 1 + cp) * H + h;
+        voffP[j] = ok ? (unsigned)((m * C + csrc) * 2) : K3_OOB;
+    }
+    auto load_q = [&](int k0 /* tap*C + chunk*64 */, int stage) {
+#pragma unroll
+        for (int j = 0; j < QI; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qsrd, (lptr_t)(smem + stage * QB + (wave * QI + j) * 1024), 16, (int)voffQ[j], k0 * 2, 0, 0);
+    };
+    auto load_p = [&](const __amdgpu_buffer_rsrc_t srd, int chunk, int buf, int j, unsigned voff) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(smem + QTOT + buf * PBYTES + (j * NW + wave) * 1024), 16, (int)voff, chunk * 128, 0, 0);
+    };
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
+    const int kq = (kh << 2) | fq;                      // this lane's 16-byte chunk of a 128-byte row (the wave's K half)
+    const int nchunks = C / 64;
+    const int nsteps = nchunks * 9;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned qfrag0 = lds0 + (wn * 64 + frow) * 128 + ((kq ^ fx) << 4);                             // + stage*QB, + a*2048
+    // pixel fragments: lane register per dw (row c' = cb0*16 + frow + 1 + dw of plane hbase - 1), immediate per (fragment, dh)
+    unsigned pbase[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int cp = cb0 * 16 + frow + d;             // = column of the tile + 1 + dw
+        pbase[d] = lds0 + QTOT + ((hbase - 1) * PS + cp) * 128 + ((kq ^ (cp & 7)) << 4);                  // QTOT >= PS * 128: never below lds0
+    }
+
+    // ---- prologue: weight tiles of steps 0 .. DEPTH - 1, the whole halo of chunk 0; everything has landed before barrier 0
+    {
+        const __amdgpu_buffer_rsrc_t psrd = __builtin_amdgcn_make_buffer_rsrc((void*)g.P, 0, pbytes_all, 0x00020000);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) load_q(d * C, d);                    // (a step that does not exist streams rows nobody reads)
+#pragma unroll
+        for (int j = 0; j < PI; ++j) load_p(psrd, 0, 0, j, voffP[j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    u32x4 afr[FN], bfr[FM];                             // fragments: waves 4-7 carry them across the barrier
+    int qs = 0 /* s % NST */, s = 0;
+    // is fragment b multiplied at feature shift dh?  (compile time where a wave group owns all H planes)
+    auto live = [&](int b, int dh) -> bool {
+        const int hl = b / CBW + dh;
+        return !((hl < 0 && top) || (hl >= HW && bot));
+    };
+    // LOAD(s): the fragment reads of step s, then the DMA issue — a fixed number of pieces per tap: QI weights + one halo piece at taps 1 .. 5
+    auto load = [&](auto tapc, int chunk) {
+        constexpr int TAP = decltype(tapc)::value;
+        constexpr int DW = TAP / 3, DH = TAP % 3 - 1;
+        const unsigned qa = qfrag0 + qs * QB;
+        const unsigned pa = pbase[DW] + (chunk & 1) * PBYTES;
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[a]) : "v"(qa), "n"(a * 2048));
+#pragma unroll
+        for (int b = 0; b < FM; ++b)
+            if (live(b, DH))
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[b]) : "v"(pa), "n"(((b / CBW + DH + 1) * PS + (b % CBW) * 16) * 128));
+        constexpr int T2 = (TAP + DEPTH) % 9;
+        const int c2 = chunk + (TAP + DEPTH >= 9 ? 1 : 0);
+        int q2 = qs + DEPTH; if (q2 >= NST) q2 -= NST;
+        load_q(T2 * C + c2 * 64, q2);                   // past the last step: rows nobody reads into a stage nobody reads (or zeros)
+        if (TAP >= 1 && TAP <= PI) {                    // the next chunk's halo: a zero-length descriptor when there is no next chunk
+            const __amdgpu_buffer_rsrc_t psrd = __builtin_amdgcn_make_buffer_rsrc((void*)g.P, 0, chunk + 1 < nchunks ? pbytes_all : 0, 0x00020000);
+            constexpr int J = TAP >= 1 && TAP <= PI ? TAP - 1 : 0;
+            load_p(psrd, chunk + 1, (chunk + 1) & 1, J, voffP[J]);
+        }
+    };
+    // COMP: the MFMAs on the fragments in registers — nothing else
+    auto comp = [&](auto tapc) {
+        constexpr int DH = decltype(tapc)::value % 3 - 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int b = 0; b < FM; ++b)
+            if (live(b, DH)) {
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[a]), __builtin_bit_cast(bf16x8, bfr[b]),
+                                                                        acc[a][b], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // One interval = one K step, closed by ONE workgroup barrier (conv_k2.hip: waves 0-3 LOAD(s) then COMP(s); waves 4-7 COMP(s - 1) then
+    // LOAD(s)).  Before the barrier every wave retires the pieces it issued before this interval (DEPTH 2) / before the previous interval
+    // (DEPTH 3): pieces per tap are constants, so the wait is an immediate.
+    auto interval = [&](auto khc, auto tapc, int chunk) {
+        constexpr int KH = decltype(khc)::value, TAP = decltype(tapc)::value;
+        constexpr int PREV = (TAP + 8) % 9, PREV2 = (TAP + 7) % 9;
+        auto npc = [](int t) constexpr { return QI + ((t >= 1 && t <= PI) ? 1 : 0); };
+        constexpr int YOUNG = npc(TAP) + (DEPTH > 2 ? npc(PREV) : 0) + (DEPTH > 3 ? npc(PREV2) : 0);
+        if (KH == 0) {
+            load(tapc, chunk);
+            comp(tapc);
+        } else {
+            if (s > 0) comp(std::integral_constant<int, PREV>{});           // step s - 1
+            load(tapc, chunk);
+        }
+        K3_VMWAIT(YOUNG);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        ++s;
+        if (++qs == NST) qs = 0;
+    };
+    auto run = [&](auto khc) {
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            interval(khc, std::integral_constant<int, 0>{}, chunk); interval(khc, std::integral_constant<int, 1>{}, chunk);
+            interval(khc, std::integral_constant<int, 2>{}, chunk); interval(khc, std::integral_constant<int, 3>{}, chunk);
+            interval(khc, std::integral_constant<int, 4>{}, chunk); interval(khc, std::integral_constant<int, 5>{}, chunk);
+            interval(khc, std::integral_constant<int, 6>{}, chunk); interval(khc, std::integral_constant<int, 7>{}, chunk);
+            interval(khc, std::integral_constant<int, 8>{}, chunk);
+        }
+        if (decltype(khc)::value == 1) comp(std::integral_constant<int, 8>{});          // the last step's MFMAs
+    };
+    if (kh == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the pieces streamed past the last step: LDS is reused below
+    __syncthreads();
+
+    // ---- the two K halves meet: a wave keeps the pixel fragments [kh*FM/2, (kh+1)*FM/2) and hands the others to its partner (conv_k2.hip)
+    constexpr int FH = FM / 2;
+    static_assert(FH % (2 * CBW) == 0, "the feature-axis pool partner b ^ CBW stays inside a half");
+    auto tail = [&](auto half_c) {
+        constexpr int KH = decltype(half_c)::value;
+        {
+            f32x4* mine = (f32x4*)smem + (size_t)wave * (FN * FH * 64);
+            const f32x4* theirs = (const f32x4*)smem + (size_t)(wave ^ 4) * (FN * FH * 64);
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int b = 0; b < FH; ++b) mine[(a * FH + b) * 64 + lane] = acc[a][(1 - KH) * FH + b];      // what the partner finishes
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int b = 0; b < FH; ++b) acc[a][KH * FH + b] += theirs[(a * FH + b) * 64 + lane];
+        }
+        const int flags = g.flags;
+        f32x4 bv[FN];
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+            bv[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if ((flags & K3_BIAS) && n < g.N) bv[a] = *(const f32x4*)(g.bias + n);
+        }
+#pragma unroll
+        for (int bb = 0; bb < FH; ++bb) {
+            const int b = KH * FH + bb;
+            const int h = hbase + b / CBW, col = col0 + (cb0 + b % CBW) * 16 + frow;       // this lane's pixel of fragment b
+            const long m = (long)col * H + h;
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+                const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+                if (n >= g.N) continue;
+                f32x4 v = acc[a][b] + bv[a];
+                if (flags & K3_RELU) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                if (flags & K3_MASK) {
+                    u32x2 mk = *(const u32x2*)(g.mask + m * g.N + n);
+                    if (!(bf_lo(mk.x) > 0.f)) v.x = 0.f;
+                    if (!(bf_hi(mk.x) > 0.f)) v.y = 0.f;
+                    if (!(bf_lo(mk.y) > 0.f)) v.z = 0.f;
+                    if (!(bf_hi(mk.y) > 0.f)) v.w = 0.f;
+                }
+                if (flags & K3_ACCUM) {
+                    const u32x2 old = *(const u32x2*)(g.out + m * g.N + n);
+                    v.x += bf_lo(old.x); v.y += bf_hi(old.x); v.z += bf_lo(old.y); v.w += bf_hi(old.y);
+                }
+                u32x2 pk;
+                pk.x = pack_bf2(v.x, v.y);
+                pk.y = pack_bf2(v.z, v.w);
+                *(u32x2*)(g.out + m * g.N + n) = pk;
+                if (g.pool_kind) {
+                    // max-pool window of this pixel: the feature-axis neighbour (h ^ 1) is the same lane of fragment b ^ CBW, the
+                    // time-axis neighbour (col ^ 1) the lane ^ 1 of this fragment
+                    f32x4 u = acc[a][KH * FH + (bb ^ CBW)] + bv[a];
+                    f32x4 mx;
+                    mx.x = fmaxf(v.x, fmaxf(u.x, 0.f)); mx.y = fmaxf(v.y, fmaxf(u.y, 0.f));
+                    mx.z = fmaxf(v.z, fmaxf(u.z, 0.f)); mx.w = fmaxf(v.w, fmaxf(u.w, 0.f));
+                    if (g.pool_kind == 2) {
+                        mx.x = fmaxf(mx.x, __shfl_xor(mx.x, 1, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, 1, 64));
+                        mx.z = fmaxf(mx.z, __shfl_xor(mx.z, 1, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, 1, 64));
+                    }
+                    const bool writer = !(h & 1) && (g.pool_kind == 1 || !(col & 1));
+                    if (writer) {
+                        const long pidx = g.pool_kind == 1 ? (m >> 1) : (long)(col >> 1) * (H >> 1) + (h >> 1);
+                        u32x2 pp;
+                        pp.x = pack_bf2(mx.x, mx.y);
+                        pp.y = pack_bf2(mx.z, mx.w);
+                        *(u32x2*)(g.pool + pidx * g.N + n) = pp;
+                    }
+                }
+            }
+        }
+    };
+    if (kh) tail(std::integral_constant<int, 1>{}); else tail(std::integral_constant<int, 0>{});
+}
+
+template <int FM, int BN, int NST, int H>
+static int launch_k3(const K3Args& g, hipStream_t stream) {
+    constexpr int lds = NST * BN * 128 + 2 * 40 * 1024;            // weight stages, two padded halo buffers (the K-half exchange reuses them)
+    static_assert(lds <= 163840 && lds >= 8 * (FM / 2) * 4 * 1024, "LDS");
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv_k3_kernel<FM, BN, NST, H>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC;
+        attr = true;
+    }
+    const int mt = g.M / 256, nt = (g.N + BN - 1) / BN;
+    conv_k3_kernel<FM, BN, NST, H><<<mt * nt, 512, lds, stream>>>(g);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+
+// -1 = shape not covered.  tile: 'A' = 256 pixels x 128 channels, 'D' = 256 x 64 (chosen by conv_k2.hip's k2_choose)
+int k3_try_dispatch(int tile, const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
+                    const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind) {
+    if (H != 4 && H != 8) return -1;
+    if (W % (256 / H) || M % 256 || (Cin & 63) || (Cout & 63)) return -1;
+    if (flags & ~(K3_BIAS | K3_RELU | K3_MASK | K3_ACCUM)) return -1;
+    if (pool_kind && (flags & (K3_MASK | K3_ACCUM))) return -1;
+    K3Args g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind};
+    if (tile == 'A') {
+        if (Cout % 128) return -1;
+        return H == 4 ? launch_k3<8, 128, 5, 4>(g, stream) : launch_k3<8, 128, 5, 8>(g, stream);
+    }
+    return H == 4 ? launch_k3<4, 64, 4, 4>(g, stream) : launch_k3<4, 64, 4, 8>(g, stream);
+}

@@ -285,7 +285,8 @@ def _conv_ref(x, w, b):   # x [N,W,H,C], w HWIO
 @pytest.mark.parametrize("Nb,W,H,Ci,Co", [(4, 16, 8, 64, 128), (2, 12, 4, 256, 512), (64, 64, 4, 256, 512), (3, 20, 16, 64, 128),
                                           (16, 32, 16, 64, 128), (64, 128, 8, 64, 256), (5, 52, 4, 128, 192), (32, 64, 4, 512, 512),
                                           (7, 22, 8, 128, 256), (32, 64, 2, 512, 512), (3, 18, 2, 64, 128), (9, 64, 2, 128, 64),
-                                          (17, 62, 4, 128, 128), (9, 30, 16, 64, 256)])      # ragged last tiles of the 256- / 128-pixel kernels
+                                          (17, 62, 4, 128, 128), (9, 30, 16, 64, 256),       # ragged last tiles of the 256- / 128-pixel kernels
+                                          (4, 128, 8, 128, 128), (6, 192, 4, 192, 64)])      # plane-layout kernel: several tiles per image, 3 chunks
 def test_conv3x3_fwd_dgrad_wgrad(dev, Nb, W, H, Ci, Co):
     x = bf(gen((Nb, W, H, Ci), 1)); w = bf(gen((3, 3, Ci, Co), 2, 0.05)); b = gen((Co,), 3)
     ref = _conv_ref(x, w, b)
@@ -330,11 +331,14 @@ def test_conv3x3_fwd_dgrad_wgrad(dev, Nb, W, H, Ci, Co):
     assert relerr(dw2.cpu() - 1.0, wr.grad) < 1e-4
 
 
-@pytest.mark.parametrize("env", [dict(OCR_CONV_K2='1', OCR_K2_CFG='A'), dict(OCR_CONV_K2='1', OCR_K2_CFG='D'), dict(OCR_CONV_K2='0')])
+@pytest.mark.parametrize("env", [dict(OCR_CONV_K2='1', OCR_K2_CFG='A'), dict(OCR_CONV_K2='1', OCR_K2_CFG='D'),
+                                 dict(OCR_CONV_K2='1', OCR_K2_CFG='A', OCR_CONV_K3='0'), dict(OCR_CONV_K2='1', OCR_K2_CFG='D', OCR_CONV_K3='0'),
+                                 dict(OCR_CONV_K2='0')])
 def test_conv_kernel_generations_through_the_convolution_parity_tests(dev, env):
-    """conv_k2.hip (in-workgroup K split; tiles A 256 x 128 and D 256 x 64 pixels x channels) with each tile forced onto every shape it
-    covers, and the conv_halo.hip kernels alone, through the same parity / fused-pool / accumulate tests (the knobs are read once per
-    process; by default the dispatcher mixes the kernels per layer)."""
+    """conv_k2.hip / conv_k3.hip (in-workgroup K split; tiles A 256 x 128 and D 256 x 64 pixels x channels; k3 = the plane layout of the
+    halo, taken where it covers the shape) with each tile forced onto every shape it covers, conv_k2 alone (OCR_CONV_K3=0), and the
+    conv_halo.hip kernels alone, through the same parity / fused-pool / accumulate tests (the knobs are read once per process; by default
+    the dispatcher mixes the kernels per layer)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_kernels.py'), '-q', '-k', 'test_conv3x3'],
@@ -463,7 +467,7 @@ def test_maxpool(dev, kw, kh):
 
 @pytest.mark.parametrize("Nb,W,H,Ci,Co,kw,kh", [(64, 128, 16, 64, 128, 2, 2), (64, 64, 8, 256, 256, 1, 2), (64, 64, 4, 512, 512, 1, 2),
                                                (8, 64, 8, 64, 64, 2, 2), (16, 32, 4, 128, 192, 2, 2), (5, 26, 16, 64, 64, 1, 2),
-                                               (3, 40, 10, 64, 128, 1, 2)])
+                                               (3, 40, 10, 64, 128, 1, 2), (16, 64, 4, 128, 128, 2, 2), (16, 128, 8, 64, 128, 2, 2)])
 def test_conv3x3_relu_pool_fused_equals_unfused(dev, Nb, W, H, Ci, Co, kw, kh):
     """conv + bias + ReLU with the following max-pool written by the same epilogue (LSTM_train.py:26-33): the full-resolution output
     and the pooled tensor are bit-identical to conv3x3 followed by maxpool_fwd."""
