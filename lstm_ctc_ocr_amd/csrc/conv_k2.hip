@@ -429,7 +429,7 @@ static int launch_k2(const K2Args& g, hipStream_t stream) {
 // Which tile, if any?  A where its tiles fill the chip (>= 224), else D; layers with fewer than OCR_K2_MINSTEPS K steps (default 18)
 // stay on conv_halo: with 9 steps a tile is mostly prologue and epilogue, and conv_halo's two independent workgroups per CU overlap
 // those (measured: conv2 33 against 40 us; conv3_1 forward, 18 steps: 26.9 on conv_halo, 27.6 on conv_k2, 24.0 on conv_k3 — profiles/r03q).  OCR_K2_CFG = A / D forces one tile where it covers the shape.
-static int k2_choose(long M, int H, int Cin, int Cout) {
+static int k2_choose(long M, int H, int Cin, int Cout, int minsteps_k3 = -1 /* >= 0: the step floor of conv_k3.hip instead of OCR_K2_MINSTEPS */) {
     if ((Cin & 63) || (Cout & 63) || M < 4096 || H > 16 || H < 1) return 0;
     if (M * Cin * 2 >= 0x7fffffffL || (long)Cout * 9 * Cin * 2 >= 0x7fffffffL) return 0;   // 32-bit descriptor offsets
     static int force = -1, minsteps = -1, allow_a = -1;
@@ -449,7 +449,7 @@ static int k2_choose(long M, int H, int Cin, int Cout) {
         const int bn = c == 'A' ? 128 : 64;
         if (Cout % bn) continue;
         if (force) return c;
-        if (9 * (Cin / 64) < minsteps) return 0;
+        if (9 * (Cin / 64) < (minsteps_k3 >= 0 ? minsteps_k3 : minsteps)) return 0;
         if ((M + 255) / 256 * (Cout / bn) >= 224) return c;
     }
     return 0;
@@ -462,15 +462,21 @@ int k3_try_dispatch(int tile, const void* x, const void* wpack, void* y, int M, 
 int k2_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
                     const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind) {
     if (flags & ~(K2_BIAS | K2_RELU | K2_MASK | K2_ACCUM)) return -1;
+    // sixth generation (conv_k3.hip: the same tiles with the halo stored as feature-row planes) where it covers the shape; its own step floor
+    // OCR_K3_MINSTEPS (default 18 like conv_k2: the 9-step conv2 forward is no faster on it than on conv_halo's two workgroups per CU —
+    // 34.0 against 33.6 us, 41 against 39.7 behind a cache scrub, profiles/r03t); A/B knob OCR_CONV_K3 = 0
+    static int k3 = -1, k3min = -1;
+    if (k3 < 0) { const char* e = getenv("OCR_CONV_K3"); k3 = e ? atoi(e) : 1; }
+    if (k3min < 0) { const char* e = getenv("OCR_K3_MINSTEPS"); k3min = e ? atoi(e) : 18; }
+    if (k3) {
+        const int c3 = k2_choose(M, H, Cin, Cout, k3min);
+        if (c3) {
+            const int rc = k3_try_dispatch(c3, x, wpack, y, M, W, H, Cin, Cout, bias, mask, flags, stream, pool, pool_kind);
+            if (rc >= 0) return rc;
+        }
+    }
     const int c = k2_choose(M, H, Cin, Cout);
     if (!c) return -1;
-    // sixth generation (conv_k3.hip: the same tiles with the halo stored as feature-row planes) where it covers the shape; A/B knob OCR_CONV_K3 = 0
-    static int k3 = -1;
-    if (k3 < 0) { const char* e = getenv("OCR_CONV_K3"); k3 = e ? atoi(e) : 1; }
-    if (k3) {
-        const int rc = k3_try_dispatch(c, x, wpack, y, M, W, H, Cin, Cout, bias, mask, flags, stream, pool, pool_kind);
-        if (rc >= 0) return rc;
-    }
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("OCR_K2_ABL"); abl = e ? atoi(e) : 0; }
     K2Args g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, abl};

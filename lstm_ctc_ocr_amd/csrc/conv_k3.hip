@@ -20,7 +20,7 @@
 //     does not exist go through a zero-length descriptor): the counted vmcnt waits are immediates, the step is straight-line code.
 // Tiles, wave roles (2 x 2 x 2 K or 4 x 1 x 2 K), the ping-pong of the K halves with one barrier per step, weight stages / prefetch
 // distance, the K-half exchange and the epilogue (bias / ReLU / mask / accumulate / fused max-pool) are conv_k2.hip's.
-// Covered: H in {4, 8}, W % (256 / H) == 0 (hence M % 256 == 0), Cin % 64 == 0, Cout % 64 == 0; everything else stays on conv_k2 / conv_halo.
+// Covered: H in {4, 8, 16}, W % (256 / H) == 0 (hence M % 256 == 0), Cin % 64 == 0, Cout % 64 == 0; everything else stays on conv_k2 / conv_halo.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -40,15 +40,17 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #define K3_VMWAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 template <int FM /* 16-pixel fragments per wave: 8 or 4 */, int BN /* channels per tile: 128 (waves 2 pixel x 2 channel x 2 K) or 64 (4 x 1 x 2 K) */,
-          int NST /* weight stages; tile s + NST - 2 is streamed during step s */, int H /* feature rows: 4 or 8 */>
+          int NST /* weight stages; tile s + NST - 2 is streamed during step s */, int H /* feature rows: 4, 8 or 16 */,
+          bool SINGLE = false /* C == 64: one chunk, one halo buffer, no halo pieces inside the loop */>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_k3_kernel(K3Args g) {
     constexpr int NW = 8, FN = 4, BM = 256;
     constexpr int WN = BN / 64, WMW = 4 / WN;           // waves along channels / pixels (per K half)
     static_assert(FM * WMW == 16, "256-pixel tiles");
     constexpr int NC = BM / H, NCB = NC / 16;           // image columns per tile; 16-column blocks
     constexpr int PS = (NC + 2 + 7) / 8 * 8;            // rows per plane
-    constexpr int PPIECES = 40, PBYTES = PPIECES * 1024, PI = PPIECES / NW;     // every wave streams PI = 5 pieces (8 rows) per chunk
-    static_assert(H * PS <= PPIECES * 8, "planes fit the padded buffer");
+    constexpr int PPIECES = (H * PS / 8 + NW - 1) / NW * NW;                    // 40 (H = 4, 8) / 48 (H = 16) pieces of 8 rows: every wave
+    constexpr int PBYTES = PPIECES * 1024, PI = PPIECES / NW;                   // streams the same PI = 5 / 6 pieces per chunk
+    static_assert(H * PS <= PPIECES * 8 && PI <= 8, "planes fit the padded buffer; one piece per tap");
     constexpr int CBW = NCB / WMW > 0 ? NCB / WMW : 1;  // column blocks per wave group
     constexpr int HW = FM / CBW;                        // planes per wave group
     constexpr int WGC = NCB / CBW;                      // wave groups along the columns
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int c2 = chunk + (TAP + DEPTH >= 9 ? 1 : 0);
         int q2 = qs + DEPTH; if (q2 >= NST) q2 -= NST;
         load_q(T2 * C + c2 * 64, q2);                   // past the last step: rows nobody reads into a stage nobody reads (or zeros)
-        if (TAP >= 1 && TAP <= PI) {                    // the next chunk's halo: a zero-length descriptor when there is no next chunk
+        if (!SINGLE && TAP >= 1 && TAP <= PI) {         // the next chunk's halo: a zero-length descriptor when there is no next chunk
             const __amdgpu_buffer_rsrc_t psrd = __builtin_amdgcn_make_buffer_rsrc((void*)g.P, 0, chunk + 1 < nchunks ? pbytes_all : 0, 0x00020000);
             constexpr int J = TAP >= 1 && TAP <= PI ? TAP - 1 : 0;
             load_p(psrd, chunk + 1, (chunk + 1) & 1, J, voffP[J]);
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto interval = [&](auto khc, auto tapc, int chunk) {
         constexpr int KH = decltype(khc)::value, TAP = decltype(tapc)::value;
         constexpr int PREV = (TAP + 8) % 9, PREV2 = (TAP + 7) % 9;
-        auto npc = [](int t) constexpr { return QI + ((t >= 1 && t <= PI) ? 1 : 0); };
+        auto npc = [](int t) constexpr { return QI + ((!SINGLE && t >= 1 && t <= PI) ? 1 : 0); };
         constexpr int YOUNG = npc(TAP) + (DEPTH > 2 ? npc(PREV) : 0) + (DEPTH > 3 ? npc(PREV2) : 0);
         if (KH == 0) {
             load(tapc, chunk);
@@ -297,17 +299,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (kh) tail(std::integral_constant<int, 1>{}); else tail(std::integral_constant<int, 0>{});
 }
 
-template <int FM, int BN, int NST, int H>
+template <int FM, int BN, int NST, int H, bool SINGLE = false>
 static int launch_k3(const K3Args& g, hipStream_t stream) {
-    constexpr int lds = NST * BN * 128 + 2 * 40 * 1024;            // weight stages, two padded halo buffers (the K-half exchange reuses them)
-    static_assert(lds <= 163840 && lds >= 8 * (FM / 2) * 4 * 1024, "LDS");
+    constexpr int PS = (256 / H + 2 + 7) / 8 * 8, PPIECES = (H * PS / 8 + 7) / 8 * 8;
+    constexpr int need = NST * BN * 128 + (SINGLE ? 1 : 2) * PPIECES * 1024;     // weight stages, padded halo buffer(s)
+    constexpr int xch = 8 * (FM / 2) * 4 * 1024;                                  // the K-half exchange reuses them
+    constexpr int lds = need > xch ? need : xch;
+    static_assert(lds <= 163840, "LDS");
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv_k3_kernel<FM, BN, NST, H>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC;
+        if (hipFuncSetAttribute((const void*)conv_k3_kernel<FM, BN, NST, H, SINGLE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC;
         attr = true;
     }
     const int mt = g.M / 256, nt = (g.N + BN - 1) / BN;
-    conv_k3_kernel<FM, BN, NST, H><<<mt * nt, 512, lds, stream>>>(g);
+    conv_k3_kernel<FM, BN, NST, H, SINGLE><<<mt * nt, 512, lds, stream>>>(g);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
@@ -315,14 +320,17 @@ static int launch_k3(const K3Args& g, hipStream_t stream) {
 // -1 = shape not covered.  tile: 'A' = 256 pixels x 128 channels, 'D' = 256 x 64 (chosen by conv_k2.hip's k2_choose)
 int k3_try_dispatch(int tile, const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
                     const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind) {
-    if (H != 4 && H != 8) return -1;
+    if (H != 4 && H != 8 && H != 16) return -1;
     if (W % (256 / H) || M % 256 || (Cin & 63) || (Cout & 63)) return -1;
     if (flags & ~(K3_BIAS | K3_RELU | K3_MASK | K3_ACCUM)) return -1;
     if (pool_kind && (flags & (K3_MASK | K3_ACCUM))) return -1;
     K3Args g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind};
+    const bool single = Cin == 64;
     if (tile == 'A') {
         if (Cout % 128) return -1;
+        if (H == 16) return single ? launch_k3<8, 128, 5, 16, true>(g, stream) : launch_k3<8, 128, 4, 16>(g, stream);     // 2 x 48 KiB of halo: four stages
         return H == 4 ? launch_k3<8, 128, 5, 4>(g, stream) : launch_k3<8, 128, 5, 8>(g, stream);
     }
+    if (H == 16) return single ? launch_k3<4, 64, 4, 16, true>(g, stream) : launch_k3<4, 64, 4, 16>(g, stream);
     return H == 4 ? launch_k3<4, 64, 4, 4>(g, stream) : launch_k3<4, 64, 4, 8>(g, stream);
 }

@@ -25,6 +25,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <utility>
+#include <type_traits>
 
 struct W9Args {
     const bf16_t* X; const bf16_t* dY;       // [M][Cin], [M][Cout]
@@ -373,6 +374,258 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(W9Args g) {
     // sum the two pixel halves: waves kh = 1 hand their accumulators over through LDS ([wave][tap][c][r][lane], conflict free).
     // (Tried: meeting in LDS as a [tap][ci][co] tile image — ds_add_f32 from the second half, 16-byte slab stores by all eight
     // waves: +40 us per layer, LDS float atomics are slow; the slab write is bound by its 37.7 MB anyway.)
+    float* xch = (float*)smem + cb * (9 * 4 * 4 * 64) + lane;
+    if (kh == 1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xch[((t * 4 + c) * 4 + r) * 64] = acc[t][c][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+        float* slab = g.part + (long)split * 9 * g.Cin * g.Cout;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = ci0 + cb * 16 + g4 * 4 + r, co = co0 + c * 16 + L;
+                    slab[((long)t * g.Cin + ci) * g.Cout + co] = acc[t][c][r] + xch[((t * 4 + c) * 4 + r) * 64];
+                }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// PLANE-LAYOUT form of the kernel above (round 3; same slabs, same reduction, same results up to the summation order inside a step).
+// wgrad9_kernel spends ~190 VALU instructions per wave and step beside its 72 MFMAs (per-tap address selects for the SAME padding,
+// 64-bit DMA addresses with bounds tests): 4800 cycles per step against 2304 of MFMA, and VALU work does not hide behind the other
+// wave's MFMAs.  As in conv_k3.hip, a step's 128 pixels are NC = 128 / H whole image columns, staged as H planes (plane h, row c' <-
+// pixel (column c0 - 1 + c', feature row h); PS = NC + 2 rounded up to 8 rows per plane) and the dY rows in the same (h, column) order:
+//   * the 32 pixels of an MFMA's K block are 32 columns of one plane (H = 4) or 16 columns of two planes (H = 8): tap (dw, dh) reads the
+//     same rows shifted by dw in plane h + dh — a per-dw lane register (the slot XOR depends on ((c' + dw) >> 1) & 3 only) + an immediate;
+//   * a plane that does not exist is read from the zero block with no select, and an MFMA whose 32 pixels are all padding is not issued
+//     (H = 4: a sixth of them);
+//   * image edges are the halo columns c' = 0 / NC + 1 of a step (W % NC == 0): their DMA lanes get bit 31 OR-ed into the lane offset
+//     (out of range -> zeros) on the steps that start / end an image;
+//   * DMA through buffer descriptors: loop-invariant 32-bit lane offsets, the step advance is a scalar offset.
+// Covered: H in {4, 8}, W % (128 / H) == 0, M * C * 2 < 2^31; everything else stays on wgrad9_kernel.
+template <int H, int LA = 2 /* A groups kept in flight ahead of the tap being multiplied */>
+__global__ __launch_bounds__(512) void wgrad9p_kernel(W9Args g) {
+    constexpr int DMA_AT = 3, NSLOT = LA + 1;
+    constexpr int NC = 128 / H;                         // image columns per step
+    constexpr int PS = (NC + 2 + 7) / 8 * 8;            // rows per plane (40 / 24)
+    constexpr int XROWS = H * PS, XPIECES = XROWS / 8;  // 160 rows = 20 pieces / 192 rows = 24 pieces; then 128 dY rows = 16 pieces
+    static_assert(XPIECES + 16 <= 8 * W9_NDMA, "a stage holds the planes and the dY tile");
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wave & 3, kh = wave >> 2;
+    const int W = g.cW;
+    int split, tile;
+    {
+        const int b = blockIdx.x, T = g.T_ci * g.T_co;
+        if (g.map == 1) { const int x = b & 7, q = b >> 3; split = (q / T) * 8 + x; tile = q % T; }
+        else if (g.map == 2) { const int x = b & 7, q = b >> 3, G = 8 / g.S; split = x / G; tile = (x % G) * (T / G) + q; }
+        else { split = b / T; tile = b % T; }
+    }
+    const int ti = tile / g.T_co, tj = tile % g.T_co;
+    const int ci0 = ti * 64, co0 = tj * 64;
+    const int kbeg = split * g.k_per_split;
+    const int kend = min(g.M, kbeg + g.k_per_split);
+    const int nsteps = kend > kbeg ? (kend - kbeg) >> 7 : 0;       // M % 128 == 0: whole steps
+    const bool do_cs = g.cs_part != nullptr && ti == 0;
+
+    // ---- DMA geometry: instruction u = wave + 8 i covers stage bytes [u KiB, (u + 1) KiB): lane -> row 8u + (lane >> 3), LDS chunk
+    //      position lane & 7, which holds SOURCE chunk q (slot XOR (row >> 1) & 3; PS % 8 == 0: (row >> 1) & 3 == (c' >> 1) & 3)
+    const int rr = lane >> 3, pp = lane & 7;
+    const int qsrc = ((((pp >> 1) ^ ((rr >> 1) & 3)) << 1) | (pp & 1)) * 8;       // first channel of the source chunk
+    // descriptors: X from H pixels before the split (the first halo column), dY from the split; lane offsets are relative to those
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(g.X + ((long)kbeg - H) * g.Cin), 0,
+                                                                          (int)(((long)g.M - kbeg + H) * g.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)(g.dY + (long)kbeg * g.Cout), 0,
+                                                                          (int)(((long)g.M - kbeg) * g.Cout * 2), 0x00020000);
+    unsigned voff[W9_NDMA], eL[W9_NDMA], eR[W9_NDMA];
+#pragma unroll
+    for (int i = 0; i < W9_NDMA; ++i) {
+        const int u = wave + 8 * i;
+        voff[i] = OOB; eL[i] = 0; eR[i] = 0;           // spare piece: zeros
+        if (u < XPIECES) {
+            const int r = 8 * u + rr, h = r / PS, cp = r % PS;
+            if (cp < NC + 2) voff[i] = (unsigned)(((cp * H + h) * g.Cin + ci0 + qsrc) * 2);
+            eL[i] = cp == 0 ? OOB : 0; eR[i] = cp == NC + 1 ? OOB : 0;
+        } else if (u < XPIECES + 16) {
+            const int r = 8 * (u - XPIECES) + rr, h = r / NC, col = r % NC;
+            voff[i] = (unsigned)(((col * H + h) * g.Cout + co0 + qsrc) * 2);
+        }
+    }
+    const int xstep = 128 * g.Cin * 2, ystep = 128 * g.Cout * 2;            // bytes per step
+    const int wc0 = (kbeg / H) % W;                     // column (within its image) of the split's first pixel
+    auto stage_load = [&](int step, int buf, int wcs /* column of that step's first pixel */) {
+        const unsigned selL = wcs == 0 ? OOB : 0u, selR = wcs + NC == W ? OOB : 0u;
+#pragma unroll
+        for (int i = 0; i < W9_NDMA; ++i) {
+            const int u = wave + 8 * i;
+            lptr_t dst = (lptr_t)(smem + buf * W9_STAGE + u * 1024);
+            if (u < XPIECES) {
+                const unsigned vo = voff[i] | (eL[i] & selL) | (eR[i] & selR);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, dst, 16, (int)vo, step * xstep, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, dst, 16, (int)voff[i], step * ystep, 0, 0);
+            }
+        }
+    };
+
+    // ---- fragment addressing (loop invariant): lane (g4, L) supplies row 4 g4 + (L >> 2) of a 4 x 16 block, 8-byte piece L & 3
+    const int g4 = lane >> 4, L = lane & 15;
+    unsigned baseA[3], zabs[3], offB[4];
+    constexpr unsigned ZOFF = W9_NST * W9_STAGE;       // 8 KiB of zeros
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int cp = 1 + 4 * g4 + (L >> 2) + (d - 1);                          // plane row of the element this lane supplies (+16 for the second read at H = 4)
+        baseA[d] = cp * 128 + ((cb ^ ((cp >> 1) & 3)) << 5) + (L & 3) * 8;
+        zabs[d] = lds0 + ZOFF + baseA[d];
+    }
+    const int rowl = kh * 64 + 4 * g4 + (L >> 2);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) offB[c] = XROWS * 128 + rowl * 128 + ((c ^ ((rowl >> 1) & 3)) << 5) + (L & 3) * 8;
+    *(u32x4*)(smem + ZOFF + tid * 16) = (u32x4){0, 0, 0, 0};                      // 512 threads x 16 B (visible after the first barrier)
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int csq = tid & 7, csr = tid >> 3;
+    const unsigned offC = XROWS * 128 + csr * 128 + (((((csq >> 1) ^ ((csr >> 1) & 3)) << 1) | (csq & 1)) << 4);   // (csr + 64) >> 1 & 3 same
+
+    int wcl = wc0;                                      // column of the next step to be loaded
+#pragma unroll
+    for (int p = 0; p < W9_NST - 1; ++p)
+        if (p < nsteps) { stage_load(p, p, wcl); wcl += NC; if (wcl >= W) wcl -= W; }
+
+    auto run = [&](auto khc) {
+        constexpr int KH = decltype(khc)::value;
+        int cur = 0;
+        for (int step = 0; step < nsteps; ++step) {
+            if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W9_NDMA) : "memory");     // the next step may stay in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const unsigned sb = lds0 + cur * W9_STAGE;
+            unsigned sbA[3], sbB[4];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) sbA[d] = sb + baseA[d];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sbB[c] = sb + offB[c];
+            s16x4 alo[NSLOT], ahi[NSLOT], blo[2][4], bhi[2][4];
+            // planes of the two 16-pixel halves of K block kk, shifted by dh; -1: the plane does not exist
+#define W9P_PLANE(kk_, dh_, half_) (H == 4 ? (KH * 2 + (kk_) + (dh_)) : (KH * 4 + (kk_) * 2 + (half_) + (dh_)))
+#define W9P_OK(pl_) ((pl_) >= 0 && (pl_) < H)
+#define W9P_ISSUE(P_) do { \
+                if ((P_) == 0 || (P_) == 10) { \
+                    const int kb_ = (P_) == 0 ? 0 : 1; \
+                    _Pragma("unroll") for (int c = 0; c < 4; ++c) { W9_TR(blo[kb_][c], sbB[c], kb_ * 32 * 128); W9_TR(bhi[kb_][c], sbB[c], kb_ * 32 * 128 + 16 * 128); } \
+                } else { \
+                    constexpr int m_ = (P_) < 10 ? (P_) - 1 : (P_) - 2, kb_ = m_ / 9, tt_ = m_ % 9, dw_ = tt_ / 3, dh_ = tt_ % 3 - 1; \
+                    constexpr int pl_ = W9P_PLANE(kb_, dh_, 0), ph_ = W9P_PLANE(kb_, dh_, 1); \
+                    constexpr int il_ = W9P_OK(pl_) ? pl_ * PS * 128 : 0, ih_ = W9P_OK(ph_) ? ph_ * PS * 128 + (H == 4 ? 16 * 128 : 0) : (H == 4 ? 16 * 128 : 0); \
+                    W9_TR(alo[m_ % NSLOT], W9P_OK(pl_) ? sbA[dw_] : zabs[dw_], il_); \
+                    W9_TR(ahi[m_ % NSLOT], W9P_OK(ph_) ? sbA[dw_] : zabs[dw_], ih_); \
+                } } while (0)
+            // the read stream as compile-time positions (tables of wgrad9_kernel): issue everything up to tab.upto[n] before tap n
+            auto issue_to = [&](auto fromc, auto toc) {
+                constexpr int FROM = decltype(fromc)::value, TO = decltype(toc)::value;
+                if constexpr (FROM <= 0 && 0 <= TO) W9P_ISSUE(0);
+                if constexpr (FROM <= 1 && 1 <= TO) W9P_ISSUE(1);
+                if constexpr (FROM <= 2 && 2 <= TO) W9P_ISSUE(2);
+                if constexpr (FROM <= 3 && 3 <= TO) W9P_ISSUE(3);
+                if constexpr (FROM <= 4 && 4 <= TO) W9P_ISSUE(4);
+                if constexpr (FROM <= 5 && 5 <= TO) W9P_ISSUE(5);
+                if constexpr (FROM <= 6 && 6 <= TO) W9P_ISSUE(6);
+                if constexpr (FROM <= 7 && 7 <= TO) W9P_ISSUE(7);
+                if constexpr (FROM <= 8 && 8 <= TO) W9P_ISSUE(8);
+                if constexpr (FROM <= 9 && 9 <= TO) W9P_ISSUE(9);
+                if constexpr (FROM <= 10 && 10 <= TO) W9P_ISSUE(10);
+                if constexpr (FROM <= 11 && 11 <= TO) W9P_ISSUE(11);
+                if constexpr (FROM <= 12 && 12 <= TO) W9P_ISSUE(12);
+                if constexpr (FROM <= 13 && 13 <= TO) W9P_ISSUE(13);
+                if constexpr (FROM <= 14 && 14 <= TO) W9P_ISSUE(14);
+                if constexpr (FROM <= 15 && 15 <= TO) W9P_ISSUE(15);
+                if constexpr (FROM <= 16 && 16 <= TO) W9P_ISSUE(16);
+                if constexpr (FROM <= 17 && 17 <= TO) W9P_ISSUE(17);
+                if constexpr (FROM <= 18 && 18 <= TO) W9P_ISSUE(18);
+                if constexpr (FROM <= 19 && 19 <= TO) W9P_ISSUE(19);
+            };
+            auto tap = [&](auto nc) {
+                constexpr int n = decltype(nc)::value, kk = n / 9, t = n % 9, dh = t % 3 - 1;
+                if (n == DMA_AT) {
+                    // the buffer of step + 2 was last read in step - 1: free since this step's barrier
+                    if (step + 2 < nsteps) { int nb = cur + 2; if (nb >= W9_NST) nb -= W9_NST; stage_load(step + 2, nb, wcl); wcl += NC; if (wcl >= W) wcl -= W; }
+                }
+                if constexpr (n == 0) issue_to(std::integral_constant<int, 0>{}, std::integral_constant<int, W9T<LA>::tab.upto[0]>{});
+                else issue_to(std::integral_constant<int, W9T<LA>::tab.upto[n > 0 ? n - 1 : 0] + 1>{}, std::integral_constant<int, W9T<LA>::tab.upto[n]>{});
+                switch (W9T<LA>::tab.wait[n]) {              // folds: n is a constant
+                    case 0: W9_WAIT(0); break;   case 2: W9_WAIT(2); break;   case 4: W9_WAIT(4); break;   case 6: W9_WAIT(6); break;
+                    case 8: W9_WAIT(8); break;   case 10: W9_WAIT(10); break; case 12: W9_WAIT(12); break; default: W9_WAIT(14); break;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr bool live = W9P_OK(W9P_PLANE(kk, dh, 0)) || W9P_OK(W9P_PLANE(kk, dh, 1));
+                if constexpr (live) {
+                    const u32x2 lo = __builtin_bit_cast(u32x2, alo[n % NSLOT]), hi = __builtin_bit_cast(u32x2, ahi[n % NSLOT]);
+                    const u32x4 av = {lo.x, lo.y, hi.x, hi.y};
+                    const bf16x8 fa = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const u32x2 bl = __builtin_bit_cast(u32x2, blo[kk][c]), bh = __builtin_bit_cast(u32x2, bhi[kk][c]);
+                        const u32x4 bv = {bl.x, bl.y, bh.x, bh.y};
+                        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, __builtin_bit_cast(bf16x8, bv), acc[t][c], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            tap(std::integral_constant<int, 0>{});  tap(std::integral_constant<int, 1>{});  tap(std::integral_constant<int, 2>{});
+            tap(std::integral_constant<int, 3>{});  tap(std::integral_constant<int, 4>{});  tap(std::integral_constant<int, 5>{});
+            tap(std::integral_constant<int, 6>{});  tap(std::integral_constant<int, 7>{});  tap(std::integral_constant<int, 8>{});
+            tap(std::integral_constant<int, 9>{});  tap(std::integral_constant<int, 10>{}); tap(std::integral_constant<int, 11>{});
+            tap(std::integral_constant<int, 12>{}); tap(std::integral_constant<int, 13>{}); tap(std::integral_constant<int, 14>{});
+            tap(std::integral_constant<int, 15>{}); tap(std::integral_constant<int, 16>{}); tap(std::integral_constant<int, 17>{});
+#undef W9P_ISSUE
+#undef W9P_OK
+#undef W9P_PLANE
+            if (do_cs) {            // bias gradient: column sums of the dY tile
+                u32x4 v0, v1;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(v0) : "v"(sb + offC));
+                asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(v1) : "v"(sb + offC));
+                W9_WAIT(0);
+                __builtin_amdgcn_sched_barrier(0);
+                cs[0] += bf_lo(v0.x) + bf_lo(v1.x); cs[1] += bf_hi(v0.x) + bf_hi(v1.x); cs[2] += bf_lo(v0.y) + bf_lo(v1.y); cs[3] += bf_hi(v0.y) + bf_hi(v1.y);
+                cs[4] += bf_lo(v0.z) + bf_lo(v1.z); cs[5] += bf_hi(v0.z) + bf_hi(v1.z); cs[6] += bf_lo(v0.w) + bf_lo(v1.w); cs[7] += bf_hi(v0.w) + bf_hi(v1.w);
+            }
+            cur = (cur + 1 == W9_NST) ? 0 : cur + 1;
+        }
+    };
+    if (kh == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
+    __syncthreads();                                   // every DMA has landed and every tile is dead: LDS is reused below
+
+    if (do_cs) {
+        float* red = (float*)smem;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = cs[e];
+        __syncthreads();
+        if (tid < 64) {                                // channel tid = chunk tid >> 3, element tid & 7; 64 row groups
+            float s = 0.f;
+            for (int u = 0; u < 64; ++u) s += red[(u * 8 + (tid >> 3)) * 8 + (tid & 7)];
+            g.cs_part[(long)split * g.Cout + co0 + tid] = s;
+        }
+        __syncthreads();
+    }
+    // sum the two pixel halves through LDS and store the slab tile (as wgrad9_kernel)
     float* xch = (float*)smem + cb * (9 * 4 * 4 * 64) + lane;
     if (kh == 1) {
 #pragma unroll
@@ -757,6 +1010,20 @@ int wgrad9_try_dispatch(const void* x, const void* dy, float* dw, float* dbias, 
         static bool attr = false; \
         if (!attr) { if (hipFuncSetAttribute((const void*)wgrad9c_kernel<LA_, NS_, NB_, DBG_>, hipFuncAttributeMaxDynamicSharedMemorySize, W9_LDS) != hipSuccess) return OCR_ERR_EXEC; attr = true; } \
         wgrad9c_kernel<LA_, NS_, NB_, DBG_><<<grid, 512, W9_LDS, stream>>>(g); } while (0)
+    // plane-layout kernel where it covers the shape (A/B knob OCR_W9_PLANES = 0: wgrad9_kernel everywhere)
+    static int planes = -1;
+    if (planes < 0) { const char* e = getenv("OCR_W9_PLANES"); planes = e ? atoi(e) : 1; }
+    const bool use_p = planes && variant == 0 && (H == 4 || H == 8) && W % (128 / H) == 0 && M % 128 == 0 &&
+                       (long)M * (Cin > Cout ? Cin : Cout) * 2 < 0x7fffffffL;
+    if (use_p) {
+        // (look-ahead 3 and 4 of the fragment read stream measured equal to 2: profiles/r03s_wgrad9p.log)
+#define W9P_LAUNCH(H_, LA_) do { \
+            static bool attr = false; \
+            if (!attr) { if (hipFuncSetAttribute((const void*)wgrad9p_kernel<H_, LA_>, hipFuncAttributeMaxDynamicSharedMemorySize, W9_LDS) != hipSuccess) return OCR_ERR_EXEC; attr = true; } \
+            wgrad9p_kernel<H_, LA_><<<grid, 512, W9_LDS, stream>>>(g); } while (0)
+        if (H == 4) W9P_LAUNCH(4, 2); else W9P_LAUNCH(8, 2);
+#undef W9P_LAUNCH
+    } else
     switch (H == 2 ? 0 : variant) {             // H = 2 (a 4-row read block spans two image columns): only the redirecting default handles it
 #ifdef OCR_EXPERIMENTS      // timing variants / ablations of tools/w9_variants.py (round 2, all measured slower or equal)
         case 1: W9_LAUNCH(3, 0, false); break;
