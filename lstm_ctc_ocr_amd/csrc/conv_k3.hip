@@ -35,6 +35,18 @@ struct K3Args {
     bf16_t* pool; int pool_kind;          // as conv_halo: 0 none, 1 feature pairs (1 x 2), 2 2 x 2
 };
 
+#ifdef OCR_EXPERIMENTS
+// diagnostic (experiments build): wall-clock stamps (100 MHz) of every workgroup's first thread — dbg[block * 8 + {0 entry, 1 prologue landed,
+// 2 K loop done, 3 K halves exchanged, 4 stores issued, 5 stores acknowledged}] (tools/k3_phases.py)
+__device__ long long* k3_dbg;
+extern "C" int ocr_conv_k3_debug(void* dbg) {
+    long long* q = (long long*)dbg;
+    return hipMemcpyToSymbol(HIP_SYMBOL(k3_dbg), &q, sizeof(q)) == hipSuccess ? OCR_OK : OCR_ERR_MEMOPS;
+}
+#define K3_PHASE(slot) do { if (k3_dbg && threadIdx.x == 0) k3_dbg[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define K3_PHASE(slot) do { } while (0)
+#endif
 typedef __attribute__((address_space(3))) void* lptr_t;
 #define K3_OOB 0x80000000u                // lane offset of a row that does not exist: beyond any descriptor's range
 #define K3_VMWAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
@@ -61,6 +73,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];        // [NST weight stages][2 halo buffers]
 
     const int tid = threadIdx.x, lane = tid & 63;
+    K3_PHASE(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = wave >> 2, wm = (wave & 3) / WN, wn = (wave & 3) % WN;
     const int C = g.C;
@@ -134,6 +147,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    K3_PHASE(1);
 
     u32x4 afr[FN], bfr[FM];                             // fragments: waves 4-7 carry them across the barrier
     int qs = 0 /* s % NST */, s = 0;
@@ -218,6 +232,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (kh == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the pieces streamed past the last step: LDS is reused below
     __syncthreads();
+    K3_PHASE(2);
 
     // ---- the two K halves meet: a wave keeps the pixel fragments [kh*FM/2, (kh+1)*FM/2) and hands the others to its partner (conv_k2.hip)
     constexpr int FH = FM / 2;
@@ -237,6 +252,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int b = 0; b < FH; ++b) acc[a][KH * FH + b] += theirs[(a * FH + b) * 64 + lane];
         }
+        K3_PHASE(3);
         const int flags = g.flags;
         f32x4 bv[FN];
 #pragma unroll
@@ -244,6 +260,58 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
             bv[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if ((flags & K3_BIAS) && n < g.N) bv[a] = *(const f32x4*)(g.bias + n);
+        }
+        // Staged write-out (no fused pool, no accumulate): the tile goes through LDS as a bf16 [256 pixels][BN channels] image — local
+        // pixel lp = column * H + h is global row m0 + lp — and leaves as 16-byte lane stores, four (eight) whole rows per wave instruction;
+        // the ReLU mask of the layer below arrives the same way.  (The direct form below writes 8 bytes per lane, 16 pixel rows x 32 B per
+        // instruction: 4.8 us of the 57 us of conv4_2, 8.9 with the mask loads in between — profiles/r03u_k3_phases.log.)
+        if (g.pool_kind == 0 && !(flags & K3_ACCUM)) {
+            constexpr int ROWB = BN * 2, U = ROWB / 16, SWM = BN == 128 ? 7 : 3;      // row bytes; 16-byte units per row; swizzle bits of the column
+            __syncthreads();                            // the exchange region has been read
+#pragma unroll
+            for (int bb = 0; bb < FH; ++bb) {
+                const int b = KH * FH + bb;
+                const int lp = ((cb0 + b % CBW) * 16 + frow) * H + hbase + b / CBW;
+#pragma unroll
+                for (int a = 0; a < FN; ++a) {
+                    f32x4 v = acc[a][b] + bv[a];
+                    if (flags & K3_RELU) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    u32x2 pk;
+                    pk.x = pack_bf2(v.x, v.y);
+                    pk.y = pack_bf2(v.z, v.w);
+                    const int slot = wn * 16 + a * 4 + (lane >> 4);                      // 8-byte slot of the row; the column's low bits permute the 32-byte groups
+                    *(u32x2*)(smem + lp * ROWB + ((slot ^ ((frow & SWM) << 2)) << 3)) = pk;
+                }
+            }
+            __syncthreads();
+            constexpr int NIT = 256 * U / 512;
+            u32x4 val[NIT], mk[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = it * 512 + tid, lp = idx / U, u = idx % U;
+                if (flags & K3_MASK) mk[it] = *(const u32x4*)(g.mask + ((long)m0 + lp) * g.N + n0 + u * 8);
+                val[it] = *(const u32x4*)(smem + lp * ROWB + ((u ^ (((lp / H) & SWM) << 1)) << 4));
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = it * 512 + tid, lp = idx / U, u = idx % U;
+                u32x4 v = val[it];
+                if (flags & K3_MASK) {
+                    const u32x4 q = mk[it];
+                    if (!(bf_lo(q.x) > 0.f)) v.x &= 0xffff0000u;
+                    if (!(bf_hi(q.x) > 0.f)) v.x &= 0x0000ffffu;
+                    if (!(bf_lo(q.y) > 0.f)) v.y &= 0xffff0000u;
+                    if (!(bf_hi(q.y) > 0.f)) v.y &= 0x0000ffffu;
+                    if (!(bf_lo(q.z) > 0.f)) v.z &= 0xffff0000u;
+                    if (!(bf_hi(q.z) > 0.f)) v.z &= 0x0000ffffu;
+                    if (!(bf_lo(q.w) > 0.f)) v.w &= 0xffff0000u;
+                    if (!(bf_hi(q.w) > 0.f)) v.w &= 0x0000ffffu;
+                }
+                *(u32x4*)(g.out + ((long)m0 + lp) * g.N + n0 + u * 8) = v;
+            }
+            return;
         }
 #pragma unroll
         for (int bb = 0; bb < FH; ++bb) {
@@ -297,6 +365,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     if (kh) tail(std::integral_constant<int, 1>{}); else tail(std::integral_constant<int, 0>{});
+#ifdef OCR_EXPERIMENTS
+    K3_PHASE(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    K3_PHASE(5);
+#endif
 }
 
 template <int FM, int BN, int NST, int H, bool SINGLE = false>
