@@ -412,7 +412,14 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(W9Args g) {
 //     (out of range -> zeros) on the steps that start / end an image;
 //   * DMA through buffer descriptors: loop-invariant 32-bit lane offsets, the step advance is a scalar offset.
 // Covered: H in {4, 8}, W % (128 / H) == 0, M * C * 2 < 2^31; everything else stays on wgrad9_kernel.
-template <int H, int LA = 2 /* A groups kept in flight ahead of the tap being multiplied */>
+#ifdef OCR_EXPERIMENTS
+// diagnostic (experiments build, ocr_wgrad9_debug): wall-clock stamps (100 MHz) of every workgroup's first thread —
+// dbg[block * 8 + {0 entry, 1 K loop done, 2 column sums done, 3 slab stores issued, 4 acknowledged}] (tools/w9p_phases.py)
+#define W9P_PHASE(slot) do { if (w9_dbg && threadIdx.x == 0) w9_dbg[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define W9P_PHASE(slot) do { } while (0)
+#endif
+template <int H, int LA = 2 /* A groups kept in flight ahead of the tap being multiplied */, bool CONT = false /* continuous read stream: see runc */>
 __global__ __launch_bounds__(512) void wgrad9p_kernel(W9Args g) {
     constexpr int DMA_AT = 3, NSLOT = LA + 1;
     constexpr int NC = 128 / H;                         // image columns per step
@@ -422,6 +429,7 @@ __global__ __launch_bounds__(512) void wgrad9p_kernel(W9Args g) {
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
+    W9P_PHASE(0);
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = wave & 3, kh = wave >> 2;
@@ -610,8 +618,128 @@ __global__ __launch_bounds__(512) void wgrad9p_kernel(W9Args g) {
             cur = (cur + 1 == W9_NST) ? 0 : cur + 1;
         }
     };
-    if (kh == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
+    // Continuous-stream schedule (CONT): the per-step barrier above stops the read stream — after it every wave first fetches B(0), A(0,0)..
+    // with the matrix pipe idle, 3400 cycles per step against 1920 of MFMA (profiles/r03w_w9p_phases.log).  Here the barrier sits before tap
+    // NB of a step ("stage step + 1 has landed for everyone" and "everyone has left step - 1", a whole step before either matters), the last
+    // taps of a step already fetch the next step's first groups from the next stage (positions 20.. of the tables W9C), and the five DMA
+    // pieces of stage step + 2 go out one at a time between the taps behind the barrier.
+    auto runc = [&](auto khc) {
+        constexpr int KH = decltype(khc)::value;
+        constexpr int NB = 4, NSL = (LA + 1 <= 3) ? 3 : 6;
+        static_assert(18 % NSL == 0 && LA + 1 <= NSL, "slot rotation closes over a step");
+        if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W9_NDMA) : "memory");       // stage 0 landed (stage 1 may stay in flight)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        s16x4 alo[NSL], ahi[NSL], blo[2][4], bhi[2][4];
+        u32x4 cv0 = {0, 0, 0, 0}, cv1 = {0, 0, 0, 0};
+        unsigned sbA[3], sbB[4], nbA[3], nbB[4];       // fragment bases in the current and in the next stage
+#pragma unroll
+        for (int d = 0; d < 3; ++d) nbA[d] = lds0 + baseA[d];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) nbB[c] = lds0 + offB[c];
+#define W9P_PLANE(kk_, dh_, half_) (H == 4 ? (KH * 2 + (kk_) + (dh_)) : (KH * 4 + (kk_) * 2 + (half_) + (dh_)))
+#define W9P_OK(pl_) ((pl_) >= 0 && (pl_) < H)
+#define W9PC_ISSUE(P_, A_, B_) do { \
+            constexpr int q_ = (P_) % 20; \
+            if (q_ == 0 || q_ == 10) { \
+                constexpr int kb_ = q_ == 0 ? 0 : 1; \
+                _Pragma("unroll") for (int c = 0; c < 4; ++c) { W9_TR(blo[kb_][c], B_[c], kb_ * 32 * 128); W9_TR(bhi[kb_][c], B_[c], kb_ * 32 * 128 + 16 * 128); } \
+            } else { \
+                constexpr int m_ = q_ < 10 ? q_ - 1 : q_ - 2, kb_ = m_ / 9, tt_ = m_ % 9, dw_ = tt_ / 3, dh_ = tt_ % 3 - 1; \
+                constexpr int pl_ = W9P_PLANE(kb_, dh_, 0), ph_ = W9P_PLANE(kb_, dh_, 1); \
+                constexpr int il_ = W9P_OK(pl_) ? pl_ * PS * 128 : 0, ih_ = W9P_OK(ph_) ? ph_ * PS * 128 + (H == 4 ? 16 * 128 : 0) : (H == 4 ? 16 * 128 : 0); \
+                W9_TR(alo[m_ % NSL], W9P_OK(pl_) ? A_[dw_] : zabs[dw_], il_); \
+                W9_TR(ahi[m_ % NSL], W9P_OK(ph_) ? A_[dw_] : zabs[dw_], ih_); \
+            } } while (0)
+        // positions FROM .. TO of the stream: 0..19 this step's groups (current stage), 20..39 the next step's (next stage; behind the last
+        // step they are read all the same — from the same stage, unused — so that the counted waits stay exact)
+        auto issue_to = [&](auto fromc, auto toc) {
+            constexpr int FROM = decltype(fromc)::value, TO = decltype(toc)::value;
+#define W9PC_AT(P_) if constexpr (FROM <= (P_) && (P_) <= TO) { if constexpr ((P_) < 20) W9PC_ISSUE(P_, sbA, sbB); else W9PC_ISSUE(P_, nbA, nbB); }
+            W9PC_AT(0) W9PC_AT(1) W9PC_AT(2) W9PC_AT(3) W9PC_AT(4) W9PC_AT(5) W9PC_AT(6) W9PC_AT(7) W9PC_AT(8) W9PC_AT(9)
+            W9PC_AT(10) W9PC_AT(11) W9PC_AT(12) W9PC_AT(13) W9PC_AT(14) W9PC_AT(15) W9PC_AT(16) W9PC_AT(17) W9PC_AT(18) W9PC_AT(19)
+            W9PC_AT(20) W9PC_AT(21) W9PC_AT(22) W9PC_AT(23) W9PC_AT(24) W9PC_AT(25) W9PC_AT(26) W9PC_AT(27) W9PC_AT(28) W9PC_AT(29)
+            W9PC_AT(30) W9PC_AT(31) W9PC_AT(32) W9PC_AT(33) W9PC_AT(34) W9PC_AT(35) W9PC_AT(36) W9PC_AT(37) W9PC_AT(38) W9PC_AT(39)
+#undef W9PC_AT
+        };
+        issue_to(std::integral_constant<int, 20>{}, std::integral_constant<int, W9C<LA>::tab.upto[17]>{});     // read-stream prologue of step 0 (from stage 0)
+        int cur = 0;
+        for (int step = 0; step < nsteps; ++step) {
+            const int nxt = (cur + 1 == W9_NST) ? 0 : cur + 1, nn = (nxt + 1 == W9_NST) ? 0 : nxt + 1;
+            const bool more = step + 1 < nsteps, more2 = step + 2 < nsteps;
+            const unsigned sb = lds0 + cur * W9_STAGE, sbn = lds0 + (more ? nxt : cur) * W9_STAGE;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { sbA[d] = nbA[d]; nbA[d] = sbn + baseA[d]; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { sbB[c] = nbB[c]; nbB[c] = sbn + offB[c]; }
+            const unsigned selL = wcl == 0 ? OOB : 0u, selR = wcl + NC == W ? OOB : 0u;      // edges of the step whose stage is streamed during this one
+            auto tap = [&](auto nc) {
+                constexpr int n = decltype(nc)::value, kk = n / 9, t = n % 9, dh = t % 3 - 1;
+                if constexpr (n == NB) {
+                    // own DMA pieces of stage step + 1 (issued a step ago) have landed; behind the barrier that holds for every wave's pieces,
+                    // and every wave has left step - 1: its buffer (the one of step + 2) may be refilled
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (do_cs) {                 // bias gradient: this step's dY tile, two 16-byte reads riding in the stream
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(cv0) : "v"(sb + offC));
+                        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(cv1) : "v"(sb + offC));
+                    }
+                }
+                if constexpr (n > NB && ((n - NB) & 1) && (n - NB) / 2 < W9_NDMA) {
+                    if (more2) {
+                        constexpr int i = (n - NB) / 2;
+                        const int u = wave + 8 * i;
+                        lptr_t dst = (lptr_t)(smem + nn * W9_STAGE + u * 1024);
+                        if (u < XPIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, dst, 16, (int)(voff[i] | (eL[i] & selL) | (eR[i] & selR)), (step + 2) * xstep, 0, 0);
+                        else __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, dst, 16, (int)voff[i], (step + 2) * ystep, 0, 0);
+                    }
+                }
+                constexpr int prev = n == 0 ? W9C<LA>::tab.upto[17] - 20 : W9C<LA>::tab.upto[n > 0 ? n - 1 : 0];
+                issue_to(std::integral_constant<int, prev + 1>{}, std::integral_constant<int, W9C<LA>::tab.upto[n]>{});
+                switch (W9C<LA>::tab.wait[n]) {              // folds: n is a constant
+                    case 0: W9_WAIT(0); break;   case 2: W9_WAIT(2); break;   case 4: W9_WAIT(4); break;   case 6: W9_WAIT(6); break;
+                    case 8: W9_WAIT(8); break;   case 10: W9_WAIT(10); break; case 12: W9_WAIT(12); break; default: W9_WAIT(13); break;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr bool live = W9P_OK(W9P_PLANE(kk, dh, 0)) || W9P_OK(W9P_PLANE(kk, dh, 1));
+                if constexpr (live) {
+                    const u32x2 lo = __builtin_bit_cast(u32x2, alo[n % NSL]), hi = __builtin_bit_cast(u32x2, ahi[n % NSL]);
+                    const u32x4 av = {lo.x, lo.y, hi.x, hi.y};
+                    const bf16x8 fa = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const u32x2 bl = __builtin_bit_cast(u32x2, blo[kk][c]), bh = __builtin_bit_cast(u32x2, bhi[kk][c]);
+                        const u32x4 bv = {bl.x, bl.y, bh.x, bh.y};
+                        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, __builtin_bit_cast(bf16x8, bv), acc[t][c], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            tap(std::integral_constant<int, 0>{});  tap(std::integral_constant<int, 1>{});  tap(std::integral_constant<int, 2>{});
+            tap(std::integral_constant<int, 3>{});  tap(std::integral_constant<int, 4>{});  tap(std::integral_constant<int, 5>{});
+            tap(std::integral_constant<int, 6>{});  tap(std::integral_constant<int, 7>{});  tap(std::integral_constant<int, 8>{});
+            tap(std::integral_constant<int, 9>{});  tap(std::integral_constant<int, 10>{}); tap(std::integral_constant<int, 11>{});
+            tap(std::integral_constant<int, 12>{}); tap(std::integral_constant<int, 13>{}); tap(std::integral_constant<int, 14>{});
+            tap(std::integral_constant<int, 15>{}); tap(std::integral_constant<int, 16>{}); tap(std::integral_constant<int, 17>{});
+            if (do_cs) {            // the two reads were issued 13 taps (>= 26 younger reads, all waited for in order) ago
+                asm volatile("" : "+v"(cv0), "+v"(cv1));
+                cs[0] += bf_lo(cv0.x) + bf_lo(cv1.x); cs[1] += bf_hi(cv0.x) + bf_hi(cv1.x); cs[2] += bf_lo(cv0.y) + bf_lo(cv1.y); cs[3] += bf_hi(cv0.y) + bf_hi(cv1.y);
+                cs[4] += bf_lo(cv0.z) + bf_lo(cv1.z); cs[5] += bf_hi(cv0.z) + bf_hi(cv1.z); cs[6] += bf_lo(cv0.w) + bf_lo(cv1.w); cs[7] += bf_hi(cv0.w) + bf_hi(cv1.w);
+            }
+            if (more2) { wcl += NC; if (wcl >= W) wcl -= W; }
+            cur = nxt;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef W9PC_ISSUE
+#undef W9P_OK
+#undef W9P_PLANE
+    };
+    if (CONT) { if (kh == 0) runc(std::integral_constant<int, 0>{}); else runc(std::integral_constant<int, 1>{}); }
+    else { if (kh == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{}); }
     __syncthreads();                                   // every DMA has landed and every tile is dead: LDS is reused below
+    W9P_PHASE(1);
 
     if (do_cs) {
         float* red = (float*)smem;
@@ -625,6 +753,7 @@ __global__ __launch_bounds__(512) void wgrad9p_kernel(W9Args g) {
         }
         __syncthreads();
     }
+    W9P_PHASE(2);
     // sum the two pixel halves through LDS and store the slab tile (as wgrad9_kernel)
     float* xch = (float*)smem + cb * (9 * 4 * 4 * 64) + lane;
     if (kh == 1) {
@@ -648,6 +777,11 @@ __global__ __launch_bounds__(512) void wgrad9p_kernel(W9Args g) {
                     slab[((long)t * g.Cin + ci) * g.Cout + co] = acc[t][c][r] + xch[((t * 4 + c) * 4 + r) * 64];
                 }
     }
+#ifdef OCR_EXPERIMENTS
+    W9P_PHASE(3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W9P_PHASE(4);
+#endif
 }
 
 // Continuous-stream form of the kernel above (measured with s_memtime stamps: after the per-step barrier every wave spent
@@ -1017,11 +1151,21 @@ int wgrad9_try_dispatch(const void* x, const void* dy, float* dw, float* dbias, 
                        (long)M * (Cin > Cout ? Cin : Cout) * 2 < 0x7fffffffL;
     if (use_p) {
         // (look-ahead 3 and 4 of the fragment read stream measured equal to 2: profiles/r03s_wgrad9p.log)
-#define W9P_LAUNCH(H_, LA_) do { \
+#define W9P_LAUNCH(H_, LA_, C_) do { \
             static bool attr = false; \
-            if (!attr) { if (hipFuncSetAttribute((const void*)wgrad9p_kernel<H_, LA_>, hipFuncAttributeMaxDynamicSharedMemorySize, W9_LDS) != hipSuccess) return OCR_ERR_EXEC; attr = true; } \
-            wgrad9p_kernel<H_, LA_><<<grid, 512, W9_LDS, stream>>>(g); } while (0)
-        if (H == 4) W9P_LAUNCH(4, 2); else W9P_LAUNCH(8, 2);
+            if (!attr) { if (hipFuncSetAttribute((const void*)wgrad9p_kernel<H_, LA_, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, W9_LDS) != hipSuccess) return OCR_ERR_EXEC; attr = true; } \
+            wgrad9p_kernel<H_, LA_, C_><<<grid, 512, W9_LDS, stream>>>(g); } while (0)
+        // (the continuous-read-stream schedule `runc` — barrier in the middle of a step, the next step's first fragments fetched by the
+        // last taps — measured equal or slower, look-ahead 2 and 5: profiles/r03x_wgrad9p_cont.log; only `make EXPERIMENTS=1` builds it)
+#ifdef OCR_EXPERIMENTS
+        static int cont = -1;                   // A/B knob OCR_W9P_CONT: 0 barrier at the top of a step, 1 continuous stream (look-ahead 2), 2 (look-ahead 5)
+        if (cont < 0) { const char* e = getenv("OCR_W9P_CONT"); cont = e ? atoi(e) : 0; }
+        if (cont == 1 || cont == 2) {
+            if (H == 4) { if (cont == 1) W9P_LAUNCH(4, 2, true); else W9P_LAUNCH(4, 5, true); }
+            else { if (cont == 1) W9P_LAUNCH(8, 2, true); else W9P_LAUNCH(8, 5, true); }
+        } else
+#endif
+        if (H == 4) W9P_LAUNCH(4, 2, false); else W9P_LAUNCH(8, 2, false);
 #undef W9P_LAUNCH
     } else
     switch (H == 2 ? 0 : variant) {             // H = 2 (a 4-row read block spans two image columns): only the redirecting default handles it
