@@ -748,6 +748,241 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
     }
 }
 
+#ifdef OCR_EXPERIMENTS
+// ---- fused batch-norm passes (round 3, MEASURED AND REJECTED — experiments build only, OCR_BN_FUSED=1): ONE launch per pass.
+// Result (profiles/r03z_bn_fused.log): correct (engine and golden tests pass), but a grid barrier across the 8 XCDs costs 10-20 us (one
+// counter: ~20, two-level: ~10; device-scope atomics and the L2 write-back / invalidate of the release / acquire fences), so a fused pass
+// takes ~41 us against ~25 for the three launches it replaces: the headline step 1.333 -> 1.397 ms, the deep one 5.27 -> 6.54 ms.  The three-kernel forms above read x twice (x, y and dy twice in the backward
+// pass) and pay three dependent launches of 5-14 us for 17 MB tensors: 2 x (19 + 33) us per step of the headline net, 6 launches per
+// layer-pass of the 35 BN layers of the deep one.  Here the whole tensor stays in REGISTERS between the statistics and the apply phase
+// (<= 256 workgroups x 256 threads x 16 rows x 8 channels = 8.4 M elements: every BN layer of both nets), the per-block partial sums
+// meet through two grid barriers: phase 1 block partials -> barrier -> phase 2 block b finalises channels b, b + NB, .. (fixed order,
+// double) -> barrier -> phase 3 apply from registers.  All workgroups of the grid are co-resident by construction (<= 256 workgroups of
+// 256 threads); the barrier spins on a generation word with a bounded wait (a time-out poisons the output instead of hanging the GPU).
+// Two-level barrier: 16 groups (block & 15) count on their own 128-byte lines, the last block of a group counts on the global line, the
+// last group releases 16 generation words (one per group, polled by its <= 16 members).  (One counter for all 256 blocks serialised 256
+// same-address device-scope atomics: ~20 us per barrier, a fused pass 64 us.)
+struct BnBar { unsigned cnt[16][32]; unsigned gen[16][32]; unsigned gcnt[32]; unsigned timeouts[32]; };
+__device__ BnBar bn_bar;
+__device__ __forceinline__ bool bn_grid_barrier(unsigned nblocks) {
+    __syncthreads();                                   // every thread's global stores have been issued and counted (workgroup scope)
+    __shared__ int ok_s;
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        __threadfence();                               // release at agent scope ONCE per block (a fence per thread — 65 536 L2 write-backs
+                                                       // and invalidates — made a pass 93 us)
+        const unsigned g = blockIdx.x & 15u, ngroups = nblocks < 16u ? nblocks : 16u, ng = (nblocks - g + 15u) >> 4;
+        const unsigned gen = __hip_atomic_load(&bn_bar.gen[g][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned prev = __hip_atomic_fetch_add(&bn_bar.cnt[g][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool released = false;
+        if (prev == ng - 1) {
+            __hip_atomic_store(&bn_bar.cnt[g][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned gp = __hip_atomic_fetch_add(&bn_bar.gcnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gp == ngroups - 1) {
+                __hip_atomic_store(&bn_bar.gcnt[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (unsigned k = 0; k < ngroups; ++k) __hip_atomic_store(&bn_bar.gen[k][0], gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                released = true;
+            }
+        }
+        if (!released) {
+            long spins = 0;
+            while (__hip_atomic_load(&bn_bar.gen[g][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1L << 22)) { ok = 0; atomicAdd(&bn_bar.timeouts[0], 1u); break; }   // ~ a second: something is badly wrong
+            }
+        }
+        __threadfence();                               // acquire: the other blocks' writes (invalidates this XCD's view)
+        ok_s = ok;
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+// rows of a block: rows_per_block = NIT_MAX * rlanes at most; thread (rl, gq) owns rows r0 + rl + i * rlanes, channels gq*8 .. gq*8+7
+constexpr int BNF_NIT = 16;
+// this block's share of the finalisation: channel ch (block-uniform); 256 threads add the NB partial rows of the pair (ch, C + ch) in double
+__device__ __forceinline__ void bnf_pair_total(const float* __restrict__ part, int nblk, int C, int ch, double* red /* [2][256] */, double& t0, double& t1) {
+    double a0 = 0, a1 = 0;
+    for (int b = threadIdx.x; b < nblk; b += 256) { a0 += (double)part[(long)b * 2 * C + ch]; a1 += (double)part[(long)b * 2 * C + C + ch]; }
+    red[threadIdx.x] = a0; red[256 + threadIdx.x] = a1;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { red[threadIdx.x] += red[threadIdx.x + s]; red[256 + threadIdx.x] += red[256 + threadIdx.x + s]; }
+        __syncthreads();
+    }
+    t0 = red[0]; t1 = red[256];
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void bn_fused_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ rstd,
+                                                           float* __restrict__ part, long M, int C, float eps, int relu, int rows_per_block,
+                                                           const bf16_t* __restrict__ res) {
+    const int groups = C >> 3, rl = threadIdx.x / groups, gq = threadIdx.x % groups, rlanes = 256 / groups;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const bool act = rl < rlanes;
+    u32x4 v[BNF_NIT];
+    float s[8], ss[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { s[c] = 0.f; ss[c] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < BNF_NIT; ++i) {
+        const long r = r0 + rl + (long)i * rlanes;
+        v[i] = (u32x4){0, 0, 0, 0};
+        if (act && r < r1) v[i] = *(const u32x4*)(x + r * C + gq * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < BNF_NIT; ++i) {                // rows past r1 are zeros: they add nothing
+        float f[8];
+        unpack8(v[i], f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { s[c] += f[c]; ss[c] = fmaf(f[c], f[c], ss[c]); }
+    }
+    __shared__ float red[2048];
+    __shared__ double red2[512];
+    float* dst = part + (long)blockIdx.x * 2 * C;
+    block_channel_reduce<float, true>(s, red, dst, C, groups, rl, gq, rlanes);
+    block_channel_reduce<float, true>(ss, red, dst + C, C, groups, rl, gq, rlanes);
+    bool ok = bn_grid_barrier(gridDim.x);
+    for (int ch = blockIdx.x; ch < C; ch += gridDim.x) {
+        double t0, t1;
+        bnf_pair_total(part, gridDim.x, C, ch, red2, t0, t1);
+        if (threadIdx.x == 0) {
+            const double mu = t0 / (double)M;
+            double var = t1 / (double)M - mu * mu;
+            if (var < 0) var = 0;
+            mean[ch] = (float)mu;
+            rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+    }
+    ok = bn_grid_barrier(gridDim.x) && ok;
+    if (!act) return;
+    float mu[8], rs[8], gm[8], bt[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = gq * 8 + c;
+        mu[c] = mean[ch]; rs[c] = ok ? rstd[ch] : __builtin_nanf(""); gm[c] = gamma[ch]; bt[c] = beta[ch];
+    }
+#pragma unroll
+    for (int i = 0; i < BNF_NIT; ++i) {
+        const long r = r0 + rl + (long)i * rlanes;
+        if (r >= r1) continue;
+        float f[8], o[8];
+        unpack8(v[i], f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = (f[c] - mu[c]) * rs[c] * gm[c] + bt[c];
+        if (res != nullptr) {                          // as bn_apply_kernel: the batch-norm output is rounded to bf16 before the add
+            float q[8];
+            unpack8(*(const u32x4*)(res + r * C + gq * 8), q);
+            u32x4 rb = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+            unpack8(rb, o);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[c] += q[c];
+        }
+        if (relu) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[c] = fmaxf(o[c], 0.f);
+        }
+        u32x4 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+        *(u32x4*)(y + r * C + gq * 8) = pk;
+    }
+}
+__global__ __launch_bounds__(256) void bn_fused_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const bf16_t* __restrict__ dy,
+                                                           bf16_t* __restrict__ dx, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, float* __restrict__ part, double* __restrict__ sums,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, long M, int C, int relu,
+                                                           int rows_per_block) {
+    const int groups = C >> 3, rl = threadIdx.x / groups, gq = threadIdx.x % groups, rlanes = 256 / groups;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const bool act = rl < rlanes;
+    u32x4 vx[BNF_NIT], vg[BNF_NIT];
+    float s[8], sx[8], mu[8], rs[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { s[c] = 0.f; sx[c] = 0.f; mu[c] = mean[gq * 8 + c]; rs[c] = rstd[gq * 8 + c]; }
+#pragma unroll
+    for (int i = 0; i < BNF_NIT; ++i) {
+        const long r = r0 + rl + (long)i * rlanes;
+        vx[i] = (u32x4){0, 0, 0, 0}; vg[i] = (u32x4){0, 0, 0, 0};
+        if (act && r < r1) {
+            vx[i] = *(const u32x4*)(x + r * C + gq * 8);
+            u32x4 g = *(const u32x4*)(dy + r * C + gq * 8);
+            if (relu) {                                // dz = dy * (y > 0): cleared halves are exact zeros
+                const u32x4 q = *(const u32x4*)(y + r * C + gq * 8);
+                if (!(bf_lo(q.x) > 0.f)) g.x &= 0xffff0000u;
+                if (!(bf_hi(q.x) > 0.f)) g.x &= 0x0000ffffu;
+                if (!(bf_lo(q.y) > 0.f)) g.y &= 0xffff0000u;
+                if (!(bf_hi(q.y) > 0.f)) g.y &= 0x0000ffffu;
+                if (!(bf_lo(q.z) > 0.f)) g.z &= 0xffff0000u;
+                if (!(bf_hi(q.z) > 0.f)) g.z &= 0x0000ffffu;
+                if (!(bf_lo(q.w) > 0.f)) g.w &= 0xffff0000u;
+                if (!(bf_hi(q.w) > 0.f)) g.w &= 0x0000ffffu;
+            }
+            vg[i] = g;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BNF_NIT; ++i) {                // rows past r1: dz = 0 adds nothing
+        float xv[8], g[8];
+        unpack8(vx[i], xv); unpack8(vg[i], g);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { s[c] += g[c]; sx[c] = fmaf(g[c], (xv[c] - mu[c]) * rs[c], sx[c]); }
+    }
+    __shared__ float red[2048];
+    __shared__ double red2[512];
+    float* dst = part + (long)blockIdx.x * 2 * C;
+    block_channel_reduce<float, true>(s, red, dst, C, groups, rl, gq, rlanes);
+    block_channel_reduce<float, true>(sx, red, dst + C, C, groups, rl, gq, rlanes);
+    bool ok = bn_grid_barrier(gridDim.x);
+    for (int ch = blockIdx.x; ch < C; ch += gridDim.x) {
+        double t0, t1;
+        bnf_pair_total(part, gridDim.x, C, ch, red2, t0, t1);
+        if (threadIdx.x == 0) {
+            sums[ch] = t0; sums[C + ch] = t1;
+            dbeta[ch] += (float)t0;
+            dgamma[ch] += (float)t1;
+        }
+    }
+    ok = bn_grid_barrier(gridDim.x) && ok;
+    if (!act) return;
+    const double invM = 1.0 / (double)M;
+    float gr[8], mdz[8], mdzx[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = gq * 8 + c;
+        gr[c] = ok ? gamma[ch] * rs[c] : __builtin_nanf("");
+        mdz[c] = (float)(sums[ch] * invM); mdzx[c] = (float)(sums[C + ch] * invM);
+    }
+#pragma unroll
+    for (int i = 0; i < BNF_NIT; ++i) {
+        const long r = r0 + rl + (long)i * rlanes;
+        if (r >= r1) continue;
+        float xv[8], g[8], o[8];
+        unpack8(vx[i], xv); unpack8(vg[i], g);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float xh = (xv[c] - mu[c]) * rs[c];
+            o[c] = gr[c] * (g[c] - mdz[c] - xh * mdzx[c]);
+        }
+        u32x4 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+        *(u32x4*)(dx + r * C + gq * 8) = pk;
+    }
+}
+// launch geometry of the fused passes; 0 blocks = not covered (the three-kernel form runs)
+static int bnf_blocks(long M, int C, int* rows_per_block) {
+    static int on = -1;                         // A/B knob OCR_BN_FUSED = 1 (default 0: the three-kernel passes)
+    if (on < 0) { const char* e = getenv("OCR_BN_FUSED"); on = e ? atoi(e) : 0; }
+    const int groups = C >> 3;
+    if (!on || groups < 1 || groups > 256) return 0;
+    const int rlanes = 256 / groups;
+    long rpb = (M + 255) / 256;                 // at most 256 workgroups
+    rpb = (rpb + rlanes - 1) / rlanes * rlanes;
+    if (rpb > (long)BNF_NIT * rlanes) return 0; // more than 16 rows per thread: does not fit the registers
+    const long nb = (M + rpb - 1) / rpb;
+    const long ws_rows = ceil_div(M, (long)bn_rows_per_block_host(M, 512));      // what ocr_bn_workspace_bytes sized the partial rows for
+    if (nb > 256 || nb > ws_rows) return 0;
+    *rows_per_block = (int)rpb;
+    return (int)nb;
+}
+#endif
+
 // ============================================================================================
 // column sums: out[c] += sum_m a[m][c]   (bias gradients; a is bf16 [M][C], out fp32)
 // ============================================================================================
@@ -1114,6 +1349,18 @@ extern "C" int ocr_bn_train_fwd(const void* x, void* y, const float* gamma, cons
     if (!x || !y || !gamma || !beta || !save_mean || !save_rstd || !workspace || (C & 7) || C > 2048 || M <= 0)
         return OCR_ERR_INVALID;
     int rlanes = 256 / (C >> 3); if (rlanes < 1) return OCR_ERR_INVALID;
+#ifdef OCR_EXPERIMENTS
+    {
+        int frpb = 0;
+        const int fnb = bnf_blocks(M, C, &frpb);
+        if (fnb > 0) {
+            bn_fused_fwd_kernel<<<fnb, 256, 0, stream>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, save_mean, save_rstd, (float*)workspace, M, C,
+                                                         eps, relu, frpb, (const bf16_t*)residual);
+            OCR_CHECK_LAUNCH();
+            return OCR_OK;
+        }
+    }
+#endif
     const int rpb = bn_rows_per_block_host(M, 256);
     const int nblk = (int)ceil_div(M, (long)rpb);
     bn_stats_kernel<<<nblk, 256, 0, stream>>>((const bf16_t*)x, (float*)workspace, M, C, rpb);
@@ -1137,6 +1384,18 @@ extern "C" int ocr_bn_train_bwd(const void* x, const void* y, const void* dy, vo
     const int nblk = (int)ceil_div(M, (long)rpb);
     float* part = (float*)workspace;
     double* sums = (double*)((char*)workspace + (size_t)nblk * 2 * C * sizeof(float));
+#ifdef OCR_EXPERIMENTS
+    {
+        int frpb = 0;
+        const int fnb = bnf_blocks(M, C, &frpb);
+        if (fnb > 0) {
+            bn_fused_bwd_kernel<<<fnb, 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, save_mean, save_rstd,
+                                                         gamma, part, sums, dgamma, dbeta, M, C, relu, frpb);
+            OCR_CHECK_LAUNCH();
+            return OCR_OK;
+        }
+    }
+#endif
     bn_bwd_stats_kernel<<<nblk, 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, save_mean,
                                                   save_rstd, part, M, C, rpb, relu);
     OCR_CHECK_LAUNCH();
