@@ -432,7 +432,8 @@ static int launch_k2(const K2Args& g, hipStream_t stream) {
 static int k2_choose(long M, int H, int Cin, int Cout, int minsteps_k3 = -1 /* >= 0: the step floor of conv_k3.hip instead of OCR_K2_MINSTEPS */) {
     if ((Cin & 63) || (Cout & 63) || M < 4096 || H > 16 || H < 1) return 0;
     if (M * Cin * 2 >= 0x7fffffffL || (long)Cout * 9 * Cin * 2 >= 0x7fffffffL) return 0;   // 32-bit descriptor offsets
-    static int force = -1, minsteps = -1, allow_a = -1;
+    static int force = -1, minsteps = -1, allow_a = -1, mintiles = -1;
+    if (mintiles < 0) { const char* e = getenv("OCR_K2_MINTILES"); mintiles = e ? atoi(e) : 128; }
     if (force < 0) { const char* e = getenv("OCR_K2_CFG"); force = (e && (e[0] == 'A' || e[0] == 'D')) ? e[0] : 0; }
     if (minsteps < 0) { const char* e = getenv("OCR_K2_MINSTEPS"); minsteps = e ? atoi(e) : 18; }
     // OCR_K2_TILES = D keeps the dispatcher off tile A.  With prefetch distance 2 tile A was SLOWER than conv_halo inside the train step
@@ -450,7 +451,7 @@ static int k2_choose(long M, int H, int Cin, int Cout, int minsteps_k3 = -1 /* >
         if (Cout % bn) continue;
         if (force) return c;
         if (9 * (Cin / 64) < (minsteps_k3 >= 0 ? minsteps_k3 : minsteps)) return 0;
-        if ((M + 255) / 256 * (Cout / bn) >= 224) return c;
+        if ((M + 255) / 256 * (Cout / bn) >= mintiles) return c;
     }
     return 0;
 }
