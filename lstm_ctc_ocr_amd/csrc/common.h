@@ -2,6 +2,7 @@
 // Everything in this directory is written for wave64 / MFMA / 160 KiB LDS only;
 // there is deliberately no other backend.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -76,4 +77,14 @@ __device__ __forceinline__ void dma16_saddr(unsigned lds_dst, unsigned voff, con
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
 }
 
+// Tuning knobs (tile policies, stage counts, ...): read from the environment only by `make EXPERIMENTS=1` builds — the A/B tools load that
+// library through OCR_NATIVE_LIB; the product library uses the measured defaults.  Kernel-selection knobs that the parity tests force
+// (OCR_CONV_K2 / OCR_CONV_K3 / OCR_K2_CFG / OCR_W9_PLANES / OCR_LSTM_PROTO / OCR_LSTM_ROWS) are read by both.
+static inline const char* ocr_tune_env(const char* name) {
+#ifdef OCR_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name; return nullptr;
+#endif
+}
 __host__ __device__ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

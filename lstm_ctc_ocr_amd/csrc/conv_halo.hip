@@ -348,11 +348,11 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
     // of phase, so one's MFMA burst covers the other's barrier / DMA-issue / LDS-read phase (+5-7 % where the grid then still
     // has two workgroups for every CU).  Otherwise 256-pixel workgroups of 8 waves, one per CU.
     static int nw = -1;                                  // A/B knob OCR_HALO_NW: 8 / 4 force one kind, unset = by grid size
-    if (nw < 0) { const char* e = getenv("OCR_HALO_NW"); nw = e ? atoi(e) : 0; }
+    if (nw < 0) { const char* e = ocr_tune_env("OCR_HALO_NW"); nw = e ? atoi(e) : 0; }
     static int stag = -1, stag_bit = 32;                 // experiment knob OCR_HALO_STAGGER=units[,bit] (units of 64 clocks; default off)
-    if (stag < 0) { const char* e = getenv("OCR_HALO_STAGGER"); stag = e ? atoi(e) : 0; const char* c = e ? strchr(e, ',') : nullptr; if (c) stag_bit = atoi(c + 1); if (stag < 0) stag = 0; }
+    if (stag < 0) { const char* e = ocr_tune_env("OCR_HALO_STAGGER"); stag = e ? atoi(e) : 0; const char* c = e ? strchr(e, ',') : nullptr; if (c) stag_bit = atoi(c + 1); if (stag < 0) stag = 0; }
     static int prio = -1;
-    if (prio < 0) { const char* e = getenv("OCR_HALO_PRIO"); prio = e ? atoi(e) : 1; }      // measured: 451 against 458 us over the ten launches
+    if (prio < 0) { const char* e = ocr_tune_env("OCR_HALO_PRIO"); prio = e ? atoi(e) : 1; }      // measured: 451 against 458 us over the ten launches
     HaloArgs g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, stag, stag_bit, prio};
 #ifdef OCR_EXPERIMENTS      // measured and rejected in round 2: dense = equal, wide = 27 % slower
     static int dense = -1;                               // A/B knob OCR_HALO_DENSE=1: 8 waves per 128-pixel tile (4 waves per SIMD with two workgroups per CU)

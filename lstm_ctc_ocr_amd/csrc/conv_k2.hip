@@ -433,15 +433,15 @@ static int k2_choose(long M, int H, int Cin, int Cout, int minsteps_k3 = -1 /* >
     if ((Cin & 63) || (Cout & 63) || M < 4096 || H > 16 || H < 1) return 0;
     if (M * Cin * 2 >= 0x7fffffffL || (long)Cout * 9 * Cin * 2 >= 0x7fffffffL) return 0;   // 32-bit descriptor offsets
     static int force = -1, minsteps = -1, allow_a = -1, mintiles = -1;
-    if (mintiles < 0) { const char* e = getenv("OCR_K2_MINTILES"); mintiles = e ? atoi(e) : 128; }
+    if (mintiles < 0) { const char* e = ocr_tune_env("OCR_K2_MINTILES"); mintiles = e ? atoi(e) : 128; }
     if (force < 0) { const char* e = getenv("OCR_K2_CFG"); force = (e && (e[0] == 'A' || e[0] == 'D')) ? e[0] : 0; }
-    if (minsteps < 0) { const char* e = getenv("OCR_K2_MINSTEPS"); minsteps = e ? atoi(e) : 18; }
+    if (minsteps < 0) { const char* e = ocr_tune_env("OCR_K2_MINSTEPS"); minsteps = e ? atoi(e) : 18; }
     // OCR_K2_TILES = D keeps the dispatcher off tile A.  With prefetch distance 2 tile A was SLOWER than conv_halo inside the train step
     // (1.461 against 1.435 ms, profiles/r03k) and 15-25 % slower behind a cache scrub (profiles/r03m) although 6 % faster when the same
     // launch repeats back to back: one 8-wave workgroup per CU in lock step has nothing to run while a piece arrives late from HBM.
     // With distance 3 (five weight stages) it is faster in all three settings (profiles/r03n: cold 474 against 504 us over the ten
     // layers, hot 416 against 446, step 1.415 against 1.440 ms).
-    if (allow_a < 0) { const char* e = getenv("OCR_K2_TILES"); allow_a = (e && e[0] == 'D') ? 0 : 1; }
+    if (allow_a < 0) { const char* e = ocr_tune_env("OCR_K2_TILES"); allow_a = (e && e[0] == 'D') ? 0 : 1; }
     const char order[2] = {'A', 'D'};
     for (int i = 0; i < 2; ++i) {
         const char c = order[i];
@@ -468,7 +468,7 @@ int k2_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int
     // 34.0 against 33.6 us, 41 against 39.7 behind a cache scrub, profiles/r03t); A/B knob OCR_CONV_K3 = 0
     static int k3 = -1, k3min = -1;
     if (k3 < 0) { const char* e = getenv("OCR_CONV_K3"); k3 = e ? atoi(e) : 1; }
-    if (k3min < 0) { const char* e = getenv("OCR_K3_MINSTEPS"); k3min = e ? atoi(e) : 18; }
+    if (k3min < 0) { const char* e = ocr_tune_env("OCR_K3_MINSTEPS"); k3min = e ? atoi(e) : 18; }
     if (k3) {
         const int c3 = k2_choose(M, H, Cin, Cout, k3min);
         if (c3) {
@@ -479,11 +479,11 @@ int k2_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int
     const int c = k2_choose(M, H, Cin, Cout);
     if (!c) return -1;
     static int abl = -1;
-    if (abl < 0) { const char* e = getenv("OCR_K2_ABL"); abl = e ? atoi(e) : 0; }
+    if (abl < 0) { const char* e = ocr_tune_env("OCR_K2_ABL"); abl = e ? atoi(e) : 0; }
     K2Args g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, abl};
 #ifdef OCR_EXPERIMENTS
     static int nst = -1;                                 // A/B knob OCR_K2_NST: weight stages (prefetch distance + 2)
-    if (nst < 0) { const char* e = getenv("OCR_K2_NST"); nst = e ? atoi(e) : 0; }
+    if (nst < 0) { const char* e = ocr_tune_env("OCR_K2_NST"); nst = e ? atoi(e) : 0; }
     if (c == 'A' && nst == 4) return launch_k2<8, 128, 4>(g, stream);
     if (c == 'D' && nst == 5) return launch_k2<4, 64, 5>(g, stream);
     if (c == 'D' && nst == 6) return launch_k2<4, 64, 6>(g, stream);

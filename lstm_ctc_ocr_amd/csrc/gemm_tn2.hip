@@ -293,7 +293,7 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
     // plain products run on 8-wave workgroups, ONE per CU (two waves per SIMD without doubling the split count and its atomic
     // traffic): conv5 30.3 -> 27.1 us, both BiLSTM directions 35.7 -> 32.9 us (tools/tn_split_sweep.py).  A/B knob OCR_TN2_NW=4.
     static int nw8 = -1;
-    if (nw8 < 0) { const char* e = getenv("OCR_TN2_NW"); nw8 = (e && atoi(e) == 4) ? 0 : 1; }
+    if (nw8 < 0) { const char* e = ocr_tune_env("OCR_TN2_NW"); nw8 = (e && atoi(e) == 4) ? 0 : 1; }
     const bool wide = nw8 && mode == 0;
     const long wg_lo = wide ? 200 : 400, wg_hi = wide ? 256 : 512;
     const double ideal = (wide ? 232.0 : 432.0) / (double)tiles;
@@ -317,7 +317,7 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
             if (splits <= 0 && wg > wg_hi) cost += (wg - wg_hi) * 4.0e6;       // a third, ragged round of workgroups
             if (cost < best) { best = cost; bXS = XS; bXJ = XJ; bXI = XI; bS = S; }
         }
-    static const char* part_env = getenv("OCR_TN2_PART");    // experiment knob "XS,XJ,XI,S", read once per process
+    static const char* part_env = ocr_tune_env("OCR_TN2_PART");    // experiment knob "XS,XJ,XI,S", read once per process
     if (const char* e = part_env) {
         int xs, xj, xi, sp;
         if (sscanf(e, "%d,%d,%d,%d", &xs, &xj, &xi, &sp) == 4 && xs * xj * xi == 8 && IT % xi == 0 && JT % xj == 0 && sp % xs == 0 && sp >= 1) {
@@ -329,7 +329,7 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
     g.XS = bXS; g.XJ = bXJ; g.XI = bXI; g.taps = taps; g.itl = IT / bXI; g.jtl = JT / bXJ;
     g.k_per_split = ceil_div(ceil_div(Mk, splits), 64) * 64;
     static int cfg = -1;                           // A/B knob OCR_TN2_PIPE: 0 = 64-row stages x 2 (default), 1 = 32 x 4, 2 = 32 x 3, 3 = 64 x 3
-    if (cfg < 0) { const char* e = getenv("OCR_TN2_PIPE"); cfg = e ? atoi(e) : 0; if (cfg < 0 || cfg > 3) cfg = 0; }
+    if (cfg < 0) { const char* e = ocr_tune_env("OCR_TN2_PIPE"); cfg = e ? atoi(e) : 0; if (cfg < 0 || cfg > 3) cfg = 0; }
     const int km = pair ? 2 : mode;
     dim3 grid((unsigned)(tiles * splits));          // empty splits (kbeg >= Mk) return at once
 #define TN2_LAUNCH(M_, BK_, NS_) do { \

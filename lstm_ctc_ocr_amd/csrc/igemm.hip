@@ -263,7 +263,7 @@ int ig_try_dispatch(const void* P, long ldp, const void* Q, long ldq, void* out,
     // 128-row tiles of 4 waves (72 KiB of LDS with three stages at BN = 64, 64 KiB with two at BN = 128: two workgroups per
     // CU) when the 256-row grid cannot give every CU two waves' worth of work — the M = 4032 GEMMs of conv5 / LSTM / FC.
     static int ig_nw = -1;                                 // A/B knob OCR_IG_NW: 8 / 4 force, unset = by grid size
-    if (ig_nw < 0) { const char* e = getenv("OCR_IG_NW"); ig_nw = e ? atoi(e) : 0; }
+    if (ig_nw < 0) { const char* e = ocr_tune_env("OCR_IG_NW"); ig_nw = e ? atoi(e) : 0; }
     if (mode == 0 && ig_nw != 8) {
         const long mt4 = (M + 127) / 128;
         const long wg8 = (long)((M + 255) / 256) * ((N + 127) / 128);

@@ -477,9 +477,9 @@ static long long* g_lstm_dbg = nullptr;
 extern "C" int ocr_lstm_seq_debug(void* dbg) { g_lstm_dbg = (long long*)dbg; return OCR_OK; }
 
 // environment knobs are looked up ONCE per process (the launch path runs every step when graphs are off)
-static int seq_env_int(const char* name, int slot, int dflt) {
+static int seq_env_int(const char* name, int slot, int dflt, bool tuning = false /* read by experiments builds only */) {
     static int val[4], seen[4];
-    if (!seen[slot]) { const char* e = getenv(name); val[slot] = e ? atoi(e) : dflt; seen[slot] = 1; }
+    if (!seen[slot]) { const char* e = tuning ? ocr_tune_env(name) : getenv(name); val[slot] = e ? atoi(e) : dflt; seen[slot] = 1; }
     return val[slot];
 }
 // batch rows per workgroup: the smallest tile whose grid still fits one workgroup per CU (measured at N = 64, U = 256, us per
@@ -562,7 +562,7 @@ extern "C" int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, cons
     OCR_CHECK_LAUNCH();
     LstmSeqFwdArgs a = {xproj, (const bf16_t*)whT_packed, seq_len, (bf16_t*)hout, gates, cell, (unsigned*)sync,
                         (unsigned char*)((unsigned*)sync + cwords), (int*)sync + words - 1, Nb, T, forget_bias, g_lstm_dbg,
-                        seq_env_int("OCR_LSTM_PRESLEEP_F", 0, 0)};
+                        seq_env_int("OCR_LSTM_PRESLEEP_F", 0, 0, true)};
     const dim3 grid3(U / 16, 2, nz), grid1((U / 16) * 8 * ceil_div(2 * nz, 8));
 #define FWD(UU) do { if (proto == 0) launch_fwd<UU, 0>(a, rows, grid3, grid1, stream); else launch_fwd<UU, 4>(a, rows, grid3, grid1, stream); } while (0)
     if (U == 256) FWD(256); else FWD(512);
@@ -587,7 +587,7 @@ extern "C" int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, con
     OCR_CHECK_LAUNCH();
     LstmSeqBwdArgs a = {(const bf16_t*)wh, ldw, w_dir_stride, seq_len, (const bf16_t*)dhout, gates, cell, (bf16_t*)dz,
                         (unsigned*)sync, (unsigned char*)((unsigned*)sync + cwords), (int*)sync + words - 1, Nb, T, g_lstm_dbg,
-                        seq_env_int("OCR_LSTM_PRESLEEP", 1, 4)};
+                        seq_env_int("OCR_LSTM_PRESLEEP", 1, 4, true)};
     const dim3 grid3(U / 16, 2, nz), grid1((U / 16) * 8 * ceil_div(2 * nz, 8));
 #define BWD(UU) do { if (proto == 0) launch_bwd<UU, 0>(a, rows, grid3, grid1, stream); else launch_bwd<UU, 4>(a, rows, grid3, grid1, stream); } while (0)
     if (U == 256) BWD(256); else BWD(512);

@@ -1248,7 +1248,7 @@ __global__ __launch_bounds__(256) void eltwise_bf16_kernel(int op, const bf16_t*
 // loads are hidden by its occupancy.  OCR_COL2IM_V1=1: the scalar col2im (13.3 us against 5.9 for the 16-byte one).
 static bool nn_knob(const char* name, int slot) {
     static int v[2] = {-1, -1};
-    if (v[slot] < 0) { const char* e = getenv(name); v[slot] = (e && atoi(e) != 0) ? 1 : 0; }
+    if (v[slot] < 0) { const char* e = ocr_tune_env(name); v[slot] = (e && atoi(e) != 0) ? 1 : 0; }
     return v[slot] == 1;
 }
 static bool conv1_v1() { return !nn_knob("OCR_CONV1_V2", 0); }

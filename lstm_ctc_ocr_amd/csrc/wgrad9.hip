@@ -1100,7 +1100,7 @@ static bool w9_plan(int M, int W, int H, int Cin, int Cout, W9Plan* p) {
     if ((Cin & 63) || (Cout & 63) || (H != 2 && H != 4 && H != 8 && H != 16) || M < 512 || (M % H) || W * H < 32) return false;
     const int T_ci = Cin / 64, T_co = Cout / 64, T = T_ci * T_co;
     static int smax = -1;                       // A/B knob OCR_W9_SMAX: cap on the split count (partial slabs cost 2 x 147 KB x workgroups of HBM traffic)
-    if (smax < 0) { const char* e = getenv("OCR_W9_SMAX"); smax = e ? atoi(e) : 64; if (smax < 1) smax = 1; }
+    if (smax < 0) { const char* e = ocr_tune_env("OCR_W9_SMAX"); smax = e ? atoi(e) : 64; if (smax < 1) smax = 1; }
     int S = 1;
     while ((long)S * 2 * T <= 256 && S * 2 <= smax && M / (S * 2) >= 512) S *= 2;   // <= one workgroup per CU, >= four steps each
     p->S = S; p->T_ci = T_ci; p->T_co = T_co;
@@ -1129,7 +1129,7 @@ int wgrad9_try_dispatch(const void* x, const void* dy, float* dw, float* dbias, 
     const int M = Nb * W * H;
     if (!workspace || !w9_plan(M, W, H, Cin, Cout, &p) || ws_bytes < p.bytes) return -1;
     static int variant = -1;                    // A/B knob OCR_W9_VARIANT (see the table below); default 0
-    if (variant < 0) { const char* e = getenv("OCR_W9_VARIANT"); variant = e ? atoi(e) : 0; }
+    if (variant < 0) { const char* e = ocr_tune_env("OCR_W9_VARIANT"); variant = e ? atoi(e) : 0; }
     W9Args g = {};
     g.X = (const bf16_t*)x; g.dY = (const bf16_t*)dy; g.M = M; g.Cin = Cin; g.Cout = Cout; g.cW = W; g.cH = H;
     g.k_per_split = p.k_per_split; g.S = p.S; g.T_ci = p.T_ci; g.T_co = p.T_co; g.map = p.map;
