@@ -47,6 +47,16 @@ extern "C" int ocr_conv_k3_debug(void* dbg) {
 #else
 #define K3_PHASE(slot) do { } while (0)
 #endif
+// packed bf16 max (exact: keeps the raw bits of the larger half)
+__device__ __forceinline__ uint32_t k3_max2(uint32_t a, uint32_t b) {
+    const uint32_t lo = (bf_lo(b) > bf_lo(a)) ? (b & 0xffffu) : (a & 0xffffu);
+    const uint32_t hi = (bf_hi(b) > bf_hi(a)) ? (b & 0xffff0000u) : (a & 0xffff0000u);
+    return lo | hi;
+}
+__device__ __forceinline__ u32x4 k3_max8(u32x4 a, u32x4 b) {
+    u32x4 r = {k3_max2(a.x, b.x), k3_max2(a.y, b.y), k3_max2(a.z, b.z), k3_max2(a.w, b.w)};
+    return r;
+}
 typedef __attribute__((address_space(3))) void* lptr_t;
 #define K3_OOB 0x80000000u                // lane offset of a row that does not exist: beyond any descriptor's range
 #define K3_VMWAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
@@ -261,11 +271,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             bv[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if ((flags & K3_BIAS) && n < g.N) bv[a] = *(const f32x4*)(g.bias + n);
         }
-        // Staged write-out (no fused pool, no accumulate): the tile goes through LDS as a bf16 [256 pixels][BN channels] image — local
+        // Staged write-out (everything but the bf16 accumulate form): the tile goes through LDS as a bf16 [256 pixels][BN channels] image — local
         // pixel lp = column * H + h is global row m0 + lp — and leaves as 16-byte lane stores, four (eight) whole rows per wave instruction;
         // the ReLU mask of the layer below arrives the same way.  (The direct form below writes 8 bytes per lane, 16 pixel rows x 32 B per
         // instruction: 4.8 us of the 57 us of conv4_2, 8.9 with the mask loads in between — profiles/r03u_k3_phases.log.)
-        if (g.pool_kind == 0 && !(flags & K3_ACCUM)) {
+        if (!(flags & K3_ACCUM)) {
             constexpr int ROWB = BN * 2, U = ROWB / 16, SWM = BN == 128 ? 7 : 3;      // row bytes; 16-byte units per row; swizzle bits of the column
             __syncthreads();                            // the exchange region has been read
 #pragma unroll
@@ -310,6 +320,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (!(bf_hi(q.w) > 0.f)) v.w &= 0x0000ffffu;
                 }
                 *(u32x4*)(g.out + ((long)m0 + lp) * g.N + n0 + u * 8) = v;
+            }
+            if (g.pool_kind) {
+                // fused max-pool from the staged image (post-ReLU values; bf16 max is exact, so this equals max-pooling the stored tensor):
+                // kind 1 pairs the feature rows (h, h + 1) of a column — local pixels 2q, 2q + 1 -> pooled row m0 / 2 + q; kind 2 the 2 x 2
+                // window of columns (2c, 2c + 1) -> pooled row (col0 / 2) * (H / 2) + c * (H / 2) + h / 2
+                const int kind = g.pool_kind;
+                const int nq = kind == 1 ? 128 : 64;
+                const long pbase = kind == 1 ? ((long)m0 >> 1) : (long)(col0 >> 1) * (H >> 1);
+                for (int idx = tid; idx < nq * U; idx += 512) {
+                    const int q = idx / U, u = idx % U;
+                    int lp0, cl;
+                    if (kind == 1) { lp0 = 2 * q; cl = lp0 / H; }
+                    else { cl = 2 * (q / (H >> 1)); lp0 = cl * H + 2 * (q % (H >> 1)); }
+                    const unsigned char* r0 = smem + lp0 * ROWB;
+                    const int u0 = (u ^ ((cl & SWM) << 1)) << 4;
+                    u32x4 m = k3_max8(*(const u32x4*)(r0 + u0), *(const u32x4*)(r0 + ROWB + u0));
+                    if (kind == 2) {
+                        const int u1 = (u ^ (((cl + 1) & SWM) << 1)) << 4;
+                        m = k3_max8(m, k3_max8(*(const u32x4*)(r0 + H * ROWB + u1), *(const u32x4*)(r0 + (H + 1) * ROWB + u1)));
+                    }
+                    *(u32x4*)(g.pool + (pbase + q) * g.N + n0 + u * 8) = m;
+                }
             }
             return;
         }
