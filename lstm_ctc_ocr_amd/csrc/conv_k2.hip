@@ -442,17 +442,21 @@ static int k2_choose(long M, int H, int Cin, int Cout, int minsteps_k3 = -1 /* >
     // With distance 3 (five weight stages) it is faster in all three settings (profiles/r03n: cold 474 against 504 us over the ten
     // layers, hot 416 against 446, step 1.415 against 1.440 ms).
     if (allow_a < 0) { const char* e = ocr_tune_env("OCR_K2_TILES"); allow_a = (e && e[0] == 'D') ? 0 : 1; }
+    // first a tile whose grid fills the chip (>= 224 workgroups: A, then D), else one that fills at least half of it (OCR_K2_MINTILES, 128:
+    // the small-batch layers of configs[4], 6090 -> 6513 images/s; for the headline net preferring A with 128 tiles over D with 256 cost
+    // 22 us per step, profiles/r03_final_a_* against r03y)
     const char order[2] = {'A', 'D'};
-    for (int i = 0; i < 2; ++i) {
-        const char c = order[i];
-        if (force && c != force) continue;
-        if (!force && c == 'A' && !allow_a) continue;
-        const int bn = c == 'A' ? 128 : 64;
-        if (Cout % bn) continue;
-        if (force) return c;
-        if (9 * (Cin / 64) < (minsteps_k3 >= 0 ? minsteps_k3 : minsteps)) return 0;
-        if ((M + 255) / 256 * (Cout / bn) >= mintiles) return c;
-    }
+    for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < 2; ++i) {
+            const char c = order[i];
+            if (force && c != force) continue;
+            if (!force && c == 'A' && !allow_a) continue;
+            const int bn = c == 'A' ? 128 : 64;
+            if (Cout % bn) continue;
+            if (force) return c;
+            if (9 * (Cin / 64) < (minsteps_k3 >= 0 ? minsteps_k3 : minsteps)) return 0;
+            if ((M + 255) / 256 * (Cout / bn) >= (pass == 0 ? 224 : mintiles)) return c;
+        }
     return 0;
 }
 
