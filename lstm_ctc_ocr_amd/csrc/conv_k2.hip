@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         K2_STAMP(1);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        if (kh) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);      // the K half that multiplies first drains first (conv_k3.hip, profiles/r03af)
         if (!(abl & 4)) {
 #pragma unroll
             for (int b = 0; b < FM; ++b)

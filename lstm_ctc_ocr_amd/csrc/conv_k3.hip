@@ -33,6 +33,7 @@ struct K3Args {
     int cW, cH;
     bf16_t* out; const float* bias; const bf16_t* mask; int flags;
     bf16_t* pool; int pool_kind;          // as conv_halo: 0 none, 1 feature pairs (1 x 2), 2 2 x 2
+    int prio;                             // MFMA priority of waves 4-7 (the K half that multiplies FIRST in an interval); waves 0-3 use 1
 };
 
 #ifdef OCR_EXPERIMENTS
@@ -190,11 +191,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     // COMP: the MFMAs on the fragments in registers — nothing else
-    auto comp = [&](auto tapc) {
+    auto comp = [&](auto tapc, auto khc) {
         constexpr int DH = decltype(tapc)::value % 3 - 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        // waves 4-7 multiply first in an interval and load second: with a HIGHER priority than waves 0-3 their 32 MFMAs drain before the
+        // partner's start, so their load segment runs beside the partner's MFMAs instead of behind both interleaved MFMA bursts
+        // (equal priorities: 1260 clocks per step against 853 of MFMA; skewed: ~1040 — profiles/r03af_conv_k3_prio.log)
+        if (decltype(khc)::value == 1 && g.prio == 3) __builtin_amdgcn_s_setprio(3);
+        else if (decltype(khc)::value == 1 && g.prio == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int b = 0; b < FM; ++b)
             if (live(b, DH)) {
@@ -216,9 +222,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr int YOUNG = npc(TAP) + (DEPTH > 2 ? npc(PREV) : 0) + (DEPTH > 3 ? npc(PREV2) : 0);
         if (KH == 0) {
             load(tapc, chunk);
-            comp(tapc);
+            comp(tapc, khc);
         } else {
-            if (s > 0) comp(std::integral_constant<int, PREV>{});           // step s - 1
+            if (s > 0) comp(std::integral_constant<int, PREV>{}, khc);           // step s - 1
             load(tapc, chunk);
         }
         K3_VMWAIT(YOUNG);
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             interval(khc, std::integral_constant<int, 6>{}, chunk); interval(khc, std::integral_constant<int, 7>{}, chunk);
             interval(khc, std::integral_constant<int, 8>{}, chunk);
         }
-        if (decltype(khc)::value == 1) comp(std::integral_constant<int, 8>{});          // the last step's MFMAs
+        if (decltype(khc)::value == 1) comp(std::integral_constant<int, 8>{}, khc);          // the last step's MFMAs
     };
     if (kh == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the pieces streamed past the last step: LDS is reused below
@@ -429,7 +435,9 @@ int k3_try_dispatch(int tile, const void* x, const void* wpack, void* y, int M, 
     if (W % (256 / H) || M % 256 || (Cin & 63) || (Cout & 63)) return -1;
     if (flags & ~(K3_BIAS | K3_RELU | K3_MASK | K3_ACCUM)) return -1;
     if (pool_kind && (flags & (K3_MASK | K3_ACCUM))) return -1;
-    K3Args g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind};
+    static int prio = -1;
+    if (prio < 0) { const char* e = ocr_tune_env("OCR_K3_PRIO"); prio = e ? atoi(e) : 2; }      // measured: 1 (equal) 349 us, 2 322, 3 324 over the ten layers (profiles/r03af)
+    K3Args g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, prio};
     const bool single = Cin == 64;
     if (tile == 'A') {
         if (Cout % 128) return -1;
