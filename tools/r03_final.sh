@@ -4,7 +4,7 @@
 T=${1:-r03_final}
 O=gpurun_out; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -4 | tee $O/${T}_gpu_suite.log
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -4 | tee $O/${T}_gpu_suite.log
 timeout 400 python bench.py > $O/${T}_bench_full.json 2> $O/${T}_bench.err; tail -c 2500 $O/${T}_bench_full.json; echo
 timeout 300 python bench.py --workload deep --no-cpu-baseline > $O/${T}_deep.json 2>/dev/null
 timeout 300 python bench.py --workload varwidth --no-cpu-baseline > $O/${T}_varwidth.json 2>/dev/null
