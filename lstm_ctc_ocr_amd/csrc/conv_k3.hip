@@ -19,7 +19,12 @@
 //   * every wave issues the same, compile-time number of DMA pieces per step (P buffers padded to 40 pieces, the pieces of a chunk that
 //     does not exist go through a zero-length descriptor): the counted vmcnt waits are immediates, the step is straight-line code.
 // Tiles, wave roles (2 x 2 x 2 K or 4 x 1 x 2 K), the ping-pong of the K halves with one barrier per step, weight stages / prefetch
-// distance, the K-half exchange and the epilogue (bias / ReLU / mask / accumulate / fused max-pool) are conv_k2.hip's.
+// distance and the K-half exchange are conv_k2.hip's.  Two more things were measured here first (and copied to conv_k2 where they apply):
+//   * the wave group that multiplies FIRST in an interval runs its MFMAs at s_setprio 2, the other at 1: with equal priorities the two
+//     bursts of a SIMD interleave, both finish late and the first group's load segment runs behind them (1260 clocks per step against 853
+//     of MFMA; skewed ~1040: profiles/r03af_conv_k3_prio.log);
+//   * the output tile is staged through LDS as a bf16 [256 pixels][BN] image and leaves as 16-byte row stores; mask and fused max-pool work
+//     on that image (store phase 4.8 -> 2.8 us per launch, 8.9 -> 4.2 with the mask: profiles/r03u / r03v_k3_phases_*.log).
 // Covered: H in {4, 8, 16}, W % (256 / H) == 0 (hence M % 256 == 0), Cin % 64 == 0, Cout % 64 == 0; everything else stays on conv_k2 / conv_halo.
 #include "common.h"
 #include <stdlib.h>
@@ -351,6 +356,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             return;
         }
+        // accumulate form (y += result: one fp32 sum, one rounding — a residual gradient with several consumers; never with a fused pool):
+        // direct 8-byte stores from the accumulator layout
 #pragma unroll
         for (int bb = 0; bb < FH; ++bb) {
             const int b = KH * FH + bb;
@@ -379,26 +386,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 pk.x = pack_bf2(v.x, v.y);
                 pk.y = pack_bf2(v.z, v.w);
                 *(u32x2*)(g.out + m * g.N + n) = pk;
-                if (g.pool_kind) {
-                    // max-pool window of this pixel: the feature-axis neighbour (h ^ 1) is the same lane of fragment b ^ CBW, the
-                    // time-axis neighbour (col ^ 1) the lane ^ 1 of this fragment
-                    f32x4 u = acc[a][KH * FH + (bb ^ CBW)] + bv[a];
-                    f32x4 mx;
-                    mx.x = fmaxf(v.x, fmaxf(u.x, 0.f)); mx.y = fmaxf(v.y, fmaxf(u.y, 0.f));
-                    mx.z = fmaxf(v.z, fmaxf(u.z, 0.f)); mx.w = fmaxf(v.w, fmaxf(u.w, 0.f));
-                    if (g.pool_kind == 2) {
-                        mx.x = fmaxf(mx.x, __shfl_xor(mx.x, 1, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, 1, 64));
-                        mx.z = fmaxf(mx.z, __shfl_xor(mx.z, 1, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, 1, 64));
-                    }
-                    const bool writer = !(h & 1) && (g.pool_kind == 1 || !(col & 1));
-                    if (writer) {
-                        const long pidx = g.pool_kind == 1 ? (m >> 1) : (long)(col >> 1) * (H >> 1) + (h >> 1);
-                        u32x2 pp;
-                        pp.x = pack_bf2(mx.x, mx.y);
-                        pp.y = pack_bf2(mx.z, mx.w);
-                        *(u32x2*)(g.pool + pidx * g.N + n) = pp;
-                    }
-                }
             }
         }
     };
