@@ -115,7 +115,7 @@ def conv_roofline(eng, device):
         src = os.path.basename(cands[-1])
         pm = json.load(open(cands[-1]))
         pmc_commit = pm.get("commit")
-        conv = [k for k in pm.get("kernels", []) if k["symbol"].startswith(("_Z16conv_halo_kernel", "_Z14conv_k2_kernel", "_Z14conv_k3_kernel"))]
+        conv = [k for k in pm.get("kernels", []) if k["symbol"].startswith(("_Z16conv_halo_kernel", "_Z14conv_k2_kernel", "_Z14conv_k3_kernel", "_Z15conv_k3w_kernel"))]
         lib = open(nat.LIB_PATH, "rb").read()
         missing = [k["symbol"] for k in conv if k["symbol"].encode() not in lib]
         if missing or not conv:

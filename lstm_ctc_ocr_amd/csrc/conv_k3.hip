@@ -25,7 +25,8 @@
 //     of MFMA; skewed ~1040: profiles/r03af_conv_k3_prio.log);
 //   * the output tile is staged through LDS as a bf16 [256 pixels][BN] image and leaves as 16-byte row stores; mask and fused max-pool work
 //     on that image (store phase 4.8 -> 2.8 us per launch, 8.9 -> 4.2 with the mask: profiles/r03u / r03v_k3_phases_*.log).
-// Covered: H in {4, 8, 16}, W % (256 / H) == 0 (hence M % 256 == 0), Cin % 64 == 0, Cout % 64 == 0; everything else stays on conv_k2 / conv_halo.
+// Covered: H in {4, 8, 16} with W % (256 / H) == 0; H in {2, 4, 8} with any W whose boundary rows fit the plane (GENW, see the template
+// parameter); M % 256 == 0, Cin % 64 == 0, Cout % 64 == 0; everything else stays on conv_k2 / conv_halo.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -69,8 +70,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int FM /* 16-pixel fragments per wave: 8 or 4 */, int BN /* channels per tile: 128 (waves 2 pixel x 2 channel x 2 K) or 64 (4 x 1 x 2 K) */,
           int NST /* weight stages; tile s + NST - 2 is streamed during step s */, int H /* feature rows: 4, 8 or 16 */,
-          bool SINGLE = false /* C == 64: one chunk, one halo buffer, no halo pieces inside the loop */>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_k3_kernel(K3Args g) {
+          bool SINGLE = false /* C == 64: one chunk, one halo buffer, no halo pieces inside the loop */,
+          bool GENW = false /* any image width: a tile's columns may cross image boundaries — a zero row sits in every plane in front of each
+                               interior boundary column, local column c at plane row 1 + c + k(c), k(c) = boundaries in [1, c]; the fragment
+                               base is then a lane register per (dw, column block) */>
+__device__ __forceinline__ void k3_body(const K3Args& g) {
     constexpr int NW = 8, FN = 4, BM = 256;
     constexpr int WN = BN / 64, WMW = 4 / WN;           // waves along channels / pixels (per K half)
     static_assert(FM * WMW == 16, "256-pixel tiles");
@@ -115,13 +119,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int n = n0 + (wave * QI + j) * 8 + rsub;
         voffQ[j] = n < g.N ? (unsigned)(((long)n * 9 * C + csrc) * 2) : K3_OOB;
     }
+    // GENW: interior boundary columns of this tile t_i = b0 + i W (b0 = W - col0 % W in 1 .. W); k(c) = #{i : c >= t_i}
+    constexpr int KMAX = 8;
+    const int b0w = g.cW - col0 % g.cW;
+    auto kof = [&](int c) { int k = 0;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) k += (c >= b0w + i * g.cW) ? 1 : 0;
+        return k; };
 #pragma unroll
     for (int j = 0; j < PI; ++j) {                      // this wave's halo pieces are j * 8 + wave
         const int r = (j * NW + wave) * 8 + rsub;       // buffer row: plane r / PS, plane row r % PS (r & 7 == rsub == plane row & 7)
         const int h = r / PS, cp = r % PS;
-        const bool ok = h < H && cp < NC + 2 && !(cp == 0 && edge_l) && !(cp == NC + 1 && edge_r);
-        const long m = (long)(col0 - 1 + cp) * H + h;
-        voffP[j] = ok ? (unsigned)((m * C + csrc) * 2) : K3_OOB;
+        if (!GENW) {
+            const bool ok = h < H && cp < NC + 2 && !(cp == 0 && edge_l) && !(cp == NC + 1 && edge_r);
+            const long m = (long)(col0 - 1 + cp) * H + h;
+            voffP[j] = ok ? (unsigned)((m * C + csrc) * 2) : K3_OOB;
+        } else {
+            // plane row cp -> local column: q = cp - 1 counts columns AND the zero rows in front of it; zero row i sits at q = t_i + i
+            const int q = cp - 1, last = NC + kof(NC - 1);           // q of the right halo column
+            int n = 0; bool pad = false;
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i) { const int z = b0w + i * g.cW + i; n += (q >= z) ? 1 : 0; pad = pad || q == z; }
+            int col = col0 + q - n;                                  // q in [0, last): a column of the tile unless a zero row
+            bool ok = h < H && q >= 0 && q < last && !pad;
+            if (h < H && q == -1) { ok = !edge_l; col = col0 - 1; }
+            if (h < H && q == last) { ok = !edge_r; col = col0 + NC; }
+            const long m = (long)col * H + h;
+            voffP[j] = ok ? (unsigned)((m * C + csrc) * 2) : K3_OOB;
+        }
     }
     auto load_q = [&](int k0 /* tap*C + chunk*64 */, int stage) {
 #pragma unroll
@@ -145,12 +170,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
     const unsigned qfrag0 = lds0 + (wn * 64 + frow) * 128 + ((kq ^ fx) << 4);                             // + stage*QB, + a*2048
     // pixel fragments: lane register per dw (row c' = cb0*16 + frow + 1 + dw of plane hbase - 1), immediate per (fragment, dh)
-    unsigned pbase[3];
+    constexpr int NPB = GENW ? CBW : 1;                 // GENW: the zero rows shift the column blocks of a wave group differently
+    unsigned pbase[3][NPB];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const int cp = cb0 * 16 + frow + d;             // = column of the tile + 1 + dw
-        pbase[d] = lds0 + QTOT + ((hbase - 1) * PS + cp) * 128 + ((kq ^ (cp & 7)) << 4);                  // QTOT >= PS * 128: never below lds0
-    }
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int cbl = 0; cbl < NPB; ++cbl) {
+            const int c = (cb0 + cbl) * 16 + frow;      // local column of this lane's pixel
+            const int cp = c + d + (GENW ? kof(c) : 0); // = plane row of the column + dw
+            pbase[d][cbl] = lds0 + QTOT + ((hbase - 1) * PS + cp) * 128 + ((kq ^ (cp & 7)) << 4);         // QTOT >= PS * 128: never below lds0
+        }
 
     // ---- prologue: weight tiles of steps 0 .. DEPTH - 1, the whole halo of chunk 0; everything has landed before barrier 0
     {
@@ -177,14 +206,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr int TAP = decltype(tapc)::value;
         constexpr int DW = TAP / 3, DH = TAP % 3 - 1;
         const unsigned qa = qfrag0 + qs * QB;
-        const unsigned pa = pbase[DW] + (chunk & 1) * PBYTES;
+        unsigned pa[NPB];
+#pragma unroll
+        for (int cbl = 0; cbl < NPB; ++cbl) pa[cbl] = pbase[DW][cbl] + (chunk & 1) * PBYTES;
 #pragma unroll
         for (int a = 0; a < FN; ++a)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[a]) : "v"(qa), "n"(a * 2048));
 #pragma unroll
         for (int b = 0; b < FM; ++b)
-            if (live(b, DH))
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[b]) : "v"(pa), "n"(((b / CBW + DH + 1) * PS + (b % CBW) * 16) * 128));
+            if (live(b, DH)) {
+                if (GENW) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[b]) : "v"(pa[b % NPB]), "n"(((b / CBW + DH + 1) * PS) * 128));
+                else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[b]) : "v"(pa[0]), "n"(((b / CBW + DH + 1) * PS + (b % CBW) * 16) * 128));
+            }
         constexpr int T2 = (TAP + DEPTH) % 9;
         const int c2 = chunk + (TAP + DEPTH >= 9 ? 1 : 0);
         int q2 = qs + DEPTH; if (q2 >= NST) q2 -= NST;
@@ -257,7 +290,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- the two K halves meet: a wave keeps the pixel fragments [kh*FM/2, (kh+1)*FM/2) and hands the others to its partner (conv_k2.hip)
     constexpr int FH = FM / 2;
-    static_assert(FH % (2 * CBW) == 0, "the feature-axis pool partner b ^ CBW stays inside a half");
     auto tail = [&](auto half_c) {
         constexpr int KH = decltype(half_c)::value;
         {
@@ -397,7 +429,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
 }
 
+// the kernels: aligned widths (the names the round's profiles carry) and the general-width form
 template <int FM, int BN, int NST, int H, bool SINGLE = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_k3_kernel(K3Args g) { k3_body<FM, BN, NST, H, SINGLE, false>(g); }
+template <int FM, int BN, int NST, int H>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_k3w_kernel(K3Args g) { k3_body<FM, BN, NST, H, false, true>(g); }
+
+template <int FM, int BN, int NST, int H, bool SINGLE = false, bool GENW = false>
 static int launch_k3(const K3Args& g, hipStream_t stream) {
     constexpr int PS = (256 / H + 2 + 7) / 8 * 8, PPIECES = (H * PS / 8 + 7) / 8 * 8;
     constexpr int need = NST * BN * 128 + (SINGLE ? 1 : 2) * PPIECES * 1024;     // weight stages, padded halo buffer(s)
@@ -405,12 +443,20 @@ static int launch_k3(const K3Args& g, hipStream_t stream) {
     constexpr int lds = need > xch ? need : xch;
     static_assert(lds <= 163840, "LDS");
     static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv_k3_kernel<FM, BN, NST, H, SINGLE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC;
-        attr = true;
-    }
     const int mt = g.M / 256, nt = (g.N + BN - 1) / BN;
-    conv_k3_kernel<FM, BN, NST, H, SINGLE><<<mt * nt, 512, lds, stream>>>(g);
+    if constexpr (GENW) {
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)conv_k3w_kernel<FM, BN, NST, H>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC;
+            attr = true;
+        }
+        conv_k3w_kernel<FM, BN, NST, H><<<mt * nt, 512, lds, stream>>>(g);
+    } else {
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)conv_k3_kernel<FM, BN, NST, H, SINGLE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC;
+            attr = true;
+        }
+        conv_k3_kernel<FM, BN, NST, H, SINGLE><<<mt * nt, 512, lds, stream>>>(g);
+    }
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
@@ -418,14 +464,28 @@ static int launch_k3(const K3Args& g, hipStream_t stream) {
 // -1 = shape not covered.  tile: 'A' = 256 pixels x 128 channels, 'D' = 256 x 64 (chosen by conv_k2.hip's k2_choose)
 int k3_try_dispatch(int tile, const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
                     const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind) {
-    if (H != 4 && H != 8 && H != 16) return -1;
-    if (W % (256 / H) || M % 256 || (Cin & 63) || (Cout & 63)) return -1;
-    if (flags & ~(K3_BIAS | K3_RELU | K3_MASK | K3_ACCUM)) return -1;
-    if (pool_kind && (flags & (K3_MASK | K3_ACCUM))) return -1;
+    if (H != 2 && H != 4 && H != 8 && H != 16) return -1;
+    if (M % 256 || (Cin & 63) || (Cout & 63)) return -1;
+    const int NC = 256 / H, PS = (NC + 2 + 7) / 8 * 8;
+    const bool genw = W % NC != 0;                       // tiles cross image boundaries: the general-width form (one zero row per boundary)
+    if (genw && (H == 16 || NC + 2 + (NC + W - 1) / W > PS)) return -1;       // (H = 16: 16-column tiles, W >= 16 there — not instantiated)
+    if (H == 2 && (!genw || pool_kind)) return -1;       // H = 2 exists in the general-width form only (128-column tiles)
+    static int genw_on = -1;                             // A/B knob OCR_K3_GENW = 0: general-width shapes stay on conv_k2 / conv_halo
+    if (genw_on < 0) { const char* e = ocr_tune_env("OCR_K3_GENW"); genw_on = e ? atoi(e) : 1; }
+    if (genw && !genw_on) return -1;
     static int prio = -1;
     if (prio < 0) { const char* e = ocr_tune_env("OCR_K3_PRIO"); prio = e ? atoi(e) : 2; }      // measured: 1 (equal) 349 us, 2 322, 3 324 over the ten layers (profiles/r03af)
     K3Args g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, prio};
     const bool single = Cin == 64;
+    if (genw) {
+        if (tile == 'A') {
+            if (Cout % 128) return -1;
+            return H == 2 ? launch_k3<8, 128, 5, 2, false, true>(g, stream) : H == 4 ? launch_k3<8, 128, 5, 4, false, true>(g, stream)
+                                                                                      : launch_k3<8, 128, 5, 8, false, true>(g, stream);
+        }
+        return H == 2 ? launch_k3<4, 64, 4, 2, false, true>(g, stream) : H == 4 ? launch_k3<4, 64, 4, 4, false, true>(g, stream)
+                                                                                  : launch_k3<4, 64, 4, 8, false, true>(g, stream);
+    }
     if (tile == 'A') {
         if (Cout % 128) return -1;
         if (H == 16) return single ? launch_k3<8, 128, 5, 16, true>(g, stream) : launch_k3<8, 128, 4, 16>(g, stream);     // 2 x 48 KiB of halo: four stages

@@ -287,7 +287,8 @@ def _conv_ref(x, w, b):   # x [N,W,H,C], w HWIO
                                           (7, 22, 8, 128, 256), (32, 64, 2, 512, 512), (3, 18, 2, 64, 128), (9, 64, 2, 128, 64),
                                           (17, 62, 4, 128, 128), (9, 30, 16, 64, 256),       # ragged last tiles of the 256- / 128-pixel kernels
                                           (4, 128, 8, 128, 128), (6, 192, 4, 192, 64),       # plane-layout kernel: several tiles per image, 3 chunks
-                                          (8, 48, 16, 128, 64), (16, 32, 16, 128, 128), (8, 64, 16, 64, 64)])   # ... at H = 16 (one / two halo buffers)
+                                          (8, 48, 16, 128, 64), (16, 32, 16, 128, 128), (8, 64, 16, 64, 64),    # ... at H = 16 (one / two halo buffers)
+                                          (32, 40, 4, 128, 128), (32, 24, 8, 64, 128), (16, 50, 8, 128, 64)])   # ... tiles crossing image boundaries (general width)
 def test_conv3x3_fwd_dgrad_wgrad(dev, Nb, W, H, Ci, Co):
     x = bf(gen((Nb, W, H, Ci), 1)); w = bf(gen((3, 3, Ci, Co), 2, 0.05)); b = gen((Co,), 3)
     ref = _conv_ref(x, w, b)
@@ -469,7 +470,8 @@ def test_maxpool(dev, kw, kh):
 @pytest.mark.parametrize("Nb,W,H,Ci,Co,kw,kh", [(64, 128, 16, 64, 128, 2, 2), (64, 64, 8, 256, 256, 1, 2), (64, 64, 4, 512, 512, 1, 2),
                                                (8, 64, 8, 64, 64, 2, 2), (16, 32, 4, 128, 192, 2, 2), (5, 26, 16, 64, 64, 1, 2),
                                                (3, 40, 10, 64, 128, 1, 2), (16, 64, 4, 128, 128, 2, 2), (16, 128, 8, 64, 128, 2, 2),
-                                               (8, 32, 16, 64, 128, 2, 2), (8, 32, 16, 128, 64, 1, 2)])
+                                               (8, 32, 16, 64, 128, 2, 2), (8, 32, 16, 128, 64, 1, 2), (32, 40, 4, 64, 128, 2, 2),
+                                               (32, 24, 8, 64, 64, 1, 2)])
 def test_conv3x3_relu_pool_fused_equals_unfused(dev, Nb, W, H, Ci, Co, kw, kh):
     """conv + bias + ReLU with the following max-pool written by the same epilogue (LSTM_train.py:26-33): the full-resolution output
     and the pooled tensor are bit-identical to conv3x3 followed by maxpool_fwd."""

@@ -61,3 +61,29 @@ def test_output_pixels_and_staged_write_out(H, BN):
         assert sorted(lps) == list(range(256))             # the wave groups of a channel half cover the tile's 256 pixels once
     dup, bad, n = km.staged_roundtrip(g)
     assert dup == 0 and bad == 0 and n == 256 * BN // 4    # every 8-byte slot of the staged image written once, read back in order
+
+
+GENW_CASES = [(4, 128, 40, 0), (4, 128, 40, 64), (4, 64, 23, 128), (8, 128, 24, 32), (8, 64, 50, 96), (2, 128, 64, 128), (2, 64, 64, 0),
+              (16, 64, 20, 16), (4, 128, 64, 64), (8, 64, 32, 64)]
+
+
+@pytest.mark.parametrize("H,BN,W,col0", GENW_CASES)
+def test_general_width_layout_reads_the_right_pixels(H, BN, W, col0):
+    """Tiles that cross image boundaries (W not a multiple of the tile's columns): a zero row in front of every interior boundary column."""
+    g = km.Geometry(H, BN)
+    assert km.genw_fits(g, W)
+    lds = km.genw_dma_fill(g, col0, W)
+    assert len(lds) == g.PPIECES * 64
+    for wave in range(km.NW):
+        for lane in range(64):
+            for (b, tap, live, row, pos, kq) in km.genw_fragment_reads(g, col0, W, wave, lane):
+                col, h = km.expected_pixel(g, col0, wave, lane, b, tap)
+                own = km.expected_pixel(g, col0, wave, lane, b, 4)[0]        # the pixel's own column (centre tap)
+                if not live:
+                    assert not (0 <= h < H)
+                    continue
+                got = lds[(row, pos)]
+                if col < 0 or col // W != own // W:                          # the neighbour column belongs to another image
+                    assert got is None, (wave, lane, b, tap, got)
+                else:
+                    assert got == (col, h, kq), (wave, lane, b, tap, got, (col, h, kq))

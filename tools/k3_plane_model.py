@@ -133,3 +133,64 @@ def bank_conflicts(g, wave):
             slots = [((per_lane[l][i][3] * 128 + per_lane[l][i][4] * 16) % 256) // 16 for l in grp]
             bad += len(set(slots)) != 16
     return bad
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# General image width (GENW): a tile's NC columns may cross image boundaries.  One zero row is inserted in every plane in front of each
+# local column c in [1, NC) with (col0 + c) % W == 0, so that the dw = +-1 taps of the columns on either side of the boundary read
+# zeros; local column c sits at plane row 1 + c + k(c), k(c) = number of such boundaries in [1, c].
+def genw_k(col0, W, c):
+    return (col0 + c) // W - col0 // W if c >= 1 else 0
+
+
+def genw_fits(g, W):
+    return g.NC + 2 + (g.NC + W - 1) // W <= g.PS
+
+
+def genw_dma_fill(g, col0, W):
+    """As dma_fill for any W: dict (row, pos) -> (column, h, chunk) or None."""
+    H, NC = g.H, g.NC
+    edge_l, edge_r = col0 % W == 0, (col0 + NC) % W == 0
+    last_row = 1 + NC + genw_k(col0, W, NC - 1)                       # the right halo column's row (plane-relative)
+    lds = {}
+    for wave in range(NW):
+        for j in range(g.PI):
+            u = j * NW + wave
+            for lane in range(64):
+                rsub, pos = lane >> 3, lane & 7
+                r = u * 8 + rsub
+                h, p = r // g.PS, r % g.PS
+                val = None
+                if h < H:
+                    if p == 0:
+                        val = None if edge_l else (col0 - 1, h, pos ^ rsub)
+                    elif p == last_row:
+                        val = None if edge_r else (col0 + NC, h, pos ^ rsub)
+                    elif p < last_row:
+                        for k in range(0, 8):                      # the kernel tries the few possible boundary counts
+                            c = p - 1 - k
+                            if 0 <= c < NC and genw_k(col0, W, c) == k:
+                                val = (col0 + c, h, pos ^ rsub)
+                                break
+                assert (r, pos) not in lds
+                lds[(r, pos)] = val
+    return lds
+
+
+def genw_fragment_reads(g, col0, W, wave, lane):
+    kh, wm = wave >> 2, (wave & 3) // g.WN
+    cb0, hbase = (wm % g.WGC) * g.CBW, (wm // g.WGC) * g.HW
+    top, bot = g.static_h or hbase == 0, g.static_h or hbase + g.HW == g.H
+    frow, fq = lane & 15, lane >> 4
+    kq = (kh << 2) | fq
+    out = []
+    for tap in range(9):
+        d, dh = tap // 3, tap % 3 - 1
+        for b in range(g.FM):
+            c = (cb0 + b % g.CBW) * 16 + frow                     # local column of this lane's pixel
+            p = 1 + c + genw_k(col0, W, c) + (d - 1)               # lane register pbase[d][b % CBW]
+            hl = b // g.CBW + dh
+            live = not ((hl < 0 and top) or (hl >= g.HW and bot))
+            row = (hbase - 1) * g.PS + p + (b // g.CBW + dh + 1) * g.PS
+            out.append((b, tap, live, row, kq ^ (p & 7), kq))
+    return out
