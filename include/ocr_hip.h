@@ -67,11 +67,13 @@ int ocr_ctc_beam_decode(const float* activations, const int* input_lengths, int 
 int ocr_gemm_nt_bf16(const void* P, long ldp, const void* Q, long ldq, void* out, long ldo, int M, int N, int K,
                      const float* bias, const void* mask, long ldmask, int flags, int splits, int row_group,
                      int row_skip, int swap_inner, int swap_outer, void* stream);
-/* engine selector for A/B measurements: 1 (default) = tap-reuse halo conv + 256-row LDS-DMA GEMM tiles, 4 = ping-pong halo conv
- * (waves of a SIMD half a step apart; slower, kept for A/B), 0 = 128x128 tiles, 2 / 3 = LDS-DMA tiles without the halo kernels */
+/* engine selector for A/B measurements: 1 (default) = tap-reuse convolution kernels (conv_k3 / conv_k2 / conv_halo, chosen per shape:
+ * DESIGN section 3) + 256-row LDS-DMA GEMM tiles, 0 = 128x128 register-staged tiles, 2 / 3 = LDS-DMA tiles without the tap-reuse kernels
+ * (4 = round 2's ping-pong halo conv: experiments build only) */
 int ocr_set_gemm_engine(int use_large_tile);
 /* 3x3 SAME stride-1 convolution, x bf16 [Nb,W,H,Cin], wpack bf16 [Cout][3][3][Cin], y [Nb,W,H,Cout]
- * (conv_single network.py:160-191; also its data gradient with flipped/transposed weights) */
+ * (conv_single network.py:160-191; also its data gradient with flipped/transposed weights).  The result does not depend on which kernel
+ * the dispatcher takes beyond fp32 summation order (environment OCR_CONV_K2 / OCR_CONV_K3 / OCR_K2_CFG select for the parity tests). */
 int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int Nb, int W, int H, int Cin, int Cout,
                      const float* bias, const void* mask, int flags, void* stream);
 /* non-zero: ocr_conv3x3_bf16 accepts OCR_EPI_ACCUM for this shape (y (bf16) += result: the data gradient of a tensor with several
