@@ -76,6 +76,10 @@ int ocr_set_gemm_engine(int use_large_tile);
  * the dispatcher takes beyond fp32 summation order (environment OCR_CONV_K2 / OCR_CONV_K3 / OCR_K2_CFG select for the parity tests). */
 int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int Nb, int W, int H, int Cin, int Cout,
                      const float* bias, const void* mask, int flags, void* stream);
+/* Which kernel family the two convolution entry points run for a shape — a host-only query (nothing is launched, works without a GPU):
+ * 0 generic GEMM engines, 1 conv_halo, 2 / 3 conv_k2 tile A (256 x 128) / D (256 x 64), 4 / 5 conv_k3 A / D, 6 / 7 conv_k3w (tiles that
+ * cross image boundaries) A / D.  flags as for ocr_conv3x3_bf16; (kw, kh) = (0, 0) or the window of the fused max-pool. */
+int ocr_conv3x3_kernel_choice(int Nb, int W, int H, int Cin, int Cout, int flags, int kw, int kh);
 /* non-zero: ocr_conv3x3_bf16 accepts OCR_EPI_ACCUM for this shape (y (bf16) += result: the data gradient of a tensor with several
  * consumers is added to what was already delivered, no scratch tensor + add pass) */
 int ocr_conv3x3_accum_supported(int Nb, int W, int H, int Cin, int Cout);

@@ -292,6 +292,7 @@ void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 8 * NW */
 
 template <int BN, int NW, int ABL = 0, int RPW = 32, int FNV = 4>
 static int launch_halo_(const HaloArgs& g, hipStream_t stream) {
+    if (!g.P) return 1;                                  // plan query (ocr_conv3x3_kernel_choice): this file's kernels, nothing is launched
     constexpr int BM = RPW * NW;
     const int NR = BM + 2 * g.cH + 2;
     const int NRpad = (NR + 8 * NW) / (8 * NW) * (8 * NW);       // strictly greater than NR: the spare rows are the zero rows

@@ -409,6 +409,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // fill the chip); 512 x 64 and 128 x 128 were built and measured too (profiles/r03e / r03h_conv*.log): never faster than these two
 template <int FM, int BN, int NST = 4>
 static int launch_k2(const K2Args& g, hipStream_t stream) {
+    if (!g.P) return BN == 128 ? 2 : 3;                  // plan query (ocr_conv3x3_kernel_choice): nothing is launched
     constexpr int BM = (4 / (BN / 64)) * FM * 16;
     const int NRpad = (BM + 2 * g.cH + 4 + 7) / 8 * 8;             // needed rows + two zero rows, in 8-row DMA pieces
     int lds = 2 * NRpad * 128 + NST * BN * 128;                     // halo stages, weight stages (the K-half exchange reuses them)

@@ -437,6 +437,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 template <int FM, int BN, int NST, int H, bool SINGLE = false, bool GENW = false>
 static int launch_k3(const K3Args& g, hipStream_t stream) {
+    if (!g.P) return (GENW ? 6 : 4) + (BN == 128 ? 0 : 1);       // plan query (ocr_conv3x3_kernel_choice): nothing is launched
     constexpr int PS = (256 / H + 2 + 7) / 8 * 8, PPIECES = (H * PS / 8 + 7) / 8 * 8;
     constexpr int need = NST * BN * 128 + (SINGLE ? 1 : 2) * PPIECES * 1024;     // weight stages, padded halo buffer(s)
     constexpr int xch = 8 * (FM / 2) * 4 * 1024;                                  // the K-half exchange reuses them

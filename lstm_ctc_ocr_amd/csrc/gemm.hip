@@ -299,6 +299,20 @@ bool halo_covers(long M, int W, int H, int Cin, int Cout);
 extern "C" int ocr_conv3x3_accum_supported(int Nb, int W, int H, int Cin, int Cout) {
     return g_use_halo && !g_use_pp && halo_covers((long)Nb * W * H, W, H, Cin, Cout);
 }
+// Which kernel family ocr_conv3x3_bf16 / ocr_conv3x3_relu_pool_bf16 would run for this shape (host-only: nothing is launched, no GPU is
+// needed): 0 the generic GEMM engines (igemm / gemm), 1 conv_halo, 2 / 3 conv_k2 tile A (256 x 128) / D (256 x 64), 4 / 5 conv_k3 A / D,
+// 6 / 7 conv_k3w (general width) A / D.  flags as for ocr_conv3x3_bf16; (kw, kh) = (0, 0) or the window of a fused max-pool.
+extern "C" int ocr_conv3x3_kernel_choice(int Nb, int W, int H, int Cin, int Cout, int flags, int kw, int kh) {
+    if (Nb <= 0 || W <= 0 || H <= 0 || Cin <= 0 || Cout <= 0) return OCR_ERR_INVALID;
+    const int pool_kind = (kw == 1 && kh == 2) ? 1 : ((kw == 2 && kh == 2) ? 2 : 0);
+    if ((kw || kh) && !pool_kind) return 0;
+    const int fl = flags & ~(EPI_ATOMIC | EPI_ROWSWAP);
+    if (!g_use_halo) return 0;
+    const int rc = halo_try_dispatch(nullptr, nullptr, nullptr, Nb * W * H, W, H, Cin, Cout, (fl & EPI_BIAS) ? (const float*)16 : nullptr,
+                                     (fl & EPI_MASK) ? (const void*)16 : nullptr, fl, nullptr, pool_kind ? (void*)16 : nullptr, pool_kind);
+    return rc >= 1 ? rc : 0;
+}
+
 // 3x3 SAME stride-1 convolution over the reference layout [Nb, W, H, C] as an implicit GEMM.
 // wpack is [Cout][3][3][Cin] bf16 (K-contiguous rows).  Used for the forward (wpack = packed
 // weights) and for dgrad (x := dY, wpack := flipped/transposed weights, Cin/Cout swapped).
