@@ -69,7 +69,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #define K3_VMWAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 template <int FM /* 16-pixel fragments per wave: 8 or 4 */, int BN /* channels per tile: 128 (waves 2 pixel x 2 channel x 2 K) or 64 (4 x 1 x 2 K) */,
-          int NST /* weight stages; tile s + NST - 2 is streamed during step s */, int H /* feature rows: 4, 8 or 16 */,
+          int NST /* weight stages; tile s + NST - 2 is streamed during step s */, int H /* feature rows: 4, 8 or 16; 2 in the general-width form */,
           bool SINGLE = false /* C == 64: one chunk, one halo buffer, no halo pieces inside the loop */,
           bool GENW = false /* any image width: a tile's columns may cross image boundaries — a zero row sits in every plane in front of each
                                interior boundary column, local column c at plane row 1 + c + k(c), k(c) = boundaries in [1, c]; the fragment
