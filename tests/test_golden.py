@@ -128,6 +128,115 @@ def test_device_matches_headline_fixture(dev):
     assert eng.decode(x, sl, method='beam') == odec.reference_decode(logits, sl, beam_width=100)
 
 
+def _grad_fixture(tag):
+    import sys
+    sys.path.insert(0, G)
+    import make_headline_grad_golden as mh
+    d = np.load(os.path.join(G, 'graph_%s_grad.npz' % tag))
+    x, labels, ll, sl = mh.headline_inputs() if tag == 'c2' else mh.ragged_inputs()
+    assert abs(float(np.abs(x.astype(np.float64)).sum()) - float(d['x_checksum'])) < 1e-9 * float(d['x_checksum'])
+    return mh, d, (x, labels, ll, sl)
+
+
+def test_oracle_reproduces_headline_gradient_fixture():
+    """graph_c2_grad.npz freezes the oracle's backward + clip + Adam at N = 64, W = 256 (bf16-simulating walk)."""
+    mh, d, (x, labels, ll, sl) = _grad_fixture('c2')
+    params = mh.fixture_params()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    total, ctc, _ = og.loss_fn(leaves, torch.from_numpy(x), labels, ll, sl.tolist(), float(d['wd']), sim_bf16=True)
+    total.backward()
+    assert abs(float(total.detach()) - float(d['loss_total_bf16sim'])) < 1e-5 * float(d['loss_total_bf16sim'])
+    grads = {k: v.grad for k, v in leaves.items()}
+    _, norm = og.clip_by_global_norm(grads, 10.0)
+    assert abs(norm - float(d['clip_norm_bf16sim'])) < 1e-4 * norm
+    for k in ('conv2/weights', 'conv4_2/weights', 'logits/fw/weights', 'logits/weights', 'conv4_1/conv4_1/gamma'):
+        g = (grads[k] - float(d['wd']) * params[k] if og.REGULARISED(k) else grads[k]).reshape(-1)
+        got = g[torch.from_numpy(mh.sample_index(k, g.numel()))].numpy().astype(np.float64)
+        ref = d['grad_bf16sim/' + k].astype(np.float64)
+        assert np.linalg.norm(got - ref) < 2e-3 * np.linalg.norm(ref), k      # thread-count dependent fp32 summation order + routing flips
+
+
+def _device_gradient_parity(tag, N, W):
+    """The benchmarked step's BACKWARD half at the size it is benchmarked (lib/lstm/train.py:79-83 over LSTM_train.py:22-38): per
+    parameter tensor, the device gradient against the committed sample of the bf16-simulating oracle's (relative L2 <= GRAD_L2_BAR of
+    tests/test_gpu_engine.py — the same per-tensor bars as the N = 8 test — and <= 20 % to the fp32 oracle's), full-tensor norm ratio
+    0.97..1.03, clip norm within 1 %; then ONE clip + Adam step from the same state against the oracle's post-step parameters."""
+    from lstm_ctc_ocr_amd.config import cfg
+    from lstm_ctc_ocr_amd.engine import Engine
+    from lstm_ctc_ocr_amd.models import get_network
+    from test_gpu_engine import GRAD_L2_BAR, GRAD_L2_BAR_FP32
+    mh, d, (x, labels, ll, sl) = _grad_fixture(tag)
+    params = mh.fixture_params()
+    lr, wd = float(d['lr']), float(d['wd'])
+    old_wd = cfg.TRAIN.WEIGHT_DECAY
+    cfg.TRAIN.WEIGHT_DECAY = wd
+    try:
+        eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=1)
+        eng.load_arrays({k: v.numpy() for k, v in params.items()})
+        sp = eng.plan(N, W)
+        eng._bind(sp, x, sl, labels, ll)
+        eng._run(sp, 'fb')
+        torch.cuda.synchronize()
+        ctc_dev = float(sp.costs.cpu().numpy().astype(np.float64).mean())
+        for otag in ('bf16sim', 'fp32'):
+            assert abs(ctc_dev - float(d['loss_ctc_' + otag])) < 1e-3 * float(d['loss_ctc_' + otag]), (otag, ctc_dev)
+        names = d['names'].tolist()
+        bad = []
+        for i, name in enumerate(names):
+            g = eng.grad(name).reshape(-1)
+            idx = torch.from_numpy(mh.sample_index(name, g.numel())).to(g.device)
+            got = g[idx].double().cpu().numpy()
+            ref, ref32 = d['grad_bf16sim/' + name].astype(np.float64), d['grad_fp32/' + name].astype(np.float64)
+            if name in ('conv4_1/biases', 'conv4_2/biases'):      # mathematically zero (BN removes the mean): rounding noise on both sides
+                scale = np.abs(d['grad_bf16sim/' + name.replace('biases', 'weights')]).max()
+                assert np.isfinite(got).all() and np.abs(got).max() < scale, name
+                continue
+            e_sim = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            e_f32 = float(np.linalg.norm(got - ref32) / np.linalg.norm(ref32))
+            nr = float(g.double().norm().cpu()) / float(d['grad_norm_bf16sim'][i])
+            print('grad %-28s L2-rel vs bf16sim %.3e  vs fp32 %.3e  norm ratio %.4f' % (name, e_sim, e_f32, nr))
+            if not (e_sim < GRAD_L2_BAR.get(name, GRAD_L2_BAR['default']) and e_f32 < GRAD_L2_BAR_FP32 and 0.97 < nr < 1.03):
+                bad.append((name, e_sim, e_f32, nr))
+        assert not bad, bad
+        # ---- one optimisation step from the same state (captured graph: forward + CTC + backward + clip + Adam + re-pack)
+        eng.setup_optimizer('Adam', lr)
+        loss = eng.train_step(x, labels, ll, sl)
+        assert abs(loss - float(d['loss_total_bf16sim'])) < 1e-3 * float(d['loss_total_bf16sim'])
+        assert abs(eng.last_gnorm - float(d['clip_norm_bf16sim'])) < 1e-2 * float(d['clip_norm_bf16sim']), eng.last_gnorm
+        after = eng.state_arrays()
+        worst = 1.0
+        for name in names:
+            if name in ('conv4_1/biases', 'conv4_2/biases'):
+                continue
+            idx = mh.sample_index(name, after[name].size)
+            a = after[name].reshape(-1)[idx].astype(np.float64)
+            before = params[name].reshape(-1).numpy()[idx].astype(np.float64)
+            ref = d['new_bf16sim/' + name].astype(np.float64)
+            # first Adam step = lr * g / (|g| + 3e-7 / clip scale): +-lr wherever the gradient is not tiny, so an entry can differ by at most
+            # 2 lr, and does where device and oracle disagree about the SIGN of a near-zero gradient entry
+            assert np.abs(a - ref).max() <= 2.02 * lr, name
+            assert np.abs(a - before).max() <= 1.01 * lr, name
+            big = np.abs(d['grad_bf16sim/' + name]) > 0.05 * np.abs(d['grad_bf16sim/' + name]).max()
+            agree = float((np.sign(a - before) == np.sign(ref - before))[big].mean())
+            mean_err = float(np.abs(a - ref).mean() / lr)
+            worst = min(worst, agree)
+            print('adam %-28s update sign agreement on the large entries %.4f, mean |dev - oracle| %.3f lr' % (name, agree, mean_err))
+            assert agree > 0.995 and mean_err < 0.15, (name, agree, mean_err)
+    finally:
+        cfg.TRAIN.WEIGHT_DECAY = old_wd
+
+
+@pytest.mark.gpu
+def test_device_matches_headline_fixture_gradients(dev):
+    _device_gradient_parity('c2', 64, 256)
+
+
+@pytest.mark.gpu
+def test_device_matches_ragged_fixture_gradients(dev):
+    """BASELINE configs[3]: one ragged batch, W_i in [80, 320] padded to 320 (conv_k3w tiles, masked CTC, per-sample LSTM lengths)."""
+    _device_gradient_parity('v', 64, 320)
+
+
 def test_deep_fixture_parameters_are_reproducible():
     """tests/golden/deep_c4.npz was made from host_parameters(RESNET_train, seed): the same draw must come out today."""
     sys_path = os.path.join(G)

@@ -288,7 +288,12 @@ def _conv_ref(x, w, b):   # x [N,W,H,C], w HWIO
                                           (17, 62, 4, 128, 128), (9, 30, 16, 64, 256),       # ragged last tiles of the 256- / 128-pixel kernels
                                           (4, 128, 8, 128, 128), (6, 192, 4, 192, 64),       # plane-layout kernel: several tiles per image, 3 chunks
                                           (8, 48, 16, 128, 64), (16, 32, 16, 128, 128), (8, 64, 16, 64, 64),    # ... at H = 16 (one / two halo buffers)
-                                          (32, 40, 4, 128, 128), (32, 24, 8, 64, 128), (16, 50, 8, 128, 64)])   # ... tiles crossing image boundaries (general width)
+                                          (32, 40, 4, 128, 128), (32, 24, 8, 64, 128), (16, 50, 8, 128, 64),    # ... tiles crossing image boundaries (general width)
+                                          # the EXACT shapes of the benchmarked step (BASELINE configs[1], N = 64, W = 256): conv2, conv3_1, conv3_2, conv4_2
+                                          # (conv4_1 is (64, 64, 4, 256, 512) above) — the dispatcher's full-chip tiles / 64-split slabs only exist at this size
+                                          (64, 128, 16, 64, 128), (64, 64, 8, 128, 256), (64, 64, 8, 256, 256), (64, 64, 4, 512, 512),
+                                          # ... and the extremes of configs[3] (W = 80 and W = 320 padded batches)
+                                          (64, 40, 16, 64, 128), (64, 20, 4, 512, 512), (64, 80, 8, 256, 256), (64, 80, 4, 256, 512)])
 def test_conv3x3_fwd_dgrad_wgrad(dev, Nb, W, H, Ci, Co):
     x = bf(gen((Nb, W, H, Ci), 1)); w = bf(gen((3, 3, Ci, Co), 2, 0.05)); b = gen((Co,), 3)
     ref = _conv_ref(x, w, b)
