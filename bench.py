@@ -59,7 +59,7 @@ def synth_batches(n_batches, seed, device):
     return out
 
 
-def conv_roofline(eng, device):
+def conv_roofline(eng, device, workload):
     """Every launch of the dominant kernel (conv_k3 / conv_k2 / conv_halo, as the dispatcher picks them: the 3x3 SAME convolutions of the workload that was timed — forward
     and data gradient) timed with HIP events on the launch stream; achieved = sum(algorithmic flop) / sum(time).
     The layer shapes are read from the plan the timed steps ran (the widest one for variable-width batches)."""
@@ -69,24 +69,31 @@ def conv_roofline(eng, device):
     for op in eng.ops:
         if getattr(op, 'kind', None) == '3x3':
             (N, W, H, Ci), _ = sp.shape[op.key]
-            shapes.append((N, W, H, Ci, op.co, hasattr(op, 'wdgrad')))
-    tot_fl, tot_t, n_launch = 0.0, 0.0, 0
+            pool = None
+            if op.pool_after is not None and op.pool_after.key in getattr(sp, 'fused_pools', ()):
+                pool = (op.pool_after.kw_t, op.pool_after.kh_f)          # the step's launch writes the max-pool too: time that form
+            shapes.append((N, W, H, Ci, op.co, hasattr(op, 'wdgrad'), pool))
+    tot_fl, exe_fl, tot_t, n_launch = 0.0, 0.0, 0.0, 0
     # shader clock the kernel really runs at: workgroup 0 stamps {shader-clock counter, 100 MHz wall clock} at entry and exit
     from lstm_ctc_ocr_amd import _native as nat
     clk = torch.zeros(4, dtype=torch.int64, device=device)
     nat.call("ocr_conv_halo_clock_debug", clk.data_ptr())
     clk_cycles = clk_ticks = 0.0
-    for (N, W, H, Ci, Co, has_dgrad) in shapes:
+    for (N, W, H, Ci, Co, has_dgrad, pool) in shapes:
         x = torch.randn(N, W, H, Ci, device=device).to(torch.bfloat16)
         y = torch.randn(N, W, H, Co, device=device).to(torch.bfloat16)
         wf = (torch.randn(Co, 3, 3, Ci, device=device) * 0.05).to(torch.bfloat16)
         wd = (torch.randn(Ci, 3, 3, Co, device=device) * 0.05).to(torch.bfloat16)
         b = torch.zeros(Co, device=device)
         oy, ox = torch.empty_like(y), torch.empty_like(x)
-        fns = [lambda: ops.conv3x3(x, wf, out=oy, bias=b, relu=True)]
+        if pool is not None:
+            pooled = torch.empty(N, W // pool[0], H // pool[1], Co, device=device, dtype=torch.bfloat16)
+            fns = [(lambda: ops.conv3x3_relu_pool(x, wf, oy, pooled, b, pool[0], pool[1]), ops.conv3x3_kernel_choice(N, W, H, Ci, Co, pool=pool))]
+        else:
+            fns = [(lambda: ops.conv3x3(x, wf, out=oy, bias=b, relu=True), ops.conv3x3_kernel_choice(N, W, H, Ci, Co))]
         if has_dgrad:
-            fns.append(lambda: ops.conv3x3(y, wd, out=ox, mask=x))
-        for fn in fns:
+            fns.append((lambda: ops.conv3x3(y, wd, out=ox, mask=x), ops.conv3x3_kernel_choice(N, W, H, Co, Ci, bias=False, relu=False, mask=True)))
+        for fn, kname in fns:
             for _ in range(3):
                 fn()
             clk.zero_()
@@ -98,6 +105,7 @@ def conv_roofline(eng, device):
             torch.cuda.synchronize()
             tot_t += e0.elapsed_time(e1) * 1e-3 / 10
             tot_fl += 2.0 * N * W * H * 9 * Ci * Co
+            exe_fl += 2.0 * N * W * H * 9 * Ci * Co * ((1.0 - 2.0 / (3.0 * H)) if kname.startswith("conv_k3") else 1.0)
             n_launch += 1
             c = clk.cpu().numpy()                       # last of the ten back-to-back launches
             if c[3] > c[1]:
@@ -108,18 +116,29 @@ def conv_roofline(eng, device):
     # HBM bytes per launch and matrix-pipe occupancy of the same kernels from the separate rocprofv3 --pmc passes over THIS script
     # (tools/prof_step_pmc.sh -> profiles/rNN_pmc_step.json; FETCH_SIZE doubled: the guide's gfx950 correction).  The file names the
     # commit it was taken at and its kernel symbols: numbers whose symbols are not in the library loaded now are refused.
-    traffic, mfma_busy, src, pmc_commit, pmc_error = None, None, None, None, None
+    traffic, mfma_busy, src, pmc_commit, pmc_error, pmc_build = None, None, None, None, None, None
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step*.json")))
-    if cands:
+    build_id = nat.build_id()
+    try:
+        build_commit = open(os.path.join(ROOT, ".build_commit")).read().strip()
+    except OSError:
+        build_commit = None
+    # the newest profile of THIS workload; it must name the workload and the build id (source hash) of the library that is loaded now —
+    # anything else is refused, not borrowed (the varwidth / deep lines used to print the headline's counters)
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_%s.json" % workload)))
+    if not cands:
+        pmc_error = "no profiles/r*_pmc_step_%s.json for this workload" % workload
+    else:
         src = os.path.basename(cands[-1])
         pm = json.load(open(cands[-1]))
-        pmc_commit = pm.get("commit")
+        pmc_commit, pmc_build = pm.get("commit"), pm.get("build_id")
         conv = [k for k in pm.get("kernels", []) if k["symbol"].startswith(("_Z16conv_halo_kernel", "_Z14conv_k2_kernel", "_Z14conv_k3_kernel", "_Z15conv_k3w_kernel"))]
-        lib = open(nat.LIB_PATH, "rb").read()
-        missing = [k["symbol"] for k in conv if k["symbol"].encode() not in lib]
-        if missing or not conv:
-            pmc_error = "kernel symbols of %s are not in the loaded library: %s" % (src, missing[:2]) if missing else "no convolution kernels in %s" % src
+        if pm.get("workload") != workload:
+            pmc_error = "%s was taken on workload %r, this run is %r" % (src, pm.get("workload"), workload)
+        elif pmc_build != build_id:
+            pmc_error = "%s was taken on build %s (commit %s), the loaded library is build %s (commit %s)" % (src, pmc_build, pmc_commit, build_id, build_commit)
+        elif not conv:
+            pmc_error = "no convolution kernels in %s" % src
         else:
             nl = float(sum(k["launches"] for k in conv))
             tm = float(sum(k["launches"] * k["avg_us"] for k in conv))
@@ -130,7 +149,11 @@ def conv_roofline(eng, device):
     return {"bound": "mfma", "kernel": "conv_k3_kernel / conv_k2_kernel / conv_halo_kernel (implicit-GEMM 3x3 SAME conv, forward + data gradient: %d launches/step)" % n_launch,
             "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK,
             "avg_launch_us": tot_t / n_launch * 1e6, "algorithmic_gflop_per_launch": tot_fl / n_launch / 1e9,
-            "traffic": traffic, "mfma_busy_frac": mfma_busy, "pmc_commit": pmc_commit, "pmc_error": pmc_error,
+            "executed_flop_frac": exe_fl / tot_fl, "achieved_executed": exe_fl / tot_t / 1e12,
+            "executed_note": "`achieved` counts 2*M*K*N of every launch (SURVEY 8d) including the SAME-padding taps the plane-layout kernels "
+                             "(conv_k3 / conv_k3w) never issue: 2/(3H) of a layer's MFMAs (H=4: a sixth); `achieved_executed` counts only issued MFMAs",
+            "traffic": traffic, "mfma_busy_frac": mfma_busy, "pmc_commit": pmc_commit, "pmc_build_id": pmc_build, "build_id": build_id,
+            "build_commit": build_commit, "pmc_error": pmc_error,
             "shader_clock_mhz": mhz, "frac_of_peak_at_that_clock": (ach / (MFMA_BF16_PEAK * mhz / PEAK_CLOCK_MHZ)) if mhz else None,
             "clock_note": "shader clock measured inside the kernel (s_memtime / s_memrealtime of workgroup 0, time-weighted over the launches); "
                           "`peak` is the guide's dense bf16 figure at %d MHz" % PEAK_CLOCK_MHZ,
@@ -179,6 +202,21 @@ def cpu_baseline(budget_s=12.0):
             "c1_sample": "BASELINE configs[0]: %d training steps / %d forward+greedy-decode passes of 8 images (W=88, L=4)" % (c1_steps, reps)}
 
 
+def self_launch(n):
+    """Re-run this command line as n ranks under `python -m torch.distributed.run` on a free local port and pass the exit code on.
+    Refuses when the box shows fewer GPUs than ranks (except with OCR_DIST_BACKEND=gloo, the test transport that shares one GPU)."""
+    import socket
+    import subprocess
+    visible = torch.cuda.device_count()
+    if os.environ.get("OCR_DIST_BACKEND", "nccl") == "nccl" and n > visible:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible" % (n, visible))
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,8 +233,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without the launcher: re-exec under torch.distributed.run, one process per GPU (VERDICT r3 item 7 —
+        # the driver's documented form passes the launcher itself; this makes the bare form produce the same line instead of nothing)
+        return self_launch(args.gpus)
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (one process per GPU: torch.distributed.run --nproc-per-node %d)"
+                         % (args.gpus, world, args.gpus))
     # OCR_DIST_BACKEND=gloo is for the test-suite only (tests/test_gpu_bench_two_ranks.py: two ranks of this script sharing the one GPU
     # of a test box, gradients staged through the host by lstm_ctc_ocr_amd.dist); the driver's runs use RCCL ("nccl")
     backend = os.environ.get("OCR_DIST_BACKEND", "nccl")
@@ -314,7 +357,7 @@ def main():
         # reported inside the line instead of being swallowed)
         if not args.no_roofline:
             try:
-                line["roofline"] = conv_roofline(eng, device)
+                line["roofline"] = conv_roofline(eng, device, args.workload)
             except Exception as e:              # noqa: BLE001
                 line["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
@@ -329,4 +372,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -28,6 +28,9 @@ enum {
 
 const char* ocr_status_string(int status);           /* warp-ctc: ctcGetStatusString */
 int ocr_abi_version(void);
+/* first 16 hex digits of sha256 over the sources this library was built from (csrc/Makefile; "-exp" appended by the experiments
+ * flavour): profiles are pinned to it, and lstm_ctc_ocr_amd._native.source_build_id() recomputes it from the tree to detect a stale .so */
+const char* ocr_build_id(void);
 
 /* ---- CTC (replaces warpctc_tensorflow.ctc, network.py:653-654; warp-ctc get_workspace_size/compute_ctc_loss) */
 int ocr_ctc_workspace_size(int max_label_len, int max_time, int minibatch, size_t* bytes);
@@ -78,7 +81,8 @@ int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int Nb, int W, i
                      const float* bias, const void* mask, int flags, void* stream);
 /* Which kernel family the two convolution entry points run for a shape — a host-only query (nothing is launched, works without a GPU):
  * 0 generic GEMM engines, 1 conv_halo, 2 / 3 conv_k2 tile A (256 x 128) / D (256 x 64), 4 / 5 conv_k3 A / D, 6 / 7 conv_k3w (tiles that
- * cross image boundaries) A / D.  flags as for ocr_conv3x3_bf16; (kw, kh) = (0, 0) or the window of the fused max-pool. */
+ * cross image boundaries) A / D; a NEGATIVE value (-OCR_STATUS_INVALID) for non-positive sizes.  flags as for ocr_conv3x3_bf16;
+ * (kw, kh) = (0, 0) or the window of the fused max-pool. */
 int ocr_conv3x3_kernel_choice(int Nb, int W, int H, int Cin, int Cout, int flags, int kw, int kh);
 /* non-zero: ocr_conv3x3_bf16 accepts OCR_EPI_ACCUM for this shape (y (bf16) += result: the data gradient of a tensor with several
  * consumers is added to what was already delivered, no scratch tensor + add pass) */
@@ -239,6 +243,9 @@ int ocr_wgrad9_debug(void* dbg);
 int ocr_probe_tr16(const int* addr /* 64 */, int* out /* 64*4 */, void* stream);
 /* out[id] = XCC_ID of workgroup id of a 1-D grid, out[nblocks + id] = its HW_ID register (evidence for id & 7 == XCD) */
 int ocr_probe_xcc(int* out /* 2*nblocks */, int nblocks, int threads, void* stream);
+/* counter calibration: every wave issues iters x 8 back-to-back v_mfma_f32_16x16x32_bf16 (a saturated matrix pipe with an exactly known
+ * instruction count); clk[4] = {shader clock, 100 MHz clock} of workgroup 0 at loop entry and exit, or NULL (tools/mfma_busy_probe.py) */
+int ocr_mfma_busy_probe(float* out, int nblocks, int threads /* multiple of 64, <= 512 */, int iters, long long* clk, void* stream);
 
 #ifdef __cplusplus
 }

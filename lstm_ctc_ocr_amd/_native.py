@@ -19,6 +19,7 @@ _P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_floa
 
 _SIGS = {
     "ocr_abi_version": ([], _I),
+    "ocr_build_id": ([], ctypes.c_char_p),
     "ocr_status_string": ([_I], ctypes.c_char_p),
     "ocr_ctc_workspace_size": ([_I, _I, _I, ctypes.POINTER(ctypes.c_size_t)], _I),
     "ocr_ctc_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P], _I),
@@ -91,6 +92,7 @@ _SIGS = {
     "ocr_probe_tr16": ([_P, _P, _P], _I),
     "ocr_set_lstm_proto": ([_I], _I),
     "ocr_probe_xcc": ([_P, _I, _I, _P], _I),
+    "ocr_mfma_busy_probe": ([_P, _I, _I, _I, _P, _P], _I),
 }
 
 
@@ -103,6 +105,22 @@ def declared_symbols(header=HEADER_PATH):
     text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(ocr_[a-z0-9_]+)\s*\(", text)))
+
+
+def source_build_id(csrc=os.path.join(_HERE, "csrc")):
+    """The id `make` compiles into the library (csrc/Makefile: sha256 over the sorted product *.hip, common.h and the Makefile, 16 hex
+    digits), recomputed from the source tree: equal to build_id() unless the .so is stale."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip"))) + [os.path.join(csrc, "common.h"), os.path.join(csrc, "Makefile")]:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_id():
+    """Source hash the loaded library was built from (+ '-exp' for the experiments flavour)."""
+    return lib().ocr_build_id().decode()
 
 
 _lib = None

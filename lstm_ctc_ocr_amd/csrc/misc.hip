@@ -36,6 +36,37 @@ extern "C" int ocr_probe_xcc(int* out, int nblocks, int threads, void* stream) {
     return OCR_OK;
 }
 
+// Calibration of the SQ_VALU_MFMA_BUSY_CYCLES counter (the busy fraction and the FLOP fraction of conv_k3 did not reconcile).
+// Every wave issues `iters` x 8 v_mfma_f32_16x16x32_bf16 on eight independent accumulators (no operand loads, no LDS, no waits inside the
+// loop), so the matrix pipe of its SIMD is saturated by construction and the number of MFMA instructions is known exactly:
+// grid x (threads / 64) x iters x 8.  At 1024 flop / clock / SIMD (2.5 PFLOP/s = 256 CUs x 4 SIMDs x 1024 x 2.4 GHz) one such MFMA occupies
+// the pipe for 16 clocks.  clk[0..3] = shader clock / 100 MHz wall clock of workgroup 0 at loop entry and exit (the clock the loop ran at).
+// tools/mfma_busy_probe.py runs it under rocprofv3 --pmc and derives the counter's unit.
+__global__ void __launch_bounds__(512) mfma_busy_probe_kernel(float* __restrict__ out, int iters, long long* __restrict__ clk) {
+    bf16x8 a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(float)((threadIdx.x + j) & 3); b[j] = (__bf16)(float)((threadIdx.x * 3 + j) & 1); }
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = (long long)__builtin_amdgcn_s_memtime(); clk[1] = (long long)wall_clock64(); }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
+    }
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = (long long)__builtin_amdgcn_s_memtime(); clk[3] = (long long)wall_clock64(); }
+    float r = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    if (r == 123456.789f) out[0] = r;             // keeps the accumulators alive; never true for these operands
+}
+extern "C" int ocr_mfma_busy_probe(float* out, int nblocks, int threads, int iters, long long* clk, void* stream) {
+    if (!out || nblocks <= 0 || threads <= 0 || threads > 512 || (threads & 63) || iters <= 0) return OCR_ERR_INVALID;
+    mfma_busy_probe_kernel<<<nblocks, threads, 0, (hipStream_t)stream>>>(out, iters, clk);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+
 extern "C" const char* ocr_status_string(int status) {
     switch (status) {
         case OCR_OK: return "no error";

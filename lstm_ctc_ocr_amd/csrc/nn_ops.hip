@@ -155,6 +155,7 @@ __device__ __forceinline__ void conv1_window(const float* __restrict__ xn, int W
     }
 }
 
+#ifdef OCR_EXPERIMENTS   // measured and rejected: compiled, reachable (OCR_CONV1_V2=1) and tested only in the experiments flavour
 // Second generation of the two fused kernels (round 2; behind OCR_CONV1_V2=1 — measured slightly SLOWER than the first, see conv1_v1()).  The ISA of the first showed, per
 // loop iteration, two 64-bit integer divisions (~130 instructions each, half of them scalar with readfirstlane round trips), 16 patch
 // loads each in its own exec-masked branch, and the loads placed right in front of their first use — so every iteration exposed a
@@ -333,6 +334,7 @@ void conv1_pool_bwd2_kernel(const float* __restrict__ x, const float* __restrict
         else atomicAdd(db + c, v);
     }
 }
+#endif   // OCR_EXPERIMENTS (second-generation conv1 + pool kernels)
 
 __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, bf16_t* __restrict__ p,
@@ -1251,8 +1253,11 @@ static bool nn_knob(const char* name, int slot) {
     if (v[slot] < 0) { const char* e = ocr_tune_env(name); v[slot] = (e && atoi(e) != 0) ? 1 : 0; }
     return v[slot] == 1;
 }
+#ifdef OCR_EXPERIMENTS
 static bool conv1_v1() { return !nn_knob("OCR_CONV1_V2", 0); }
-static bool col2im_v1() { return nn_knob("OCR_COL2IM_V1", 1); }
+#endif
+static bool col2im_v1() { return nn_knob("OCR_COL2IM_V1", 1); }      // product build: always false (ocr_tune_env); the scalar kernel is also the
+                                                                     // fallback for HC % 8 != 0 / unaligned buffers, which is how the tests reach it
 static inline int grid_for(long total, int cap = 4096) {
     long b = (total + 255) / 256;
     if (b > cap) b = cap;
@@ -1289,9 +1294,11 @@ extern "C" int ocr_conv1_pool_fwd(const float* x, const float* w, const float* b
                                   void* stream) {
     if (!x || !w || !bias || !p || (Cout & 7) || Cout > 1024 || 256 % (Cout >> 3) || (W & 1) || (H & 1)) return OCR_ERR_INVALID;
     long total = (long)Nb * (W / 2) * (H / 2) * (Cout >> 3);
+#ifdef OCR_EXPERIMENTS
     if (!conv1_v1() && (long)Nb * (W / 2) * (H / 2) < 0x7fffffffL && (long)Nb * W * H < 0x7fffffffL && (long)W * H < 0x7fffffffL)
         conv1_pool_fwd2_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout);
     else
+#endif
         conv1_pool_fwd_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
@@ -1301,10 +1308,12 @@ extern "C" int ocr_conv1_pool_bwd(const float* x, const float* w, const float* b
     if (!x || !w || !bias || !dp || !dw || !db || Cout != 64 || (W & 1) || (H & 1)) return OCR_ERR_INVALID;
     long npix = (long)Nb * (W / 2) * (H / 2);
     int ppb = 256;
+#ifdef OCR_EXPERIMENTS
     if (!conv1_v1() && npix < 0x7fffffffL - 512 && (long)Nb * W * H < 0x7fffffffL)
         conv1_pool_bwd2_kernel<<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, w, bias, (const bf16_t*)dp, dw, db, Nb, W, H,
                                                                                      Cout, ppb);
     else
+#endif
         conv1_pool_bwd_kernel<<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, w, bias, (const bf16_t*)dp, dw, db, Nb, W, H,
                                                                                     Cout, ppb);
     OCR_CHECK_LAUNCH();

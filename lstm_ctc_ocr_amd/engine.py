@@ -1426,8 +1426,10 @@ class Engine(object):
         """Queue a report of this step into the watchdog's OWN slot and evaluate the one queued 64 steps ago (an event query, no wait):
         a persistent-LSTM time-out raises at most 64 steps late instead of costing a pipeline drain every 64 steps."""
         pending = getattr(self, '_watch_pending', None)
-        if pending is not None and pending[1].query():
-            self.report_wait(pending)
+        if pending is not None:
+            if not pending[1].query():
+                return                            # the 'watch' slot's copy is still in flight: keep that handle, queue nothing over it (ADVICE r3)
+            self.report_wait(pending, update_mirrors=False)      # a 64-steps-old report must not overwrite last_ctc / last_reg / last_gnorm
         self._watch_pending = self.report_async(_slot='watch')
 
     def last_loss(self):
@@ -1469,15 +1471,19 @@ class Engine(object):
         ev.record(torch.cuda.current_stream(self.device))
         return (host, ev, words, self.opt_ready, slot)
 
-    def report_wait(self, handle):
+    def report_wait(self, handle, update_mirrors=True):
         host, ev, words, opt_ready, slot = handle
         ev.synchronize()
         slot[3] = False
         ctc, reg2, gnorm, bits = (float(v) for v in host.numpy())
         reg = 0.5 * float(self.cfg.TRAIN.WEIGHT_DECAY) * reg2 if (self.cfg.TRAIN.WEIGHT_DECAY > 0 and opt_ready) else 0.0
-        self.last_ctc, self.last_reg, self.last_gnorm = ctc, reg, gnorm if opt_ready else 0.0
+        if update_mirrors:
+            self.last_ctc, self.last_reg, self.last_gnorm = ctc, reg, gnorm if opt_ready else 0.0
         if bits != 0.0:
             bad = [i for i in range(len(words)) if (int(bits) >> i) & 1]
-            raise NativeError('persistent LSTM %s kernel: inter-workgroup wait timed out (results invalid); counters %s'
-                              % (('forward', 'backward')[bad[0] % 2], words[bad[0]][::64].tolist()))
+            # the sync block = group counters (64-word stride, at most 2 * ceil(N / 16) of them) | hand-off ring | error word: print the
+            # counters only (the ring is hundreds of thousands of 0xFFFFFFFF words)
+            w = words[bad[0]]
+            raise NativeError('persistent LSTM %s kernel: inter-workgroup wait timed out (results invalid); group counters %s, error word %d'
+                              % (('forward', 'backward')[bad[0] % 2], w[:64 * 16:64].tolist(), int(w[-1])))
         return ctc + reg

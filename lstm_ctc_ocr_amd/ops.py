@@ -115,7 +115,10 @@ CONV_KERNEL_NAMES = ("gemm", "conv_halo", "conv_k2/A", "conv_k2/D", "conv_k3/A",
 def conv3x3_kernel_choice(Nb, W, H, Cin, Cout, *, bias=True, relu=True, mask=False, accumulate=False, pool=(0, 0)):
     """Name of the kernel family ocr_conv3x3_bf16 / ocr_conv3x3_relu_pool_bf16 take for this shape (host-only query, no GPU needed)."""
     flags = (nat.EPI_BIAS if bias else 0) | (nat.EPI_RELU if relu else 0) | (nat.EPI_MASK if mask else 0) | (nat.EPI_ACCUM if accumulate else 0)
-    return CONV_KERNEL_NAMES[nat.lib().ocr_conv3x3_kernel_choice(int(Nb), int(W), int(H), int(Cin), int(Cout), flags, int(pool[0]), int(pool[1]))]
+    rc = nat.lib().ocr_conv3x3_kernel_choice(int(Nb), int(W), int(H), int(Cin), int(Cout), flags, int(pool[0]), int(pool[1]))
+    if rc < 0:
+        raise nat.NativeError("ocr_conv3x3_kernel_choice failed: status %d (%s)" % (-rc, nat.status_string(-rc)))
+    return CONV_KERNEL_NAMES[rc]
 
 
 def conv3x3_accum_supported(Nb, W, H, Cin, Cout):

@@ -317,14 +317,19 @@ def normalise_name(name):
     return name
 
 
-def convert(prefix, out_path, wanted=None, iteration=None, verify=False, output_dir=None):
+def convert(prefix, out_path, wanted=None, iteration=None, verify=False, output_dir=None, restore_lr=False):
     """TensorFlow checkpoint `prefix` -> `.npz` snapshot for checkpoint.restore().  `wanted` = the engine's variable names (Engine.specs);
     variables are matched by exact name, then by name with the RNN helper scopes removed.  Adam slots (`<var>/Adam`, `<var>/Adam_1`,
     `beta1_power`, `beta2_power`) become slot1 / slot2 / optimiser scalars; batch-norm moving averages are dropped (the reference never
     uses them: network.py:176-178 runs batch norm with is_training=True everywhere).  Returns (matched, unmatched TF names).
-    The reference creates its learning-rate and step variables UNNAMED (`lr = tf.Variable(...)`, `global_step = tf.Variable(0, ...)`:
-    lib/lstm/train.py:73,78), so a checkpoint it wrote holds them as `Variable` (float scalar, the possibly decayed learning rate) and
-    `Variable_1` (integer scalar, the step count); `global_step` is accepted too.
+    EXPERIMENTAL (pinned only on bundles of this module's own writer: no TensorFlow-written file exists offline).
+    The reference builds its `tf.train.Saver` in `SolverWrapper.__init__` (lib/lstm/train.py:18), BEFORE `lr`, `global_step` and the Adam
+    slots exist (train.py:73-85), so the checkpoints the reference itself writes hold NONE of them, and its own restore re-derives the
+    iteration from the file name (train.py:100-104).  A checkpoint written by a Saver created later (or by other TF code for the same
+    graph) may hold the unnamed `Variable` (float scalar: learning rate) / `Variable_1` or `global_step` (integer scalar: step count) and
+    the Adam slots; they are carried over as follows.  Step count: the integer step variable, else the value derived from `beta2_power`
+    (exact up to ~87 000 steps) / `beta1_power`, and only then the `_iter_<n>` of the file name.  Learning rate: the driver's configured
+    rate is KEPT, as the reference does (it never restores `lr`); `restore_lr=True` opts into taking the checkpoint's `Variable`.
     output_dir: write the snapshot as `<output_dir>/<basename>_iter_<n>.ckpt` instead of `out_path` and register it in that
     directory's `checkpoint` index, so that test_net / train_net --restore find it (checkpoint.latest_checkpoint)."""
     tf_vars = read_bundle(prefix, verify=verify)
@@ -352,17 +357,20 @@ def convert(prefix, out_path, wanted=None, iteration=None, verify=False, output_
         if step_var is not None:
             step = int(np.asarray(tf_vars[step_var]).reshape(-1)[0])
             used.add(step_var)
-        elif re.search(r'_iter_(\d+)', os.path.basename(prefix)):        # the Saver's file name carries the iteration (train.py:27-36)
-            step = max(0, int(re.search(r'_iter_(\d+)', os.path.basename(prefix)).group(1)) - 1)
-        elif 0 < b2t < 1:
+        elif 0 < b2t < 1:                                                # exact: what Adam itself multiplied up
             step = int(round(np.log(b2t) / np.log(0.999)))
+        elif 0 < b1t < 1:
+            step = int(round(np.log(b1t) / np.log(0.9)))
+        elif re.search(r'_iter_(\d+)', os.path.basename(prefix)):        # both powers underflowed: the Saver's file name (train.py:27-36)
+            step = max(0, int(re.search(r'_iter_(\d+)', os.path.basename(prefix)).group(1)) - 1)
         else:
-            step = int(round(np.log(b1t) / np.log(0.9))) if 0 < b1t < 1 else 0
+            step = 0
         sc = np.zeros(8, np.float64)                    # csrc/optim.hip: [2] lr (set by the driver), [4] beta1^t, [5] beta2^t, [6] step
         sc[4], sc[5], sc[6] = 0.9 ** step, 0.999 ** step, step
-        lr_var = tf_vars.get('Variable')                # the reference's unnamed learning-rate variable: restored like the reference does
+        lr_var = tf_vars.get('Variable')                # an unnamed float scalar = the learning-rate variable of train.py:73
         if lr_var is not None and np.asarray(lr_var).size == 1 and np.issubdtype(np.asarray(lr_var).dtype, np.floating):
-            sc[2] = float(np.asarray(lr_var).reshape(-1)[0])
+            if restore_lr:                              # opt-in: checkpoint.restore() sets engine.lr from sc[2] > 0; by default the driver's
+                sc[2] = float(np.asarray(lr_var).reshape(-1)[0])          # configured rate stays, which is what the reference does
             used.add('Variable')
         arrays['opt/scalars'] = sc
         arrays['opt/solver'] = np.int64(0)
@@ -392,6 +400,8 @@ def main(argv=None):
     ap.add_argument('out', nargs='?', help='snapshot to write (default: only list the variables)')
     ap.add_argument('--network', default='LSTM_train', help='match against this network\'s variable names')
     ap.add_argument('--verify', action='store_true', help='check every tensor\'s stored crc32c (pure Python, ~1 s per MB)')
+    ap.add_argument('--restore-lr', action='store_true', help='take the learning rate from the checkpoint (default: keep the driver\'s, '
+                    'as the reference does)')
     ap.add_argument('--output-dir', default=None, help='write <output-dir>/<name>_iter_<n>.ckpt and register it in that directory\'s '
                                                        '`checkpoint` index, so that test_net / train_net --restore load it')
     args = ap.parse_args(argv)
@@ -400,7 +410,7 @@ def main(argv=None):
     if args.out or args.output_dir:
         from .models import get_network
         wanted = list(get_network(args.network).param_specs)
-        matched, rest = convert(args.prefix, args.out, wanted, verify=args.verify, output_dir=args.output_dir)
+        matched, rest = convert(args.prefix, args.out, wanted, verify=args.verify, output_dir=args.output_dir, restore_lr=args.restore_lr)
         print('matched %d of %d variables of %s; unmatched in the network: %s; unused in the checkpoint: %s'
               % (len(matched), len(wanted), args.network, sorted(set(wanted) - set(matched)), rest))
 

@@ -15,6 +15,20 @@ def test_library_exports_every_declared_symbol():
     assert lib.ocr_abi_version() == 1
 
 
+def test_library_is_built_from_the_sources_in_the_tree():
+    """ocr_build_id() (csrc/Makefile: sha256 over the product sources) against the same hash recomputed from the tree: a stale .so —
+    e.g. one left over from before an edit, which would travel to the GPU box as it is — fails here, on the CPU."""
+    assert nat.build_id() == nat.source_build_id(), 'libocrhip.so is stale: run `python -c "import __graft_entry__ as g; g.build()"`'
+
+
+def test_kernel_choice_reports_invalid_sizes_out_of_band():
+    import pytest
+    from lstm_ctc_ocr_amd import ops
+    assert nat.lib().ocr_conv3x3_kernel_choice(0, 64, 4, 256, 512, 0, 0, 0) < 0          # 0..7 are kernel families (ADVICE r3)
+    with pytest.raises(nat.NativeError):
+        ops.conv3x3_kernel_choice(64, 64, 0, 256, 512)
+
+
 def test_status_codes_and_host_side_validation():
     lib = nat.lib()
     assert nat.status_string(0) == 'no error' and nat.status_string(2) == 'invalid value'

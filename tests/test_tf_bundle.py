@@ -138,25 +138,34 @@ def test_conversion_to_a_snapshot(tmp_path):
     assert np.array_equal(snap['slot2/logits/fw/weights'], arrays['logits/bidirectional_rnn/fw/lstm_cell/weights/Adam_1'])
     sc = snap['opt/scalars']
     assert sc[6] == 1234 and sc[4] == 0.9 ** 1234 and sc[5] == 0.999 ** 1234 and int(snap['meta/iteration']) == 2000
-    # without a step variable the count comes from the Saver's file name (`_iter_2000` = 1999 completed steps: the reference's loop
-    # starts at 1 and names a snapshot iter + 1, train.py:27-36,111), and only then from beta2^t (beta1^t = 0.9^1234 is 0 in float32)
+    # without a step variable the count comes from what Adam itself multiplied up — beta2^t (beta1^t = 0.9^1234 is 0 in float32) — whatever
+    # the file is called (the `_iter_<n>` of the name used to take precedence over the exact value) ...
     del arrays['global_step']
     tb.write_bundle(prefix, arrays)
     tb.convert(prefix, out, wanted)
-    assert np.load(out)['opt/scalars'][6] == 1999
+    assert np.load(out)['opt/scalars'][6] == 1234
     plain = str(tmp_path / 'weights_only_name.ckpt')
     tb.write_bundle(plain, arrays)
     tb.convert(plain, out, wanted)
     assert np.load(out)['opt/scalars'][6] == 1234
+    # ... and from the Saver's file name only when both powers have underflowed (`_iter_2000` = 1999 completed steps: the reference's loop
+    # starts at 1 and names a snapshot iter + 1, train.py:27-36,111)
+    flushed = dict(arrays, beta1_power=np.float32(0.0), beta2_power=np.float32(0.0))
+    tb.write_bundle(prefix, flushed)
+    tb.convert(prefix, out, wanted)
+    assert np.load(out)['opt/scalars'][6] == 1999
     assert tb.normalise_name('logits/bidirectional_rnn/bw/lstm_cell/biases') == 'logits/bw/biases'
-    # what the REFERENCE writes: its learning-rate and step variables are unnamed (train.py:73,78) -> `Variable` (float) / `Variable_1` (int);
-    # the decayed learning rate is restored like the reference restores it, the step comes from the integer, not from float32 beta powers
+    # a Saver created AFTER the optimiser (not the reference's own: train.py:18 builds it before lr / global_step / the Adam slots exist)
+    # also holds the unnamed learning-rate and step variables (train.py:73,78) -> `Variable` (float) / `Variable_1` (int): the step comes
+    # from the integer, not from float32 beta powers; the learning rate stays the DRIVER's (the reference never restores it) unless asked for
     arrays['Variable'], arrays['Variable_1'] = np.float32(1e-5), np.int32(54321)
     arrays['beta2_power'] = np.float32(0.0)                                      # denormal / flushed after ~87k steps: must not be used
     tb.write_bundle(prefix, arrays)
     matched, rest = tb.convert(prefix, out, wanted)
     sc = np.load(out)['opt/scalars']
-    assert sc[6] == 54321 and abs(sc[2] - 1e-5) < 1e-12 and 'Variable' not in rest and 'Variable_1' not in rest
+    assert sc[6] == 54321 and sc[2] == 0.0 and 'Variable' not in rest and 'Variable_1' not in rest
+    tb.convert(prefix, out, wanted, restore_lr=True)
+    assert abs(np.load(out)['opt/scalars'][2] - 1e-5) < 1e-12
     # --output-dir: written under the Saver's naming and registered in the directory's `checkpoint` index -> latest_checkpoint finds it
     from lstm_ctc_ocr_amd import checkpoint
     outdir = str(tmp_path / 'out')

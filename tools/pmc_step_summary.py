@@ -3,11 +3,18 @@ HBM read bytes (FETCH_SIZE x 2: MI355X_MICROARCH.md — gfx950 reports half of w
 write bytes (as reported, uncalibrated), matrix-pipe occupancy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) with kernel
 cycles = GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs), L2 hit rate, LDS conflict share, VALU instructions per MFMA — together with
 the git commit and the kernel symbols, so that bench.py can refuse numbers taken from another build.
-usage: python tools/pmc_step_summary.py <txt> <repo root>"""
+The json is pinned to the library that ran by `build_id` (ocr_build_id(): the hash of the sources the .so was built from) and names the
+bench.py workload it was taken on: bench.py refuses numbers from another build or another workload.
+usage: python tools/pmc_step_summary.py <txt> <repo root> [workload]"""
 import json
 import re
 import subprocess
 import sys
+
+
+# What SQ_VALU_MFMA_BUSY_CYCLES adds up to per shader-clock cycle when every matrix pipe of the chip is saturated.  Rounds 1-3 assumed
+# 1024 (one tick per SIMD and cycle); tools/mfma_busy_probe.py measures it (profiles/r04_mfma_busy_calibration.md).
+MFMA_BUSY_UNITS_PER_CHIP_CYCLE = 1024.0
 
 
 def main():
@@ -28,6 +35,10 @@ def main():
         commit = commit or open(sys.argv[2] + '/.build_commit').read().strip()
     except Exception:
         pass
+    sys.path.insert(0, sys.argv[2])
+    from lstm_ctc_ocr_amd import _native
+    build_id = _native.build_id()
+    workload = sys.argv[3] if len(sys.argv) > 3 else 'fixed'
     rows = []
     for name, k in kern.items():
         c = k['counters']
@@ -36,7 +47,7 @@ def main():
         if g('FETCH_SIZE') is not None: row['read_mb'] = 2.0 * g('FETCH_SIZE') * 1024 / 1e6
         if g('WRITE_SIZE') is not None: row['write_mb'] = g('WRITE_SIZE') * 1024 / 1e6
         if g('SQ_VALU_MFMA_BUSY_CYCLES') is not None and g('GRBM_GUI_ACTIVE'):
-            row['mfma_busy_frac'] = g('SQ_VALU_MFMA_BUSY_CYCLES') / (1024.0 * g('GRBM_GUI_ACTIVE') / 8.0)
+            row['mfma_busy_frac'] = g('SQ_VALU_MFMA_BUSY_CYCLES') / (MFMA_BUSY_UNITS_PER_CHIP_CYCLE * g('GRBM_GUI_ACTIVE') / 8.0)
         if g('SQ_INSTS_MFMA'): row['valu_per_mfma'] = (g('SQ_INSTS_VALU') or 0.0) / g('SQ_INSTS_MFMA')
         if g('SQ_WAVE_CYCLES'):
             row['wait_any_frac'] = (g('SQ_WAIT_ANY') or 0.0) / g('SQ_WAVE_CYCLES'); row['wait_inst_frac'] = (g('SQ_WAIT_INST_ANY') or 0.0) / g('SQ_WAVE_CYCLES')
@@ -46,7 +57,9 @@ def main():
     rows.sort(key=lambda r: -r['launches'] * r['avg_us'])
     print(json.dumps({'source': 'rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* + GRBM_GUI_ACTIVE | LDS + TCC; --kernel-trace only) over '
                                 'bench.py --no-graphs --steps 3 --warmup 2 (5 eager train steps + the side loops of the line); FETCH_SIZE doubled '
-                                '(gfx950 correction of MI355X_MICROARCH.md), WRITE_SIZE uncalibrated', 'commit': commit, 'kernels': rows}, indent=1))
+                                '(gfx950 correction of MI355X_MICROARCH.md), WRITE_SIZE uncalibrated; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (MFMA_BUSY_UNITS_PER_CHIP_CYCLE x GRBM_GUI_ACTIVE / 8), '
+                                'the divisor calibrated with tools/mfma_busy_probe.py (profiles/r04_mfma_busy_calibration.md)',
+                      'commit': commit, 'build_id': build_id, 'workload': workload, 'kernels': rows}, indent=1))
 
 
 if __name__ == '__main__':
