@@ -295,6 +295,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dp_host = None
+    if eng.dp_host_s[5]:
+        n = float(eng.dp_host_s[5])
+        dp_host = {k: round(v / n * 1e6, 1) for k, v in zip(("graph1_fwd_ctc_bwd_late", "allreduce_late_enqueue", "graph2_bwd_early",
+                                                               "allreduce_early_enqueue_and_join", "graph3_clip_optimiser_repack"), eng.dp_host_s[:5])}
+        dp_host["note"] = "host-side enqueue time per step and phase (us), rank 0, timed steps + warm-up"
     if world > 1:
         dt = float(reduce_(torch.tensor([dt], dtype=torch.float64, device=device), dist.ReduceOp.MAX).item())
     loss = eng.last_loss()
@@ -345,7 +351,7 @@ def main():
                                     "bs=32/GPU (BASELINE.json configs[4]; bf16 MFMA operands where BASELINE says fp16: same MFMA rate, fp32 accumulation)"),
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world, "hipgraph": not args.no_graphs},
             "final_loss": loss,
-            "dp_check": dp_check,
+            "dp_check": dp_check, "dp_host_enqueue_us": dp_host,
             "with_loss_fetch_every_step": {"value": BATCH * world * args.steps / dt_fetch, "ms_per_step": dt_fetch / args.steps * 1e3},
             "with_loss_read_one_step_behind": {"value": BATCH * world * args.steps / dt_lag, "ms_per_step": dt_lag / args.steps * 1e3},
             "model_tflops_per_gpu": value / world * TRAIN_GFLOP_PER_IMG * 1e9 / 1e12,

@@ -18,6 +18,7 @@ optimiser math.  oracle/graph.py(sim_bf16=True) rounds at the same points.
 import math
 
 import os
+import time
 
 import numpy as np
 import torch
@@ -882,6 +883,7 @@ class Engine(object):
         self.defer_w9 = os.environ.get('OCR_W9_DEFER', '1') != '0'
         self.w9_defer_max_bytes = int(os.environ.get('OCR_W9_DEFER_MAX_MB', self.W9_DEFER_MAX_BYTES >> 20)) << 20
         self.comm_stream = torch.cuda.Stream(device=self.device)
+        self.dp_host_s = [0.0, 0.0, 0.0, 0.0, 0.0, 0]      # host enqueue seconds of the data-parallel schedule's phases + step count (train_step)
         self._lower(net)                                 # operators first: the parameter layout follows their EXECUTION order
         self._layout(net)
         self._init_params(cfg.RNG_SEED if seed is None else seed)
@@ -1396,18 +1398,29 @@ class Engine(object):
         self._bind(sp, data, seq_len, labels, labels_len)
         if (self.world > 1 or self.force_allreduce) and self.overlap_allreduce and self.split_op > 0:
             main = torch.cuda.current_stream(self.device)
+            pc = time.perf_counter
+            t0 = pc()
             rest = self._run_split(sp)
+            t1 = pc()
             self.comm_stream.wait_stream(main)
             with torch.cuda.stream(self.comm_stream):
                 self.allreduce_grads(self.late_begin, self.n_total)
+            t2 = pc()
             rest()                                       # backward of the early layers, concurrent with the exchange above
+            t3 = pc()
             # the early bucket goes out on the SAME stream as the late one: both collectives of a step are issued from one ordering
             # domain, in the same order on every rank (two streams relied on ProcessGroupNCCL's internal ordering)
             self.comm_stream.wait_stream(main)
             with torch.cuda.stream(self.comm_stream):
                 self.allreduce_grads(0, self.late_begin)
             main.wait_stream(self.comm_stream)
+            t4 = pc()
             self.optimizer_step()
+            t5 = pc()
+            # host-side enqueue time of the five phases (seconds, summed; bench.py prints the per-step averages so that a scaling record
+            # explains itself: a host-bound schedule shows here, not in the kernel profile)
+            h = self.dp_host_s
+            h[0] += t1 - t0; h[1] += t2 - t1; h[2] += t3 - t2; h[3] += t4 - t3; h[4] += t5 - t4; h[5] += 1
         elif self.world == 1 and not self.force_allreduce and self.use_graphs:
             self._run_step(sp)                            # single GPU: forward, backward and optimiser as ONE graph
         else:
