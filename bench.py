@@ -116,7 +116,7 @@ def conv_roofline(eng, device, workload):
     # HBM bytes per launch and matrix-pipe occupancy of the same kernels from the separate rocprofv3 --pmc passes over THIS script
     # (tools/prof_step_pmc.sh -> profiles/rNN_pmc_step.json; FETCH_SIZE doubled: the guide's gfx950 correction).  The file names the
     # commit it was taken at and its kernel symbols: numbers whose symbols are not in the library loaded now are refused.
-    traffic, mfma_busy, src, pmc_commit, pmc_error, pmc_build = None, None, None, None, None, None
+    traffic, mfma_busy, src, pmc_commit, pmc_error, pmc_build, pmc_clock, pmc_avg_us = None, None, None, None, None, None, None, None
     import glob
     build_id = nat.build_id()
     try:
@@ -146,17 +146,23 @@ def conv_roofline(eng, device, workload):
                 traffic = sum(k["launches"] * (k["read_mb"] + k["write_mb"]) for k in conv) / nl * 1e6
             if all("mfma_busy_frac" in k for k in conv):
                 mfma_busy = sum(k["launches"] * k["avg_us"] * k["mfma_busy_frac"] for k in conv) / tm
+            if all("clock_mhz" in k for k in conv):
+                pmc_clock = sum(k["launches"] * k["avg_us"] * k["clock_mhz"] for k in conv) / tm
+            pmc_avg_us = tm / nl
     return {"bound": "mfma", "kernel": "conv_k3_kernel / conv_k2_kernel / conv_halo_kernel (implicit-GEMM 3x3 SAME conv, forward + data gradient: %d launches/step)" % n_launch,
             "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK,
             "avg_launch_us": tot_t / n_launch * 1e6, "algorithmic_gflop_per_launch": tot_fl / n_launch / 1e9,
             "executed_flop_frac": exe_fl / tot_fl, "achieved_executed": exe_fl / tot_t / 1e12,
             "executed_note": "`achieved` counts 2*M*K*N of every launch (SURVEY 8d) including the SAME-padding taps the plane-layout kernels "
                              "(conv_k3 / conv_k3w) never issue: 2/(3H) of a layer's MFMAs (H=4: a sixth); `achieved_executed` counts only issued MFMAs",
-            "traffic": traffic, "mfma_busy_frac": mfma_busy, "pmc_commit": pmc_commit, "pmc_build_id": pmc_build, "build_id": build_id,
+            "traffic": traffic, "mfma_busy_frac": mfma_busy, "pmc_clock_mhz": pmc_clock, "pmc_avg_launch_us": pmc_avg_us, "pmc_commit": pmc_commit, "pmc_build_id": pmc_build, "build_id": build_id,
             "build_commit": build_commit, "pmc_error": pmc_error,
             "shader_clock_mhz": mhz, "frac_of_peak_at_that_clock": (ach / (MFMA_BF16_PEAK * mhz / PEAK_CLOCK_MHZ)) if mhz else None,
-            "clock_note": "shader clock measured inside the kernel (s_memtime / s_memrealtime of workgroup 0, time-weighted over the launches); "
-                          "`peak` is the guide's dense bf16 figure at %d MHz" % PEAK_CLOCK_MHZ,
+            "executed_frac_of_peak_at_that_clock": (exe_fl / tot_t / (MFMA_BF16_PEAK * mhz / PEAK_CLOCK_MHZ)) if mhz else None,
+            "clock_note": "shader clock measured inside EVERY timed convolution launch (s_memtime / s_memrealtime of workgroup 0 of conv_k3 / conv_k3w / "
+                          "conv_halo, time-weighted); `peak` is the guide's dense bf16 figure at %d MHz; executed_frac_of_peak_at_that_clock is the "
+                          "matrix-pipe occupancy of THIS run (issued MFMA cycles / available SIMD cycles) and is what mfma_busy_frac measures in the "
+                          "separate counter run at that run's clock (profiles/r04_mfma_busy_calibration.md)" % PEAK_CLOCK_MHZ,
             "traffic_note": "HBM bytes per launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) and SQ_VALU_MFMA_BUSY_CYCLES / "
                             "available SIMD cycles of the same kernels inside this script's train step, from profiles/%s" % src}
 

@@ -87,7 +87,7 @@ int ocr_conv3x3_kernel_choice(int Nb, int W, int H, int Cin, int Cout, int flags
 /* non-zero: ocr_conv3x3_bf16 accepts OCR_EPI_ACCUM for this shape (y (bf16) += result: the data gradient of a tensor with several
  * consumers is added to what was already delivered, no scratch tensor + add pass) */
 int ocr_conv3x3_accum_supported(int Nb, int W, int H, int Cin, int Cout);
-/* diagnostic: workgroup 0 of the halo convolution kernel stamps {shader clock counter, 100 MHz wall clock} at entry and exit into
+/* diagnostic: workgroup 0 of the convolution kernels (conv_halo, conv_k3 / conv_k3w) stamps {shader clock counter, 100 MHz wall clock} at entry and exit into
  * dbg (device int64[4]; NULL = off) */
 int ocr_conv_halo_clock_debug(void* dbg);
 /* conv3x3 + bias + ReLU AND the max-pool behind it from one epilogue (LSTM_train.py:26-33): y [Nb,W,H,Cout] and pooled

@@ -107,15 +107,19 @@ def declared_symbols(header=HEADER_PATH):
     return sorted(set(re.findall(r"\b(ocr_[a-z0-9_]+)\s*\(", text)))
 
 
-def source_build_id(csrc=os.path.join(_HERE, "csrc")):
-    """The id `make` compiles into the library (csrc/Makefile: sha256 over the sorted product *.hip, common.h and the Makefile, 16 hex
-    digits), recomputed from the source tree: equal to build_id() unless the .so is stale."""
+def source_build_id(csrc=os.path.join(_HERE, "csrc"), experiments=False):
+    """The id `make` compiles into the library (csrc/Makefile: sha256 over the sorted sources, common.h and the Makefile, 16 hex digits;
+    the experiments flavour adds experiments/conv_*.hip and the suffix '-exp'), recomputed from the source tree: equal to build_id()
+    unless the .so is stale."""
     import glob
     import hashlib
+    rel = [os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.hip"))]
+    if experiments:
+        rel += ["experiments/" + os.path.basename(f) for f in glob.glob(os.path.join(csrc, "experiments", "conv_*.hip"))]
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(csrc, "*.hip"))) + [os.path.join(csrc, "common.h"), os.path.join(csrc, "Makefile")]:
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    for f in sorted(rel) + ["common.h", "Makefile"]:          # make's $(sort ...) orders the same byte-wise way
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16] + ("-exp" if experiments else "")
 
 
 def build_id():

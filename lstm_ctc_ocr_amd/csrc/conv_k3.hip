@@ -54,6 +54,13 @@ extern "C" int ocr_conv_k3_debug(void* dbg) {
 #else
 #define K3_PHASE(slot) do { } while (0)
 #endif
+// diagnostic (ocr_conv_halo_clock_debug sets it together with conv_halo's): workgroup 0 stamps {shader-clock counter, 100 MHz wall clock} at
+// entry and exit, so bench.py reports the clock the plane-layout kernels really ran at (round 3 measured it inside conv_halo launches only)
+__device__ long long* g_k3_clk;
+int k3_set_clock_debug(void* dbg) {
+    long long* p = (long long*)dbg;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_k3_clk), &p, sizeof(p)) == hipSuccess ? OCR_OK : OCR_ERR_EXEC;
+}
 // packed bf16 max (exact: keeps the raw bits of the larger half)
 __device__ __forceinline__ uint32_t k3_max2(uint32_t a, uint32_t b) {
     const uint32_t lo = (bf_lo(b) > bf_lo(a)) ? (b & 0xffffu) : (a & 0xffffu);
@@ -94,6 +101,8 @@ __device__ __forceinline__ void k3_body(const K3Args& g) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     K3_PHASE(0);
+    long long* const clk = g_k3_clk;
+    if (clk && blockIdx.x == 0 && tid == 0) { clk[0] = (long long)__builtin_amdgcn_s_memtime(); clk[1] = (long long)wall_clock64(); }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = wave >> 2, wm = (wave & 3) / WN, wn = (wave & 3) % WN;
     const int C = g.C;
@@ -422,6 +431,7 @@ __device__ __forceinline__ void k3_body(const K3Args& g) {
         }
     };
     if (kh) tail(std::integral_constant<int, 1>{}); else tail(std::integral_constant<int, 0>{});
+    if (clk && blockIdx.x == 0 && tid == 0) { clk[2] = (long long)__builtin_amdgcn_s_memtime(); clk[3] = (long long)wall_clock64(); }
 #ifdef OCR_EXPERIMENTS
     K3_PHASE(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -435,6 +435,15 @@ def test_conv1_pool_second_generation_kernels(dev):
     exp = os.path.join(os.path.dirname(nat.LIB_PATH), 'libocrhip_exp.so')
     if not os.path.exists(exp):
         pytest.skip('experiments flavour not built (make -C lstm_ctc_ocr_amd/csrc EXPERIMENTS=1)')
+    import ctypes
+    try:
+        fn = ctypes.CDLL(exp).ocr_build_id
+        fn.restype = ctypes.c_char_p
+        have = fn().decode()
+    except (OSError, AttributeError):
+        have = None
+    if have != nat.source_build_id(experiments=True):
+        pytest.skip('libocrhip_exp.so is stale (%s, tree %s): rebuild it with make EXPERIMENTS=1' % (have, nat.source_build_id(experiments=True)))
     env = dict(os.environ, OCR_CONV1_V2='1', OCR_NATIVE_LIB=exp)
     code = ("import sys; sys.path.insert(0, %r); import torch; from tests import test_gpu_kernels as t; "
             "[t._conv1_pool_fused_equals_unfused(torch.device('cuda', 0), *s) for s in ((5, 24, 32), (40, 250, 32), (3, 30, 12))]; print('V2_OK')"

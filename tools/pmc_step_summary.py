@@ -48,6 +48,8 @@ def main():
         if g('WRITE_SIZE') is not None: row['write_mb'] = g('WRITE_SIZE') * 1024 / 1e6
         if g('SQ_VALU_MFMA_BUSY_CYCLES') is not None and g('GRBM_GUI_ACTIVE'):
             row['mfma_busy_frac'] = g('SQ_VALU_MFMA_BUSY_CYCLES') / (MFMA_BUSY_UNITS_PER_CHIP_CYCLE * g('GRBM_GUI_ACTIVE') / 8.0)
+        if g('GRBM_GUI_ACTIVE'): row['clock_mhz'] = g('GRBM_GUI_ACTIVE') / 8.0 / k['avg_us']       # shader clocks per us of THIS (eager, one-at-a-time) run
+        if g('SQ_INSTS_MFMA'): row['mfma_insts'] = g('SQ_INSTS_MFMA')
         if g('SQ_INSTS_MFMA'): row['valu_per_mfma'] = (g('SQ_INSTS_VALU') or 0.0) / g('SQ_INSTS_MFMA')
         if g('SQ_WAVE_CYCLES'):
             row['wait_any_frac'] = (g('SQ_WAIT_ANY') or 0.0) / g('SQ_WAVE_CYCLES'); row['wait_inst_frac'] = (g('SQ_WAIT_INST_ANY') or 0.0) / g('SQ_WAVE_CYCLES')

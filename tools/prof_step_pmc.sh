@@ -2,7 +2,7 @@
 # rocprofv3 --pmc passes over bench.py itself (eager launches: --no-graphs, a few steps) -> per-kernel HBM bytes, matrix-pipe occupancy,
 # L2 hit rate and LDS conflicts for EVERY kernel of the train step, pinned to the commit and to the kernel symbols of the library
 # that ran.  Counters are collected in their own runs with --kernel-trace only (never with the trace domains gpurun refuses).
-# usage (GPU box): bash tools/prof_step_pmc.sh <tag> [bench.py args]      -> gpurun_out/<tag>_pmc_step.json (+ _pmc_step.txt)
+# usage (GPU box): bash tools/prof_step_pmc.sh <tag> [bench.py args, e.g. --workload deep]      -> gpurun_out/<tag>_pmc_step_<workload>.json (+ _pmc_step.txt)
 TAG=${1:-rXX}; shift
 REPO=$(pwd); OUT=$REPO/gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -15,10 +15,11 @@ for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ
   python $REPO/tools/rocpd_pmc.py $(ls $OUT/*pmc${i}_results.db $OUT/*/*pmc${i}_results.db 2>/dev/null | head -1) >> $REPO/gpurun_out/${TAG}_pmc_step.txt 2>&1
 done
 rm -rf $OUT/*.db $OUT/*/*.db
-python $REPO/tools/pmc_step_summary.py $REPO/gpurun_out/${TAG}_pmc_step.txt $REPO > $REPO/gpurun_out/${TAG}_pmc_step.json
+WL=fixed; for a in "$@"; do case "$prev" in --workload) WL=$a;; esac; prev=$a; done
+python $REPO/tools/pmc_step_summary.py $REPO/gpurun_out/${TAG}_pmc_step.txt $REPO $WL > $REPO/gpurun_out/${TAG}_pmc_step_$WL.json
 python - <<P
 import json
-d = json.load(open('$REPO/gpurun_out/${TAG}_pmc_step.json'))
+d = json.load(open('$REPO/gpurun_out/${TAG}_pmc_step_$WL.json'))
 print('commit', d['commit'], 'kernels', len(d['kernels']))
 for k in d['kernels'][:14]:
     print('%-46s n=%3d %8.1f us  rd %7.2f MB wr %7.2f MB  mfma %s  l2hit %s' % (k['short'][:46], k['launches'], k['avg_us'], k.get('read_mb') or 0, k.get('write_mb') or 0,
