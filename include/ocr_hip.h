@@ -79,6 +79,13 @@ int ocr_set_gemm_engine(int use_large_tile);
  * the dispatcher takes beyond fp32 summation order (environment OCR_CONV_K2 / OCR_CONV_K3 / OCR_K2_CFG select for the parity tests). */
 int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int Nb, int W, int H, int Cin, int Cout,
                      const float* bias, const void* mask, int flags, void* stream);
+/* The convolution that also leaves the batch-norm statistics of its output behind (network.py:173-178: conv -> bias -> batch_norm):
+ * partials = float [rows][2][Cout] with rows = ocr_conv3x3_stats_rows(...) = Nb*W*H / 256: per 256-pixel tile the per-channel sum and sum
+ * of squares of the bf16 values that were stored (what a statistics pass over y would read).  Only where the plane-layout kernels take the
+ * shape: the query returns 0 otherwise and the call OCR_STATUS_INVALID (run ocr_conv3x3_bf16 + ocr_bn_train_fwd then).  flags: BIAS / RELU. */
+int ocr_conv3x3_stats_rows(int Nb, int W, int H, int Cin, int Cout, int flags);
+int ocr_conv3x3_bf16_stats(const void* x, const void* wpack, void* y, int Nb, int W, int H, int Cin, int Cout, const float* bias, int flags,
+                           float* partials, void* stream);
 /* Which kernel family the two convolution entry points run for a shape — a host-only query (nothing is launched, works without a GPU):
  * 0 generic GEMM engines, 1 conv_halo, 2 / 3 conv_k2 tile A (256 x 128) / D (256 x 64), 4 / 5 conv_k3 A / D, 6 / 7 conv_k3w (tiles that
  * cross image boundaries) A / D; a NEGATIVE value (-OCR_STATUS_INVALID) for non-positive sizes.  flags as for ocr_conv3x3_bf16;
@@ -153,6 +160,16 @@ int ocr_bn_train_fwd(const void* x, void* y, const float* gamma, const float* be
 int ocr_bn_train_bwd(const void* x, const void* y, const void* dy, void* dx, const float* gamma,
                      const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, long M, int C,
                      int relu, void* workspace, void* stream);
+/* Round 4 forms.  partial_rows > 0: the workspace already holds that many rows [rows][2][C] of per-tile sums / sums of squares written by
+ * the producing convolution's epilogue (ocr_conv3x3_bf16_stats) - no statistics pass over x.  pooled (may be NULL): the 1 x 2 max-pool over
+ * row pairs (2q, 2q + 1) that follows the layer (LSTM_train.py:33) is written by the apply pass too ([M / 2][C]; M even, no residual);
+ * bit-identical to ocr_maxpool_fwd on y.  pooled_dy != 0: `dy` is the gradient of that pool ([M / 2][C]); both backward passes route it to
+ * the first maximum of each row pair themselves - bit-identical to ocr_maxpool_bwd followed by ocr_bn_train_bwd. */
+int ocr_bn_train_fwd2(const void* x, void* y, const float* gamma, const float* beta, float* save_mean, float* save_rstd, long M, int C,
+                      float eps, int relu, void* workspace, const void* residual, int partial_rows, void* pooled, void* stream);
+int ocr_bn_train_bwd2(const void* x, const void* y, const void* dy, void* dx, const float* gamma, const float* save_mean,
+                      const float* save_rstd, float* dgamma, float* dbeta, long M, int C, int relu, void* workspace, int pooled_dy,
+                      void* stream);
 int ocr_colsum_bf16(const void* a, float* out, long M, int C, long lda, void* stream);
 int ocr_pack_transpose(const float* in, void* out, int R, int Cc, long ldin, int lstm_units, void* stream);
 int ocr_pack_conv_dgrad(const float* w, void* out, int Cin, int Cout, void* stream);

@@ -58,6 +58,10 @@ _SIGS = {
     "ocr_bn_workspace_bytes": ([_L, _I], ctypes.c_size_t),
     "ocr_bn_train_fwd": ([_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P, _P, _P], _I),
     "ocr_bn_train_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P], _I),
+    "ocr_bn_train_fwd2": ([_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P, _P, _I, _P, _P], _I),
+    "ocr_bn_train_bwd2": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P], _I),
+    "ocr_conv3x3_stats_rows": ([_I, _I, _I, _I, _I, _I], _I),
+    "ocr_conv3x3_bf16_stats": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P], _I),
     "ocr_bn_infer_fwd": ([_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P], _I),
     "ocr_bn_infer_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P], _I),
     "ocr_dropout_bf16": ([_P, _P, _L, ctypes.c_uint, _P, _F, _P], _I),

@@ -88,7 +88,7 @@ def restore(engine, path, with_optimizer=True):
         if engine.state2 is not None:
             engine.state2.copy_(torch.from_numpy(s2))
         sc = torch.from_numpy(data['opt/scalars'])          # the first 8 doubles are state, the rest per-step scratch
-        n = min(sc.numel(), engine.scalars.numel())
+        n = min(sc.numel(), engine.scalars.numel(), 8)      # state only: bins and arrival tickets are per-step scratch that a finished step leaves zero
         engine.scalars[:n].copy_(sc[:n])
         if float(data['opt/scalars'][2]) > 0:
             engine.lr = float(data['opt/scalars'][2])       # host mirror of the device learning rate (console line, scale_lr)

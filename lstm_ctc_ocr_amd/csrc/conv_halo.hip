@@ -331,6 +331,12 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
                       const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind) {
     if ((Cin & 63) || (Cout & 3) || M < 1024 || H > 30) return -1;
     if (flags & ~(IGH_BIAS | IGH_RELU | IGH_MASK | IGH_ACCUM)) return -1;
+    if (pool_kind == 3) {    // batch-norm statistics from the epilogue (`pool` = float partial rows): the plane-layout kernels only
+        if (!pool || (flags & (IGH_MASK | IGH_ACCUM)) || (M & 255)) return -1;
+        static int k2s = -1;
+        if (k2s < 0) { const char* e = getenv("OCR_CONV_K2"); k2s = e ? atoi(e) : K2_DEFAULT; }
+        return k2s ? k2_try_dispatch(x, wpack, y, M, W, H, Cin, Cout, bias, mask, flags, stream, pool, pool_kind) : -1;
+    }
     if (pool_kind) {         // fused max-pool: ReLU epilogue without mask, even feature axis, 2 x 2 only for H in {4, 8, 16} and even W
         if (!pool || (flags & (IGH_MASK | IGH_ACCUM)) || !(flags & IGH_RELU) || (H & 1) || (Cout & 3) || (Cout % 64 && Cout % 128)) return -1;
         if (pool_kind == 2 && ((H != 4 && H != 8 && H != 16) || (W & 1))) return -1;

@@ -38,7 +38,8 @@ struct K3Args {
     int M, N, C;                          // C % 64 == 0
     int cW, cH;
     bf16_t* out; const float* bias; const bf16_t* mask; int flags;
-    bf16_t* pool; int pool_kind;          // as conv_halo: 0 none, 1 feature pairs (1 x 2), 2 2 x 2
+    bf16_t* pool; int pool_kind;          // as conv_halo: 0 none, 1 feature pairs (1 x 2), 2 2 x 2; 3 = `pool` is float [M / 256][2][N]: per-tile
+                                          // partial sums / sums of squares of the stored bf16 outputs (batch-norm statistics, nn_ops.hip)
     int prio;                             // MFMA priority of waves 4-7 (the K half that multiplies FIRST in an interval); waves 0-3 use 1
 };
 
@@ -350,6 +351,7 @@ __device__ __forceinline__ void k3_body(const K3Args& g) {
             __syncthreads();
             constexpr int NIT = 256 * U / 512;
             u32x4 val[NIT], mk[NIT];
+            float st_s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, st_q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int idx = it * 512 + tid, lp = idx / U, u = idx % U;
@@ -372,8 +374,30 @@ __device__ __forceinline__ void k3_body(const K3Args& g) {
                     if (!(bf_hi(q.w) > 0.f)) v.w &= 0x0000ffffu;
                 }
                 *(u32x4*)(g.out + ((long)m0 + lp) * g.N + n0 + u * 8) = v;
+                if (g.pool_kind == 3) {                  // statistics of what is stored: the bf16 values, as a separate pass over the tensor would see them
+                    const float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { st_s[c] += f[c]; st_q[c] = fmaf(f[c], f[c], st_q[c]); }
+                }
             }
-            if (g.pool_kind) {
+            if (g.pool_kind == 3) {
+                // Batch-norm statistics from the producing convolution (VERDICT r3 item 3 iv / 6): this tile's per-channel sum and sum of
+                // squares over its 256 pixel rows -> partial row m0 / 256 of [M / 256][2][N] (fp32; bn_finalize_kernel adds the rows in
+                // double, fixed order: deterministic).  A thread's 16-byte unit u = tid % U is the same in every iteration (512 % U == 0),
+                // so it holds the sums of 8 channels over NIT rows; the 512 / U threads of a unit meet in LDS behind the staged image.
+                constexpr int RL = 512 / U;
+                float* red = (float*)(smem + 256 * ROWB);
+                const int u = tid % U, rl = tid / U;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { red[rl * BN + u * 8 + c] = st_s[c]; red[(RL + rl) * BN + u * 8 + c] = st_q[c]; }
+                __syncthreads();
+                if (tid < 2 * BN) {
+                    const int which = tid / BN, ch = tid % BN;
+                    float t = 0.f;
+                    for (int r = 0; r < RL; ++r) t += red[(which * RL + r) * BN + ch];
+                    if (n0 + ch < g.N) ((float*)g.pool)[((long)(m0 / 256) * 2 + which) * g.N + n0 + ch] = t;
+                }
+            } else if (g.pool_kind) {
                 // fused max-pool from the staged image (post-ReLU values; bf16 max is exact, so this equals max-pooling the stored tensor):
                 // kind 1 pairs the feature rows (h, h + 1) of a column — local pixels 2q, 2q + 1 -> pooled row m0 / 2 + q; kind 2 the 2 x 2
                 // window of columns (2c, 2c + 1) -> pooled row (col0 / 2) * (H / 2) + c * (H / 2) + h / 2
@@ -453,6 +477,7 @@ static int launch_k3(const K3Args& g, hipStream_t stream) {
     constexpr int xch = 8 * (FM / 2) * 4 * 1024;                                  // the K-half exchange reuses them
     constexpr int lds = need > xch ? need : xch;
     static_assert(lds <= 163840, "LDS");
+    static_assert(256 * BN * 2 + 2 * (512 / (BN / 8)) * BN * 4 <= lds, "staged image + the statistics scratch behind it");
     static bool attr = false;
     const int mt = g.M / 256, nt = (g.N + BN - 1) / BN;
     if constexpr (GENW) {
@@ -480,7 +505,8 @@ int k3_try_dispatch(int tile, const void* x, const void* wpack, void* y, int M, 
     const int NC = 256 / H, PS = (NC + 2 + 7) / 8 * 8;
     const bool genw = W % NC != 0;                       // tiles cross image boundaries: the general-width form (one zero row per boundary)
     if (genw && (H == 16 || NC + 2 + (NC + W - 1) / W > PS)) return -1;       // (H = 16: 16-column tiles, W >= 16 there — not instantiated)
-    if (H == 2 && (!genw || pool_kind)) return -1;       // H = 2 exists in the general-width form only (128-column tiles)
+    if (H == 2 && (!genw || (pool_kind && pool_kind != 3))) return -1;       // H = 2 exists in the general-width form only (128-column tiles)
+    if (pool_kind == 3 && (flags & K3_ACCUM)) return -1; // statistics are taken in the staged write-out
     static int genw_on = -1;                             // A/B knob OCR_K3_GENW = 0: general-width shapes stay on conv_k2 / conv_halo
     if (genw_on < 0) { const char* e = ocr_tune_env("OCR_K3_GENW"); genw_on = e ? atoi(e) : 1; }
     if (genw && !genw_on) return -1;

@@ -344,6 +344,27 @@ extern "C" int ocr_conv3x3_bf16(const void* x, const void* wpack, void* y, int N
     }
     return dispatch_gemm(g, 1, 1, (hipStream_t)stream);
 }
+// conv3x3 (+ bias, optional ReLU) that also leaves the batch-norm statistics of its output behind (network.py:173-178: conv -> bias ->
+// batch_norm): partials = float [rows][2][Cout], rows = ocr_conv3x3_stats_rows(...) = Nb*W*H / 256 — per 256-pixel tile the per-channel sum
+// and sum of squares of the bf16 values that were stored.  ocr_bn_train_fwd2(partial_rows = rows) finishes from them without reading the
+// tensor for a statistics pass.  Only where the plane-layout kernels (conv_k3 / conv_k3w) take the shape: the query returns 0 otherwise
+// and the call OCR_STATUS_INVALID (the caller then runs ocr_conv3x3_bf16 + the three-pass batch norm).
+extern "C" int ocr_conv3x3_stats_rows(int Nb, int W, int H, int Cin, int Cout, int flags) {
+    if (Nb <= 0 || W <= 0 || H <= 0 || Cin <= 0 || Cout <= 0 || !g_use_halo || g_use_pp) return 0;
+    const long M = (long)Nb * W * H;
+    const int fl = flags & ~(EPI_ATOMIC | EPI_ROWSWAP);
+    if (M > 0x7fffffffL || (M & 255) || (fl & (EPI_MASK | EPI_ACCUM))) return 0;
+    const int rc = halo_try_dispatch(nullptr, nullptr, nullptr, (int)M, W, H, Cin, Cout, (fl & EPI_BIAS) ? (const float*)16 : nullptr, nullptr, fl,
+                                     nullptr, (void*)16, 3);
+    return rc >= 4 ? (int)(M / 256) : 0;
+}
+extern "C" int ocr_conv3x3_bf16_stats(const void* x, const void* wpack, void* y, int Nb, int W, int H, int Cin, int Cout, const float* bias,
+                                      int flags, float* partials, void* stream) {
+    if (!x || !wpack || !y || !partials || ((flags & EPI_BIAS) && !bias) || !ocr_conv3x3_stats_rows(Nb, W, H, Cin, Cout, flags)) return OCR_ERR_INVALID;
+    const int rc = halo_try_dispatch(x, wpack, y, Nb * W * H, W, H, Cin, Cout, bias, nullptr, flags & ~(EPI_ATOMIC | EPI_ROWSWAP), (hipStream_t)stream,
+                                     partials, 3);
+    return rc >= 0 ? rc : OCR_ERR_INVALID;
+}
 // conv3x3 + bias + ReLU with the max-pool that follows it (LSTM_train.py:26-33: conv2 -> pool2 2 x 2, conv3_2 / conv4_2 -> 1 x 2
 // over the feature axis) written by the same epilogue: y (kept for the backward pass) AND pooled.  kw = window along W (time),
 // kh = window along H (feature): (1, 2) or (2, 2).  Only the halo kernel has this epilogue: OCR_ERR_INVALID when the shape is

@@ -31,6 +31,7 @@ struct Tn2Args {
     // stream both operands completely: TCC hit rate 2-66 %, 180-245 MB fetched per launch against 33-50 MB of operands).
     int XS, XJ, XI, taps, itl, jtl;                // itl = i tiles per XCD, jtl = j tiles per XCD
     int nbatch; long sA, sB, sO, sC;               // batched plain mode: problem b uses A + b*sA, B + b*sB, out + b*sO, colsum + b*sC
+    int owned;                                     // plain mode, one split: every output tile belongs to ONE workgroup -> `out +=` without atomics
     __device__ int cH_or1() const { return cH > 0 ? cH : 1; }
 };
 
@@ -265,7 +266,8 @@ __global__ __launch_bounds__(64 * NWV) void gemm_tn2_kernel(Tn2Args g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = i0 + wi * 64 + a * 16 + (lane >> 4) * 4 + r;
-                atomicAdd(out + (long)i * ldo + j, acc[a][b][r] * g.scale);
+                if (g.owned) out[(long)i * ldo + j] += acc[a][b][r] * g.scale;       // one workgroup per output tile (no split, plain mode): no atomics
+                else atomicAdd(out + (long)i * ldo + j, acc[a][b][r] * g.scale);
             }
         }
 }
@@ -328,8 +330,9 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
     splits = bS;
     g.XS = bXS; g.XJ = bXJ; g.XI = bXI; g.taps = taps; g.itl = IT / bXI; g.jtl = JT / bXJ;
     g.k_per_split = ceil_div(ceil_div(Mk, splits), 64) * 64;
+    g.owned = (mode == 0 && splits == 1) ? 1 : 0;
     static int cfg = -1;                           // A/B knob OCR_TN2_PIPE: 0 = 64-row stages x 2 (default), 1 = 32 x 4, 2 = 32 x 3, 3 = 64 x 3
-    if (cfg < 0) { const char* e = ocr_tune_env("OCR_TN2_PIPE"); cfg = e ? atoi(e) : 0; if (cfg < 0 || cfg > 3) cfg = 0; }
+    if (cfg < 0) { const char* e = ocr_tune_env("OCR_TN2_PIPE"); cfg = e ? atoi(e) : 0; if (cfg < 0 || cfg > 4) cfg = 0; }      // 4 = 64 x 4 (8-wave form only)
     const int km = pair ? 2 : mode;
     dim3 grid((unsigned)(tiles * splits));          // empty splits (kbeg >= Mk) return at once
 #define TN2_LAUNCH(M_, BK_, NS_) do { \
@@ -338,9 +341,12 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
         gemm_tn2_kernel<M_, BK_, NS_><<<grid, 256, lds, stream>>>(g); } while (0)
 #define TN2_MODE(BK_, NS_) do { if (km == 2) TN2_LAUNCH(2, BK_, NS_); else if (km == 1) TN2_LAUNCH(1, BK_, NS_); else TN2_LAUNCH(0, BK_, NS_); } while (0)
     if (wide) {                                    // 8 waves, 64-row stages x 2 (or x 3 with OCR_TN2_PIPE=3)
-        static bool attr8[2] = {false, false};
-        const int ns = cfg == 3 ? 3 : 2, lds = ns * 2 * 64 * 256;
-        if (ns == 3) {
+        static bool attr8[3] = {false, false, false};
+        const int ns = cfg == 4 ? 4 : (cfg == 3 ? 3 : 2), lds = ns * 2 * 64 * 256;
+        if (ns == 4) {
+            if (!attr8[2]) { if (hipFuncSetAttribute((const void*)gemm_tn2_kernel<0, 64, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC; attr8[2] = true; }
+            gemm_tn2_kernel<0, 64, 4, 8><<<grid, 512, lds, stream>>>(g);
+        } else if (ns == 3) {
             if (!attr8[1]) { if (hipFuncSetAttribute((const void*)gemm_tn2_kernel<0, 64, 3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC; attr8[1] = true; }
             gemm_tn2_kernel<0, 64, 3, 8><<<grid, 512, lds, stream>>>(g);
         } else {
@@ -348,7 +354,7 @@ int tn2_try_dispatch(const void* A, long lda, const void* B, long ldb, float* ou
             gemm_tn2_kernel<0, 64, 2, 8><<<grid, 512, lds, stream>>>(g);
         }
     }
-    else if (cfg == 1) TN2_MODE(32, 4);
+    else if (cfg == 1 || cfg == 4) TN2_MODE(32, 4);
     else if (cfg == 2) TN2_MODE(32, 3);
     else if (cfg == 3) TN2_MODE(64, 3);
     else TN2_MODE(64, 2);

@@ -670,11 +670,60 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
         *(u32x4*)(y + r * C + gq * 8) = pk;
     }
 }
+// pass 3 with the max-pool that follows the layer (LSTM_train.py:33: conv4_2 -> max_pool 1 x 2 over the feature axis = row pairs (2q, 2q + 1)
+// of the [M][C] view): y is written as by bn_apply_kernel (the backward pass needs it) AND pooled[q] = max(y[2q], y[2q + 1]) — bf16 max of the
+// rounded values, i.e. bit-identical to maxpool_fwd_kernel<1, 2> on the stored tensor.  A thread keeps one channel group and walks PAIRS.
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, bf16_t* __restrict__ pooled,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            long M, int C, int relu, int pairs_per_block) {
+    const int groups = C >> 3;
+    const int rl = threadIdx.x / groups, gq = threadIdx.x % groups, rlanes = 256 / groups;
+    if (rl >= rlanes) return;
+    float mu[8], rs[8], gm[8], bt[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = gq * 8 + c;
+        mu[c] = mean[ch]; rs[c] = rstd[ch]; gm[c] = gamma[ch]; bt[c] = beta[ch];
+    }
+    const long q0 = (long)blockIdx.x * pairs_per_block, q1 = min(M >> 1, q0 + pairs_per_block);
+#pragma unroll 2
+    for (long q = q0 + rl; q < q1; q += rlanes) {
+        u32x4 pk[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float v[8], o[8];
+            unpack8(*(const u32x4*)(x + (2 * q + e) * C + gq * 8), v);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                o[c] = (v[c] - mu[c]) * rs[c] * gm[c] + bt[c];
+                if (relu) o[c] = fmaxf(o[c], 0.f);
+            }
+            pk[e] = (u32x4){pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+            *(u32x4*)(y + (2 * q + e) * C + gq * 8) = pk[e];
+        }
+        *(u32x4*)(pooled + q * C + gq * 8) = max8(pk[0], pk[1]);
+    }
+}
+// The gradient of row r when the layer's consumer is that 1 x 2 max-pool and dy holds the POOLED gradient [M / 2][C]: the pool routes
+// dp[r / 2] to the FIRST maximum of the pair (maxpool_bwd_kernel: row 2q + 1 wins only if y[2q + 1] > y[2q]); the ReLU mask follows as usual.
+__device__ __forceinline__ void bn_pool_route(const bf16_t* __restrict__ y, const bf16_t* __restrict__ dp, long r, int C, int gq,
+                                              const float (&yv)[8], float (&g)[8]) {
+    float other[8];
+    unpack8(*(const u32x4*)(y + (r ^ 1) * C + gq * 8), other);
+    unpack8(*(const u32x4*)(dp + (r >> 1) * C + gq * 8), g);
+    const bool odd = (r & 1) != 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const bool win = odd ? (yv[c] > other[c]) : !(other[c] > yv[c]);
+        if (!win) g[c] = 0.f;
+    }
+}
 // backward pass 1: dz = dy * (y > 0) [if relu]; part[block][0][C] = sum dz, part[block][1][C] = sum dz * xhat over the block's rows
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
                                                            const bf16_t* __restrict__ dy, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float* __restrict__ part,
-                                                           long M, int C, int rows_per_block, int relu) {
+                                                           long M, int C, int rows_per_block, int relu, int pooled) {
     const int groups = C >> 3;
     const int rl = threadIdx.x / groups, gq = threadIdx.x % groups, rlanes = 256 / groups;
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
@@ -686,9 +735,10 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const bf16_t* __restr
         for (long r = r0 + rl; r < r1; r += rlanes) {
             float xv[8], yv[8], g[8];
             unpack8(*(const u32x4*)(x + r * C + gq * 8), xv);
-            unpack8(*(const u32x4*)(dy + r * C + gq * 8), g);
+            if (relu || pooled) unpack8(*(const u32x4*)(y + r * C + gq * 8), yv);
+            if (pooled) bn_pool_route(y, dy, r, C, gq, yv, g);        // dy = the pooled gradient [M / 2][C]
+            else unpack8(*(const u32x4*)(dy + r * C + gq * 8), g);
             if (relu) {
-                unpack8(*(const u32x4*)(y + r * C + gq * 8), yv);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) if (!(yv[c] > 0.f)) g[c] = 0.f;
             }
@@ -717,7 +767,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const double* __restrict__ sums,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           long M, int C, int relu, int rows_per_block) {
+                                                           long M, int C, int relu, int rows_per_block, int pooled) {
     const int groups = C >> 3;
     const int rl = threadIdx.x / groups, gq = threadIdx.x % groups, rlanes = 256 / groups;
     if (rl >= rlanes) return;
@@ -734,9 +784,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
     for (long r = r0 + rl; r < r1; r += rlanes) {
         float xv[8], yv[8], g[8], o[8];
         unpack8(*(const u32x4*)(x + r * C + gq * 8), xv);
-        unpack8(*(const u32x4*)(dy + r * C + gq * 8), g);
+        if (relu || pooled) unpack8(*(const u32x4*)(y + r * C + gq * 8), yv);
+        if (pooled) bn_pool_route(y, dy, r, C, gq, yv, g);
+        else unpack8(*(const u32x4*)(dy + r * C + gq * 8), g);
         if (relu) {
-            unpack8(*(const u32x4*)(y + r * C + gq * 8), yv);
 #pragma unroll
             for (int c = 0; c < 8; ++c) if (!(yv[c] > 0.f)) g[c] = 0.f;
         }
@@ -1352,14 +1403,20 @@ extern "C" size_t ocr_bn_workspace_bytes(long M, int C) {
     const long nblk = ceil_div(M, (long)bn_rows_per_block_host(M, 512));      // the larger of the two passes' block counts
     return (size_t)nblk * 2 * C * sizeof(float) + 2 * (size_t)C * sizeof(double);
 }
-extern "C" int ocr_bn_train_fwd(const void* x, void* y, const float* gamma, const float* beta, float* save_mean,
-                                float* save_rstd, long M, int C, float eps, int relu, void* workspace, const void* residual, void* stream_) {
+// partial_rows > 0: the workspace already holds that many partial rows [rows][2][C] (sum, sum of squares) written by the producing
+// convolution (ocr_conv3x3_bf16_stats) — no statistics pass over x.  pooled != NULL: the 1 x 2 max-pool over row pairs that follows the layer
+// is written by the apply pass as well (M even, no residual).
+static int bn_train_fwd_impl(const void* x, void* y, const float* gamma, const float* beta, float* save_mean,
+                             float* save_rstd, long M, int C, float eps, int relu, void* workspace, const void* residual,
+                             int partial_rows, void* pooled, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !y || !gamma || !beta || !save_mean || !save_rstd || !workspace || (C & 7) || C > 2048 || M <= 0)
         return OCR_ERR_INVALID;
     int rlanes = 256 / (C >> 3); if (rlanes < 1) return OCR_ERR_INVALID;
+    if (partial_rows < 0 || (size_t)partial_rows * 2 * C * sizeof(float) > ocr_bn_workspace_bytes(M, C) - 2 * (size_t)C * sizeof(double)) return OCR_ERR_INVALID;
+    if (pooled && ((M & 1) || residual)) return OCR_ERR_INVALID;
 #ifdef OCR_EXPERIMENTS
-    {
+    if (!partial_rows && !pooled) {
         int frpb = 0;
         const int fnb = bnf_blocks(M, C, &frpb);
         if (fnb > 0) {
@@ -1371,23 +1428,40 @@ extern "C" int ocr_bn_train_fwd(const void* x, void* y, const float* gamma, cons
     }
 #endif
     const int rpb = bn_rows_per_block_host(M, 256);
-    const int nblk = (int)ceil_div(M, (long)rpb);
-    bn_stats_kernel<<<nblk, 256, 0, stream>>>((const bf16_t*)x, (float*)workspace, M, C, rpb);
-    OCR_CHECK_LAUNCH();
+    int nblk = (int)ceil_div(M, (long)rpb);
+    if (partial_rows > 0) nblk = partial_rows;
+    else {
+        bn_stats_kernel<<<nblk, 256, 0, stream>>>((const bf16_t*)x, (float*)workspace, M, C, rpb);
+        OCR_CHECK_LAUNCH();
+    }
     bn_finalize_kernel<<<ceil_div(C, 16), 256, 0, stream>>>((const float*)workspace, nblk, save_mean, save_rstd, M, C, eps);
     OCR_CHECK_LAUNCH();
     const int arows = 4 * rlanes;                                   // rows per block of the apply pass: 4 per thread
-    bn_apply_kernel<<<ceil_div(M, (long)arows), 256, 0, stream>>>((const bf16_t*)x, (bf16_t*)y, save_mean, save_rstd, gamma,
-                                                                    beta, M, C, relu, arows, (const bf16_t*)residual);
+    if (pooled)
+        bn_apply_pool_kernel<<<ceil_div(M / 2, (long)(2 * rlanes)), 256, 0, stream>>>((const bf16_t*)x, (bf16_t*)y, (bf16_t*)pooled, save_mean, save_rstd,
+                                                                                        gamma, beta, M, C, relu, 2 * rlanes);
+    else
+        bn_apply_kernel<<<ceil_div(M, (long)arows), 256, 0, stream>>>((const bf16_t*)x, (bf16_t*)y, save_mean, save_rstd, gamma,
+                                                                        beta, M, C, relu, arows, (const bf16_t*)residual);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
-extern "C" int ocr_bn_train_bwd(const void* x, const void* y, const void* dy, void* dx, const float* gamma,
-                                const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, long M,
-                                int C, int relu, void* workspace, void* stream_) {
+extern "C" int ocr_bn_train_fwd(const void* x, void* y, const float* gamma, const float* beta, float* save_mean,
+                                float* save_rstd, long M, int C, float eps, int relu, void* workspace, const void* residual, void* stream_) {
+    return bn_train_fwd_impl(x, y, gamma, beta, save_mean, save_rstd, M, C, eps, relu, workspace, residual, 0, nullptr, stream_);
+}
+extern "C" int ocr_bn_train_fwd2(const void* x, void* y, const float* gamma, const float* beta, float* save_mean, float* save_rstd, long M,
+                                 int C, float eps, int relu, void* workspace, const void* residual, int partial_rows, void* pooled, void* stream_) {
+    return bn_train_fwd_impl(x, y, gamma, beta, save_mean, save_rstd, M, C, eps, relu, workspace, residual, partial_rows, pooled, stream_);
+}
+// pooled_dy: dy is the gradient of the 1 x 2 max-pool that consumes the layer ([M / 2][C]); both passes route it themselves (first maximum of
+// the row pair, bn_pool_route) instead of reading a full-resolution gradient that a max-pool backward pass wrote.
+static int bn_train_bwd_impl(const void* x, const void* y, const void* dy, void* dx, const float* gamma,
+                             const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, long M,
+                             int C, int relu, void* workspace, int pooled_dy, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !y || !dy || !dx || !gamma || !save_mean || !save_rstd || !dgamma || !dbeta || !workspace || (C & 7) ||
-        C > 2048 || M <= 0)
+        C > 2048 || M <= 0 || (pooled_dy && (M & 1)))
         return OCR_ERR_INVALID;
     const int rpb = bn_rows_per_block_host(M, 512);
     const int nblk = (int)ceil_div(M, (long)rpb);
@@ -1396,7 +1470,7 @@ extern "C" int ocr_bn_train_bwd(const void* x, const void* y, const void* dy, vo
 #ifdef OCR_EXPERIMENTS
     {
         int frpb = 0;
-        const int fnb = bnf_blocks(M, C, &frpb);
+        const int fnb = pooled_dy ? 0 : bnf_blocks(M, C, &frpb);
         if (fnb > 0) {
             bn_fused_bwd_kernel<<<fnb, 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, save_mean, save_rstd,
                                                          gamma, part, sums, dgamma, dbeta, M, C, relu, frpb);
@@ -1406,16 +1480,26 @@ extern "C" int ocr_bn_train_bwd(const void* x, const void* y, const void* dy, vo
     }
 #endif
     bn_bwd_stats_kernel<<<nblk, 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, save_mean,
-                                                  save_rstd, part, M, C, rpb, relu);
+                                                  save_rstd, part, M, C, rpb, relu, pooled_dy);
     OCR_CHECK_LAUNCH();
     bn_bwd_finalize_kernel<<<ceil_div(C, 16), 256, 0, stream>>>(part, nblk, sums, dgamma, dbeta, C);
     OCR_CHECK_LAUNCH();
     const int arows = 4 * (256 / (C >> 3));                         // rows per block of the apply pass: 4 per thread
     bn_bwd_apply_kernel<<<ceil_div(M, (long)arows), 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy,
                                                                         (bf16_t*)dx, save_mean, save_rstd, gamma,
-                                                                        sums, dgamma, dbeta, M, C, relu, arows);
+                                                                        sums, dgamma, dbeta, M, C, relu, arows, pooled_dy);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
+}
+extern "C" int ocr_bn_train_bwd(const void* x, const void* y, const void* dy, void* dx, const float* gamma,
+                                const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, long M,
+                                int C, int relu, void* workspace, void* stream_) {
+    return bn_train_bwd_impl(x, y, dy, dx, gamma, save_mean, save_rstd, dgamma, dbeta, M, C, relu, workspace, 0, stream_);
+}
+extern "C" int ocr_bn_train_bwd2(const void* x, const void* y, const void* dy, void* dx, const float* gamma, const float* save_mean,
+                                 const float* save_rstd, float* dgamma, float* dbeta, long M, int C, int relu, void* workspace,
+                                 int pooled_dy, void* stream_) {
+    return bn_train_bwd_impl(x, y, dy, dx, gamma, save_mean, save_rstd, dgamma, dbeta, M, C, relu, workspace, pooled_dy, stream_);
 }
 extern "C" int ocr_colsum_bf16(const void* a, float* out, long M, int C, long lda, void* stream) {
     if (!a || !out || (C & 7) || C > 2048 || M <= 0) return OCR_ERR_INVALID;

@@ -142,6 +142,8 @@ class _ConvOp(_Op):
                                # residual add + relu and writes the add's output (the add's forward is then a no-op)
     mask_from = None           # set by Engine._lower: the fused add + relu that is this (BN, no ReLU) conv's only consumer: its batch-norm
                                # backward reads the add's gradient and applies the add's ReLU mask itself (no masked copy pass)
+    bn_pool = None             # set by Engine._lower: the 1 x 2 max-pool that is this batch-norm layer's only consumer (written by the BN apply
+                               # pass; its gradient is routed inside the BN backward passes)
     pool_after = None          # set by Engine._lower: the max-pool that follows this 3x3 conv + ReLU; where the shape allows, the conv's
                                # epilogue writes the pooled tensor too (the full-resolution output is still kept for the backward pass)
 
@@ -159,6 +161,15 @@ class _ConvOp(_Op):
             sp.buf[self.key + '/mean'] = torch.empty(self.co, dtype=F32, device=dev)
             sp.buf[self.key + '/rstd'] = torch.empty(self.co, dtype=F32, device=dev)
             sp.buf[self.key + '/bnws'] = ops.bn_workspace(o[0] * o[1] * o[2], self.co, dev)
+            # batch-norm statistics from the convolution's own epilogue where a plane-layout kernel takes the shape (partial rows into the
+            # BN workspace: it must hold them), else a statistics pass over z
+            rows = 0
+            if self.kind == '3x3' and self.eng.fuse_bn_stats:
+                rows = ops.conv3x3_stats_rows(s[0], s[1], s[2], self.ci, self.co, bias=self.biased)
+                if rows * 2 * self.co * 4 > sp.buf[self.key + '/bnws'].numel() - 2 * self.co * 8:
+                    rows = 0
+            sp.bn_stat_rows = getattr(sp, 'bn_stat_rows', {})
+            sp.bn_stat_rows[self.key] = rows
         if self.kind == 'full':
             N, W, H, C = s
             sp.buf[self.key + '/col'] = torch.empty((N * o[1], self.kh * H * C), dtype=BF16, device=dev)
@@ -207,6 +218,8 @@ class _ConvOp(_Op):
         if self.kind == '3x3' and self.pool_after is not None and self.pool_after.key in sp.fused_pools:
             p = self.pool_after
             ops.conv3x3_relu_pool(x, self.wpack.view(self.co, 3, 3, self.ci), y, p.y(sp), bias, p.kw_t, p.kh_f)
+        elif self.kind == '3x3' and self.bn and sp.bn_stat_rows[self.key]:
+            ops.conv3x3_stats(x, self.wpack.view(self.co, 3, 3, self.ci), tgt, sp.buf[self.key + '/bnws'], bias=bias)
         elif self.kind == '3x3':
             ops.conv3x3(x, self.wpack.view(self.co, 3, 3, self.ci), out=tgt, bias=bias, relu=relu_now)
         elif self.kind == '1x1':
@@ -223,10 +236,12 @@ class _ConvOp(_Op):
             if self.tail_into is not None:          # y_add = relu(bf16(bn(z)) + other input): written straight into the add's buffer
                 add, other = self.tail_into
                 y, res, relu = add.y(sp), other.y(sp).view(M, self.co), True
+            pooled = self.bn_pool.y(sp).view(M // 2, self.co) if self.bn_pool is not None else None
             ops.bn_train_fwd(tgt.view(M, self.co), e.param('%s/%s/gamma' % (self.name, self.name)),
                              e.param('%s/%s/beta' % (self.name, self.name)), BN_EPS, relu,
                              sp.buf[self.key + '/bnws'], out=y.view(M, self.co),
-                             save_mean=sp.buf[self.key + '/mean'], save_rstd=sp.buf[self.key + '/rstd'], residual=res)
+                             save_mean=sp.buf[self.key + '/mean'], save_rstd=sp.buf[self.key + '/rstd'], residual=res,
+                             partial_rows=sp.bn_stat_rows[self.key], pooled=pooled)
 
     def bwd(self, sp):
         e = self.eng
@@ -244,11 +259,14 @@ class _ConvOp(_Op):
             ymask, relu = self.y(sp), self.relu
             if self.mask_from is not None:          # gradient and ReLU mask straight from the residual add + relu behind this layer
                 dy, ymask, relu = self.mask_from.dy(sp), self.mask_from.y(sp), True
-            ops.bn_train_bwd(sp.buf[self.key + '/z'].view(M, self.co), ymask.view(M, self.co), dy.view(M, self.co),
+            dy2 = dy.view(M, self.co)
+            if self.bn_pool is not None:            # the pooled gradient, routed by the passes themselves
+                dy2 = self.bn_pool.dy(sp).view(M // 2, self.co)
+            ops.bn_train_bwd(sp.buf[self.key + '/z'].view(M, self.co), ymask.view(M, self.co), dy2,
                              e.param('%s/%s/gamma' % (self.name, self.name)), sp.buf[self.key + '/mean'],
                              sp.buf[self.key + '/rstd'], e.grad('%s/%s/gamma' % (self.name, self.name)),
                              e.grad('%s/%s/beta' % (self.name, self.name)), relu, sp.buf[self.key + '/bnws'],
-                             out=dz.view(M, self.co))
+                             out=dz.view(M, self.co), pooled_dy=self.bn_pool is not None)
         dw = e.grad(self.name + '/weights')
         db = e.grad(self.name + '/biases') if self.biased else None
         if self.kind == 'c1':
@@ -320,13 +338,16 @@ class _PoolOp(_Op):
         sp.buf[self.key + '/dy'] = torch.empty(o, dtype=BF16, device=self.eng.device)
 
     fused_into = None          # the conv1 op that computes this pool's output itself
+    bn_fused_into = None       # the batch-norm conv whose apply pass writes this pool's output and whose backward passes route its gradient
 
     def fwd(self, sp):
+        if self.bn_fused_into is not None:
+            return
         if self.fused_into is None and self.key not in getattr(sp, 'fused_pools', ()):      # else: written by the producing conv's epilogue
             ops.maxpool_fwd(self.prev.y(sp), self.kw_t, self.kh_f, out=self.y(sp))
 
     def bwd(self, sp):
-        if self.fused_into is not None:
+        if self.fused_into is not None or self.bn_fused_into is not None:
             return
         pdy, finish = self.eng.grad_dst(sp, self.prev)
         if pdy is not None:
@@ -868,6 +889,7 @@ class Engine(object):
         self.use_graphs = use_graphs
         self.persistent_lstm = persistent_lstm
         self.fuse_conv1_pool = fuse_conv1_pool
+        self.fuse_bn_stats = os.environ.get('OCR_FUSE_BN_STATS', '1') != '0'      # batch-norm statistics from the producing convolution's epilogue
         self.group = group
         self.world = 1
         self._check_xcd_placement()
@@ -1073,6 +1095,15 @@ class Engine(object):
                 if (isinstance(b, _PoolOp) and isinstance(a, _ConvOp) and a.kind == '3x3' and a.relu and not a.bn and a.biased
                         and a.consumers == 1 and (b.kw_t, b.kh_f) in ((1, 2), (2, 2))):
                     a.pool_after = b
+        if os.environ.get('OCR_FUSE_BN_POOL', '1') != '0':
+            # conv + batch norm + ReLU followed by the 1 x 2 max-pool over the feature axis as its only consumer (LSTM_train.py:32-33: conv4_2
+            # -> pool): the batch-norm apply pass writes the pooled tensor too, and the batch-norm backward passes route the pool's gradient
+            # themselves — no max-pool forward / backward launches, no full-resolution gradient tensor written and re-read twice
+            for b in self.ops:
+                a = b.prev
+                if (isinstance(b, _PoolOp) and isinstance(a, _ConvOp) and a.bn and a.kind != 'c1' and a.consumers == 1
+                        and a.tail_into is None and a.mask_from is None and (b.kw_t, b.kh_f) == (1, 2)):
+                    a.bn_pool, b.bn_fused_into = b, a
         if self.fuse_conv1_pool:
             for a, b in zip(self.ops[:-1], self.ops[1:]):
                 if (isinstance(a, _ConvOp) and a.kind == 'c1' and a.relu and isinstance(b, _PoolOp) and b.prev is a

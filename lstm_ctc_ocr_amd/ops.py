@@ -271,22 +271,51 @@ def bn_workspace(M, C, device):
     return torch.empty(int(nat.lib().ocr_bn_workspace_bytes(int(M), int(C))), dtype=torch.uint8, device=device)
 
 
-def bn_train_fwd(x2d, gamma, beta, eps, relu, workspace, out=None, save_mean=None, save_rstd=None, residual=None):
-    """residual (bf16 [M, C]): out = [relu](bf16(bn(x)) + residual) — batch norm, add and relu of a residual block in one apply pass"""
+def bn_train_fwd(x2d, gamma, beta, eps, relu, workspace, out=None, save_mean=None, save_rstd=None, residual=None, partial_rows=0,
+                 pooled=None):
+    """residual (bf16 [M, C]): out = [relu](bf16(bn(x)) + residual) — batch norm, add and relu of a residual block in one apply pass.
+    partial_rows > 0: the workspace already holds that many partial statistics rows from the producing convolution (conv3x3_stats);
+    pooled (bf16 [M / 2, C]): the 1 x 2 max-pool over row pairs that follows the layer, written by the apply pass."""
     M, C = x2d.shape
     if out is None: out = torch.empty_like(x2d)
     if save_mean is None: save_mean = torch.empty(C, dtype=F32, device=x2d.device)
     if save_rstd is None: save_rstd = torch.empty(C, dtype=F32, device=x2d.device)
-    call("ocr_bn_train_fwd", ptr(_dev(x2d)), ptr(out), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_rstd), M, C,
-         float(eps), int(relu), ptr(workspace), ptr(residual), _st())
+    if partial_rows or pooled is not None:
+        call("ocr_bn_train_fwd2", ptr(_dev(x2d)), ptr(out), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_rstd), M, C,
+             float(eps), int(relu), ptr(workspace), ptr(residual), int(partial_rows), ptr(pooled), _st())
+    else:
+        call("ocr_bn_train_fwd", ptr(_dev(x2d)), ptr(out), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_rstd), M, C,
+             float(eps), int(relu), ptr(workspace), ptr(residual), _st())
     return out, save_mean, save_rstd
 
 
-def bn_train_bwd(x2d, y2d, dy2d, gamma, save_mean, save_rstd, dgamma, dbeta, relu, workspace, out=None):
+def bn_train_bwd(x2d, y2d, dy2d, gamma, save_mean, save_rstd, dgamma, dbeta, relu, workspace, out=None, pooled_dy=False):
+    """pooled_dy: dy2d is the gradient of the 1 x 2 max-pool behind the layer ([M / 2, C]); the passes route it themselves."""
     M, C = x2d.shape
     if out is None: out = torch.empty_like(x2d)
-    call("ocr_bn_train_bwd", ptr(_dev(x2d)), ptr(y2d), ptr(dy2d), ptr(out), ptr(gamma), ptr(save_mean), ptr(save_rstd),
-         ptr(dgamma), ptr(dbeta), M, C, int(relu), ptr(workspace), _st())
+    if pooled_dy:
+        assert tuple(dy2d.shape) == (M // 2, C)
+        call("ocr_bn_train_bwd2", ptr(_dev(x2d)), ptr(y2d), ptr(dy2d), ptr(out), ptr(gamma), ptr(save_mean), ptr(save_rstd),
+             ptr(dgamma), ptr(dbeta), M, C, int(relu), ptr(workspace), 1, _st())
+    else:
+        call("ocr_bn_train_bwd", ptr(_dev(x2d)), ptr(y2d), ptr(dy2d), ptr(out), ptr(gamma), ptr(save_mean), ptr(save_rstd),
+             ptr(dgamma), ptr(dbeta), M, C, int(relu), ptr(workspace), _st())
+    return out
+
+
+def conv3x3_stats_rows(Nb, W, H, Cin, Cout, *, bias=True, relu=False):
+    """Partial-statistics rows the convolution's epilogue would write for this shape (Nb*W*H / 256), 0 where no kernel with that epilogue
+    takes it (host-only query)."""
+    flags = (EPI_BIAS if bias else 0) | (EPI_RELU if relu else 0)
+    return int(nat.lib().ocr_conv3x3_stats_rows(int(Nb), int(W), int(H), int(Cin), int(Cout), flags))
+
+
+def conv3x3_stats(x, wpack, out, partials, *, bias=None, relu=False):
+    """out = conv3x3(x) (+ bias, optional relu) and partials[rows][2][Cout] (fp32) = per-256-pixel-tile sums / sums of squares of out."""
+    Nb, W, H, Cin = x.shape
+    Cout = wpack.shape[0]
+    flags = (EPI_BIAS if bias is not None else 0) | (EPI_RELU if relu else 0)
+    call("ocr_conv3x3_bf16_stats", ptr(_dev(x)), ptr(wpack), ptr(out), Nb, W, H, Cin, Cout, ptr(bias), flags, ptr(partials), _st())
     return out
 
 

@@ -569,6 +569,62 @@ def test_batchnorm(dev, M, C):
     assert relerr(dx.float().cpu(), bf(xr.grad)) < 2e-2
 
 
+@pytest.mark.parametrize("M,C,relu", [(16384, 512, True), (4096, 256, True), (20480, 512, False), (1000, 64, True)])
+def test_batchnorm_with_the_pool_behind_it(dev, M, C, relu):
+    """Round 4: the 1 x 2 max-pool over row pairs that is a batch-norm layer's only consumer (LSTM_train.py:32-33) — written by the apply pass,
+    and its gradient routed inside both backward passes: BIT-identical to batch norm + maxpool_fwd, and to maxpool_bwd + batch-norm backward."""
+    x = bf(gen((M, C), 1) * 2 + 0.5).to(dev).to(BF)
+    x[5] = x[4]                                                    # an exact tie inside a pair: the FIRST row of the pair wins
+    gamma = (gen((C,), 2) + 1.5).to(dev); beta = gen((C,), 3).to(dev)
+    ws = ops.bn_workspace(M, C, dev)
+    y0, sm, sr = ops.bn_train_fwd(x, gamma, beta, 1e-3, relu, ws)
+    p0 = ops.maxpool_fwd(y0.view(1, M // 2, 2, C), 1, 2)
+    pooled = torch.empty(M // 2, C, dtype=BF, device=dev)
+    y1, sm1, sr1 = ops.bn_train_fwd(x, gamma, beta, 1e-3, relu, ws, pooled=pooled)
+    assert torch.equal(y1, y0) and torch.equal(pooled, p0.view(M // 2, C)) and torch.equal(sm1, sm) and torch.equal(sr1, sr)
+    dp = bf(gen((M // 2, C), 4)).to(dev).to(BF)
+    dy = ops.maxpool_bwd(y0.view(1, M // 2, 2, C), dp.view(1, M // 2, 1, C), 1, 2, relu_mask=False)
+    dg0 = torch.zeros(C, device=dev); db0 = torch.zeros(C, device=dev)
+    dx0 = ops.bn_train_bwd(x, y0, dy.view(M, C), gamma, sm, sr, dg0, db0, relu, ws)
+    dg1 = torch.zeros(C, device=dev); db1 = torch.zeros(C, device=dev)
+    dx1 = ops.bn_train_bwd(x, y0, dp, gamma, sm, sr, dg1, db1, relu, ws, pooled_dy=True)
+    assert torch.equal(dx1, dx0) and torch.equal(dg1, dg0) and torch.equal(db1, db0)
+
+
+@pytest.mark.parametrize("Nb,W,H,Ci,Co", [(64, 64, 4, 256, 512), (64, 64, 4, 512, 512), (64, 80, 4, 256, 512), (32, 64, 4, 256, 256), (16, 64, 8, 128, 128),
+                                          (32, 64, 2, 512, 512), (8, 22, 4, 256, 512)])
+def test_conv3x3_with_batchnorm_statistics_in_the_epilogue(dev, Nb, W, H, Ci, Co):
+    """Round 4: conv_k3 / conv_k3w leave per-tile partial sums of their (bf16) output behind; batch norm finishes from them.  The stored
+    tensor is bit-identical to the plain convolution's; the statistics equal the ones of a pass over it up to fp32 summation order."""
+    rows = ops.conv3x3_stats_rows(Nb, W, H, Ci, Co)
+    if (Nb, W, H) == (8, 22, 4):
+        assert rows == 0                                            # 704 pixels: no plane-layout tile -> the caller keeps the statistics pass
+        return
+    M = Nb * W * H
+    assert rows == M // 256
+    x = bf(gen((Nb, W, H, Ci), 1)).to(dev).to(BF); w = bf(gen((3, 3, Ci, Co), 2, 0.05)); b = gen((Co,), 3).to(dev)
+    wpack = torch.empty((Co, 3, 3, Ci), dtype=BF, device=dev)
+    ops.pack_transpose(w.reshape(9 * Ci, Co).to(dev), wpack)
+    y0 = ops.conv3x3(x, wpack, bias=b, relu=False)
+    ws = ops.bn_workspace(M, Co, dev)
+    ws.fill_(0x7f)
+    y1 = torch.empty_like(y0)
+    ops.conv3x3_stats(x, wpack, y1, ws, bias=b)
+    assert torch.equal(y1, y0)
+    part = ws[:rows * 2 * Co * 4].view(torch.float32).view(rows, 2, Co).double()
+    yd = y0.view(M, Co).double()
+    assert relerr(part[:, 0].sum(0).cpu(), yd.sum(0).cpu()) < 1e-5 and relerr(part[:, 1].sum(0).cpu(), (yd * yd).sum(0).cpu()) < 1e-5
+    # every tile's own row: rows t*256 .. t*256+255 of the [M][Co] view
+    t = rows // 2
+    assert relerr(part[t, 0].cpu(), yd[t * 256:(t + 1) * 256].sum(0).cpu()) < 1e-5
+    gamma = (gen((Co,), 4) + 1.5).to(dev); beta = gen((Co,), 5).to(dev)
+    ws2 = ops.bn_workspace(M, Co, dev)
+    z0, m0, r0 = ops.bn_train_fwd(y0.view(M, Co), gamma, beta, 1e-3, True, ws2)
+    z1, m1, r1 = ops.bn_train_fwd(y1.view(M, Co), gamma, beta, 1e-3, True, ws, partial_rows=rows)
+    assert relerr(m1.cpu(), m0.cpu()) < 1e-5 and relerr(r1.cpu(), r0.cpu()) < 1e-5
+    assert maxerr(z1.float().cpu(), z0.float().cpu()) <= 2.0 ** -6 * float(z0.float().abs().max())       # one bf16 ulp where a value sits on a rounding edge
+
+
 def test_small_ops(dev):
     a = bf(gen((1000, 512), 1))
     out = torch.ones(512, device=dev)
