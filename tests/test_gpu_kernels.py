@@ -597,10 +597,10 @@ def test_conv3x3_with_batchnorm_statistics_in_the_epilogue(dev, Nb, W, H, Ci, Co
     """Round 4: conv_k3 / conv_k3w leave per-tile partial sums of their (bf16) output behind; batch norm finishes from them.  The stored
     tensor is bit-identical to the plain convolution's; the statistics equal the ones of a pass over it up to fp32 summation order."""
     rows = ops.conv3x3_stats_rows(Nb, W, H, Ci, Co)
-    if (Nb, W, H) == (8, 22, 4):
-        assert rows == 0                                            # 704 pixels: no plane-layout tile -> the caller keeps the statistics pass
-        return
     M = Nb * W * H
+    if not ops.conv3x3_kernel_choice(Nb, W, H, Ci, Co, relu=False).startswith('conv_k3'):
+        assert rows == 0          # (8, 22, 4): 704 pixels; (16, 64, 8, 128, 128): 32 tiles — no plane-layout kernel: the caller keeps the statistics pass
+        return
     assert rows == M // 256
     x = bf(gen((Nb, W, H, Ci), 1)).to(dev).to(BF); w = bf(gen((3, 3, Ci, Co), 2, 0.05)); b = gen((Co,), 3).to(dev)
     wpack = torch.empty((Co, 3, 3, Ci), dtype=BF, device=dev)
