@@ -111,6 +111,23 @@ int ocr_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* ou
 int ocr_gemm_tn_batched_bf16(const void* A, long lda, long strideA, const void* B, long ldb, long strideB, float* out, long ldo,
                              long strideOut, int Mk, int I, int J, int nbatch, float scale, int splits, float* colsum,
                              long strideColsum, void* stream);
+/* Round 4: several plain weight-gradient products in ONE launch of the ping-pong kernel (csrc/gemm_tn3.hip): one workgroup per 128 x 128
+ * output tile over the whole contraction - no split over m, no atomics, bit-reproducible.  For every job and b < nbatch:
+ *     out_b[I][J] += scale * A_b^T B_b,   colsum_b[J] += scale * column sums of B_b   (colsum may be NULL)
+ * with A_b = A + b*strideA ([Mk rows][lda], rows in groups of row_group with row_skip unused rows behind each group; 0 = plain), B_b = B +
+ * b*strideB, element strides.  jobs is a HOST array of 1 or 2 descriptors.  Needs I % 128 == 0, J % 128 == 0, Mk >= 256, 16-byte aligned
+ * rows: ocr_gemm_tn_jobs_supported tells beforehand (host-only); OCR_STATUS_INVALID otherwise (use ocr_gemm_tn_bf16 / _batched_bf16). */
+typedef struct ocr_tn_job {
+    const void* A; long lda; long strideA;
+    const void* B; long ldb; long strideB;
+    float* out; long ldo; long strideOut;
+    float* colsum; long strideColsum;
+    int Mk, I, J, nbatch;
+    int row_group, row_skip;
+    float scale; int reserved;
+} ocr_tn_job;
+int ocr_gemm_tn_jobs_supported(const ocr_tn_job* jobs, int njobs);
+int ocr_gemm_tn_jobs_bf16(const ocr_tn_job* jobs, int njobs, void* stream);
 /* A/B knob: 2 (default) = nine-tap slab kernel for conv weight gradients when a workspace is given (else as 1);
  * 1 = LDS-DMA per-tap tiles + fp32 atomics where I,J % 128 == 0; 0 = register-staged kernel */
 int ocr_set_wgrad_engine(int engine);

@@ -33,6 +33,8 @@ _SIGS = {
     "ocr_gemm_nt_bf16": ([_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P], _I),
     "ocr_set_gemm_engine": ([_I], _I),
     "ocr_gemm_tn_batched_bf16": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _F, _I, _P, _L, _P], _I),
+    "ocr_gemm_tn_jobs_supported": ([_P, _I], _I),
+    "ocr_gemm_tn_jobs_bf16": ([_P, _I, _P], _I),
     "ocr_lstm_xh": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "ocr_set_wgrad_engine": ([_I], _I),
     "ocr_conv3x3_bf16": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P], _I),

@@ -300,8 +300,11 @@ class _ConvOp(_Op):
             N, W, H, C = s
             Wo = o[1]
             K = self.kh * H * C
-            ops.gemm_tn(x, dz.view(M, self.co), dw.view(K, self.co), Mk=M, I=K, J=self.co, lda=H * C, ldb=self.co,
-                        ldo=self.co, row_group=Wo, row_skip=self.kh - 1, colsum=db)
+            dz2, dw2 = dz.view(M, self.co), dw.view(K, self.co)
+            e.tn_push(sp, ops.tn_job(x, H * C, dz2, self.co, dw2, self.co, M, K, self.co, row_group=Wo, row_skip=self.kh - 1, colsum=db),
+                      (x, dz2, dw2, db),
+                      lambda: ops.gemm_tn(x, dz2, dw2, Mk=M, I=K, J=self.co, lda=H * C, ldb=self.co,
+                                          ldo=self.co, row_group=Wo, row_skip=self.kh - 1, colsum=db))
             if pdy is not None:
                 if pmask is not None or self.kh != 2:
                     raise NotImplementedError('%s: data gradient of a full-height VALID conv is lowered for k_h = 2 '
@@ -815,9 +818,12 @@ class _BiLstmOp(_Op):
             # concat([x_t, h_{t-1}]), network.py:104-107): 4 short-K weight-gradient launches become 1
             xh = b[self.key + '/xh']
             ops.lstm_xh(x, hout, sp.seq_len, xh, N, T, D, U, ND)
-            ops.gemm_tn_batched(xh, D + U, R * (D + U), dz, ND * 4 * U, 4 * U, gw[0], 4 * U, stride, R, D + U, 4 * U, ND,
-                                colsum=gb[0],
-                                strideColsum=(e.offset(self.cells[1] + '/biases') - e.offset(self.cells[0] + '/biases')) if ND == 2 else 0)
+            scs = (e.offset(self.cells[1] + '/biases') - e.offset(self.cells[0] + '/biases')) if ND == 2 else 0
+            e.tn_push(sp, ops.tn_job(xh, D + U, dz, ND * 4 * U, gw[0], 4 * U, R, D + U, 4 * U, nbatch=ND, strideA=R * (D + U), strideB=4 * U,
+                                     strideOut=stride, colsum=gb[0], strideColsum=scs),
+                      (xh, dz, gw[0], gb[0]),
+                      lambda: ops.gemm_tn_batched(xh, D + U, R * (D + U), dz, ND * 4 * U, 4 * U, gw[0], 4 * U, stride, R, D + U, 4 * U, ND,
+                                                  colsum=gb[0], strideColsum=scs))
         else:
             ops.lstm_hprev(hout, sp.seq_len, b[self.key + '/hprev'], N, T, U, ND)
             for d in range(ND):
@@ -847,6 +853,7 @@ class ShapePlan(object):
         self.scratch = {}
         self.dy_done = set()
         self.w9_pending, self.w9_tables = [], {}    # deferred weight-gradient reductions of the running backward pass / their device tables
+        self.tn_pending = []                        # plain weight-gradient products waiting for a partner (Engine.tn_push)
         for op in eng.ops:
             s = self.oshape[op.prev.key]
             op.alloc(self, s)
@@ -890,6 +897,7 @@ class Engine(object):
         self.persistent_lstm = persistent_lstm
         self.fuse_conv1_pool = fuse_conv1_pool
         self.fuse_bn_stats = os.environ.get('OCR_FUSE_BN_STATS', '1') != '0'      # batch-norm statistics from the producing convolution's epilogue
+        self.tn_defer = os.environ.get('OCR_TN_JOBS', '1') != '0'                 # pairs of plain weight-gradient products as one gemm_tn3 launch
         self.group = group
         self.world = 1
         self._check_xcd_placement()
@@ -1216,6 +1224,7 @@ class Engine(object):
     def _loss_and_backward(self, sp, flush=True):
         sp.dy_done = set()
         sp.w9_pending = []
+        sp.tn_pending = []
         logits = self.ops[-1].y(sp)
         # loss = mean over the GLOBAL batch -> d loss / d cost_n = 1 / (N * world)   (network.py:655)
         scale = ocr_dist.loss_scale(sp.N, self.world)
@@ -1228,13 +1237,35 @@ class Engine(object):
             ops.tnc_to_ntc_bf16(sp.ctc_grad, self.ops[-1].dy(sp), scale)
         for op in reversed(self.ops[self.split_op:]):
             op.bwd(sp)
+        self._flush_tn(sp)                  # (always: the exchange of the late gradients may follow this body)
         if flush:
             self._flush_w9(sp)
 
     def _backward_early(self, sp):
         for op in reversed(self.ops[:self.split_op]):
             op.bwd(sp)
+        self._flush_tn(sp)
         self._flush_w9(sp)
+
+    def tn_push(self, sp, job, keep, fallback):
+        """A plain weight-gradient product (X^T dY of conv5 / of the BiLSTM cells) joins the pending list; TWO of them go out as ONE launch of
+        the ping-pong kernel (csrc/gemm_tn3.hip: no split over the contraction, no atomics).  `keep`: tensors the descriptor points into;
+        `fallback`: the product as its own launch (gemm_tn2), used when it stays alone — with a split over the pixels that kernel fills the
+        chip better than 64-96 unsplit tiles would."""
+        if not self.tn_defer or not ops.gemm_tn_jobs_supported([job]):
+            fallback()
+            return
+        sp.tn_pending.append((job, keep, fallback))
+        if len(sp.tn_pending) == 2:
+            self._flush_tn(sp)
+
+    def _flush_tn(self, sp):
+        pend, sp.tn_pending = sp.tn_pending, []
+        if len(pend) == 2:
+            ops.gemm_tn_jobs([pend[0][0], pend[1][0]])
+        else:
+            for _, _, fallback in pend:
+                fallback()
 
     W9_DEFER_MAX_BYTES = 192 << 20       # total slab bytes of a plan up to which the reductions are deferred (Infinity Cache: 256 MB;
                                          # the headline plan has 162 MB); OCR_W9_DEFER_MAX_MB overrides

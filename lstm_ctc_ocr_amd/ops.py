@@ -172,6 +172,34 @@ def gemm_tn_batched(A, lda, strideA, B, ldb, strideB, out, ldo, strideOut, Mk, I
     return out
 
 
+class TnJob(ctypes.Structure):
+    """ocr_tn_job (include/ocr_hip.h): one batched product out_b[I][J] += scale * A_b^T B_b (+ column sums of B_b) of ocr_gemm_tn_jobs_bf16."""
+    _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_long), ("strideA", ctypes.c_long),
+                ("B", ctypes.c_void_p), ("ldb", ctypes.c_long), ("strideB", ctypes.c_long),
+                ("out", ctypes.c_void_p), ("ldo", ctypes.c_long), ("strideOut", ctypes.c_long),
+                ("colsum", ctypes.c_void_p), ("strideColsum", ctypes.c_long),
+                ("Mk", ctypes.c_int), ("I", ctypes.c_int), ("J", ctypes.c_int), ("nbatch", ctypes.c_int),
+                ("row_group", ctypes.c_int), ("row_skip", ctypes.c_int), ("scale", ctypes.c_float), ("reserved", ctypes.c_int)]
+
+
+def tn_job(A, lda, B, ldb, out, ldo, Mk, I, J, *, nbatch=1, strideA=0, strideB=0, strideOut=0, colsum=None, strideColsum=0, row_group=0,
+           row_skip=0, scale=1.0):
+    """Descriptor of a plain weight-gradient product for gemm_tn_jobs (the tensors must stay alive and untouched until the launch)."""
+    return TnJob(ptr(_dev(A)), lda, strideA, ptr(_dev(B)), ldb, strideB, ptr(out), ldo, strideOut, ptr(colsum), strideColsum,
+                 Mk, I, J, nbatch, row_group, row_skip, float(scale), 0)
+
+
+def gemm_tn_jobs_supported(jobs):
+    arr = (TnJob * len(jobs))(*jobs)
+    return bool(nat.lib().ocr_gemm_tn_jobs_supported(ctypes.cast(arr, ctypes.c_void_p), len(jobs)))
+
+
+def gemm_tn_jobs(jobs):
+    """1 or 2 products in ONE launch of the ping-pong kernel (no split over the contraction, no atomics)."""
+    arr = (TnJob * len(jobs))(*jobs)
+    call("ocr_gemm_tn_jobs_bf16", ctypes.cast(arr, ctypes.c_void_p), len(jobs), _st())
+
+
 def lstm_xh(x2d, hout, seq_len, xh, Nb, T, D, U, ndir=2):
     call("ocr_lstm_xh", ptr(_dev(x2d)), ptr(hout), ptr(seq_len), ptr(xh), Nb, T, D, U, ndir, _st())
     return xh

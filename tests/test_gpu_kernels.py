@@ -397,6 +397,50 @@ def test_gemm_tn_batched_and_xh(dev):
     assert float(out[(D + U) * 4 * U:(D + U) * 4 * U + gap].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("Nb,W,HC,Co,R2,I2,J2", [(64, 64, 1024, 512, 4032, 768, 1024),       # the headline step's two products: conv5 + both BiLSTM cells
+                                                 (13, 21, 128, 128, 1000, 128, 256),          # contraction not a multiple of 64 (zero-page tail), tiles % 8 != 0
+                                                 (3, 90, 64, 256, 300, 256, 128)])            # row groups of 89 rows: several 64-row stages per group
+def test_gemm_tn_jobs(dev, Nb, W, HC, Co, R2, I2, J2):
+    """csrc/gemm_tn3.hip (round 4): two plain weight-gradient products in ONE launch, one workgroup per 128 x 128 tile over the whole
+    contraction (ping-pong K halves, no atomics): conv5-style overlapping rows (row_group W - 1, skip 1) with the bias column sums, and a
+    batch of two products with strides — against fp64 references, accumulating into non-zero outputs, bit-identical from run to run."""
+    rng = np.random.RandomState(7)
+    x = bf(torch.from_numpy(rng.randn(Nb, W, HC).astype(np.float32)))
+    M1 = Nb * (W - 1)
+    dy = bf(torch.from_numpy((rng.randn(M1, Co) * 0.1).astype(np.float32)))
+    rows = torch.stack([torch.cat([x[n, w], x[n, w + 1]]) for n in range(Nb) for w in range(W - 1)])
+    xh = bf(torch.from_numpy(rng.randn(2, R2, I2).astype(np.float32)))
+    dz = bf(torch.from_numpy((rng.randn(R2, 2 * J2) * 0.1).astype(np.float32)))
+    xd, dyd, xhd, dzd = x.to(dev).to(BF), dy.to(dev).to(BF), xh.to(dev).to(BF), dz.to(dev).to(BF)
+    gap = 256
+    runs = []
+    for _ in range(2):
+        dw1 = torch.full((2 * HC, Co), 0.5, device=dev); db1 = torch.full((Co,), 0.25, device=dev)
+        dw2 = torch.ones(2 * I2 * J2 + gap, device=dev); db2 = torch.ones(2 * J2 + 128, device=dev)
+        j1 = ops.tn_job(xd, HC, dyd, Co, dw1, Co, M1, 2 * HC, Co, row_group=W - 1, row_skip=1, colsum=db1)
+        j2 = ops.tn_job(xhd, I2, dzd, 2 * J2, dw2, J2, R2, I2, J2, nbatch=2, strideA=R2 * I2, strideB=J2, strideOut=I2 * J2 + gap,
+                        colsum=db2, strideColsum=J2 + 128)
+        assert ops.gemm_tn_jobs_supported([j1, j2])
+        ops.gemm_tn_jobs([j1, j2])
+        runs.append((dw1.cpu(), db1.cpu(), dw2.cpu(), db2.cpu()))
+    dw1, db1, dw2, db2 = runs[0]
+    assert relerr(dw1.double() - 0.5, rows.double().t() @ dy.double()) < 1e-4
+    assert relerr(db1.double() - 0.25, dy.double().sum(0)) < 1e-4
+    so = I2 * J2 + gap
+    for d in range(2):
+        want = xh[d].double().t() @ dz[:, d * J2:(d + 1) * J2].double()
+        assert relerr(dw2[d * so:d * so + I2 * J2].view(I2, J2).double() - 1.0, want) < 1e-4
+        assert relerr(db2[d * (J2 + 128):d * (J2 + 128) + J2].double() - 1.0, dz[:, d * J2:(d + 1) * J2].double().sum(0)) < 1e-4
+    assert float((dw2[I2 * J2:I2 * J2 + gap] - 1.0).abs().max()) == 0.0 and float((db2[J2:J2 + 128] - 1.0).abs().max()) == 0.0
+    assert all(torch.equal(a, b) for a, b in zip(runs[0], runs[1]))                    # no atomics: bit-reproducible
+    # one job alone, and what is not covered
+    dw1 = torch.zeros((2 * HC, Co), device=dev)
+    ops.gemm_tn_jobs([ops.tn_job(xd, HC, dyd, Co, dw1, Co, M1, 2 * HC, Co, row_group=W - 1, row_skip=1)])
+    assert relerr(dw1.cpu().double(), rows.double().t() @ dy.double()) < 1e-4
+    assert not ops.gemm_tn_jobs_supported([ops.tn_job(xd, HC, dyd, Co, dw1, Co, M1, 2 * HC, 64)])           # J % 128 != 0
+    assert not ops.gemm_tn_jobs_supported([ops.tn_job(xd, HC, dyd, Co, dw1, Co, 100, 2 * HC, Co)])          # fewer than 256 rows
+
+
 def test_gemm_tn_conv5_rows(dev):
     Nb, W, HC, Co = 3, 9, 64, 128
     x = bf(gen((Nb, W, HC), 3)); dy = bf(gen((Nb * (W - 1), Co), 4))
