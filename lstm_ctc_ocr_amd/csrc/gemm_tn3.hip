@@ -55,7 +55,12 @@ __device__ __forceinline__ void tn3_body(const Tn3Job& g, const int bid, unsigne
     const int IT = g.I >> 7, JT = g.J >> 7, T = IT * JT * g.nbatch;
     int L = bid;
     if ((T & 7) == 0) L = (bid & 7) * (T >> 3) + (bid >> 3);          // XCD-aware: each XCD (private L2) owns a contiguous run of tiles
-    const int jt = L % JT, it = (L / JT) % IT, bi = L / (JT * IT);     // j fastest: an XCD's run shares its A panels
+    // an XCD's run of tiles re-reads one operand from every XCD and keeps the other disjoint: the LARGER operand stays disjoint (conv5: A = 16.5 MB
+    // against B = 4 MB -> j fastest, an XCD owns two i-tiles; a BiLSTM cell: A = 6.2 MB, B = 8.3 MB -> i fastest, an XCD owns two j-tiles)
+    int jt, it;
+    if ((long)g.I >= (long)g.J) { jt = L % JT; it = (L / JT) % IT; }
+    else { it = L % IT; jt = (L / IT) % JT; }
+    const int bi = L / (JT * IT);
     const bf16_t* A = g.A + (long)bi * g.sA;
     const bf16_t* B = g.B + (long)bi * g.sB;
     float* out = g.out + (long)bi * g.sO;

@@ -5,9 +5,9 @@
 // (wd * ||w||^2 / 2 on conv + FC weights) folded in as g += wd * w.
 //
 // All parameters live in ONE flat fp32 buffer in which the L2-regularised tensors form one contiguous range, so the whole
-// step is two HBM-bound grid-stride kernels over that buffer; the norm pass's last-arriving block advances the
+// step is two HBM-bound grid-stride kernels over that buffer (+ a 1-thread "tick" that advances the
 // Adam bias correction on the device, which keeps the step replayable from a hipGraph with no host
-// scalars baked in (round 4: that "tick" used to be a launch of its own).  The same flat gradient buffer is what the data-parallel all-reduce sees.
+// scalars baked in).  The same flat gradient buffer is what the data-parallel all-reduce sees.
 #include "common.h"
 #include <math.h>
 
@@ -27,19 +27,39 @@
 #define SC_BINS 32
 #define SC_NORM_BINS 8
 #define SC_REG_BINS 40
-// [72 .. 72+32) arrival tickets of the norm pass per bin, [104] arrival ticket of the bins: the LAST block of optim_prep_kernel to arrive
-// adds the bins up, publishes the norm, clears bins and tickets and advances the Adam bias correction — what used to be a launch of its own
-// (optim_tick_kernel, ~5 us of dependent-launch latency per step) and 2048 x 64 redundant bin reads in the update kernel.
-#define SC_TICKET_BINS 72
-#define SC_TICKET_ALL 104
-#define SC_TOTAL 112
+#define SC_TOTAL 72
+// Round 4, measured and reverted (profiles/r04c_kernel_stats.md): folding the tick into the norm pass — last-arriving block by two-level
+// arrival tickets, __threadfence() between a block's bin atomics and its ticket — made optim_prep_kernel 62.8 us instead of 16.9 (+ 4.9 for
+// the tick launch it saved): a device-scope release fence on this chip writes the XCD's L2 back (the pass has just stored 22 MB of
+// gradients), once per block.  The tick stays a launch of its own.
 
-// device-scope read of a value other workgroups add to with atomics (an atomic RMW is served where the atomics are, never from a stale L1 line)
-__device__ __forceinline__ double optim_peek(double* p) { return atomicAdd(p, 0.0); }
+__global__ void optim_tick_kernel(double* sc, double beta1, double beta2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double b1t = sc[SC_B1T] * beta1, b2t = sc[SC_B2T] * beta2;
+        sc[SC_B1T] = b1t; sc[SC_B2T] = b2t;
+        sc[SC_STEP] += 1.0;
+        sc[SC_LRT] = sc[SC_LR] * sqrt(1.0 - b2t) / (1.0 - b1t);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 2 * SC_BINS) sc[SC_NORM_BINS + threadIdx.x] = 0.0;
+}
+// totals of the two bin arrays, computed by every block of an update kernel (64 cached loads); block 0 also publishes them
+__device__ __forceinline__ float optim_gnorm(double* sc) {
+    __shared__ double tot[2];
+    if (threadIdx.x < 64) {
+        double a = threadIdx.x < SC_BINS ? sc[SC_NORM_BINS + threadIdx.x] : 0.0;
+        double b = threadIdx.x < SC_BINS ? sc[SC_REG_BINS + threadIdx.x] : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+        if (threadIdx.x == 0) { tot[0] = a; tot[1] = b; }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc[SC_NORM2] = tot[0]; sc[SC_REG2] = tot[1]; sc[SC_GNORM] = sqrt(tot[0]); }
+    return (float)sqrt(tot[0]);
+}
 
 // pass 1: g += wd * w on the regularised range [reg0, reg1); accumulate sum g^2 (all) and sum w^2 (that range)
 __global__ __launch_bounds__(256) void optim_prep_kernel(const float* __restrict__ p, float* __restrict__ g, long n,
-                                                         long reg0, long reg1, float wd, double* sc, double beta1, double beta2) {
+                                                         long reg0, long reg1, float wd, double* sc) {
     float s2 = 0.f, r2 = 0.f;
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 256 * 4;
@@ -62,28 +82,6 @@ __global__ __launch_bounds__(256) void optim_prep_kernel(const float* __restrict
         const int bin = blockIdx.x & (SC_BINS - 1);
         atomicAdd(&sc[SC_NORM_BINS + bin], (double)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
         atomicAdd(&sc[SC_REG_BINS + bin], (double)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
-        // two-level arrival count (one same-address atomic per block would serialise ~12 ns each): the last block of a bin counts on the
-        // global ticket, the last bin's block finishes the pass.  Release / acquire by __threadfence around device-scope atomics.
-        __threadfence();
-        const int in_bin = ((int)gridDim.x - bin + SC_BINS - 1) / SC_BINS;            // blocks with (blockIdx & 31) == bin
-        if (atomicAdd(&sc[SC_TICKET_BINS + bin], 1.0) == (double)(in_bin - 1)) {
-            const int nbins = (int)gridDim.x < SC_BINS ? (int)gridDim.x : SC_BINS;
-            __threadfence();
-            if (atomicAdd(&sc[SC_TICKET_ALL], 1.0) == (double)(nbins - 1)) {
-                __threadfence();
-                double a = 0.0, b = 0.0;
-                for (int i = 0; i < SC_BINS; ++i) { a += optim_peek(&sc[SC_NORM_BINS + i]); b += optim_peek(&sc[SC_REG_BINS + i]); }
-                sc[SC_NORM2] = a; sc[SC_REG2] = b; sc[SC_GNORM] = sqrt(a);
-                for (int i = 0; i < 2 * SC_BINS; ++i) sc[SC_NORM_BINS + i] = 0.0;      // (bins and tickets: ready for the next step's launch)
-                for (int i = 0; i < SC_BINS; ++i) sc[SC_TICKET_BINS + i] = 0.0;
-                sc[SC_TICKET_ALL] = 0.0;
-                // the tick: advance the Adam bias correction on the device (graph-replayable: no host scalar is baked in)
-                const double b1t = sc[SC_B1T] * beta1, b2t = sc[SC_B2T] * beta2;
-                sc[SC_B1T] = b1t; sc[SC_B2T] = b2t;
-                sc[SC_STEP] += 1.0;
-                sc[SC_LRT] = sc[SC_LR] * sqrt(1.0 - b2t) / (1.0 - b1t);
-            }
-        }
     }
 }
 
@@ -92,7 +90,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p,
                                                           float* __restrict__ m, float* __restrict__ v, long n,
                                                           float beta1, float beta2, float eps, float clip,
                                                           double* sc) {
-    const float gnorm = (float)sc[SC_GNORM];                 // published by the norm pass's last block
+    const float gnorm = optim_gnorm(sc);
     const float scale = (clip > 0.f) ? clip / fmaxf(gnorm, clip) : 1.f;
     const float lrt = (float)sc[SC_LRT];
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -111,7 +109,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p,
 __global__ __launch_bounds__(256) void momentum_update_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                               float* __restrict__ m, long n, float mom, float clip,
                                                               double* sc) {
-    const float gnorm = (float)sc[SC_GNORM];                 // published by the norm pass's last block
+    const float gnorm = optim_gnorm(sc);
     const float scale = (clip > 0.f) ? clip / fmaxf(gnorm, clip) : 1.f;
     const float lr = (float)sc[SC_LR];
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -127,7 +125,7 @@ __global__ __launch_bounds__(256) void momentum_update_kernel(float* __restrict_
 __global__ __launch_bounds__(256) void rmsprop_update_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                              float* __restrict__ ms, long n, float decay, float eps,
                                                              float clip, double* sc) {
-    const float gnorm = (float)sc[SC_GNORM];                 // published by the norm pass's last block
+    const float gnorm = optim_gnorm(sc);
     const float scale = (clip > 0.f) ? clip / fmaxf(gnorm, clip) : 1.f;
     const float lr = (float)sc[SC_LR];
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -146,7 +144,7 @@ __global__ void optim_init_kernel(double* sc, double lr) {
         sc[SC_NORM2] = 0; sc[SC_REG2] = 0; sc[SC_LR] = lr; sc[SC_LRT] = lr; sc[SC_B1T] = 1.0; sc[SC_B2T] = 1.0;
         sc[SC_STEP] = 0; sc[SC_GNORM] = 0;
     }
-    for (int i = threadIdx.x; i < SC_TOTAL - SC_NORM_BINS; i += blockDim.x) if (blockIdx.x == 0) sc[SC_NORM_BINS + i] = 0.0;      // bins and tickets
+    if (blockIdx.x == 0 && threadIdx.x < 2 * SC_BINS) sc[SC_NORM_BINS + threadIdx.x] = 0.0;
 }
 __global__ void optim_set_lr_kernel(double* sc, double lr) {
     if (threadIdx.x == 0 && blockIdx.x == 0) sc[SC_LR] = lr;
@@ -183,11 +181,11 @@ extern "C" int ocr_optim_step(float* params, float* grads, float* state1, float*
         return OCR_ERR_INVALID;
     if (solver == 0 && !state2) return OCR_ERR_INVALID;
     double* sc = (double*)scalars;
+    optim_tick_kernel<<<1, 64, 0, stream>>>(sc, (double)beta1, (double)beta2);
+    OCR_CHECK_LAUNCH();
     int blocks = (int)((n / 4 + 255) / 256); if (blocks > 2048) blocks = 2048;
     int pblocks = blocks > 1024 ? 1024 : blocks;       // the atomics at the end go to 32 bins, see SC_BINS
-    // bias-correction factors of the solver that has them (Momentum / RMSProp pass beta2 = 0: lr_t is not used by their update kernels)
-    optim_prep_kernel<<<pblocks, 256, 0, stream>>>(params, grads, n, reg_begin, weight_decay > 0.f ? reg_end : reg_begin, weight_decay, sc,
-                                                   (double)beta1, (double)beta2);
+    optim_prep_kernel<<<pblocks, 256, 0, stream>>>(params, grads, n, reg_begin, weight_decay > 0.f ? reg_end : reg_begin, weight_decay, sc);
     OCR_CHECK_LAUNCH();
     if (solver == 0) adam_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, state2, n, beta1, beta2, eps, clip_norm, sc);
     else if (solver == 1) momentum_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, n, beta1, clip_norm, sc);
