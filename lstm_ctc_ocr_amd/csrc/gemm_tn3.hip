@@ -15,6 +15,7 @@
 // source chunk and again in the read address; ds_read_b64_tr_b16 delivers 4 consecutive m of one channel per lane.
 // Requires I % 128 == 0, J % 128 == 0; other shapes stay on gemm_tn2 / gemm_tn.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 struct Tn3Job {                     // = ocr_tn_job (include/ocr_hip.h), element strides
@@ -45,9 +46,9 @@ __device__ __forceinline__ int tn3_frag_off(int cb, int lane) {
     return r0 * 256 + p * 16 + (L & 1) * 8;
 }
 
-template <int KH>
+template <int KH, int NST /* LDS stages: 4 (prefetch distance 2) or 5 (distance 3: all 160 KiB) */>
 __device__ __forceinline__ void tn3_body(const Tn3Job& g, const int bid, unsigned char* smem) {
-    constexpr int NST = 4, TILE = 64 * 256, STAGE = 2 * TILE;
+    constexpr int TILE = 64 * 256, STAGE = 2 * TILE, DEPTH = NST - 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = (wave & 3) >> 1, wj = wave & 1;
@@ -122,9 +123,9 @@ __device__ __forceinline__ void tn3_body(const Tn3Job& g, const int bid, unsigne
     }
 
     const int nst = (Mk + 63) >> 6;
-    // ---- prologue: stages 0 and 1, landed before barrier 0
-    stage_load(0);
-    stage_load(1);
+    // ---- prologue: stages 0 .. DEPTH - 1, landed before barrier 0
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) stage_load(d);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -156,13 +157,13 @@ __device__ __forceinline__ void tn3_body(const Tn3Job& g, const int bid, unsigne
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
-    // One interval = one 64-row stage, closed by ONE barrier.  Group 0: LOAD(s), DMA(s + 2), COMP(s) [, column sums of B(s)];
-    // group 1: COMP(s - 1), LOAD(s), DMA(s + 2).  Stage s + 2 goes into the buffer of stage s - 2, whose last readers (group 1's LOAD(s - 2),
-    // retired by the lgkmcnt(0) in front of its COMP in interval s - 1) passed barrier s - 1.  Every wave issues exactly 4 pieces per interval
-    // (rows past the contraction come from a zero page), so "stage s + 1 has landed" is vmcnt(4).
+    // One interval = one 64-row stage, closed by ONE barrier.  Group 0: LOAD(s), DMA(s + DEPTH), COMP(s) [, column sums of B(s)];
+    // group 1: COMP(s - 1), LOAD(s), DMA(s + DEPTH).  Stage s + DEPTH goes into the buffer of stage s - 2, whose last readers (group 1's
+    // LOAD(s - 2), retired by the lgkmcnt(0) in front of its COMP in interval s - 1) passed barrier s - 1.  Every wave issues exactly 4 pieces
+    // per interval (rows past the contraction come from a zero page), so "stage s + 1 has landed" is vmcnt(4 * (DEPTH - 1)).
     int buf = 0;
     for (int s = 0; s < nst; ++s) {
-        int nb = buf + 2; if (nb >= NST) nb -= NST;
+        int nb = buf + DEPTH; if (nb >= NST) nb -= NST;
         if (KH == 0) {
             load(buf);
             stage_load(nb);
@@ -190,7 +191,7 @@ __device__ __forceinline__ void tn3_body(const Tn3Job& g, const int bid, unsigne
             load(buf);
             stage_load(nb);
         }
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DEPTH - 1)) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -250,14 +251,15 @@ __device__ __forceinline__ void tn3_body(const Tn3Job& g, const int bid, unsigne
                     old[a2][b][r] + acc[KH * 2 + a2][b][r] * scale;
 }
 
+template <int NST>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn3_kernel(Tn3Job j0, Tn3Job j1, int nblk0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int kh = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
     const int bid = (int)blockIdx.x;
     if (bid < nblk0) {
-        if (kh == 0) tn3_body<0>(j0, bid, smem); else tn3_body<1>(j0, bid, smem);
+        if (kh == 0) tn3_body<0, NST>(j0, bid, smem); else tn3_body<1, NST>(j0, bid, smem);
     } else {
-        if (kh == 0) tn3_body<0>(j1, bid - nblk0, smem); else tn3_body<1>(j1, bid - nblk0, smem);
+        if (kh == 0) tn3_body<0, NST>(j1, bid - nblk0, smem); else tn3_body<1, NST>(j1, bid - nblk0, smem);
     }
 }
 
@@ -281,13 +283,17 @@ extern "C" int ocr_gemm_tn_jobs_bf16(const void* jobs, int njobs, void* stream) 
     const Tn3Job* j = (const Tn3Job*)jobs;
     const int t0 = (j[0].I >> 7) * (j[0].J >> 7) * j[0].nbatch;
     const int t1 = njobs > 1 ? (j[1].I >> 7) * (j[1].J >> 7) * j[1].nbatch : 0;
-    constexpr int lds = 4 * 2 * 64 * 256;            // four stages x (A tile | B tile) = 128 KiB; the K-half exchange (64 KiB) reuses them
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)gemm_tn3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC;
-        attr = true;
+    static int nst = -1;                             // kernel-selection knob OCR_TN3_NST: 4 stages (prefetch distance 2) / 5 (distance 3, all 160 KiB of LDS)
+    if (nst < 0) { const char* e = getenv("OCR_TN3_NST"); nst = (e && atoi(e) == 4) ? 4 : 5; }
+    static bool attr[2] = {false, false};
+    const int lds = nst * 2 * 64 * 256;              // stages x (A tile | B tile); the K-half exchange (64 KiB) reuses them
+    if (nst == 4) {
+        if (!attr[0]) { if (hipFuncSetAttribute((const void*)gemm_tn3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC; attr[0] = true; }
+        gemm_tn3_kernel<4><<<t0 + t1, 512, lds, (hipStream_t)stream>>>(j[0], njobs > 1 ? j[1] : j[0], t0);
+    } else {
+        if (!attr[1]) { if (hipFuncSetAttribute((const void*)gemm_tn3_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC; attr[1] = true; }
+        gemm_tn3_kernel<5><<<t0 + t1, 512, lds, (hipStream_t)stream>>>(j[0], njobs > 1 ? j[1] : j[0], t0);
     }
-    gemm_tn3_kernel<<<t0 + t1, 512, lds, (hipStream_t)stream>>>(j[0], njobs > 1 ? j[1] : j[0], t0);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
