@@ -331,8 +331,10 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
                       const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind) {
     if ((Cin & 63) || (Cout & 3) || M < 1024 || H > 30) return -1;
     if (flags & ~(IGH_BIAS | IGH_RELU | IGH_MASK | IGH_ACCUM)) return -1;
-    if (pool_kind == 3) {    // batch-norm statistics from the epilogue (`pool` = float partial rows): the plane-layout kernels only
-        if (!pool || (flags & (IGH_MASK | IGH_ACCUM)) || (M & 255)) return -1;
+    if (pool_kind >= 3) {    // batch-norm statistics from the epilogue (3: forward, `pool` = float partial rows; 4: backward sums of a masked data
+                             // gradient, `pool` = host K3BnBwd): the plane-layout kernels only
+        if (pool_kind > 4 || !pool || (flags & IGH_ACCUM) || (M & 255)) return -1;
+        if (pool_kind == 3 ? (flags & IGH_MASK) != 0 : !(flags & IGH_MASK)) return -1;
         static int k2s = -1;
         if (k2s < 0) { const char* e = getenv("OCR_CONV_K2"); k2s = e ? atoi(e) : K2_DEFAULT; }
         return k2s ? k2_try_dispatch(x, wpack, y, M, W, H, Cin, Cout, bias, mask, flags, stream, pool, pool_kind) : -1;

@@ -481,7 +481,7 @@ int k2_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int
             if (rc >= 0) return rc;
         }
     }
-    if (pool_kind == 3) return -1;                       // batch-norm statistics in the epilogue: conv_k3 only
+    if (pool_kind >= 3) return -1;                       // batch-norm statistics in the epilogue: conv_k3 only
     const int c = k2_choose(M, H, Cin, Cout);
     if (!c) return -1;
     static int abl = -1;

@@ -41,7 +41,12 @@ struct K3Args {
     bf16_t* pool; int pool_kind;          // as conv_halo: 0 none, 1 feature pairs (1 x 2), 2 2 x 2; 3 = `pool` is float [M / 256][2][N]: per-tile
                                           // partial sums / sums of squares of the stored bf16 outputs (batch-norm statistics, nn_ops.hip)
     int prio;                             // MFMA priority of waves 4-7 (the K half that multiplies FIRST in an interval); waves 0-3 use 1
+    // pool_kind 4 (a data gradient whose producer is a batch-norm + ReLU layer): the stored values are g = mask(y > 0) * result, and `pool` receives
+    // the partial sums of the batch-norm BACKWARD pass per tile: [M / 256][2][N] = (sum g, sum g * xhat), xhat = (bnz - bn_mean) * bn_rstd
+    const bf16_t* bnz; const float* bn_mean; const float* bn_rstd;
 };
+// what `pool` points to (HOST memory) when k3_try_dispatch is called with pool_kind 4
+struct K3BnBwd { float* partials; const void* z; const float* mean; const float* rstd; };
 
 #ifdef OCR_EXPERIMENTS
 // diagnostic (experiments build): wall-clock stamps (100 MHz) of every workgroup's first thread — dbg[block * 8 + {0 entry, 1 prologue landed,
@@ -350,12 +355,18 @@ __device__ __forceinline__ void k3_body(const K3Args& g) {
             }
             __syncthreads();
             constexpr int NIT = 256 * U / 512;
-            u32x4 val[NIT], mk[NIT];
+            u32x4 val[NIT], mk[NIT], zt[NIT];
             float st_s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, st_q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float bmu[8], brs[8];
+            if (g.pool_kind == 4) {                       // this thread's 8 channels are the same in every iteration (512 % U == 0)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { bmu[c] = g.bn_mean[n0 + (tid % U) * 8 + c]; brs[c] = g.bn_rstd[n0 + (tid % U) * 8 + c]; }
+            }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int idx = it * 512 + tid, lp = idx / U, u = idx % U;
                 if (flags & K3_MASK) mk[it] = *(const u32x4*)(g.mask + ((long)m0 + lp) * g.N + n0 + u * 8);
+                if (g.pool_kind == 4) zt[it] = *(const u32x4*)(g.bnz + ((long)m0 + lp) * g.N + n0 + u * 8);
                 val[it] = *(const u32x4*)(smem + lp * ROWB + ((u ^ (((lp / H) & SWM) << 1)) << 4));
             }
 #pragma unroll
@@ -378,9 +389,15 @@ __device__ __forceinline__ void k3_body(const K3Args& g) {
                     const float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
 #pragma unroll
                     for (int c = 0; c < 8; ++c) { st_s[c] += f[c]; st_q[c] = fmaf(f[c], f[c], st_q[c]); }
+                } else if (g.pool_kind == 4) {           // batch-norm backward sums of the masked gradient that is stored (bn_bwd_stats_kernel's terms)
+                    const u32x4 z = zt[it];
+                    const float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+                    const float zf[8] = {bf_lo(z.x), bf_hi(z.x), bf_lo(z.y), bf_hi(z.y), bf_lo(z.z), bf_hi(z.z), bf_lo(z.w), bf_hi(z.w)};
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { st_s[c] += f[c]; st_q[c] = fmaf(f[c], (zf[c] - bmu[c]) * brs[c], st_q[c]); }
                 }
             }
-            if (g.pool_kind == 3) {
+            if (g.pool_kind >= 3) {
                 // Batch-norm statistics from the producing convolution (VERDICT r3 item 3 iv / 6): this tile's per-channel sum and sum of
                 // squares over its 256 pixel rows -> partial row m0 / 256 of [M / 256][2][N] (fp32; bn_finalize_kernel adds the rows in
                 // double, fixed order: deterministic).  A thread's 16-byte unit u = tid % U is the same in every iteration (512 % U == 0),
@@ -505,14 +522,20 @@ int k3_try_dispatch(int tile, const void* x, const void* wpack, void* y, int M, 
     const int NC = 256 / H, PS = (NC + 2 + 7) / 8 * 8;
     const bool genw = W % NC != 0;                       // tiles cross image boundaries: the general-width form (one zero row per boundary)
     if (genw && (H == 16 || NC + 2 + (NC + W - 1) / W > PS)) return -1;       // (H = 16: 16-column tiles, W >= 16 there — not instantiated)
-    if (H == 2 && (!genw || (pool_kind && pool_kind != 3))) return -1;       // H = 2 exists in the general-width form only (128-column tiles)
-    if (pool_kind == 3 && (flags & K3_ACCUM)) return -1; // statistics are taken in the staged write-out
+    if (H == 2 && (!genw || (pool_kind && pool_kind < 3))) return -1;       // H = 2 exists in the general-width form only (128-column tiles)
+    if (pool_kind >= 3 && (flags & K3_ACCUM)) return -1; // statistics are taken in the staged write-out
+    if (pool_kind == 4 && !(flags & K3_MASK)) return -1;  // batch-norm backward sums: of the ReLU-masked gradient
     static int genw_on = -1;                             // A/B knob OCR_K3_GENW = 0: general-width shapes stay on conv_k2 / conv_halo
     if (genw_on < 0) { const char* e = ocr_tune_env("OCR_K3_GENW"); genw_on = e ? atoi(e) : 1; }
     if (genw && !genw_on) return -1;
     static int prio = -1;
     if (prio < 0) { const char* e = ocr_tune_env("OCR_K3_PRIO"); prio = e ? atoi(e) : 2; }      // measured: 1 (equal) 349 us, 2 322, 3 324 over the ten layers (profiles/r03af)
-    K3Args g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, prio};
+    K3Args g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, prio,
+                nullptr, nullptr, nullptr};
+    if (pool_kind == 4 && x) {                           // (plan queries pass no operands)
+        const K3BnBwd* e = (const K3BnBwd*)pool;
+        g.pool = (bf16_t*)e->partials; g.bnz = (const bf16_t*)e->z; g.bn_mean = e->mean; g.bn_rstd = e->rstd;
+    }
     const bool single = Cin == 64;
     if (genw) {
         if (tile == 'A') {

@@ -365,6 +365,26 @@ extern "C" int ocr_conv3x3_bf16_stats(const void* x, const void* wpack, void* y,
                                      partials, 3);
     return rc >= 0 ? rc : OCR_ERR_INVALID;
 }
+// The data gradient of a convolution whose INPUT came from a batch-norm + ReLU layer (network.py:176-182 -> the next conv_single): dx = (y > 0) ?
+// conv3x3(dy, flipped weights) : 0 as ocr_conv3x3_bf16 with OCR_EPI_MASK writes it, and in the same epilogue the two per-channel sums the
+// batch-norm backward pass of that producer needs — partials [rows][2][Cout] = (sum dx, sum dx * xhat) per 256-pixel tile, xhat = (z - mean) *
+// rstd of the producer's pre-normalisation output z.  ocr_bn_train_bwd2(partial_rows = rows, premasked) finishes from them: no statistics
+// pass over (z, y, dy), no second read of y.  rows = ocr_conv3x3_bnbwd_rows(...) (0: not covered - use the separate passes).
+struct K3BnBwdHost { float* partials; const void* z; const float* mean; const float* rstd; };      // = conv_k3.hip: K3BnBwd
+extern "C" int ocr_conv3x3_bnbwd_rows(int Nb, int W, int H, int Cin, int Cout) {
+    if (Nb <= 0 || W <= 0 || H <= 0 || Cin <= 0 || Cout <= 0 || !g_use_halo || g_use_pp) return 0;
+    const long M = (long)Nb * W * H;
+    if (M > 0x7fffffffL || (M & 255)) return 0;
+    const int rc = halo_try_dispatch(nullptr, nullptr, nullptr, (int)M, W, H, Cin, Cout, nullptr, (const void*)16, EPI_MASK, nullptr, (void*)16, 4);
+    return rc >= 4 ? (int)(M / 256) : 0;
+}
+extern "C" int ocr_conv3x3_dgrad_bnbwd_bf16(const void* dy, const void* wdgrad, void* dx, int Nb, int W, int H, int Cin, int Cout, const void* mask_y,
+                                            const void* z, const float* mean, const float* rstd, float* partials, void* stream) {
+    if (!dy || !wdgrad || !dx || !mask_y || !z || !mean || !rstd || !partials || !ocr_conv3x3_bnbwd_rows(Nb, W, H, Cin, Cout)) return OCR_ERR_INVALID;
+    K3BnBwdHost e = {partials, z, mean, rstd};
+    const int rc = halo_try_dispatch(dy, wdgrad, dx, Nb * W * H, W, H, Cin, Cout, nullptr, mask_y, EPI_MASK, (hipStream_t)stream, &e, 4);
+    return rc >= 0 ? rc : OCR_ERR_INVALID;
+}
 // conv3x3 + bias + ReLU with the max-pool that follows it (LSTM_train.py:26-33: conv2 -> pool2 2 x 2, conv3_2 / conv4_2 -> 1 x 2
 // over the feature axis) written by the same epilogue: y (kept for the backward pass) AND pooled.  kw = window along W (time),
 // kh = window along H (feature): (1, 2) or (2, 2).  Only the halo kernel has this epilogue: OCR_ERR_INVALID when the shape is

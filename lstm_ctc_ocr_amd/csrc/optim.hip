@@ -57,18 +57,17 @@ __device__ __forceinline__ float optim_gnorm(double* sc) {
     return (float)sqrt(tot[0]);
 }
 
-// pass 1: g += wd * w on the regularised range [reg0, reg1); accumulate sum g^2 (all) and sum w^2 (that range)
-__global__ __launch_bounds__(256) void optim_prep_kernel(const float* __restrict__ p, float* __restrict__ g, long n,
+// pass 1: sum (g + wd * w)^2 (wd on the regularised range [reg0, reg1) only) and sum w^2 over that range
+__global__ __launch_bounds__(256) void optim_prep_kernel(const float* __restrict__ p, const float* __restrict__ g, long n,
                                                          long reg0, long reg1, float wd, double* sc) {
     float s2 = 0.f, r2 = 0.f;
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 256 * 4;
     for (; i < n; i += stride) {   // n, reg0, reg1 % 4 == 0
         f32x4 gv = *(const f32x4*)(g + i);
-        if (i >= reg0 && i < reg1) {
-            f32x4 pv = *(const f32x4*)(p + i);
+        if (i >= reg0 && i < reg1) {            // (round 4: the sum is not stored any more — the update kernel forms it again from g and w, which it
+            f32x4 pv = *(const f32x4*)(p + i);  //  reads anyway: 22 MB of stores less per step; the flat gradient buffer keeps the loss term alone)
             gv = gv + pv * wd;
-            *(f32x4*)(g + i) = gv;
             r2 += pv.x * pv.x + pv.y * pv.y + pv.z * pv.z + pv.w * pv.w;
         }
         s2 += gv.x * gv.x + gv.y * gv.y + gv.z * gv.z + gv.w * gv.w;
@@ -89,15 +88,17 @@ __global__ __launch_bounds__(256) void optim_prep_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v, long n,
                                                           float beta1, float beta2, float eps, float clip,
-                                                          double* sc) {
+                                                          double* sc, long reg0, long reg1, float wd) {
     const float gnorm = optim_gnorm(sc);
     const float scale = (clip > 0.f) ? clip / fmaxf(gnorm, clip) : 1.f;
     const float lrt = (float)sc[SC_LRT];
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 256 * 4;
     for (; i < n; i += stride) {
-        f32x4 gv = *(const f32x4*)(g + i) * scale;
         f32x4 mv = *(const f32x4*)(m + i), vv = *(const f32x4*)(v + i), pv = *(const f32x4*)(p + i);
+        f32x4 gv = *(const f32x4*)(g + i);
+        if (i >= reg0 && i < reg1) gv = gv + pv * wd;          // the L2 term, exactly as the norm pass formed it
+        gv = gv * scale;
         mv = mv * beta1 + gv * (1.f - beta1);
         vv = vv * beta2 + gv * gv * (1.f - beta2);
 #pragma unroll
@@ -108,32 +109,37 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p,
 // Momentum (TF MomentumOptimizer): acc = mom*acc + g; w -= lr*acc
 __global__ __launch_bounds__(256) void momentum_update_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                               float* __restrict__ m, long n, float mom, float clip,
-                                                              double* sc) {
+                                                              double* sc, long reg0, long reg1, float wd) {
     const float gnorm = optim_gnorm(sc);
     const float scale = (clip > 0.f) ? clip / fmaxf(gnorm, clip) : 1.f;
     const float lr = (float)sc[SC_LR];
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 256 * 4;
     for (; i < n; i += stride) {
-        f32x4 gv = *(const f32x4*)(g + i) * scale;
+        f32x4 pv = *(const f32x4*)(p + i);
+        f32x4 gv = *(const f32x4*)(g + i);
+        if (i >= reg0 && i < reg1) gv = gv + pv * wd;
+        gv = gv * scale;
         f32x4 mv = *(const f32x4*)(m + i) * mom + gv;
-        f32x4 pv = *(const f32x4*)(p + i) - mv * lr;
+        pv = pv - mv * lr;
         *(f32x4*)(m + i) = mv; *(f32x4*)(p + i) = pv;
     }
 }
 // RMSProp (TF RMSPropOptimizer defaults: decay .9, momentum 0, eps 1e-10): ms = d ms + (1-d) g^2; w -= lr g / sqrt(ms + eps)
 __global__ __launch_bounds__(256) void rmsprop_update_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                              float* __restrict__ ms, long n, float decay, float eps,
-                                                             float clip, double* sc) {
+                                                             float clip, double* sc, long reg0, long reg1, float wd) {
     const float gnorm = optim_gnorm(sc);
     const float scale = (clip > 0.f) ? clip / fmaxf(gnorm, clip) : 1.f;
     const float lr = (float)sc[SC_LR];
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 256 * 4;
     for (; i < n; i += stride) {
-        f32x4 gv = *(const f32x4*)(g + i) * scale;
-        f32x4 sv = *(const f32x4*)(ms + i) * decay + gv * gv * (1.f - decay);
         f32x4 pv = *(const f32x4*)(p + i);
+        f32x4 gv = *(const f32x4*)(g + i);
+        if (i >= reg0 && i < reg1) gv = gv + pv * wd;
+        gv = gv * scale;
+        f32x4 sv = *(const f32x4*)(ms + i) * decay + gv * gv * (1.f - decay);
 #pragma unroll
         for (int r = 0; r < 4; ++r) pv[r] -= lr * gv[r] / sqrtf(sv[r] + eps);
         *(f32x4*)(ms + i) = sv; *(f32x4*)(p + i) = pv;
@@ -187,9 +193,10 @@ extern "C" int ocr_optim_step(float* params, float* grads, float* state1, float*
     int pblocks = blocks > 1024 ? 1024 : blocks;       // the atomics at the end go to 32 bins, see SC_BINS
     optim_prep_kernel<<<pblocks, 256, 0, stream>>>(params, grads, n, reg_begin, weight_decay > 0.f ? reg_end : reg_begin, weight_decay, sc);
     OCR_CHECK_LAUNCH();
-    if (solver == 0) adam_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, state2, n, beta1, beta2, eps, clip_norm, sc);
-    else if (solver == 1) momentum_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, n, beta1, clip_norm, sc);
-    else if (solver == 2) rmsprop_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, n, beta1, eps, clip_norm, sc);
+    const long r0 = reg_begin, r1 = weight_decay > 0.f ? reg_end : reg_begin;
+    if (solver == 0) adam_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, state2, n, beta1, beta2, eps, clip_norm, sc, r0, r1, weight_decay);
+    else if (solver == 1) momentum_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, n, beta1, clip_norm, sc, r0, r1, weight_decay);
+    else if (solver == 2) rmsprop_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, n, beta1, eps, clip_norm, sc, r0, r1, weight_decay);
     else return OCR_ERR_INVALID;
     OCR_CHECK_LAUNCH();
     return OCR_OK;

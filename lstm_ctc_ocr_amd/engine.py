@@ -279,6 +279,9 @@ class _ConvOp(_Op):
                 job, nblk = ops.conv3x3_wgrad_deferred(x, dz, dw, db, own_ws)
                 if job is not None:
                     sp.w9_pending.append((job, nblk))
+                    sp.w9_pending_bytes = getattr(sp, 'w9_pending_bytes', 0) + own_ws.numel()
+                    if e.w9_flush_bytes and sp.w9_pending_bytes >= e.w9_flush_bytes:
+                        e._flush_w9(sp)         # (knob OCR_W9_FLUSH_MB: reduce while the slabs are still in the Infinity Cache)
             else:
                 ops.conv3x3_wgrad(x, dz, dw, dbias=db, workspace=sp.buf.get('wgrad_ws'))   # bias gradient rides on the same pass
             # a producer with several consumers (residual graphs): where the halo kernel runs, its epilogue adds to what was already
@@ -897,6 +900,7 @@ class Engine(object):
         self.persistent_lstm = persistent_lstm
         self.fuse_conv1_pool = fuse_conv1_pool
         self.fuse_bn_stats = os.environ.get('OCR_FUSE_BN_STATS', '1') != '0'      # batch-norm statistics from the producing convolution's epilogue
+        self.w9_flush_bytes = int(float(os.environ.get('OCR_W9_FLUSH_MB', '0')) * (1 << 20))     # 0: one merged slab reduction per backward body
         self.tn_defer = os.environ.get('OCR_TN_JOBS', '1') != '0'                 # pairs of plain weight-gradient products as one gemm_tn3 launch
         self.group = group
         self.world = 1
@@ -1277,6 +1281,7 @@ class Engine(object):
         slabs, db += column sums).  The job table depends only on the plan's buffers, so it is uploaded once — on the eager run
         that precedes every capture — and the captured graphs replay the launch with the same device table."""
         pend, sp.w9_pending = sp.w9_pending, []
+        sp.w9_pending_bytes = 0
         if not pend:
             return
         raw = b''.join(job for job, _ in pend)
