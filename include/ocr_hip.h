@@ -186,7 +186,14 @@ int ocr_bn_train_fwd2(const void* x, void* y, const float* gamma, const float* b
                       float eps, int relu, void* workspace, const void* residual, int partial_rows, void* pooled, void* stream);
 int ocr_bn_train_bwd2(const void* x, const void* y, const void* dy, void* dx, const float* gamma, const float* save_mean,
                       const float* save_rstd, float* dgamma, float* dbeta, long M, int C, int relu, void* workspace, int pooled_dy,
-                      void* stream);
+                      int partial_rows, void* stream);
+/* partial_rows > 0 (not with pooled_dy): dy is ALREADY ReLU-masked and the workspace holds that many rows [rows][2][C] of (sum dz, sum dz *
+ * xhat) from the data-gradient kernel that wrote dy — ocr_conv3x3_dgrad_bnbwd_bf16: dx = (mask_y > 0) ? conv3x3(dy, wdgrad) : 0 plus those
+ * per-256-pixel-tile sums with xhat = (z - mean) * rstd, rows = ocr_conv3x3_bnbwd_rows(...) (0: shape not covered, use the separate passes).
+ * The batch-norm backward of the producing layer then needs no statistics pass over (z, y, dy) and no second read of y. */
+int ocr_conv3x3_bnbwd_rows(int Nb, int W, int H, int Cin, int Cout);
+int ocr_conv3x3_dgrad_bnbwd_bf16(const void* dy, const void* wdgrad, void* dx, int Nb, int W, int H, int Cin, int Cout, const void* mask_y,
+                                 const void* z, const float* mean, const float* rstd, float* partials, void* stream);
 int ocr_colsum_bf16(const void* a, float* out, long M, int C, long lda, void* stream);
 int ocr_pack_transpose(const float* in, void* out, int R, int Cc, long ldin, int lstm_units, void* stream);
 int ocr_pack_conv_dgrad(const float* w, void* out, int Cin, int Cout, void* stream);

@@ -61,7 +61,9 @@ _SIGS = {
     "ocr_bn_train_fwd": ([_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P, _P, _P], _I),
     "ocr_bn_train_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P], _I),
     "ocr_bn_train_fwd2": ([_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P, _P, _I, _P, _P], _I),
-    "ocr_bn_train_bwd2": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P], _I),
+    "ocr_bn_train_bwd2": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _I, _P], _I),
+    "ocr_conv3x3_bnbwd_rows": ([_I, _I, _I, _I, _I], _I),
+    "ocr_conv3x3_dgrad_bnbwd_bf16": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P], _I),
     "ocr_conv3x3_stats_rows": ([_I, _I, _I, _I, _I, _I], _I),
     "ocr_conv3x3_bf16_stats": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P], _I),
     "ocr_bn_infer_fwd": ([_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P], _I),

@@ -86,7 +86,9 @@ template <int FM /* 16-pixel fragments per wave: 8 or 4 */, int BN /* channels p
           bool SINGLE = false /* C == 64: one chunk, one halo buffer, no halo pieces inside the loop */,
           bool GENW = false /* any image width: a tile's columns may cross image boundaries — a zero row sits in every plane in front of each
                                interior boundary column, local column c at plane row 1 + c + k(c), k(c) = boundaries in [1, c]; the fragment
-                               base is then a lane register per (dw, column block) */>
+                               base is then a lane register per (dw, column block) */,
+          bool BNB = false /* pool_kind 4 (batch-norm backward sums in the write-out): its own instances — compiled into the common epilogue its
+                              48 extra live registers spilled in the 256 x 128 kernels */>
 __device__ __forceinline__ void k3_body(const K3Args& g) {
     constexpr int NW = 8, FN = 4, BM = 256;
     constexpr int WN = BN / 64, WMW = 4 / WN;           // waves along channels / pixels (per K half)
@@ -355,10 +357,10 @@ __device__ __forceinline__ void k3_body(const K3Args& g) {
             }
             __syncthreads();
             constexpr int NIT = 256 * U / 512;
-            u32x4 val[NIT], mk[NIT], zt[NIT];
+            u32x4 val[NIT], mk[NIT], zt[BNB ? NIT : 1];
             float st_s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, st_q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float bmu[8], brs[8];
-            if (g.pool_kind == 4) {                       // this thread's 8 channels are the same in every iteration (512 % U == 0)
+            if (BNB) {                                    // this thread's 8 channels are the same in every iteration (512 % U == 0)
 #pragma unroll
                 for (int c = 0; c < 8; ++c) { bmu[c] = g.bn_mean[n0 + (tid % U) * 8 + c]; brs[c] = g.bn_rstd[n0 + (tid % U) * 8 + c]; }
             }
@@ -366,7 +368,7 @@ __device__ __forceinline__ void k3_body(const K3Args& g) {
             for (int it = 0; it < NIT; ++it) {
                 const int idx = it * 512 + tid, lp = idx / U, u = idx % U;
                 if (flags & K3_MASK) mk[it] = *(const u32x4*)(g.mask + ((long)m0 + lp) * g.N + n0 + u * 8);
-                if (g.pool_kind == 4) zt[it] = *(const u32x4*)(g.bnz + ((long)m0 + lp) * g.N + n0 + u * 8);
+                if (BNB) zt[it] = *(const u32x4*)(g.bnz + ((long)m0 + lp) * g.N + n0 + u * 8);
                 val[it] = *(const u32x4*)(smem + lp * ROWB + ((u ^ (((lp / H) & SWM) << 1)) << 4));
             }
 #pragma unroll
@@ -385,11 +387,11 @@ __device__ __forceinline__ void k3_body(const K3Args& g) {
                     if (!(bf_hi(q.w) > 0.f)) v.w &= 0x0000ffffu;
                 }
                 *(u32x4*)(g.out + ((long)m0 + lp) * g.N + n0 + u * 8) = v;
-                if (g.pool_kind == 3) {                  // statistics of what is stored: the bf16 values, as a separate pass over the tensor would see them
+                if (!BNB && g.pool_kind == 3) {          // statistics of what is stored: the bf16 values, as a separate pass over the tensor would see them
                     const float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
 #pragma unroll
                     for (int c = 0; c < 8; ++c) { st_s[c] += f[c]; st_q[c] = fmaf(f[c], f[c], st_q[c]); }
-                } else if (g.pool_kind == 4) {           // batch-norm backward sums of the masked gradient that is stored (bn_bwd_stats_kernel's terms)
+                } else if (BNB) {                        // batch-norm backward sums of the masked gradient that is stored (bn_bwd_stats_kernel's terms)
                     const u32x4 z = zt[it];
                     const float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
                     const float zf[8] = {bf_lo(z.x), bf_hi(z.x), bf_lo(z.y), bf_hi(z.y), bf_lo(z.z), bf_hi(z.z), bf_lo(z.w), bf_hi(z.w)};
@@ -397,7 +399,7 @@ __device__ __forceinline__ void k3_body(const K3Args& g) {
                     for (int c = 0; c < 8; ++c) { st_s[c] += f[c]; st_q[c] = fmaf(f[c], (zf[c] - bmu[c]) * brs[c], st_q[c]); }
                 }
             }
-            if (g.pool_kind >= 3) {
+            if (BNB || g.pool_kind == 3) {
                 // Batch-norm statistics from the producing convolution (VERDICT r3 item 3 iv / 6): this tile's per-channel sum and sum of
                 // squares over its 256 pixel rows -> partial row m0 / 256 of [M / 256][2][N] (fp32; bn_finalize_kernel adds the rows in
                 // double, fixed order: deterministic).  A thread's 16-byte unit u = tid % U is the same in every iteration (512 % U == 0),
@@ -485,6 +487,25 @@ template <int FM, int BN, int NST, int H, bool SINGLE = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_k3_kernel(K3Args g) { k3_body<FM, BN, NST, H, SINGLE, false>(g); }
 template <int FM, int BN, int NST, int H>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_k3w_kernel(K3Args g) { k3_body<FM, BN, NST, H, false, true>(g); }
+// ... and with the batch-norm backward sums in the write-out (pool_kind 4)
+template <int FM, int BN, int NST, int H, bool GENW>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_k3b_kernel(K3Args g) { k3_body<FM, BN, NST, H, false, GENW, true>(g); }
+
+template <int FM, int BN, int NST, int H, bool GENW>
+static int launch_k3b(const K3Args& g, hipStream_t stream) {
+    if (!g.P) return (GENW ? 6 : 4) + (BN == 128 ? 0 : 1);
+    constexpr int PS = (256 / H + 2 + 7) / 8 * 8, PPIECES = (H * PS / 8 + 7) / 8 * 8;
+    constexpr int need = NST * BN * 128 + 2 * PPIECES * 1024, xch = 8 * (FM / 2) * 4 * 1024, lds = need > xch ? need : xch;
+    static_assert(lds <= 163840 && 256 * BN * 2 + 2 * (512 / (BN / 8)) * BN * 4 <= lds, "LDS");
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv_k3b_kernel<FM, BN, NST, H, GENW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC;
+        attr = true;
+    }
+    conv_k3b_kernel<FM, BN, NST, H, GENW><<<(g.M / 256) * ((g.N + BN - 1) / BN), 512, lds, stream>>>(g);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
 
 template <int FM, int BN, int NST, int H, bool SINGLE = false, bool GENW = false>
 static int launch_k3(const K3Args& g, hipStream_t stream) {
@@ -537,6 +558,16 @@ int k3_try_dispatch(int tile, const void* x, const void* wpack, void* y, int M, 
         g.pool = (bf16_t*)e->partials; g.bnz = (const bf16_t*)e->z; g.bn_mean = e->mean; g.bn_rstd = e->rstd;
     }
     const bool single = Cin == 64;
+    if (pool_kind == 4) {                                // instances exist for the shapes batch-norm layers have here: H in {4, 8}, several chunks
+        if (single || (H != 4 && H != 8)) return -1;
+        if (tile == 'A') {
+            if (Cout % 128) return -1;
+            if (genw) return H == 4 ? launch_k3b<8, 128, 5, 4, true>(g, stream) : launch_k3b<8, 128, 5, 8, true>(g, stream);
+            return H == 4 ? launch_k3b<8, 128, 5, 4, false>(g, stream) : launch_k3b<8, 128, 5, 8, false>(g, stream);
+        }
+        if (genw) return H == 4 ? launch_k3b<4, 64, 4, 4, true>(g, stream) : launch_k3b<4, 64, 4, 8, true>(g, stream);
+        return H == 4 ? launch_k3b<4, 64, 4, 4, false>(g, stream) : launch_k3b<4, 64, 4, 8, false>(g, stream);
+    }
     if (genw) {
         if (tile == 'A') {
             if (Cout % 128) return -1;

@@ -1456,12 +1456,14 @@ extern "C" int ocr_bn_train_fwd2(const void* x, void* y, const float* gamma, con
 }
 // pooled_dy: dy is the gradient of the 1 x 2 max-pool that consumes the layer ([M / 2][C]); both passes route it themselves (first maximum of
 // the row pair, bn_pool_route) instead of reading a full-resolution gradient that a max-pool backward pass wrote.
+// partial_rows > 0: `dy` is already the ReLU-masked gradient and the workspace holds that many rows [rows][2][C] of (sum dz, sum dz * xhat) written
+// by the data-gradient kernel that produced it (ocr_conv3x3_dgrad_bnbwd_bf16): no statistics pass, and the apply pass reads neither y nor a mask.
 static int bn_train_bwd_impl(const void* x, const void* y, const void* dy, void* dx, const float* gamma,
                              const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, long M,
-                             int C, int relu, void* workspace, int pooled_dy, void* stream_) {
+                             int C, int relu, void* workspace, int pooled_dy, int partial_rows, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !y || !dy || !dx || !gamma || !save_mean || !save_rstd || !dgamma || !dbeta || !workspace || (C & 7) ||
-        C > 2048 || M <= 0 || (pooled_dy && (M & 1)))
+        C > 2048 || M <= 0 || (pooled_dy && (M & 1)) || partial_rows < 0 || (partial_rows && pooled_dy))
         return OCR_ERR_INVALID;
     const int rpb = bn_rows_per_block_host(M, 512);
     const int nblk = (int)ceil_div(M, (long)rpb);
@@ -1470,7 +1472,7 @@ static int bn_train_bwd_impl(const void* x, const void* y, const void* dy, void*
 #ifdef OCR_EXPERIMENTS
     {
         int frpb = 0;
-        const int fnb = pooled_dy ? 0 : bnf_blocks(M, C, &frpb);
+        const int fnb = (pooled_dy || partial_rows) ? 0 : bnf_blocks(M, C, &frpb);
         if (fnb > 0) {
             bn_fused_bwd_kernel<<<fnb, 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, save_mean, save_rstd,
                                                          gamma, part, sums, dgamma, dbeta, M, C, relu, frpb);
@@ -1479,10 +1481,14 @@ static int bn_train_bwd_impl(const void* x, const void* y, const void* dy, void*
         }
     }
 #endif
-    bn_bwd_stats_kernel<<<nblk, 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, save_mean,
-                                                  save_rstd, part, M, C, rpb, relu, pooled_dy);
-    OCR_CHECK_LAUNCH();
-    bn_bwd_finalize_kernel<<<ceil_div(C, 16), 256, 0, stream>>>(part, nblk, sums, dgamma, dbeta, C);
+    if (partial_rows > nblk) return OCR_ERR_INVALID;                 // the partial rows share the block rows' space in front of `sums`
+    if (partial_rows) relu = 0;                                       // premasked
+    else {
+        bn_bwd_stats_kernel<<<nblk, 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, save_mean,
+                                                      save_rstd, part, M, C, rpb, relu, pooled_dy);
+        OCR_CHECK_LAUNCH();
+    }
+    bn_bwd_finalize_kernel<<<ceil_div(C, 16), 256, 0, stream>>>(part, partial_rows ? partial_rows : nblk, sums, dgamma, dbeta, C);
     OCR_CHECK_LAUNCH();
     const int arows = 4 * (256 / (C >> 3));                         // rows per block of the apply pass: 4 per thread
     bn_bwd_apply_kernel<<<ceil_div(M, (long)arows), 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy,
@@ -1494,12 +1500,12 @@ static int bn_train_bwd_impl(const void* x, const void* y, const void* dy, void*
 extern "C" int ocr_bn_train_bwd(const void* x, const void* y, const void* dy, void* dx, const float* gamma,
                                 const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, long M,
                                 int C, int relu, void* workspace, void* stream_) {
-    return bn_train_bwd_impl(x, y, dy, dx, gamma, save_mean, save_rstd, dgamma, dbeta, M, C, relu, workspace, 0, stream_);
+    return bn_train_bwd_impl(x, y, dy, dx, gamma, save_mean, save_rstd, dgamma, dbeta, M, C, relu, workspace, 0, 0, stream_);
 }
 extern "C" int ocr_bn_train_bwd2(const void* x, const void* y, const void* dy, void* dx, const float* gamma, const float* save_mean,
                                  const float* save_rstd, float* dgamma, float* dbeta, long M, int C, int relu, void* workspace,
-                                 int pooled_dy, void* stream_) {
-    return bn_train_bwd_impl(x, y, dy, dx, gamma, save_mean, save_rstd, dgamma, dbeta, M, C, relu, workspace, pooled_dy, stream_);
+                                 int pooled_dy, int partial_rows, void* stream_) {
+    return bn_train_bwd_impl(x, y, dy, dx, gamma, save_mean, save_rstd, dgamma, dbeta, M, C, relu, workspace, pooled_dy, partial_rows, stream_);
 }
 extern "C" int ocr_colsum_bf16(const void* a, float* out, long M, int C, long lda, void* stream) {
     if (!a || !out || (C & 7) || C > 2048 || M <= 0) return OCR_ERR_INVALID;

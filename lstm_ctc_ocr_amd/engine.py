@@ -178,6 +178,19 @@ class _ConvOp(_Op):
             sp.fused_pools = getattr(sp, 'fused_pools', set())
             if ops.conv3x3_pool_supported(s[0], s[1], s[2], self.ci, self.co, p.kw_t, p.kh_f):
                 sp.fused_pools.add(p.key)
+        if self.kind == '3x3' and hasattr(self, 'wdgrad') and self.eng.fuse_bn_stats and os.environ.get('OCR_FUSE_BN_BWD', '1') != '0':
+            # the producer is a batch-norm + ReLU convolution feeding only this one: its batch-norm BACKWARD sums (and its ReLU mask) are
+            # taken by this layer's data-gradient kernel (conv_k3's write-out), where a plane-layout kernel takes the shape
+            p = self.prev
+            rows = 0
+            if (isinstance(p, _ConvOp) and p.bn and p.relu and p.consumers == 1 and p.tail_into is None and p.mask_from is None
+                    and p.bn_pool is None and p.kind != 'c1'):
+                rows = ops.conv3x3_bnbwd_rows(s[0], s[1], s[2], self.co, self.ci)
+                if rows * 2 * self.ci * 4 > sp.buf[p.key + '/bnws'].numel() - 2 * self.ci * 8:
+                    rows = 0
+            sp.bn_bwd_rows = getattr(sp, 'bn_bwd_rows', {})
+            if isinstance(p, _ConvOp):
+                sp.bn_bwd_rows[p.key] = rows
         if self.kind == '3x3':      # scratch of the slab weight-gradient kernel
             need = ops.conv3x3_wgrad_workspace_bytes(s[0], s[1], s[2], self.ci, self.co)
             have = sp.buf.get('wgrad_ws')
@@ -266,7 +279,8 @@ class _ConvOp(_Op):
                              e.param('%s/%s/gamma' % (self.name, self.name)), sp.buf[self.key + '/mean'],
                              sp.buf[self.key + '/rstd'], e.grad('%s/%s/gamma' % (self.name, self.name)),
                              e.grad('%s/%s/beta' % (self.name, self.name)), relu, sp.buf[self.key + '/bnws'],
-                             out=dz.view(M, self.co), pooled_dy=self.bn_pool is not None)
+                             out=dz.view(M, self.co), pooled_dy=self.bn_pool is not None,
+                             partial_rows=getattr(sp, 'bn_bwd_rows', {}).get(self.key, 0))
         dw = e.grad(self.name + '/weights')
         db = e.grad(self.name + '/biases') if self.biased else None
         if self.kind == 'c1':
@@ -288,7 +302,12 @@ class _ConvOp(_Op):
             # delivered instead of writing a scratch tensor that a second pass adds
             pdy, finish, acc = e.grad_dst_acc(sp, self.prev, ops.conv3x3_accum_supported(o[0], o[1], o[2], self.co, self.ci))
             if pdy is not None:
-                ops.conv3x3(dz, self.wdgrad.view(self.ci, 3, 3, self.co), out=pdy, mask=pmask, accumulate=acc)
+                p = self.prev
+                if getattr(sp, 'bn_bwd_rows', {}).get(p.key, 0) and not acc:
+                    ops.conv3x3_dgrad_bnbwd(dz, self.wdgrad.view(self.ci, 3, 3, self.co), pdy, p.y(sp), sp.buf[p.key + '/z'],
+                                            sp.buf[p.key + '/mean'], sp.buf[p.key + '/rstd'], sp.buf[p.key + '/bnws'])
+                else:
+                    ops.conv3x3(dz, self.wdgrad.view(self.ci, 3, 3, self.co), out=pdy, mask=pmask, accumulate=acc)
                 finish()
             return
         pdy, finish = e.grad_dst(sp, self.prev)
@@ -900,7 +919,7 @@ class Engine(object):
         self.persistent_lstm = persistent_lstm
         self.fuse_conv1_pool = fuse_conv1_pool
         self.fuse_bn_stats = os.environ.get('OCR_FUSE_BN_STATS', '1') != '0'      # batch-norm statistics from the producing convolution's epilogue
-        self.w9_flush_bytes = int(float(os.environ.get('OCR_W9_FLUSH_MB', '0')) * (1 << 20))     # 0: one merged slab reduction per backward body
+        self.w9_flush_bytes = int(float(os.environ.get('OCR_W9_FLUSH_MB', '80')) * (1 << 20))    # slab bytes after which the pending reductions run (0: one at the end of the body); 80 MB: profiles/r04e
         self.tn_defer = os.environ.get('OCR_TN_JOBS', '1') != '0'                 # pairs of plain weight-gradient products as one gemm_tn3 launch
         self.group = group
         self.world = 1

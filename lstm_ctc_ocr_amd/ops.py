@@ -317,14 +317,15 @@ def bn_train_fwd(x2d, gamma, beta, eps, relu, workspace, out=None, save_mean=Non
     return out, save_mean, save_rstd
 
 
-def bn_train_bwd(x2d, y2d, dy2d, gamma, save_mean, save_rstd, dgamma, dbeta, relu, workspace, out=None, pooled_dy=False):
-    """pooled_dy: dy2d is the gradient of the 1 x 2 max-pool behind the layer ([M / 2, C]); the passes route it themselves."""
+def bn_train_bwd(x2d, y2d, dy2d, gamma, save_mean, save_rstd, dgamma, dbeta, relu, workspace, out=None, pooled_dy=False, partial_rows=0):
+    """pooled_dy: dy2d is the gradient of the 1 x 2 max-pool behind the layer ([M / 2, C]); the passes route it themselves.
+    partial_rows > 0: dy2d is already ReLU-masked and the workspace holds that many partial rows from conv3x3_dgrad_bnbwd."""
     M, C = x2d.shape
     if out is None: out = torch.empty_like(x2d)
-    if pooled_dy:
-        assert tuple(dy2d.shape) == (M // 2, C)
+    if pooled_dy or partial_rows:
+        assert tuple(dy2d.shape) == ((M // 2, C) if pooled_dy else (M, C))
         call("ocr_bn_train_bwd2", ptr(_dev(x2d)), ptr(y2d), ptr(dy2d), ptr(out), ptr(gamma), ptr(save_mean), ptr(save_rstd),
-             ptr(dgamma), ptr(dbeta), M, C, int(relu), ptr(workspace), 1, _st())
+             ptr(dgamma), ptr(dbeta), M, C, int(relu), ptr(workspace), int(bool(pooled_dy)), int(partial_rows), _st())
     else:
         call("ocr_bn_train_bwd", ptr(_dev(x2d)), ptr(y2d), ptr(dy2d), ptr(out), ptr(gamma), ptr(save_mean), ptr(save_rstd),
              ptr(dgamma), ptr(dbeta), M, C, int(relu), ptr(workspace), _st())
@@ -336,6 +337,21 @@ def conv3x3_stats_rows(Nb, W, H, Cin, Cout, *, bias=True, relu=False):
     takes it (host-only query)."""
     flags = (EPI_BIAS if bias else 0) | (EPI_RELU if relu else 0)
     return int(nat.lib().ocr_conv3x3_stats_rows(int(Nb), int(W), int(H), int(Cin), int(Cout), flags))
+
+
+def conv3x3_bnbwd_rows(Nb, W, H, Cin, Cout):
+    """Partial rows conv3x3_dgrad_bnbwd writes for a data gradient of this shape (x = dy [Nb, W, H, Cin] -> dx [.., Cout]); 0: not covered."""
+    return int(nat.lib().ocr_conv3x3_bnbwd_rows(int(Nb), int(W), int(H), int(Cin), int(Cout)))
+
+
+def conv3x3_dgrad_bnbwd(dy, wdgrad, out, mask_y, z, mean, rstd, partials):
+    """out = (mask_y > 0) ? conv3x3(dy, wdgrad) : 0 and partials[rows][2][Cout] = per-tile (sum out, sum out * (z - mean) * rstd): the data
+    gradient into a batch-norm + ReLU layer together with that layer's batch-norm backward sums."""
+    Nb, W, H, Cin = dy.shape
+    Cout = wdgrad.shape[0]
+    call("ocr_conv3x3_dgrad_bnbwd_bf16", ptr(_dev(dy)), ptr(wdgrad), ptr(out), Nb, W, H, Cin, Cout, ptr(mask_y), ptr(z), ptr(mean), ptr(rstd),
+         ptr(partials), _st())
+    return out
 
 
 def conv3x3_stats(x, wpack, out, partials, *, bias=None, relu=False):

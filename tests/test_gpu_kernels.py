@@ -669,6 +669,40 @@ def test_conv3x3_with_batchnorm_statistics_in_the_epilogue(dev, Nb, W, H, Ci, Co
     assert maxerr(z1.float().cpu(), z0.float().cpu()) <= 2.0 ** -6 * float(z0.float().abs().max())       # one bf16 ulp where a value sits on a rounding edge
 
 
+@pytest.mark.parametrize("Nb,W,H,Ci,Co", [(64, 64, 4, 512, 256), (64, 64, 4, 512, 512), (64, 80, 4, 512, 256), (32, 64, 8, 128, 128), (16, 64, 8, 128, 128)])
+def test_conv3x3_dgrad_with_batchnorm_backward_sums(dev, Nb, W, H, Ci, Co):
+    """Round 4: the data gradient INTO a batch-norm + ReLU layer (conv_k3b): dx = (y > 0) ? conv3x3(dy, flipped weights) : 0, bit-identical to
+    the masked convolution, plus that layer's batch-norm backward sums per tile; bn_train_bwd(partial_rows) then matches the three-pass form."""
+    rows = ops.conv3x3_bnbwd_rows(Nb, W, H, Ci, Co)
+    if not ops.conv3x3_kernel_choice(Nb, W, H, Ci, Co, bias=False, relu=False, mask=True).startswith('conv_k3'):
+        assert rows == 0
+        return
+    M = Nb * W * H
+    assert rows == M // 256
+    dy = bf(gen((Nb, W, H, Ci), 1)).to(dev).to(BF); w = bf(gen((3, 3, Co, Ci), 2, 0.05))
+    wd = torch.empty((Co, 3, 3, Ci), dtype=BF, device=dev)
+    ops.pack_conv_dgrad(w.to(dev), wd)                               # [Co][9][Ci]: the data-gradient operand of a conv with C_in = Co, C_out = Ci
+    z = bf(gen((M, Co), 3) * 2 + 0.5).to(dev).to(BF)
+    gamma = (gen((Co,), 4) + 1.5).to(dev); beta = gen((Co,), 5).to(dev)
+    ws = ops.bn_workspace(M, Co, dev)
+    y, mean, rstd = ops.bn_train_fwd(z, gamma, beta, 1e-3, True, ws)
+    dx0 = ops.conv3x3(dy, wd, mask=y.view(Nb, W, H, Co))
+    ws1 = ops.bn_workspace(M, Co, dev); ws1.fill_(0x7f)
+    dx1 = torch.empty_like(dx0)
+    ops.conv3x3_dgrad_bnbwd(dy, wd, dx1, y.view(Nb, W, H, Co), z, mean, rstd, ws1)
+    assert torch.equal(dx1, dx0)
+    part = ws1[:rows * 2 * Co * 4].view(torch.float32).view(rows, 2, Co).double().cpu()
+    g = dx0.view(M, Co).double().cpu()
+    xhat = (z.double().cpu() - mean.double().cpu()) * rstd.double().cpu()
+    assert relerr(part[:, 0].sum(0), g.sum(0)) < 1e-5 and relerr(part[:, 1].sum(0), (g * xhat).sum(0)) < 1e-5
+    dg0 = torch.zeros(Co, device=dev); db0 = torch.zeros(Co, device=dev)
+    dz0 = ops.bn_train_bwd(z, y, dx0.view(M, Co), gamma, mean, rstd, dg0, db0, True, ws)
+    dg1 = torch.zeros(Co, device=dev); db1 = torch.zeros(Co, device=dev)
+    dz1 = ops.bn_train_bwd(z, y, dx1.view(M, Co), gamma, mean, rstd, dg1, db1, True, ws1, partial_rows=rows)
+    assert relerr(dg1.cpu(), dg0.cpu()) < 1e-5 and relerr(db1.cpu(), db0.cpu()) < 1e-5
+    assert maxerr(dz1.float().cpu(), dz0.float().cpu()) <= 2.0 ** -6 * float(dz0.float().abs().max())
+
+
 def test_small_ops(dev):
     a = bf(gen((1000, 512), 1))
     out = torch.ones(512, device=dev)
