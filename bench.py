@@ -72,14 +72,18 @@ def conv_roofline(eng, device, workload):
             pool = None
             if op.pool_after is not None and op.pool_after.key in getattr(sp, 'fused_pools', ()):
                 pool = (op.pool_after.kw_t, op.pool_after.kh_f)          # the step's launch writes the max-pool too: time that form
-            shapes.append((N, W, H, Ci, op.co, hasattr(op, 'wdgrad'), pool))
+            # batch-norm layers: the forward launch also leaves the statistics partials behind, and the data gradient INTO a batch-norm + ReLU
+            # producer also takes that layer's backward sums (conv_k3b) — the probe times the launches the step runs
+            fwd_stats = bool(getattr(sp, 'bn_stat_rows', {}).get(op.key, 0))
+            dgrad_bnb = bool(getattr(sp, 'bn_bwd_rows', {}).get(op.prev.key, 0)) if hasattr(op, 'wdgrad') else False
+            shapes.append((N, W, H, Ci, op.co, hasattr(op, 'wdgrad'), pool, fwd_stats, dgrad_bnb))
     tot_fl, exe_fl, tot_t, n_launch = 0.0, 0.0, 0.0, 0
     # shader clock the kernel really runs at: workgroup 0 stamps {shader-clock counter, 100 MHz wall clock} at entry and exit
     from lstm_ctc_ocr_amd import _native as nat
     clk = torch.zeros(4, dtype=torch.int64, device=device)
     nat.call("ocr_conv_halo_clock_debug", clk.data_ptr())
     clk_cycles = clk_ticks = 0.0
-    for (N, W, H, Ci, Co, has_dgrad, pool) in shapes:
+    for (N, W, H, Ci, Co, has_dgrad, pool, fwd_stats, dgrad_bnb) in shapes:
         x = torch.randn(N, W, H, Ci, device=device).to(torch.bfloat16)
         y = torch.randn(N, W, H, Co, device=device).to(torch.bfloat16)
         wf = (torch.randn(Co, 3, 3, Ci, device=device) * 0.05).to(torch.bfloat16)
@@ -89,9 +93,17 @@ def conv_roofline(eng, device, workload):
         if pool is not None:
             pooled = torch.empty(N, W // pool[0], H // pool[1], Co, device=device, dtype=torch.bfloat16)
             fns = [(lambda: ops.conv3x3_relu_pool(x, wf, oy, pooled, b, pool[0], pool[1]), ops.conv3x3_kernel_choice(N, W, H, Ci, Co, pool=pool))]
+        elif fwd_stats:
+            part = ops.bn_workspace(N * W * H, Co, device)
+            fns = [(lambda: ops.conv3x3_stats(x, wf, oy, part, bias=b), ops.conv3x3_kernel_choice(N, W, H, Ci, Co, relu=False))]
         else:
             fns = [(lambda: ops.conv3x3(x, wf, out=oy, bias=b, relu=True), ops.conv3x3_kernel_choice(N, W, H, Ci, Co))]
-        if has_dgrad:
+        if has_dgrad and dgrad_bnb:
+            part2 = ops.bn_workspace(N * W * H, Ci, device)
+            mean, rstd = torch.zeros(Ci, device=device), torch.ones(Ci, device=device)
+            fns.append((lambda: ops.conv3x3_dgrad_bnbwd(y, wd, ox, x, x, mean, rstd, part2),
+                        ops.conv3x3_kernel_choice(N, W, H, Co, Ci, bias=False, relu=False, mask=True)))
+        elif has_dgrad:
             fns.append((lambda: ops.conv3x3(y, wd, out=ox, mask=x), ops.conv3x3_kernel_choice(N, W, H, Co, Ci, bias=False, relu=False, mask=True)))
         for fn, kname in fns:
             for _ in range(3):
@@ -132,7 +144,7 @@ def conv_roofline(eng, device, workload):
         src = os.path.basename(cands[-1])
         pm = json.load(open(cands[-1]))
         pmc_commit, pmc_build = pm.get("commit"), pm.get("build_id")
-        conv = [k for k in pm.get("kernels", []) if k["symbol"].startswith(("_Z16conv_halo_kernel", "_Z14conv_k2_kernel", "_Z14conv_k3_kernel", "_Z15conv_k3w_kernel"))]
+        conv = [k for k in pm.get("kernels", []) if k["symbol"].startswith(("_Z16conv_halo_kernel", "_Z14conv_k2_kernel", "_Z14conv_k3_kernel", "_Z15conv_k3w_kernel", "_Z15conv_k3b_kernel"))]
         if pm.get("workload") != workload:
             pmc_error = "%s was taken on workload %r, this run is %r" % (src, pm.get("workload"), workload)
         elif pmc_build != build_id:
@@ -149,7 +161,7 @@ def conv_roofline(eng, device, workload):
             if all("clock_mhz" in k for k in conv):
                 pmc_clock = sum(k["launches"] * k["avg_us"] * k["clock_mhz"] for k in conv) / tm
             pmc_avg_us = tm / nl
-    return {"bound": "mfma", "kernel": "conv_k3_kernel / conv_k2_kernel / conv_halo_kernel (implicit-GEMM 3x3 SAME conv, forward + data gradient: %d launches/step)" % n_launch,
+    return {"bound": "mfma", "kernel": "conv_k3_kernel / conv_k3b_kernel / conv_k2_kernel / conv_halo_kernel (implicit-GEMM 3x3 SAME conv, forward + data gradient, with their fused epilogues: %d launches/step)" % n_launch,
             "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK,
             "avg_launch_us": tot_t / n_launch * 1e6, "algorithmic_gflop_per_launch": tot_fl / n_launch / 1e9,
             "executed_flop_frac": exe_fl / tot_fl, "achieved_executed": exe_fl / tot_t / 1e12,

@@ -63,10 +63,32 @@ __global__ __launch_bounds__(256) void optim_prep_kernel(const float* __restrict
     float s2 = 0.f, r2 = 0.f;
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 256 * 4;
-    for (; i < n; i += stride) {   // n, reg0, reg1 % 4 == 0
+    // (round 4: g + wd * w is not stored any more — the update kernel forms it again from g and w, which it reads anyway: 22 MB of stores less
+    //  per step; the flat gradient buffer keeps the loss term alone.  Four independent 16-byte load pairs per iteration: the pass is a pure
+    //  read stream now and was latency-bound with one pair in flight per thread.)
+    for (; i + 3 * stride < n; i += 4 * stride) {   // n, reg0, reg1 % 4 == 0
+        f32x4 gv[4], pv[4];
+        bool in[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long ik = i + k * stride;
+            in[k] = ik >= reg0 && ik < reg1;
+            gv[k] = *(const f32x4*)(g + ik);
+            pv[k] = in[k] ? *(const f32x4*)(p + ik) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (in[k]) {
+                gv[k] = gv[k] + pv[k] * wd;
+                r2 += pv[k].x * pv[k].x + pv[k].y * pv[k].y + pv[k].z * pv[k].z + pv[k].w * pv[k].w;
+            }
+            s2 += gv[k].x * gv[k].x + gv[k].y * gv[k].y + gv[k].z * gv[k].z + gv[k].w * gv[k].w;
+        }
+    }
+    for (; i < n; i += stride) {
         f32x4 gv = *(const f32x4*)(g + i);
-        if (i >= reg0 && i < reg1) {            // (round 4: the sum is not stored any more — the update kernel forms it again from g and w, which it
-            f32x4 pv = *(const f32x4*)(p + i);  //  reads anyway: 22 MB of stores less per step; the flat gradient buffer keeps the loss term alone)
+        if (i >= reg0 && i < reg1) {
+            f32x4 pv = *(const f32x4*)(p + i);
             gv = gv + pv * wd;
             r2 += pv.x * pv.x + pv.y * pv.y + pv.z * pv.z + pv.w * pv.w;
         }

@@ -884,8 +884,10 @@ class ShapePlan(object):
         # still sit in the Infinity Cache when the merged reduction reads them (162 MB for the CRNN at 64 x 256: 18 + 4 x 36 MB).  A deep graph (configs[4]:
         # 32 layers, ~0.4 GB of slabs) would read them back from HBM — measured 3 % slower than reducing behind each layer — so
         # such a plan falls back to ONE shared workspace and immediate reductions.
+        # (round 4: with a flush threshold — OCR_W9_FLUSH_MB, default 80 — no more than that plus one layer of slabs is ever pending, so a deep
+        #  plan keeps per-layer workspaces too and reduces ~80 MB at a time in merged launches instead of behind each of its 32 layers)
         own = [k for k in self.buf if k.endswith('/w9ws')]
-        if own and sum(self.buf[k].numel() for k in own) > eng.w9_defer_max_bytes:
+        if own and sum(self.buf[k].numel() for k in own) > eng.w9_defer_max_bytes and not eng.w9_flush_bytes:
             need = max(self.buf[k].numel() for k in own)
             for k in own:
                 del self.buf[k]
