@@ -78,6 +78,7 @@ def conv_roofline(eng, device, workload):
             dgrad_bnb = bool(getattr(sp, 'bn_bwd_rows', {}).get(op.prev.key, 0)) if hasattr(op, 'wdgrad') else False
             shapes.append((N, W, H, Ci, op.co, hasattr(op, 'wdgrad'), pool, fwd_stats, dgrad_bnb))
     tot_fl, exe_fl, tot_t, n_launch = 0.0, 0.0, 0.0, 0
+    plain_t = 0.0                 # the same launches with the batch-norm work taken out of their write-outs again (secondary figure)
     # shader clock the kernel really runs at: workgroup 0 stamps {shader-clock counter, 100 MHz wall clock} at entry and exit
     from lstm_ctc_ocr_amd import _native as nat
     clk = torch.zeros(4, dtype=torch.int64, device=device)
@@ -105,7 +106,22 @@ def conv_roofline(eng, device, workload):
                         ops.conv3x3_kernel_choice(N, W, H, Co, Ci, bias=False, relu=False, mask=True)))
         elif has_dgrad:
             fns.append((lambda: ops.conv3x3(y, wd, out=ox, mask=x), ops.conv3x3_kernel_choice(N, W, H, Co, Ci, bias=False, relu=False, mask=True)))
-        for fn, kname in fns:
+        plain = {}
+        if fwd_stats:
+            plain[0] = lambda: ops.conv3x3(x, wf, out=oy, bias=b, relu=False)
+        if has_dgrad and dgrad_bnb:
+            plain[1] = lambda: ops.conv3x3(y, wd, out=ox)        # (before round 4 this launch carried neither the mask nor the sums)
+        for fi, (fn, kname) in enumerate(fns):
+            if fi in plain:
+                for _ in range(3):
+                    plain[fi]()
+                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                p0.record()
+                for _ in range(10):
+                    plain[fi]()
+                p1.record()
+                torch.cuda.synchronize()
+                plain_dt = p0.elapsed_time(p1) * 1e-3 / 10
             for _ in range(3):
                 fn()
             clk.zero_()
@@ -116,6 +132,7 @@ def conv_roofline(eng, device, workload):
             e1.record()
             torch.cuda.synchronize()
             tot_t += e0.elapsed_time(e1) * 1e-3 / 10
+            plain_t += plain_dt if fi in plain else e0.elapsed_time(e1) * 1e-3 / 10
             tot_fl += 2.0 * N * W * H * 9 * Ci * Co
             exe_fl += 2.0 * N * W * H * 9 * Ci * Co * ((1.0 - 2.0 / (3.0 * H)) if kname.startswith("conv_k3") else 1.0)
             n_launch += 1
@@ -164,6 +181,10 @@ def conv_roofline(eng, device, workload):
     return {"bound": "mfma", "kernel": "conv_k3_kernel / conv_k3b_kernel / conv_k2_kernel / conv_halo_kernel (implicit-GEMM 3x3 SAME conv, forward + data gradient, with their fused epilogues: %d launches/step)" % n_launch,
             "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK,
             "avg_launch_us": tot_t / n_launch * 1e6, "algorithmic_gflop_per_launch": tot_fl / n_launch / 1e9,
+            "frac_plain_write_outs": tot_fl / plain_t / MFMA_BF16_PEAK,
+            "fused_note": "`frac` times the launches AS THE STEP RUNS THEM: since round 4 the batch-norm layers' forward statistics and the ReLU mask + "
+                          "backward sums of a batch-norm producer ride in these kernels' write-outs (they replaced separate HBM-bound passes: the step is "
+                          "faster, these launches are longer); frac_plain_write_outs times the same convolutions without that work",
             "executed_flop_frac": exe_fl / tot_fl, "achieved_executed": exe_fl / tot_t / 1e12,
             "executed_note": "`achieved` counts 2*M*K*N of every launch (SURVEY 8d) including the SAME-padding taps the plane-layout kernels "
                              "(conv_k3 / conv_k3w) never issue: 2/(3H) of a layer's MFMAs (H=4: a sixth); `achieved_executed` counts only issued MFMAs",

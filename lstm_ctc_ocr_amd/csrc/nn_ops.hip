@@ -338,7 +338,10 @@ void conv1_pool_bwd2_kernel(const float* __restrict__ x, const float* __restrict
 
 __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, bf16_t* __restrict__ p,
-                                                             int Nb, int W, int H, int Cout) {
+                                                             int Nb, int W, int H, int Cout, f32x4* __restrict__ zero, long zero_n4) {
+    // the step's flat gradient buffer is cleared by the FIRST kernel of the forward pass (round 4: it was a fill launch of its own): the
+    // stores go out here and drain beside the VALU-bound work below
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n4; i += (long)gridDim.x * 256) zero[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int groups = Cout >> 3, gq = threadIdx.x % groups, plane = threadIdx.x / groups, planes = 256 / groups;
     float wr[9][8], br[8];
 #pragma unroll
@@ -1341,18 +1344,28 @@ extern "C" int ocr_eltwise_bf16(int op, const void* a, const void* b, void* out,
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
-extern "C" int ocr_conv1_pool_fwd(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout,
-                                  void* stream) {
+static int conv1_pool_fwd_impl(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout,
+                               float* zero, long zero_n, void* stream) {
     if (!x || !w || !bias || !p || (Cout & 7) || Cout > 1024 || 256 % (Cout >> 3) || (W & 1) || (H & 1)) return OCR_ERR_INVALID;
+    if (zero_n < 0 || (zero_n & 3) || (zero_n && (!zero || ((size_t)zero & 15)))) return OCR_ERR_INVALID;
     long total = (long)Nb * (W / 2) * (H / 2) * (Cout >> 3);
 #ifdef OCR_EXPERIMENTS
-    if (!conv1_v1() && (long)Nb * (W / 2) * (H / 2) < 0x7fffffffL && (long)Nb * W * H < 0x7fffffffL && (long)W * H < 0x7fffffffL)
+    if (!zero_n && !conv1_v1() && (long)Nb * (W / 2) * (H / 2) < 0x7fffffffL && (long)Nb * W * H < 0x7fffffffL && (long)W * H < 0x7fffffffL)
         conv1_pool_fwd2_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout);
     else
 #endif
-        conv1_pool_fwd_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout);
+        conv1_pool_fwd_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout, (f32x4*)zero, zero_n / 4);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
+}
+extern "C" int ocr_conv1_pool_fwd(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout,
+                                  void* stream) {
+    return conv1_pool_fwd_impl(x, w, bias, p, Nb, W, H, Cout, nullptr, 0, stream);
+}
+// the same launch also clears zero[0 .. zero_n) (fp32, zero_n % 4 == 0, 16-byte aligned): the flat gradient buffer of the step that begins
+extern "C" int ocr_conv1_pool_fwd_zero(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout,
+                                       float* zero, long zero_n, void* stream) {
+    return conv1_pool_fwd_impl(x, w, bias, p, Nb, W, H, Cout, zero, zero_n, stream);
 }
 extern "C" int ocr_conv1_pool_bwd(const float* x, const float* w, const float* bias, const void* dp, float* dw, float* db,
                                   int Nb, int W, int H, int Cout, void* stream) {

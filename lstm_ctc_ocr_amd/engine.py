@@ -220,7 +220,8 @@ class _ConvOp(_Op):
         s, o = sp.shape[self.key]
         bias = e.param(self.name + '/biases') if self.biased else None
         if self.fused_pool is not None:
-            ops.conv1_pool_fwd(x, e.param(self.name + '/weights'), bias, out=self.fused_pool.y(sp))
+            zero, e._zero_pending = (e.grads if e._zero_pending else None), False     # the gradient buffer's clear rides on this launch
+            ops.conv1_pool_fwd(x, e.param(self.name + '/weights'), bias, out=self.fused_pool.y(sp), zero=zero)
             return
         y = self.y(sp)
         if self.kind == 'c1':
@@ -1241,10 +1242,15 @@ class Engine(object):
 
     def _forward(self, sp, training=False):
         self.training = training
-        if training:
+        # the flat gradient buffer is cleared by the forward pass's first kernel where that is conv1 + pool (one launch less); else by a fill
+        self._zero_pending = bool(training) and self.grads.numel() % 4 == 0 and os.environ.get('OCR_FUSE_ZERO', '1') != '0'
+        if training and not self._zero_pending:
             self.grads.zero_()
         for op in self.ops:
             op.fwd(sp)
+        if self._zero_pending:
+            self.grads.zero_()
+            self._zero_pending = False
 
     def _loss_and_backward(self, sp, flush=True):
         sp.dy_done = set()

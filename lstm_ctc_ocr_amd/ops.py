@@ -264,12 +264,16 @@ def eltwise(op, a, b, out):
     return out
 
 
-def conv1_pool_fwd(x, w, bias, out=None):
+def conv1_pool_fwd(x, w, bias, out=None, zero=None):
+    """zero (fp32 tensor, numel % 4 == 0): cleared by the same launch (the step's flat gradient buffer)."""
     Nb, W, H = x.shape
     Cout = w.shape[-1]
     if out is None:
         out = torch.empty((Nb, W // 2, H // 2, Cout), dtype=BF16, device=x.device)
-    call("ocr_conv1_pool_fwd", ptr(_dev(x)), ptr(w), ptr(bias), ptr(out), Nb, W, H, Cout, _st())
+    if zero is not None:
+        call("ocr_conv1_pool_fwd_zero", ptr(_dev(x)), ptr(w), ptr(bias), ptr(out), Nb, W, H, Cout, ptr(_dev(zero)), zero.numel(), _st())
+    else:
+        call("ocr_conv1_pool_fwd", ptr(_dev(x)), ptr(w), ptr(bias), ptr(out), Nb, W, H, Cout, _st())
     return out
 
 
