@@ -162,9 +162,14 @@ int ocr_eltwise_bf16(int op, const void* a, const void* b, void* out, long n, vo
 /* conv1 + ReLU + 2x2 max-pool in one pass (LSTM_train.py:24-25); the backward recomputes the window instead of reading a
  * stored 67 MB activation: p / dp are the POOLED map [Nb, W/2, H/2, Cout] */
 int ocr_conv1_pool_fwd(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout, void* stream);
-/* ... the same launch also clears zero[0 .. zero_n) (fp32; zero_n % 4 == 0, 16-byte aligned): the step's flat gradient buffer */
-int ocr_conv1_pool_fwd_zero(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout,
-                            float* zero, long zero_n, void* stream);
+/* training form.  codes (may be NULL; Cout == 64): uint32 [Nb * W/2 * H/2][8], 4 bits per pooled output = position of the window's first
+ * maximum (bf16-rounded values, TF scan order) | ReLU bit << 2, consumed by ocr_conv1_pool_bwd_codes (bit-identical gradients without
+ * recomputing the windows).  zero (may be NULL): fp32 [zero_n] cleared by the same launch (zero_n % 4 == 0, 16-byte aligned): the step's
+ * flat gradient buffer. */
+int ocr_conv1_pool_fwd_train(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout,
+                             void* codes, float* zero, long zero_n, void* stream);
+int ocr_conv1_pool_bwd_codes(const float* x, const float* w, const float* bias, const void* dp, float* dw, float* db,
+                             int Nb, int W, int H, int Cout, const void* codes, void* stream);
 int ocr_conv1_pool_bwd(const float* x, const float* w, const float* bias, const void* dp, float* dw, float* db, int Nb,
                        int W, int H, int Cout, void* stream);
 int ocr_maxpool_fwd(const void* x, void* y, int Nb, int W, int H, int C, int kw, int kh, void* stream);

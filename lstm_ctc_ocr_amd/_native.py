@@ -54,7 +54,8 @@ _SIGS = {
     "ocr_conv1_wgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "ocr_eltwise_bf16": ([_I, _P, _P, _P, _L, _P], _I),
     "ocr_conv1_pool_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
-    "ocr_conv1_pool_fwd_zero": ([_P, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P], _I),
+    "ocr_conv1_pool_fwd_train": ([_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _L, _P], _I),
+    "ocr_conv1_pool_bwd_codes": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P], _I),
     "ocr_conv1_pool_bwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "ocr_maxpool_fwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "ocr_maxpool_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),

@@ -131,9 +131,8 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
 // pooled gradient to the first maximum (TF scan order: W outer, H inner) and accumulates dW / db in registers.
 //   reference: LSTM_train.py:24-25 (conv_single 3x3 c_i=1 -> max_pool 2,2), network.py:160-191, 343-350
 // ============================================================================================
-__device__ __forceinline__ void conv1_window(const float* __restrict__ xn, int W, int H, int w0, int h0,
-                                             const float (&wr)[9][8], const float (&br)[8], float (&o)[4][8], float (&patch)[4][4]) {
-    // 4x4 input patch around the 2x2 output window (rows w0-1..w0+2, cols h0-1..h0+2), zero outside the image
+// 4x4 input patch around the 2x2 output window (rows w0-1..w0+2, cols h0-1..h0+2), zero outside the image
+__device__ __forceinline__ void conv1_patch(const float* __restrict__ xn, int W, int H, int w0, int h0, float (&patch)[4][4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -141,6 +140,19 @@ __device__ __forceinline__ void conv1_window(const float* __restrict__ xn, int W
             const int ww = w0 - 1 + i, hh = h0 - 1 + j;
             patch[i][j] = ((unsigned)ww < (unsigned)W && (unsigned)hh < (unsigned)H) ? xn[(long)ww * H + hh] : 0.f;
         }
+}
+// arg-max of the 2x2 window on the bf16-ROUNDED outputs (what the forward stores and an unfused max-pool backward would compare: ties resolve
+// to the first element in TF scan order) and the ReLU bit of the winner: code = best | (winner > 0) << 2
+__device__ __forceinline__ int conv1_pool_code(float o0, float o1, float o2, float o3) {
+    const float r[4] = {bf_lo(pack_bf2(o0, 0.f)), bf_lo(pack_bf2(o1, 0.f)), bf_lo(pack_bf2(o2, 0.f)), bf_lo(pack_bf2(o3, 0.f))};
+    int best = 0; float bvv = r[0];
+#pragma unroll
+    for (int e = 1; e < 4; ++e) if (r[e] > bvv) { bvv = r[e]; best = e; }
+    return best | ((bvv > 0.f) ? 4 : 0);
+}
+__device__ __forceinline__ void conv1_window(const float* __restrict__ xn, int W, int H, int w0, int h0,
+                                             const float (&wr)[9][8], const float (&br)[8], float (&o)[4][8], float (&patch)[4][4]) {
+    conv1_patch(xn, W, H, w0, h0, patch);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int a = e >> 1, b = e & 1;               // window element (a over W, b over H) = TF scan order
@@ -338,7 +350,8 @@ void conv1_pool_bwd2_kernel(const float* __restrict__ x, const float* __restrict
 
 __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, bf16_t* __restrict__ p,
-                                                             int Nb, int W, int H, int Cout, f32x4* __restrict__ zero, long zero_n4) {
+                                                             int Nb, int W, int H, int Cout, f32x4* __restrict__ zero, long zero_n4,
+                                                             uint32_t* __restrict__ codes) {
     // the step's flat gradient buffer is cleared by the FIRST kernel of the forward pass (round 4: it was a fill launch of its own): the
     // stores go out here and drain beside the VALU-bound work below
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n4; i += (long)gridDim.x * 256) zero[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -364,13 +377,19 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const float* __rest
         for (int c = 0; c < 8; ++c) m[c] = fmaxf(fmaxf(o[0][c], o[1][c]), fmaxf(o[2][c], o[3][c]));   // rounding is monotone: max then round
         u32x4 pk = {pack_bf2(m[0], m[1]), pack_bf2(m[2], m[3]), pack_bf2(m[4], m[5]), pack_bf2(m[6], m[7])};
         *(u32x4*)(p + op * Cout + gq * 8) = pk;
+        if (codes != nullptr) {       // training: the pool's routing and the ReLU bit per output, 4 bits each — the backward pass need not recompute the window
+            uint32_t word = 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) word |= (uint32_t)conv1_pool_code(o[0][c], o[1][c], o[2][c], o[3][c]) << (4 * c);
+            codes[op * groups + gq] = word;
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, const bf16_t* __restrict__ dp,
                                                              float* __restrict__ dw, float* __restrict__ db, int Nb, int W,
-                                                             int H, int Cout, int pix_per_block) {
+                                                             int H, int Cout, int pix_per_block, const uint32_t* __restrict__ codes) {
     // Cout == 64: 8 channel groups x 32 pixel lanes
     const int gq = threadIdx.x & 7, pl = threadIdx.x >> 3;
     float wr[9][8], br[8];
@@ -394,19 +413,21 @@ __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const float* __rest
         const int wo = (int)(q % Wo);
         const long n = q / Wo;
         float o[4][8], patch[4][4];
-        conv1_window(x + n * W * H, W, H, wo * 2, ho * 2, wr, br, o, patch);
+        uint32_t word = 0;
+        if (codes != nullptr) {         // round 4: routing + ReLU bits saved by the forward pass (conv1_pool_code): no recomputation of the window
+            conv1_patch(x + n * W * H, W, H, wo * 2, ho * 2, patch);
+            word = codes[op * 8 + gq];
+        } else {
+            conv1_window(x + n * W * H, W, H, wo * 2, ho * 2, wr, br, o, patch);
+        }
         float g[8];
         unpack8(*(const u32x4*)(dp + op * Cout + gq * 8), g);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             // the forward stored bf16(max); compare on the same rounded values so ties resolve exactly like the unfused path
-            float r[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = bf_lo(pack_bf2(o[e][c], 0.f));
-            int best = 0; float bvv = r[0];
-#pragma unroll
-            for (int e = 1; e < 4; ++e) if (r[e] > bvv) { bvv = r[e]; best = e; }
-            const float gv = (bvv > 0.f) ? g[c] : 0.f;             // ReLU mask of the winning element
+            const int code = codes != nullptr ? (int)((word >> (4 * c)) & 7u) : conv1_pool_code(o[0][c], o[1][c], o[2][c], o[3][c]);
+            const int best = code & 3;
+            const float gv = (code & 4) ? g[c] : 0.f;              // ReLU mask of the winning element
             acc[9][c] += gv;
             const int a = best >> 1, b = best & 1;
 #pragma unroll
@@ -1345,43 +1366,58 @@ extern "C" int ocr_eltwise_bf16(int op, const void* a, const void* b, void* out,
     return OCR_OK;
 }
 static int conv1_pool_fwd_impl(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout,
-                               float* zero, long zero_n, void* stream) {
+                               float* zero, long zero_n, void* codes, void* stream) {
     if (!x || !w || !bias || !p || (Cout & 7) || Cout > 1024 || 256 % (Cout >> 3) || (W & 1) || (H & 1)) return OCR_ERR_INVALID;
     if (zero_n < 0 || (zero_n & 3) || (zero_n && (!zero || ((size_t)zero & 15)))) return OCR_ERR_INVALID;
+    if (codes && (Cout != 64 || ((size_t)codes & 3))) return OCR_ERR_INVALID;            // the routing codes exist for the 64-filter layer the backward kernel handles
     long total = (long)Nb * (W / 2) * (H / 2) * (Cout >> 3);
 #ifdef OCR_EXPERIMENTS
-    if (!zero_n && !conv1_v1() && (long)Nb * (W / 2) * (H / 2) < 0x7fffffffL && (long)Nb * W * H < 0x7fffffffL && (long)W * H < 0x7fffffffL)
+    if (!zero_n && !codes && !conv1_v1() && (long)Nb * (W / 2) * (H / 2) < 0x7fffffffL && (long)Nb * W * H < 0x7fffffffL && (long)W * H < 0x7fffffffL)
         conv1_pool_fwd2_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout);
     else
 #endif
-        conv1_pool_fwd_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout, (f32x4*)zero, zero_n / 4);
+        conv1_pool_fwd_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout, (f32x4*)zero, zero_n / 4,
+                                                                                      (uint32_t*)codes);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
 extern "C" int ocr_conv1_pool_fwd(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout,
                                   void* stream) {
-    return conv1_pool_fwd_impl(x, w, bias, p, Nb, W, H, Cout, nullptr, 0, stream);
+    return conv1_pool_fwd_impl(x, w, bias, p, Nb, W, H, Cout, nullptr, 0, nullptr, stream);
 }
-// the same launch also clears zero[0 .. zero_n) (fp32, zero_n % 4 == 0, 16-byte aligned): the flat gradient buffer of the step that begins
-extern "C" int ocr_conv1_pool_fwd_zero(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout,
-                                       float* zero, long zero_n, void* stream) {
-    return conv1_pool_fwd_impl(x, w, bias, p, Nb, W, H, Cout, zero, zero_n, stream);
+// The training form of the same launch.  codes (may be NULL; Cout == 64): uint32 [Nb * W/2 * H/2][8] — per pooled output 4 bits, the position
+// of the window's first maximum (on the bf16-rounded values, TF scan order) | ReLU bit << 2: ocr_conv1_pool_bwd_codes routes the gradient with
+// them instead of recomputing the window.  zero (may be NULL): fp32 [zero_n] cleared by the same launch (zero_n % 4 == 0, 16-byte aligned):
+// the flat gradient buffer of the step that begins.
+extern "C" int ocr_conv1_pool_fwd_train(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout,
+                                        void* codes, float* zero, long zero_n, void* stream) {
+    return conv1_pool_fwd_impl(x, w, bias, p, Nb, W, H, Cout, zero, zero_n, codes, stream);
 }
-extern "C" int ocr_conv1_pool_bwd(const float* x, const float* w, const float* bias, const void* dp, float* dw, float* db,
-                                  int Nb, int W, int H, int Cout, void* stream) {
-    if (!x || !w || !bias || !dp || !dw || !db || Cout != 64 || (W & 1) || (H & 1)) return OCR_ERR_INVALID;
+static int conv1_pool_bwd_impl(const float* x, const float* w, const float* bias, const void* dp, float* dw, float* db,
+                               int Nb, int W, int H, int Cout, const void* codes, void* stream) {
+    if (!x || !w || !bias || !dp || !dw || !db || Cout != 64 || (W & 1) || (H & 1) || ((size_t)codes & 3)) return OCR_ERR_INVALID;
     long npix = (long)Nb * (W / 2) * (H / 2);
     int ppb = 256;
 #ifdef OCR_EXPERIMENTS
-    if (!conv1_v1() && npix < 0x7fffffffL - 512 && (long)Nb * W * H < 0x7fffffffL)
+    if (!codes && !conv1_v1() && npix < 0x7fffffffL - 512 && (long)Nb * W * H < 0x7fffffffL)
         conv1_pool_bwd2_kernel<<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, w, bias, (const bf16_t*)dp, dw, db, Nb, W, H,
                                                                                      Cout, ppb);
     else
 #endif
         conv1_pool_bwd_kernel<<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, w, bias, (const bf16_t*)dp, dw, db, Nb, W, H,
-                                                                                    Cout, ppb);
+                                                                                    Cout, ppb, (const uint32_t*)codes);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
+}
+extern "C" int ocr_conv1_pool_bwd(const float* x, const float* w, const float* bias, const void* dp, float* dw, float* db,
+                                  int Nb, int W, int H, int Cout, void* stream) {
+    return conv1_pool_bwd_impl(x, w, bias, dp, dw, db, Nb, W, H, Cout, nullptr, stream);
+}
+// ... with the routing codes ocr_conv1_pool_fwd_train saved: bit-identical gradients, no recomputation of the 2 x 2 windows
+extern "C" int ocr_conv1_pool_bwd_codes(const float* x, const float* w, const float* bias, const void* dp, float* dw, float* db,
+                                        int Nb, int W, int H, int Cout, const void* codes, void* stream) {
+    if (!codes) return OCR_ERR_INVALID;
+    return conv1_pool_bwd_impl(x, w, bias, dp, dw, db, Nb, W, H, Cout, codes, stream);
 }
 extern "C" int ocr_maxpool_fwd(const void* x, void* y, int Nb, int W, int H, int C, int kw, int kh, void* stream) {
     if (!x || !y || (C & 7) || kw < 1 || kw > 2 || kh < 1 || kh > 2 || W % kw || H % kh) return OCR_ERR_INVALID;

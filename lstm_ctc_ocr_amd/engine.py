@@ -152,6 +152,9 @@ class _ConvOp(_Op):
         dev = self.eng.device
         sp.shape[self.key] = (s, o)
         if self.fused_pool is not None:
+            if self.co == 64 and os.environ.get('OCR_CONV1_CODES', '1') != '0':
+                # pool routing + ReLU bits saved by the training forward pass (4 bits per pooled output) for the backward pass
+                sp.buf[self.key + '/codes'] = torch.empty((s[0] * (s[1] // 2) * (s[2] // 2), 8), dtype=torch.int32, device=dev)
             return
         sp.buf[self.key + '/y'] = torch.empty(o, dtype=BF16, device=dev)
         sp.buf[self.key + '/dy'] = torch.empty(o, dtype=BF16, device=dev)
@@ -221,7 +224,8 @@ class _ConvOp(_Op):
         bias = e.param(self.name + '/biases') if self.biased else None
         if self.fused_pool is not None:
             zero, e._zero_pending = (e.grads if e._zero_pending else None), False     # the gradient buffer's clear rides on this launch
-            ops.conv1_pool_fwd(x, e.param(self.name + '/weights'), bias, out=self.fused_pool.y(sp), zero=zero)
+            codes = sp.buf.get(self.key + '/codes') if e.training else None
+            ops.conv1_pool_fwd(x, e.param(self.name + '/weights'), bias, out=self.fused_pool.y(sp), zero=zero, codes=codes)
             return
         y = self.y(sp)
         if self.kind == 'c1':
@@ -261,7 +265,8 @@ class _ConvOp(_Op):
         e = self.eng
         if self.fused_pool is not None:     # pool routing + ReLU mask + weight gradient in one recomputing pass
             ops.conv1_pool_bwd(self.prev.y(sp), e.param(self.name + '/weights'), e.param(self.name + '/biases'),
-                               self.fused_pool.dy(sp), e.grad(self.name + '/weights'), e.grad(self.name + '/biases'))
+                               self.fused_pool.dy(sp), e.grad(self.name + '/weights'), e.grad(self.name + '/biases'),
+                               codes=sp.buf.get(self.key + '/codes'))
             return
         s, o = sp.shape[self.key]
         x = self.prev.y(sp)

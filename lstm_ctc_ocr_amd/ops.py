@@ -264,22 +264,28 @@ def eltwise(op, a, b, out):
     return out
 
 
-def conv1_pool_fwd(x, w, bias, out=None, zero=None):
-    """zero (fp32 tensor, numel % 4 == 0): cleared by the same launch (the step's flat gradient buffer)."""
+def conv1_pool_fwd(x, w, bias, out=None, zero=None, codes=None):
+    """zero (fp32 tensor, numel % 4 == 0): cleared by the same launch (the step's flat gradient buffer).  codes (int32 [Nb * W/2 * H/2, 8]):
+    receives the pool routing + ReLU bits for conv1_pool_bwd(codes=...)."""
     Nb, W, H = x.shape
     Cout = w.shape[-1]
     if out is None:
         out = torch.empty((Nb, W // 2, H // 2, Cout), dtype=BF16, device=x.device)
-    if zero is not None:
-        call("ocr_conv1_pool_fwd_zero", ptr(_dev(x)), ptr(w), ptr(bias), ptr(out), Nb, W, H, Cout, ptr(_dev(zero)), zero.numel(), _st())
+    if zero is not None or codes is not None:
+        call("ocr_conv1_pool_fwd_train", ptr(_dev(x)), ptr(w), ptr(bias), ptr(out), Nb, W, H, Cout, ptr(codes),
+             ptr(_dev(zero)) if zero is not None else None, 0 if zero is None else zero.numel(), _st())
     else:
         call("ocr_conv1_pool_fwd", ptr(_dev(x)), ptr(w), ptr(bias), ptr(out), Nb, W, H, Cout, _st())
     return out
 
 
-def conv1_pool_bwd(x, w, bias, dp, dw, db):
+def conv1_pool_bwd(x, w, bias, dp, dw, db, codes=None):
+    """codes: what conv1_pool_fwd(codes=...) saved — the gradient is routed with them (bit-identical) instead of recomputing the windows."""
     Nb, W, H = x.shape
-    call("ocr_conv1_pool_bwd", ptr(_dev(x)), ptr(w), ptr(bias), ptr(dp), ptr(dw), ptr(db), Nb, W, H, w.shape[-1], _st())
+    if codes is not None:
+        call("ocr_conv1_pool_bwd_codes", ptr(_dev(x)), ptr(w), ptr(bias), ptr(dp), ptr(dw), ptr(db), Nb, W, H, w.shape[-1], ptr(codes), _st())
+    else:
+        call("ocr_conv1_pool_bwd", ptr(_dev(x)), ptr(w), ptr(bias), ptr(dp), ptr(dw), ptr(db), Nb, W, H, w.shape[-1], _st())
 
 
 def maxpool_fwd(x, kw, kh, out=None):

@@ -512,6 +512,15 @@ def _conv1_pool_fused_equals_unfused(dev, Nb, W, H):
     dw = torch.zeros_like(w); db = torch.zeros(Co, device=dev)
     ops.conv1_pool_bwd(x, w, b, dp, dw, db)
     assert relerr(dw.cpu(), dw_ref.cpu()) < 1e-5 and relerr(db.cpu(), db_ref.cpu()) < 1e-5
+    # round 4: the training forward also saves the pool routing + ReLU bits (4 bits per pooled output) and clears a buffer on the way; the
+    # backward pass that consumes the codes instead of recomputing the 2 x 2 windows sums the same terms in the same order
+    codes = torch.full((Nb * (W // 2) * (H // 2), 8), -1, dtype=torch.int32, device=dev)
+    junk = torch.full((4096 + 8,), 7.0, device=dev)
+    p2 = ops.conv1_pool_fwd(x, w, b, zero=junk[:4096], codes=codes)
+    assert torch.equal(p2, p) and float(junk[:4096].abs().max()) == 0.0 and float(junk[4096:].min()) == 7.0
+    dw2 = torch.zeros_like(w); db2 = torch.zeros(Co, device=dev)
+    ops.conv1_pool_bwd(x, w, b, dp, dw2, db2, codes=codes)
+    assert relerr(dw2.cpu(), dw.cpu()) < 1e-6 and relerr(db2.cpu(), db.cpu()) < 1e-6          # (atomics: block order differs from run to run)
 
 
 @pytest.mark.parametrize("kw,kh", [(2, 2), (1, 2)])
