@@ -348,10 +348,11 @@ void conv1_pool_bwd2_kernel(const float* __restrict__ x, const float* __restrict
 }
 #endif   // OCR_EXPERIMENTS (second-generation conv1 + pool kernels)
 
-__global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             const float* __restrict__ bias, bf16_t* __restrict__ p,
-                                                             int Nb, int W, int H, int Cout, f32x4* __restrict__ zero, long zero_n4,
-                                                             uint32_t* __restrict__ codes) {
+template <bool CODES>
+__device__ __forceinline__ void conv1_pool_fwd_body(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, bf16_t* __restrict__ p,
+                                                    int Nb, int W, int H, int Cout, f32x4* __restrict__ zero, long zero_n4,
+                                                    uint32_t* __restrict__ codes) {
     // the step's flat gradient buffer is cleared by the FIRST kernel of the forward pass (round 4: it was a fill launch of its own): the
     // stores go out here and drain beside the VALU-bound work below
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n4; i += (long)gridDim.x * 256) zero[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const float* __rest
         for (int c = 0; c < 8; ++c) m[c] = fmaxf(fmaxf(o[0][c], o[1][c]), fmaxf(o[2][c], o[3][c]));   // rounding is monotone: max then round
         u32x4 pk = {pack_bf2(m[0], m[1]), pack_bf2(m[2], m[3]), pack_bf2(m[4], m[5]), pack_bf2(m[6], m[7])};
         *(u32x4*)(p + op * Cout + gq * 8) = pk;
-        if (codes != nullptr) {       // training: the pool's routing and the ReLU bit per output, 4 bits each — the backward pass need not recompute the window
+        if constexpr (CODES) {        // training: the pool's routing and the ReLU bit per output, 4 bits each — the backward pass need not recompute the window
             uint32_t word = 0;
 #pragma unroll
             for (int c = 0; c < 8; ++c) word |= (uint32_t)conv1_pool_code(o[0][c], o[1][c], o[2][c], o[3][c]) << (4 * c);
@@ -386,19 +387,35 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const float* __rest
     }
 }
 
+template <bool CODES>
+__global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             bf16_t* __restrict__ p, int Nb, int W, int H, int Cout, f32x4* __restrict__ zero,
+                                                             long zero_n4, uint32_t* __restrict__ codes) {
+    conv1_pool_fwd_body<CODES>(x, w, bias, p, Nb, W, H, Cout, zero, zero_n4, codes);
+}
+// the code-writing form held to 128 registers (four waves per SIMD like the plain form; 12 bytes of scratch) — A/B knob OCR_CONV1_OCC4
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void conv1_pool_fwd_codes4_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, bf16_t* __restrict__ p,
+                                  int Nb, int W, int H, int Cout, f32x4* __restrict__ zero, long zero_n4, uint32_t* __restrict__ codes) {
+    conv1_pool_fwd_body<true>(x, w, bias, p, Nb, W, H, Cout, zero, zero_n4, codes);
+}
+
+template <bool CODES /* routing + ReLU bits from the forward pass: no window recomputation, and none of its 110 registers (weights, outputs) */>
 __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, const bf16_t* __restrict__ dp,
                                                              float* __restrict__ dw, float* __restrict__ db, int Nb, int W,
                                                              int H, int Cout, int pix_per_block, const uint32_t* __restrict__ codes) {
     // Cout == 64: 8 channel groups x 32 pixel lanes
     const int gq = threadIdx.x & 7, pl = threadIdx.x >> 3;
-    float wr[9][8], br[8];
+    float wr[CODES ? 1 : 9][8], br[8];
+    if (!CODES) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) wr[t][c] = w[t * Cout + gq * 8 + c];
+            for (int c = 0; c < 8; ++c) wr[CODES ? 0 : t][c] = w[t * Cout + gq * 8 + c];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) br[c] = bias[gq * 8 + c];
+        for (int c = 0; c < 8; ++c) br[c] = bias[gq * 8 + c];
+    }
     const int Wo = W >> 1, Ho = H >> 1;
     const long npix = (long)Nb * Wo * Ho;
     const long p0 = (long)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
@@ -407,36 +424,42 @@ __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const float* __rest
     for (int t = 0; t < 10; ++t)
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[t][c] = 0.f;
+    __shared__ float patch_lds[256 * 17];               // a thread's 4 x 4 patch, stride 17 words: equal indices of a wave's lanes fall into distinct banks
+    float* const mypatch = patch_lds + threadIdx.x * 17;
     for (long op = p0 + pl; op < p1; op += 32) {
         const int ho = (int)(op % Ho);
         const long q = op / Ho;
         const int wo = (int)(q % Wo);
         const long n = q / Wo;
-        float o[4][8], patch[4][4];
+        float o[CODES ? 1 : 4][8], patch[4][4];
         uint32_t word = 0;
-        if (codes != nullptr) {         // round 4: routing + ReLU bits saved by the forward pass (conv1_pool_code): no recomputation of the window
+        if constexpr (CODES) {          // round 4: routing + ReLU bits saved by the forward pass (conv1_pool_code): no recomputation of the window
             conv1_patch(x + n * W * H, W, H, wo * 2, ho * 2, patch);
             word = codes[op * 8 + gq];
         } else {
             conv1_window(x + n * W * H, W, H, wo * 2, ho * 2, wr, br, o, patch);
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mypatch[i * 4 + j] = patch[i][j];
         float g[8];
         unpack8(*(const u32x4*)(dp + op * Cout + gq * 8), g);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             // the forward stored bf16(max); compare on the same rounded values so ties resolve exactly like the unfused path
-            const int code = codes != nullptr ? (int)((word >> (4 * c)) & 7u) : conv1_pool_code(o[0][c], o[1][c], o[2][c], o[3][c]);
+            int code;
+            if constexpr (CODES) code = (int)((word >> (4 * c)) & 7u);
+            else code = conv1_pool_code(o[0][c], o[1][c], o[2][c], o[3][c]);
             const int best = code & 3;
             const float gv = (code & 4) ? g[c] : 0.f;              // ReLU mask of the winning element
             acc[9][c] += gv;
-            const int a = best >> 1, b = best & 1;
+            // patch[a + t/3][b + t%3] with a run-time (a, b) PER CHANNEL: looked up in this thread's private LDS copy of the patch (one
+            // ds_read with an immediate offset per tap) — as three v_cndmask per tap and channel this was 216 of the ~380 VALU instructions
+            // of an iteration (round 4)
+            const float* px = mypatch + (best >> 1) * 4 + (best & 1);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                // patch[a + t/3][b + t%3] with a run-time (a, b): select among the four window positions
-                const int i = t / 3, j = t % 3;
-                const float xv = (a == 0) ? ((b == 0) ? patch[i][j] : patch[i][j + 1]) : ((b == 0) ? patch[i + 1][j] : patch[i + 1][j + 1]);
-                acc[t][c] = fmaf(xv, gv, acc[t][c]);
-            }
+            for (int t = 0; t < 9; ++t) acc[t][c] = fmaf(px[(t / 3) * 4 + t % 3], gv, acc[t][c]);
         }
     }
     __shared__ float red[4][10][64];
@@ -1376,8 +1399,16 @@ static int conv1_pool_fwd_impl(const float* x, const float* w, const float* bias
         conv1_pool_fwd2_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout);
     else
 #endif
-        conv1_pool_fwd_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout, (f32x4*)zero, zero_n / 4,
-                                                                                      (uint32_t*)codes);
+    {
+        static int occ4 = -1;
+        if (occ4 < 0) { const char* e = getenv("OCR_CONV1_OCC4"); occ4 = e ? atoi(e) : 1; }
+        if (codes && occ4) conv1_pool_fwd_codes4_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout,
+                                                                                                              (f32x4*)zero, zero_n / 4, (uint32_t*)codes);
+        else if (codes) conv1_pool_fwd_kernel<true><<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout, (f32x4*)zero,
+                                                                                                          zero_n / 4, (uint32_t*)codes);
+        else conv1_pool_fwd_kernel<false><<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout, (f32x4*)zero,
+                                                                                                 zero_n / 4, nullptr);
+    }
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
@@ -1404,8 +1435,12 @@ static int conv1_pool_bwd_impl(const float* x, const float* w, const float* bias
                                                                                      Cout, ppb);
     else
 #endif
-        conv1_pool_bwd_kernel<<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, w, bias, (const bf16_t*)dp, dw, db, Nb, W, H,
-                                                                                    Cout, ppb, (const uint32_t*)codes);
+    {
+        if (codes) conv1_pool_bwd_kernel<true><<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, w, bias, (const bf16_t*)dp, dw, db, Nb, W, H,
+                                                                                                   Cout, ppb, (const uint32_t*)codes);
+        else conv1_pool_bwd_kernel<false><<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, w, bias, (const bf16_t*)dp, dw, db, Nb, W, H,
+                                                                                               Cout, ppb, nullptr);
+    }
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }

@@ -173,6 +173,43 @@ def test_deferred_weight_gradient_reduction_is_bit_identical(dev, monkeypatch, N
             assert float(base[n].abs().max()) > 0 and torch.equal(g[n], base[n]), (n, split, flush_mb)
 
 
+def test_round4_fusions_match_the_unfused_schedule(dev, monkeypatch):
+    """Round 4 moved work into neighbouring kernels (batch-norm statistics / pool / backward sums in convolution write-outs, two plain weight-
+    gradient products as one gemm_tn3 launch, slab reductions flushed after 80 MB, the gradient clear and the pool routing codes on the conv1
+    launch).  With every one of them switched off the engine runs round 3's schedule: same loss, same gradients up to fp32 summation order
+    (the statistics are summed per 256-pixel tile instead of per row block, which moves a few bf16 roundings downstream of them)."""
+    N, W = 64, 128
+    x, labels, ll, sl = make_batch(N, W, 2, 5, 21, varlen=True)
+    off = dict(OCR_FUSE_BN_STATS='0', OCR_FUSE_BN_POOL='0', OCR_FUSE_BN_BWD='0', OCR_TN_JOBS='0', OCR_FUSE_ZERO='0', OCR_CONV1_CODES='0',
+               OCR_W9_FLUSH_MB='0')
+
+    def run(env):
+        for k in off:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=5)
+        sp = eng.plan(N, W)
+        eng._bind(sp, x, sl, labels, ll)
+        eng._run(sp, 'fb')
+        eng._run(sp, 'fb')                            # the captured graph
+        torch.cuda.synchronize()
+        active = dict(stats=sum(1 for v in getattr(sp, 'bn_stat_rows', {}).values() if v), bwd=sum(1 for v in getattr(sp, 'bn_bwd_rows', {}).values() if v),
+                      pool=sum(1 for op in eng.ops if getattr(op, 'bn_pool', None) is not None), codes=sum(k.endswith('/codes') for k in sp.buf))
+        return {n: eng.grad(n).clone() for n in eng.specs}, float(sp.costs.double().mean()), active
+
+    g0, c0, a0 = run(off)
+    g1, c1, a1 = run({})
+    assert a0 == dict(stats=0, bwd=0, pool=0, codes=0) and a1 == dict(stats=2, bwd=1, pool=1, codes=1), (a0, a1)
+    assert abs(c1 - c0) < 1e-5 * abs(c0)
+    for n in g0:
+        ref = g0[n].double()
+        if n in ('conv4_1/biases', 'conv4_2/biases'):                  # mathematically zero (batch norm removes the mean): rounding noise
+            continue
+        e = float((g1[n].double() - ref).norm() / ref.norm().clamp_min(1e-30))
+        assert e < 2e-3, (n, e)
+
+
 def test_lstm_bias_job_follows_the_updated_parameter(dev):
     """The LSTM bias permutation is a job of the re-pack launch behind the optimiser: after training steps the packed bias is the
     permutation (u / 16) * 64 + g * 16 + u % 16 of the UPDATED gate-major TF vector."""
