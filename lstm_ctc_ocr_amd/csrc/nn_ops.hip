@@ -1428,7 +1428,9 @@ static int conv1_pool_bwd_impl(const float* x, const float* w, const float* bias
                                int Nb, int W, int H, int Cout, const void* codes, void* stream) {
     if (!x || !w || !bias || !dp || !dw || !db || Cout != 64 || (W & 1) || (H & 1) || ((size_t)codes & 3)) return OCR_ERR_INVALID;
     long npix = (long)Nb * (W / 2) * (H / 2);
-    int ppb = 256;
+    static int ppb_env = -1;                             // pooled pixels per block (a thread walks ppb / 32 of them, one memory round trip each): A/B knob OCR_CONV1_PPB
+    if (ppb_env < 0) { const char* e = getenv("OCR_CONV1_PPB"); ppb_env = e ? atoi(e) : 256; if (ppb_env < 32 || (ppb_env & 31)) ppb_env = 256; }
+    int ppb = ppb_env;
 #ifdef OCR_EXPERIMENTS
     if (!codes && !conv1_v1() && npix < 0x7fffffffL - 512 && (long)Nb * W * H < 0x7fffffffL)
         conv1_pool_bwd2_kernel<<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, w, bias, (const bf16_t*)dp, dw, db, Nb, W, H,
