@@ -170,6 +170,11 @@ int ocr_conv1_pool_fwd_train(const float* x, const float* w, const float* bias, 
                              void* codes, float* zero, long zero_n, void* stream);
 int ocr_conv1_pool_bwd_codes(const float* x, const float* w, const float* bias, const void* dp, float* dw, float* db,
                              int Nb, int W, int H, int Cout, const void* codes, void* stream);
+/* slab form: no atomics - block b leaves {dW [9][64] | db [64]} (fp32) in slab[b][640], b < ocr_conv1_pool_bwd_slab_rows(Nb, W, H); the rows
+ * are added by ocr_wgrad9_reduce_jobs (jobs with n4 = 144 / 16, slab4 = 160, S = rows): bit-reproducible.  codes may be NULL (recompute). */
+int ocr_conv1_pool_bwd_slab_rows(int Nb, int W, int H);
+int ocr_conv1_pool_bwd_slab(const float* x, const float* w, const float* bias, const void* dp, int Nb, int W, int H, int Cout,
+                            const void* codes, float* slab, void* stream);
 int ocr_conv1_pool_bwd(const float* x, const float* w, const float* bias, const void* dp, float* dw, float* db, int Nb,
                        int W, int H, int Cout, void* stream);
 int ocr_maxpool_fwd(const void* x, void* y, int Nb, int W, int H, int C, int kw, int kh, void* stream);

@@ -56,6 +56,8 @@ _SIGS = {
     "ocr_conv1_pool_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "ocr_conv1_pool_fwd_train": ([_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _L, _P], _I),
     "ocr_conv1_pool_bwd_codes": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P], _I),
+    "ocr_conv1_pool_bwd_slab_rows": ([_I, _I, _I], _I),
+    "ocr_conv1_pool_bwd_slab": ([_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P], _I),
     "ocr_conv1_pool_bwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "ocr_maxpool_fwd": ([_P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     "ocr_maxpool_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),

@@ -393,18 +393,12 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const float* __rest
                                                              long zero_n4, uint32_t* __restrict__ codes) {
     conv1_pool_fwd_body<CODES>(x, w, bias, p, Nb, W, H, Cout, zero, zero_n4, codes);
 }
-// the code-writing form held to 128 registers (four waves per SIMD like the plain form; 12 bytes of scratch) — A/B knob OCR_CONV1_OCC4
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void conv1_pool_fwd_codes4_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, bf16_t* __restrict__ p,
-                                  int Nb, int W, int H, int Cout, f32x4* __restrict__ zero, long zero_n4, uint32_t* __restrict__ codes) {
-    conv1_pool_fwd_body<true>(x, w, bias, p, Nb, W, H, Cout, zero, zero_n4, codes);
-}
-
 template <bool CODES /* routing + ReLU bits from the forward pass: no window recomputation, and none of its 110 registers (weights, outputs) */>
 __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, const bf16_t* __restrict__ dp,
                                                              float* __restrict__ dw, float* __restrict__ db, int Nb, int W,
-                                                             int H, int Cout, int pix_per_block, const uint32_t* __restrict__ codes) {
+                                                             int H, int Cout, int pix_per_block, const uint32_t* __restrict__ codes,
+                                                             float* __restrict__ slab) {
     // Cout == 64: 8 channel groups x 32 pixel lanes
     const int gq = threadIdx.x & 7, pl = threadIdx.x >> 3;
     float wr[CODES ? 1 : 9][8], br[8];
@@ -484,7 +478,11 @@ __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const float* __rest
     for (int i = threadIdx.x; i < 10 * 64; i += 256) {
         int t = i / 64, c = i % 64;
         float v = red[0][t][c] + red[1][t][c] + red[2][t][c] + red[3][t][c];
-        if (t < 9) atomicAdd(dw + t * Cout + c, v);
+        // slab form (round 4): this block's 640 partial sums go to its own row, the merged slab reduction that follows anyway adds the rows
+        // in a fixed order — 512 blocks x 640 same-address atomics were ~10 us of the kernel's 33 (it got SLOWER with more, smaller blocks:
+        // profiles/r04k), and the conv1 gradient was the last one that was not bit-reproducible
+        if (slab != nullptr) slab[(long)blockIdx.x * 640 + i] = v;
+        else if (t < 9) atomicAdd(dw + t * Cout + c, v);
         else atomicAdd(db + c, v);
     }
 }
@@ -1400,11 +1398,7 @@ static int conv1_pool_fwd_impl(const float* x, const float* w, const float* bias
     else
 #endif
     {
-        static int occ4 = -1;
-        if (occ4 < 0) { const char* e = getenv("OCR_CONV1_OCC4"); occ4 = e ? atoi(e) : 1; }
-        if (codes && occ4) conv1_pool_fwd_codes4_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout,
-                                                                                                              (f32x4*)zero, zero_n / 4, (uint32_t*)codes);
-        else if (codes) conv1_pool_fwd_kernel<true><<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout, (f32x4*)zero,
+        if (codes) conv1_pool_fwd_kernel<true><<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout, (f32x4*)zero,
                                                                                                           zero_n / 4, (uint32_t*)codes);
         else conv1_pool_fwd_kernel<false><<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout, (f32x4*)zero,
                                                                                                  zero_n / 4, nullptr);
@@ -1424,37 +1418,54 @@ extern "C" int ocr_conv1_pool_fwd_train(const float* x, const float* w, const fl
                                         void* codes, float* zero, long zero_n, void* stream) {
     return conv1_pool_fwd_impl(x, w, bias, p, Nb, W, H, Cout, zero, zero_n, codes, stream);
 }
+// pooled pixels per block of the conv1 + pool backward kernel (a thread walks ppb / 32 of them, one memory round trip each).  With atomics
+// smaller blocks were slower (profiles/r04k_conv1_ppb_ab.log: 640 same-address atomics per block); the slab form pays 2.5 KB per block instead.
+static int conv1_ppb() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OCR_CONV1_PPB"); v = e ? atoi(e) : 256; if (v < 32 || v > 1024 || (v & 31)) v = 256; }
+    return v;
+}
 static int conv1_pool_bwd_impl(const float* x, const float* w, const float* bias, const void* dp, float* dw, float* db,
-                               int Nb, int W, int H, int Cout, const void* codes, void* stream) {
-    if (!x || !w || !bias || !dp || !dw || !db || Cout != 64 || (W & 1) || (H & 1) || ((size_t)codes & 3)) return OCR_ERR_INVALID;
+                               int Nb, int W, int H, int Cout, const void* codes, float* slab, void* stream) {
+    if (!x || !w || !bias || !dp || (!slab && (!dw || !db)) || Cout != 64 || (W & 1) || (H & 1) || ((size_t)codes & 3)) return OCR_ERR_INVALID;
     long npix = (long)Nb * (W / 2) * (H / 2);
-    static int ppb_env = -1;                             // pooled pixels per block (a thread walks ppb / 32 of them, one memory round trip each): A/B knob OCR_CONV1_PPB
-    if (ppb_env < 0) { const char* e = getenv("OCR_CONV1_PPB"); ppb_env = e ? atoi(e) : 256; if (ppb_env < 32 || (ppb_env & 31)) ppb_env = 256; }
-    int ppb = ppb_env;
+    int ppb = slab ? conv1_ppb() : 256;
 #ifdef OCR_EXPERIMENTS
-    if (!codes && !conv1_v1() && npix < 0x7fffffffL - 512 && (long)Nb * W * H < 0x7fffffffL)
+    if (!codes && !slab && !conv1_v1() && npix < 0x7fffffffL - 512 && (long)Nb * W * H < 0x7fffffffL)
         conv1_pool_bwd2_kernel<<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, w, bias, (const bf16_t*)dp, dw, db, Nb, W, H,
                                                                                      Cout, ppb);
     else
 #endif
     {
         if (codes) conv1_pool_bwd_kernel<true><<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, w, bias, (const bf16_t*)dp, dw, db, Nb, W, H,
-                                                                                                   Cout, ppb, (const uint32_t*)codes);
+                                                                                                   Cout, ppb, (const uint32_t*)codes, slab);
         else conv1_pool_bwd_kernel<false><<<ceil_div(npix, ppb), 256, 0, (hipStream_t)stream>>>(x, w, bias, (const bf16_t*)dp, dw, db, Nb, W, H,
-                                                                                               Cout, ppb, nullptr);
+                                                                                               Cout, ppb, nullptr, slab);
     }
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
 extern "C" int ocr_conv1_pool_bwd(const float* x, const float* w, const float* bias, const void* dp, float* dw, float* db,
                                   int Nb, int W, int H, int Cout, void* stream) {
-    return conv1_pool_bwd_impl(x, w, bias, dp, dw, db, Nb, W, H, Cout, nullptr, stream);
+    return conv1_pool_bwd_impl(x, w, bias, dp, dw, db, Nb, W, H, Cout, nullptr, nullptr, stream);
 }
 // ... with the routing codes ocr_conv1_pool_fwd_train saved: bit-identical gradients, no recomputation of the 2 x 2 windows
 extern "C" int ocr_conv1_pool_bwd_codes(const float* x, const float* w, const float* bias, const void* dp, float* dw, float* db,
                                         int Nb, int W, int H, int Cout, const void* codes, void* stream) {
     if (!codes) return OCR_ERR_INVALID;
-    return conv1_pool_bwd_impl(x, w, bias, dp, dw, db, Nb, W, H, Cout, codes, stream);
+    return conv1_pool_bwd_impl(x, w, bias, dp, dw, db, Nb, W, H, Cout, codes, nullptr, stream);
+}
+// Slab form: no atomics — block b leaves its partial sums in slab[b][640] = {dW [9][64] | db [64]} (fp32), rows = ocr_conv1_pool_bwd_slab_rows;
+// the caller adds the rows with ocr_wgrad9_reduce_jobs (two jobs: n4 = 144 / 16, slab4 = 160, S = rows — the engine appends them to the merged
+// reduction of the 3x3 layers that runs right behind this kernel anyway): bit-reproducible conv1 gradients.  codes may be NULL (recompute).
+extern "C" int ocr_conv1_pool_bwd_slab_rows(int Nb, int W, int H) {
+    if (Nb <= 0 || W <= 0 || H <= 0 || (W & 1) || (H & 1)) return 0;
+    return (int)ceil_div((long)Nb * (W / 2) * (H / 2), (long)conv1_ppb());
+}
+extern "C" int ocr_conv1_pool_bwd_slab(const float* x, const float* w, const float* bias, const void* dp, int Nb, int W, int H, int Cout,
+                                       const void* codes, float* slab, void* stream) {
+    if (!slab || ((size_t)slab & 15)) return OCR_ERR_INVALID;
+    return conv1_pool_bwd_impl(x, w, bias, dp, nullptr, nullptr, Nb, W, H, Cout, codes, slab, stream);
 }
 extern "C" int ocr_maxpool_fwd(const void* x, void* y, int Nb, int W, int H, int C, int kw, int kh, void* stream) {
     if (!x || !y || (C & 7) || kw < 1 || kw > 2 || kh < 1 || kh > 2 || W % kw || H % kh) return OCR_ERR_INVALID;

@@ -152,6 +152,9 @@ class _ConvOp(_Op):
         dev = self.eng.device
         sp.shape[self.key] = (s, o)
         if self.fused_pool is not None:
+            if self.co == 64 and self.eng.defer_w9 and os.environ.get('OCR_CONV1_SLAB', '1') != '0':
+                # the backward kernel's per-block partial sums (no atomics); two jobs of the merged slab reduction add them
+                sp.buf[self.key + '/slab'] = torch.empty((ops.conv1_pool_bwd_slab_rows(s[0], s[1], s[2]), 640), dtype=F32, device=dev)
             if self.co == 64 and os.environ.get('OCR_CONV1_CODES', '1') != '0':
                 # pool routing + ReLU bits saved by the training forward pass (4 bits per pooled output) for the backward pass
                 sp.buf[self.key + '/codes'] = torch.empty((s[0] * (s[1] // 2) * (s[2] // 2), 8), dtype=torch.int32, device=dev)
@@ -264,6 +267,17 @@ class _ConvOp(_Op):
     def bwd(self, sp):
         e = self.eng
         if self.fused_pool is not None:     # pool routing + ReLU mask + weight gradient in one recomputing pass
+            slab = sp.buf.get(self.key + '/slab')
+            if slab is not None:
+                ops.conv1_pool_bwd_slab(self.prev.y(sp), e.param(self.name + '/weights'), e.param(self.name + '/biases'), self.fused_pool.dy(sp),
+                                        slab, codes=sp.buf.get(self.key + '/codes'))
+                S = slab.shape[0]
+                for dst, off, n4 in ((e.grad(self.name + '/weights'), 0, 144), (e.grad(self.name + '/biases'), 576, 16)):
+                    job = np.zeros(1, dtype=e.W9_JOB_DTYPE)
+                    job['dw'], job['part'], job['n4'], job['slab4'] = dst.data_ptr(), slab.data_ptr() + 4 * off, n4, 160
+                    job['S'], job['rows'], job['Cout'] = S, 8, 64
+                    sp.w9_pending.append((job.tobytes(), (n4 + 31) // 32))          # 256 / rows = 32 float4 columns per block
+                return
             ops.conv1_pool_bwd(self.prev.y(sp), e.param(self.name + '/weights'), e.param(self.name + '/biases'),
                                self.fused_pool.dy(sp), e.grad(self.name + '/weights'), e.grad(self.name + '/biases'),
                                codes=sp.buf.get(self.key + '/codes'))

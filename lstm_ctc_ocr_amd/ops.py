@@ -288,6 +288,17 @@ def conv1_pool_bwd(x, w, bias, dp, dw, db, codes=None):
         call("ocr_conv1_pool_bwd", ptr(_dev(x)), ptr(w), ptr(bias), ptr(dp), ptr(dw), ptr(db), Nb, W, H, w.shape[-1], _st())
 
 
+def conv1_pool_bwd_slab_rows(Nb, W, H):
+    return int(nat.lib().ocr_conv1_pool_bwd_slab_rows(int(Nb), int(W), int(H)))
+
+
+def conv1_pool_bwd_slab(x, w, bias, dp, slab, codes=None):
+    """No atomics: block b's partial sums {dW [9][64] | db [64]} go to slab[b] (fp32 [rows, 640]); wgrad9_reduce_jobs adds the rows."""
+    Nb, W, H = x.shape
+    assert slab.dtype == torch.float32 and tuple(slab.shape) == (conv1_pool_bwd_slab_rows(Nb, W, H), 640)
+    call("ocr_conv1_pool_bwd_slab", ptr(_dev(x)), ptr(w), ptr(bias), ptr(dp), Nb, W, H, w.shape[-1], ptr(codes), ptr(slab), _st())
+
+
 def maxpool_fwd(x, kw, kh, out=None):
     Nb, W, H, C = x.shape
     if out is None:

@@ -521,6 +521,16 @@ def _conv1_pool_fused_equals_unfused(dev, Nb, W, H):
     dw2 = torch.zeros_like(w); db2 = torch.zeros(Co, device=dev)
     ops.conv1_pool_bwd(x, w, b, dp, dw2, db2, codes=codes)
     assert relerr(dw2.cpu(), dw.cpu()) < 1e-6 and relerr(db2.cpu(), db.cpu()) < 1e-6          # (atomics: block order differs from run to run)
+    # slab form: per-block partial sums instead of atomics (the engine adds the rows with the merged slab reduction): bit-reproducible
+    rows = ops.conv1_pool_bwd_slab_rows(Nb, W, H)
+    slabs = []
+    for cd in (codes, None, codes):
+        slab = torch.full((rows, 640), float('nan'), device=dev)
+        ops.conv1_pool_bwd_slab(x, w, b, dp, slab, codes=cd)
+        slabs.append(slab.clone())
+    assert torch.equal(slabs[0], slabs[2]) and torch.equal(slabs[0], slabs[1])                # run to run, and codes against recomputation
+    tot = slabs[0].double().sum(0).cpu()
+    assert relerr(tot[:576].view(3, 3, 1, Co), dw.double().cpu()) < 1e-6 and relerr(tot[576:], db.double().cpu()) < 1e-6
 
 
 @pytest.mark.parametrize("kw,kh", [(2, 2), (1, 2)])
