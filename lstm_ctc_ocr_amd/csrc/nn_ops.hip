@@ -153,17 +153,27 @@ __device__ __forceinline__ int conv1_pool_code(float o0, float o1, float o2, flo
 __device__ __forceinline__ void conv1_window(const float* __restrict__ xn, int W, int H, int w0, int h0,
                                              const float (&wr)[9][8], const float (&br)[8], float (&o)[4][8], float (&patch)[4][4]) {
     conv1_patch(xn, W, H, w0, h0, patch);
+    // channel PAIRS per instruction (v_pk_fma_f32: two fp32 FMAs per lane at the rate of one — the kernel is VALU-bound): the same fused
+    // multiply-adds in the same order per channel, hence bit-identical results (round 4)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int a = e >> 1, b = e & 1;               // window element (a over W, b over H) = TF scan order
+        f32x2 acc2[4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) o[e][c] = 0.f;
+        for (int q = 0; q < 4; ++q) acc2[q] = (f32x2){0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t) {
+            const float pv = patch[a + t / 3][b + t % 3];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) o[e][c] = fmaf(patch[a + t / 3][b + t % 3], wr[t][c], o[e][c]);
+            for (int q = 0; q < 4; ++q)
+                acc2[q] = __builtin_elementwise_fma((f32x2){pv, pv}, (f32x2){wr[t][2 * q], wr[t][2 * q + 1]}, acc2[q]);
+        }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) o[e][c] = fmaxf(o[e][c] + br[c], 0.f);
+        for (int q = 0; q < 4; ++q) {
+            o[e][2 * q] = fmaxf(acc2[q].x + br[2 * q], 0.f);
+            o[e][2 * q + 1] = fmaxf(acc2[q].y + br[2 * q + 1], 0.f);
+        }
     }
 }
 
@@ -1503,6 +1513,12 @@ extern "C" size_t ocr_bn_workspace_bytes(long M, int C) {
 // partial_rows > 0: the workspace already holds that many partial rows [rows][2][C] (sum, sum of squares) written by the producing
 // convolution (ocr_conv3x3_bf16_stats) — no statistics pass over x.  pooled != NULL: the 1 x 2 max-pool over row pairs that follows the layer
 // is written by the apply pass as well (M even, no residual).
+// rows per THREAD of the batch-norm apply passes (a thread first loads its 8 channels' 32-40 parameters, then streams rows): A/B knob OCR_BN_ROWS
+static int bn_rows_per_thread() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OCR_BN_ROWS"); v = e ? atoi(e) : 4; if (v < 2 || v > 64 || (v & 1)) v = 4; }
+    return v;
+}
 static int bn_train_fwd_impl(const void* x, void* y, const float* gamma, const float* beta, float* save_mean,
                              float* save_rstd, long M, int C, float eps, int relu, void* workspace, const void* residual,
                              int partial_rows, void* pooled, void* stream_) {
@@ -1533,10 +1549,10 @@ static int bn_train_fwd_impl(const void* x, void* y, const float* gamma, const f
     }
     bn_finalize_kernel<<<ceil_div(C, 16), 256, 0, stream>>>((const float*)workspace, nblk, save_mean, save_rstd, M, C, eps);
     OCR_CHECK_LAUNCH();
-    const int arows = 4 * rlanes;                                   // rows per block of the apply pass: 4 per thread
+    const int arows = bn_rows_per_thread() * rlanes;                // rows per block of the apply pass
     if (pooled)
-        bn_apply_pool_kernel<<<ceil_div(M / 2, (long)(2 * rlanes)), 256, 0, stream>>>((const bf16_t*)x, (bf16_t*)y, (bf16_t*)pooled, save_mean, save_rstd,
-                                                                                        gamma, beta, M, C, relu, 2 * rlanes);
+        bn_apply_pool_kernel<<<ceil_div(M / 2, (long)(arows / 2)), 256, 0, stream>>>((const bf16_t*)x, (bf16_t*)y, (bf16_t*)pooled, save_mean, save_rstd,
+                                                                                       gamma, beta, M, C, relu, arows / 2);
     else
         bn_apply_kernel<<<ceil_div(M, (long)arows), 256, 0, stream>>>((const bf16_t*)x, (bf16_t*)y, save_mean, save_rstd, gamma,
                                                                         beta, M, C, relu, arows, (const bf16_t*)residual);
@@ -1587,7 +1603,7 @@ static int bn_train_bwd_impl(const void* x, const void* y, const void* dy, void*
     }
     bn_bwd_finalize_kernel<<<ceil_div(C, 16), 256, 0, stream>>>(part, partial_rows ? partial_rows : nblk, sums, dgamma, dbeta, C);
     OCR_CHECK_LAUNCH();
-    const int arows = 4 * (256 / (C >> 3));                         // rows per block of the apply pass: 4 per thread
+    const int arows = bn_rows_per_thread() * (256 / (C >> 3));      // rows per block of the apply pass
     bn_bwd_apply_kernel<<<ceil_div(M, (long)arows), 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy,
                                                                         (bf16_t*)dx, save_mean, save_rstd, gamma,
                                                                         sums, dgamma, dbeta, M, C, relu, arows, pooled_dy);
