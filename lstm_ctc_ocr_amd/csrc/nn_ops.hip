@@ -1513,12 +1513,9 @@ extern "C" size_t ocr_bn_workspace_bytes(long M, int C) {
 // partial_rows > 0: the workspace already holds that many partial rows [rows][2][C] (sum, sum of squares) written by the producing
 // convolution (ocr_conv3x3_bf16_stats) — no statistics pass over x.  pooled != NULL: the 1 x 2 max-pool over row pairs that follows the layer
 // is written by the apply pass as well (M even, no residual).
-// rows per THREAD of the batch-norm apply passes (a thread first loads its 8 channels' 32-40 parameters, then streams rows): A/B knob OCR_BN_ROWS
-static int bn_rows_per_thread() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OCR_BN_ROWS"); v = e ? atoi(e) : 4; if (v < 2 || v > 64 || (v & 1)) v = 4; }
-    return v;
-}
+// rows per THREAD of the batch-norm apply passes (a thread first loads its 8 channels' 32-40 parameters, then streams rows).  Measured in
+// round 4 (profiles/r04n_bn_rows_ab.log): 4 and 8 equal (1.2621-1.2630 / 1.2625-1.2640 ms per step), 16 slower (1.272-1.275: too few blocks).
+static constexpr int bn_rows_per_thread() { return 4; }
 static int bn_train_fwd_impl(const void* x, void* y, const float* gamma, const float* beta, float* save_mean,
                              float* save_rstd, long M, int C, float eps, int relu, void* workspace, const void* residual,
                              int partial_rows, void* pooled, void* stream_) {
