@@ -198,8 +198,8 @@ def conv_roofline(eng, device, workload):
                           "separate counter run at that run's clock (profiles/r04_mfma_busy_calibration.md)" % PEAK_CLOCK_MHZ,
             "traffic_note": "HBM bytes per launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) and SQ_VALU_MFMA_BUSY_CYCLES / "
                             "(1024 SIMDs x GRBM_GUI_ACTIVE / 8) of the same kernels inside this script's train step, from profiles/%s.  "
-                            "mfma_busy_frac is a LOWER bound for these 20-60 us launches: the counter window of a profiled dispatch is longer than "
-                            "the kernel (pmc_clock_mhz = window cycles / kernel duration comes out above the chip's 2400 MHz); the busy CYCLES "
+                            "mfma_busy_frac is a LOWER bound for these 20-60 us launches: GRBM_GUI_ACTIVE / 8 of a profiled dispatch exceeds "
+                            "the kernel's own cycles (pmc_clock_mhz = GRBM cycles / kernel duration comes out above the chip's 2400 MHz); the busy CYCLES "
                             "themselves are exact (16 per issued MFMA: profiles/r04_mfma_busy_calibration.md), so the occupancy over the kernel's "
                             "own duration is executed_frac_of_peak_at_that_clock above" % src}
 
