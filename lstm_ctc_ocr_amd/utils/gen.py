@@ -110,6 +110,77 @@ def render_captcha(chars, width=160, height=60):
     return img.filter(ImageFilter.SMOOTH)
 
 
+_GRAY_W = (0.114, 0.587, 0.299)         # cv2 BGR2GRAY weights applied to an RGB array (to_gray_reference)
+_MASK_CACHE = {}
+
+
+def _gray_of(rgb):
+    return int(min(255, max(0, round(_GRAY_W[0] * rgb[0] + _GRAY_W[1] * rgb[1] + _GRAY_W[2] * rgb[2]))))
+
+
+def _glyph_mask(ch, size):
+    """Coverage mask ('L') of one character at one font size, rendered ONCE per process (the RGB path renders every glyph of every image)."""
+    key = (resolve_font(), size, ch)
+    m = _MASK_CACHE.get(key)
+    if m is None:
+        f = _font(size)
+        box = f.getbbox(ch)
+        w, h = max(1, box[2] - box[0] + 4), max(1, box[3] - box[1] + 4)
+        m = Image.new('L', (w, h), 0)
+        ImageDraw.Draw(m).text((2 - box[0], 2 - box[1]), ch, font=f, fill=255)
+        _MASK_CACHE[key] = m
+    return m
+
+
+def render_captcha_gray(chars, width=160, height=60):
+    """render_captcha() followed by to_gray_reference(), computed in ONE channel: the same random draws in the same order (so the same
+    geometry for the same RNG state), every step of the RGB path is linear in the colour (alpha compositing, resize, line / arc fills, the 3 x 3
+    SMOOTH kernel), hence gray(render_captcha(...)) up to the 8-bit rounding of the intermediate images (a few gray levels at glyph edges:
+    tests/test_data.py).  About 3x cheaper per image: cached glyph masks instead of a FreeType render per glyph, 'L' instead of RGBA / RGB
+    transforms, filter and resize, no float matmul for the gray conversion — the live generator is the training loop's bottleneck, not the GPU."""
+    bg = tuple(random.randint(238, 255) for _ in range(3))
+    fg = tuple(random.randint(10, 200) for _ in range(3))
+    bgv, fgv = _gray_of(bg), _gray_of(fg)
+    # A glyph of the RGB path is an RGBA image holding the full ink wherever its coverage is non-zero; PIL rotates RGBA with PREMULTIPLIED
+    # alpha, so the rotated colour stays the ink and only the alpha is interpolated: pasting it = pasting the solid ink through the rotated mask.
+    glyphs = []
+    for ch in chars:
+        m = _glyph_mask(ch, random.choice((42, 50, 56)))
+        glyphs.append(m.rotate(random.uniform(-30, 30), Image.BILINEAR, expand=1))
+    text_w = sum(a.size[0] for a in glyphs)
+    avg = int(text_w / max(1, len(chars)))
+    x = int(0.1 * avg)
+    canvas_w = max(text_w, width)
+    canvas = Image.new('L', (canvas_w, height), bgv)
+    for a in glyphs:
+        y = int((height - a.size[1]) / 2) + random.randint(-4, 4)
+        canvas.paste(fgv, (x, max(0, y), x + a.size[0], max(0, y) + a.size[1]), a)
+        x += a.size[0] + random.randint(-int(0.25 * avg), 0)
+    if canvas_w > width:
+        canvas = canvas.resize((width, height))
+    img = canvas.crop((0, 0, width, height)) if canvas.size != (width, height) else canvas
+    d = ImageDraw.Draw(img)
+    for _ in range(30):                                       # noise dots
+        px, py = random.randint(0, width), random.randint(0, height)
+        d.line(((px, py), (px - 1, py - 1)), fill=fgv, width=3)
+    x1, x2 = random.randint(0, int(width / 5)), random.randint(width - int(width / 5), width)   # noise curve
+    y1, y2 = random.randint(int(height / 5), height - int(height / 5)), random.randint(int(height / 5), height)
+    d.arc([x1, min(y1, y2), x2, max(y1, y2) + 1], random.randint(0, 20), random.randint(160, 200), fill=fgv)
+    return img.filter(ImageFilter.SMOOTH)
+
+
+def sample_image(min_len=None, max_len=None, width=160, px_per_char=None):
+    """One training sample as the generators feed it: (image array, label string).  Single-channel configurations (the reference's:
+    cfg.NCHANNELS == 1) are rendered directly in gray unless OCR_RENDER=rgb asks for render_captcha + to_gray_reference."""
+    chars = gen_rand(min_len, max_len)
+    if px_per_char:
+        width = min(600, len(chars) * px_per_char + random.randint(-8, 8))          # 600 px -> W = 320 at H = 32
+    if cfg.NCHANNELS == 1 and os.environ.get('OCR_RENDER', 'gray') != 'rgb':
+        return np.array(render_captcha_gray(chars, width, 60)), chars
+    im = np.array(render_captcha(chars, width, 60))
+    return (to_gray_reference(im) if cfg.NCHANNELS == 1 else im), chars
+
+
 def generateImg(min_len=None, max_len=None, width=160, height=60):
     """One captcha.  Defaults = the reference (4-6 characters on ImageCaptcha's 160x60 canvas, gen.py:31-37); the keyword
     arguments produce the wider workloads of BASELINE.json (10 characters on 480x60 -> W = 256 after the resize to H = 32)."""
@@ -166,14 +237,7 @@ def generator(batch_size=32, vis=False, min_len=None, max_len=None, width=160, p
     images, labels = [], []
     while True:
         try:
-            if px_per_char:
-                chars = gen_rand(min_len, max_len)
-                canvas = min(600, len(chars) * px_per_char + random.randint(-8, 8))          # 600 px -> W = 320 at H = 32
-                im, label = np.array(render_captcha(chars, canvas, 60)), chars
-            else:
-                im, label = generateImg(min_len, max_len, width)
-            if cfg.NCHANNELS == 1:
-                im = to_gray_reference(im)
+            im, label = sample_image(min_len, max_len, width, px_per_char)
             images.append(im)
             labels.append(label)
             if len(images) == batch_size:

@@ -96,13 +96,9 @@ def _worker(index, seed, layout, buf, free_q, ready_q, halt, gen_kwargs, once=Fa
                 continue
             images, labels = [], []
             while len(images) < layout.batch:
-                if gen_kwargs.get('px_per_char'):
-                    chars = gen.gen_rand(gen_kwargs.get('min_len'), gen_kwargs.get('max_len'))
-                    canvas = min(600, len(chars) * gen_kwargs['px_per_char'] + random.randint(-8, 8))
-                    im = np.array(gen.render_captcha(chars, canvas, 60))
-                else:
-                    im, chars = gen.generateImg(gen_kwargs.get('min_len'), gen_kwargs.get('max_len'), gen_kwargs.get('width', 160))
-                images.append(gen.to_gray_reference(im) if cfg.NCHANNELS == 1 else im)
+                im, chars = gen.sample_image(gen_kwargs.get('min_len'), gen_kwargs.get('max_len'), gen_kwargs.get('width', 160),
+                                             gen_kwargs.get('px_per_char'))          # the same call, hence the same RNG order, as gen.generator
+                images.append(im)
                 labels.append(chars)
             meta, pix = layout.views(buf, slot)
             group_batch_u8(images, labels, layout, meta, pix)

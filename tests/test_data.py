@@ -27,6 +27,33 @@ def test_gray_conversion_quirk_and_generator():
     assert all(1 <= v <= 62 for v in labels)
 
 
+def test_one_channel_renderer_equals_the_rgb_path_up_to_rounding(monkeypatch):
+    """render_captcha_gray (round 4: the generators' default for the reference's single-channel configuration) consumes the RNG in the order of
+    render_captcha and composes in one channel what that path composes in three: for the same RNG state it is
+    to_gray_reference(render_captcha(...)) up to the 8-bit rounding of the intermediate images."""
+    import random
+    worst = 0
+    for seed in range(24):
+        L = random.Random(seed).randint(4, 10)
+        w = 160 if L <= 6 else 480
+        random.seed(seed)
+        chars = ''.join(random.choice(cfg.CHARSET) for _ in range(L))
+        st = random.getstate()
+        a = gen.to_gray_reference(np.array(gen.render_captcha(chars, w, 60))).astype(int)
+        after_rgb = random.getstate()
+        random.setstate(st)
+        b = np.array(gen.render_captcha_gray(chars, w, 60)).astype(int)
+        assert random.getstate() == after_rgb                       # the same number of draws: the streams stay aligned
+        assert a.shape == b.shape == (60, w)
+        worst = max(worst, int(np.abs(a - b).max()))
+    assert worst <= 3, worst
+    # OCR_RENDER=rgb restores the three-channel path in the generators
+    random.seed(7); im_gray, lab_gray = gen.sample_image()
+    monkeypatch.setenv('OCR_RENDER', 'rgb')
+    random.seed(7); im_rgb, lab_rgb = gen.sample_image()
+    assert lab_gray == lab_rgb and im_gray.shape == im_rgb.shape and np.abs(im_gray.astype(int) - im_rgb.astype(int)).max() <= 3
+
+
 def test_enqueuer_threads():
     def counter():
         i = 0

@@ -27,3 +27,7 @@ bash tools/prof_step_pmc.sh ${T} 2>&1 | tail -12
 bash tools/prof_step_pmc.sh ${T}_varwidth --workload varwidth 2>&1 | tail -6
 bash tools/prof_step_pmc.sh ${T}_deep --workload deep 2>&1 | tail -6
 ls -la $O/${T}*pmc_step_*.json
+# the real training loop through the live generator (one-channel renderer of round 4) and the shared-memory input ring, next to the device rate
+timeout 600 python tools/cli_throughput.py --iters 1500 2>&1 | grep -v amdgpu.ids | tail -4 | tee $O/${T}_cli_throughput_live.log
+# ... and the reference's own entry point end to end
+timeout 900 ./train.sh --iters 40000 2>&1 | grep -E "^iter: *[0-9]*000 |accuracy|done solving|speed" | tail -60 > $O/${T}_train_cli_40k.log; tail -4 $O/${T}_train_cli_40k.log
