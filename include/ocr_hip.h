@@ -275,6 +275,10 @@ int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, const int* seq
  * through the output tensor inside one XCD's L2 — both need workgroups with equal (id & 7) on one XCD, see ocr_probe_xcc;
  * 0 = counters (sc1): placement independent */
 int ocr_set_lstm_proto(int proto);
+/* waves per workgroup of the persistent kernels' 16-row tiles under protocol 4: 4 (default: the contraction axis, the polls and the gate
+ * math of a step split over four waves) or 1 (the one-wave kernels of rounds 2-3).  Same tensors, same hand-off ring; results equal up to
+ * fp32 summation order.  OCR_ERR_INVALID for other values.  The environment variable OCR_LSTM_KSPLIT (1 / 4) wins over this setter. */
+int ocr_set_lstm_ksplit(int waves);
 int ocr_lstm_hprev(const void* hout, const int* seq_len, void* hprev, int Nb, int T, int U, int ndir, void* stream);
 /* xh [ndir][Nb*T][D+U] = [x | h_{t-1} in direction order]: operand of the LSTMCell-matrix weight gradient (one GEMM per direction) */
 int ocr_lstm_xh(const void* x, const void* hout, const int* seq_len, void* xh, int Nb, int T, int D, int U, int ndir, void* stream);

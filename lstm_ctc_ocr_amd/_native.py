@@ -103,6 +103,7 @@ _SIGS = {
     "ocr_wgrad9_debug": ([_P], _I),
     "ocr_probe_tr16": ([_P, _P, _P], _I),
     "ocr_set_lstm_proto": ([_I], _I),
+    "ocr_set_lstm_ksplit": ([_I], _I),
     "ocr_probe_xcc": ([_P, _I, _I, _P], _I),
     "ocr_mfma_busy_probe": ([_P, _I, _I, _I, _P, _P], _I),
 }

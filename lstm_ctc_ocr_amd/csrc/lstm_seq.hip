@@ -460,6 +460,297 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
+// ---- four waves per workgroup (round 4): the step's work split FOUR ways instead of waiting four times as long ------------------------------
+// The one-wave kernels above spend 2.0 us per step: 0.84 waiting for the other workgroups' rows, 0.44 in 32 dependent-issue MFMAs of ONE
+// SIMD and 0.84 in the gate math of 4 units x 5 transcendentals per lane plus eight stores — three quarters of the CU idle throughout.
+// Here a workgroup is four waves (one per SIMD) over the same 16 batch rows x 16 units:
+//   * each wave holds a QUARTER of the contraction axis (32 / 64 VGPRs of W_h at U = 256 / 512), polls only the ring rows of that quarter
+//     (2 instead of 8 operand loads forward, 8 instead of 32 backward) and issues a quarter of the MFMAs;
+//   * the partial sums meet in LDS (barrier A), and each wave then OWNS one of the four units every lane held — unit q * 4 + wave of batch
+//     row (lane & 15): a quarter of the gate math, its c / dc in one register;
+//   * the results go back through LDS (barrier B) into the one-wave kernels' register layout (four consecutive units per lane), so the
+//     stores are the same wide ones — but spread over the waves: forward wave 0 the ring piece / refill / output row, waves 1 - 2 two saved
+//     gates each, wave 3 the cell; backward wave g the ring piece / refill / dz row of gate g.  (A first version let every owner store
+//     its own element: 2-byte and 4-byte stores scattered over 16 rows cost ~0.1 us EACH to issue — the backward pass, with twelve
+//     of them, ran 163 us against the one-wave kernel's 133, `profiles/r04o_lstm_bench.jsonl`.)
+//   * the operands that do not depend on the recurrence (x-projection; saved gates, cells and the incoming dh) are loaded wide by ONE
+//     wave each, a step AHEAD, and handed to the owners through LDS under barrier A: vmcnt retires in issue order, so a load issued at
+//     the top of a step (as the one-wave kernels do) has to return — from the Infinity Cache or HBM — before the first poll of that step
+//     can be looked at; issued right behind the previous step's successful poll it has a whole step.  For the same reason there is no
+//     counted wait at the top of a step: the poll's own wait covers every older store of the wave, the refill included, before this
+//     step's ring piece is issued;
+//   * ring layout, hand-off protocol (4: data-as-flag, the storing wave recycles its piece two steps behind — after barrier A, i.e. after
+//     ALL four waves' polls of the step have succeeded and every workgroup of the group is known to have finished the step before),
+//     output tensors and saved gates / cell are those of the one-wave kernels: the two families are interchangeable per launch
+//     (OCR_LSTM_KSPLIT = 1 / 4, ocr_set_lstm_ksplit).
+// LDS buffers are single: what is written before barrier A (B) of a step is read between A and B (behind B), and every wave has passed
+// the other barrier before anybody writes the buffer again.
+// The sums over the contraction axis are taken in a different order than in the one-wave kernels (four partial sums of K / 4 each): equal up
+// to fp32 rounding, not bit-identical.
+template <int U>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_seq4_kernel(LstmSeqFwdArgs a) {
+    constexpr int KS = U / 32 / 4, UB = U / 16;
+    constexpr unsigned SLOT = (unsigned)UB * 512u;                       // ring bytes per step and group
+    __shared__ f32x4 red[4][4][64];                                      // [source wave][unit r of the lane's four][lane] = partial {i, j, f, o}
+    __shared__ f32x4 xs[4][64];                                          // [gate][lane] = x-projection of the lane's four units
+    __shared__ f32x4 outs[6][64];                                        // [h, i, j, f, o, c][lane] = results of the lane's four units (element r by wave r)
+    const int lane = threadIdx.x & 63;
+    const int kh = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int ub, d, zb;
+    const int nzb = (a.Nb + 15) / 16;
+    if (!seq_decode<4, UB>(2 * nzb, ub, d, zb)) return;
+    const int T = a.T;
+    const int nl = lane & 15, q = lane >> 4;
+    const int n = zb * 16 + nl;
+    const bool nvalid = n < a.Nb;
+    const int nn = nvalid ? n : 0;
+    const int len = min(a.seq_len[nn], T);
+    const long R = (long)a.Nb * T;
+    const int ul0 = q * 4;
+
+    bf16x8 w[4][KS];
+    {
+        const bf16_t* wbase = a.whT + ((long)d * 4 * U + (long)ub * 64 + nl) * U + kh * (KS * 32) + q * 8;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) w[g][kk] = *(const bf16x8*)(wbase + (long)g * 16 * U + kk * 32);
+    }
+    float c = 0.f;                                                       // cell state of (row nl, unit ul0 + kh)
+    int presleep = a.presleep, streak = 0;
+    bool dead = false;
+    unsigned char* const gring = a.ring + (size_t)(zb * 2 + d) * RING * SLOT;
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)gring, 0, (int)(RING * SLOT), 0x00020000);
+    const unsigned rd0 = (unsigned)((kh * KS * 2 + (q >> 1)) * 512 + nl * 32 + (q & 1) * 16);
+    const unsigned wr0 = (unsigned)(ub * 512 + nl * 32 + q * 8);
+    // gate kh's x-projection of step s1 for the lane's four units (zero for rows past their length)
+    auto xload = [&](int s1) {
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (nvalid && s1 < len) {
+            const int t1 = d == 0 ? s1 : len - 1 - s1;
+            x = *(const f32x4*)(a.xproj + ((long)nn * T + t1) * (8L * U) + (long)d * 4 * U + (long)ub * 64 + kh * 16 + ul0);
+        }
+        return x;
+    };
+    f32x4 xn = xload(0);
+    for (int s = 0; s < T; ++s) {
+        const int dbgi = s;
+        DBG_STAMP(0);
+        const bool active = nvalid && s < len;
+        const int t = active ? (d == 0 ? s : len - 1 - s) : s;
+        const long row = (long)nn * T + t;
+        bf16x8 b[KS];
+        if (s > 0) {
+            const unsigned hoff = (unsigned)((s - 1) & (RING - 1)) * SLOT + rd0;
+            unsigned spins = 0;
+            for (int i = 0; i < presleep; ++i) __builtin_amdgcn_s_sleep(1);
+            while (true) {
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) b[kk] = load_pub<4>(rrsrc, hoff + kk * 1024u);
+                __builtin_amdgcn_sched_barrier(0);
+                unsigned m = 0;
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) m = fold_fill(m, b[kk]);
+                if (dead || !__any(active && holds_fill(m))) break;
+                if (++spins > (SPIN_LIMIT >> 4)) { if (lane == 0) atomicExch(a.err, 1); dead = true; break; }
+            }
+            DBG_STAMP(1);
+            POLL_ADAPT();
+            if (!active) {
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) b[kk] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        f32x4 xc = xn;
+        asm volatile("" : "+v"(xc));                           // taken HERE (behind the poll, whose wait covered it), not where the compiler likes
+        xn = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (s + 1 < T) xn = xload(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s > 0) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g][kk], b[kk], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[kh][r][lane] = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        }
+        xs[kh][lane] = xc;
+        __syncthreads();                                        // A
+        const float* xo = (const float*)&xs[0][lane] + kh;     // [gate][lane][element kh]
+        f32x4 z = {xo[0], xo[256], xo[512], xo[768]};           // gate pre-activations {i, j, f, o} of (row nl, unit ul0 + kh)
+        if (s > 0) z += (red[0][kh][lane] + red[1][kh][lane]) + (red[2][kh][lane] + red[3][kh][lane]);
+        const float gi = sigmoidf_(z[0]), gj = tanhf_(z[1]), gf = sigmoidf_(z[2] + a.forget_bias), go = sigmoidf_(z[3]);
+        const float cn = gf * c + gi * gj;
+        const float hn = go * tanhf_(cn);
+        if (active) c = cn;
+        float* oo = (float*)&outs[0][lane] + kh;
+        oo[0] = active ? hn : 0.f; oo[256] = gi; oo[512] = gj; oo[768] = gf; oo[1024] = go; oo[1280] = c;
+        __syncthreads();                                        // B
+        DBG_STAMP(2);
+        if (nvalid) {
+            // the one-wave kernel's stores, one part per wave (rows past their length store zeros / throw-away gate values into rows nobody reads)
+            if (kh == 0) {
+                const f32x4 h = outs[0][lane];
+                const u32x2 hp = {pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
+                *(u32x2*)(gring + (unsigned)(s & (RING - 1)) * SLOT + wr0) = hp;               // the hand-off payload goes out FIRST
+                asm volatile("" ::: "memory");
+                if (s >= 2) *(u32x2*)(gring + (unsigned)((s - 2) & (RING - 1)) * SLOT + wr0) = (u32x2){0xFFFFFFFFu, 0xFFFFFFFFu};
+                asm volatile("" ::: "memory");
+                *(u32x2*)(a.hout + row * (2L * U) + (long)d * U + ub * 16 + ul0) = hp;
+            } else if (kh == 3) {
+                *(f32x4*)(a.cell + ((long)d * R + row) * U + ub * 16 + ul0) = outs[5][lane];
+            } else {
+                float* gdst = a.gates + ((long)d * R + row) * (4L * U) + (long)ub * 64 + ul0 + (kh - 1) * 32;
+                *(f32x4*)(gdst + 0) = outs[2 * kh - 1][lane];
+                *(f32x4*)(gdst + 16) = outs[2 * kh][lane];
+            }
+        }
+        DBG_STAMP(3);
+    }
+}
+
+template <int U>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_seq4_kernel(LstmSeqBwdArgs a) {
+    constexpr int KS = U / 32, UB = U / 16;                              // wave kh multiplies gate kh's columns of W_h: K = kh U .. (kh + 1) U of 4U
+    constexpr unsigned SLOT = (unsigned)UB * 2048u;                      // ring bytes per step and group: [ub][gate][16 rows][16 units]
+    __shared__ f32x4 red[4][64];                                         // [source wave][lane] = partial dh of the lane's four units
+    __shared__ f32x4 sv[7][64];                                          // [i, j, f, o, c, c_prev, dh_in][lane] = saved operands of the lane's four units
+    __shared__ f32x4 outs[4][64];                                        // [gate][lane] = gate gradients of the lane's four units (element r by wave r)
+    const int lane = threadIdx.x & 63;
+    const int kh = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int ub, d, zb;
+    const int nzb = (a.Nb + 15) / 16;
+    if (!seq_decode<4, UB>(2 * nzb, ub, d, zb)) return;
+    const int T = a.T;
+    const int nl = lane & 15, q = lane >> 4;
+    const int n = zb * 16 + nl;
+    const bool nvalid = n < a.Nb;
+    const int nn = nvalid ? n : 0;
+    const int len = min(a.seq_len[nn], T);
+    const long R = (long)a.Nb * T;
+    const int u0 = ub * 16 + q * 4;
+
+    bf16x8 w[KS];
+    {
+        const bf16_t* wbase = a.wh + (long)d * a.w_dir_stride + ((long)ub * 16 + nl) * a.ldw + kh * (KS * 32) + q * 8;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) w[kk] = *(const bf16x8*)(wbase + kk * 32);
+    }
+    float dcs = 0.f;                                                     // cell gradient of (row nl, unit q * 4 + kh)
+    int presleep = a.presleep, streak = 0;
+    bool dead = false;
+    unsigned char* const gring = a.ring + (size_t)(zb * 2 + d) * RING * SLOT;
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)gring, 0, (int)(RING * SLOT), 0x00020000);
+    // k-step kk of this wave: gate kh, units kk 32 + q 8 .. + 8 = unit block 2 kk + (q >> 1), 16-byte half (q & 1)
+    const unsigned rdl = (unsigned)((q >> 1) * 2048 + kh * 512 + nl * 32 + (q & 1) * 16);
+    const unsigned wr0 = (unsigned)(ub * 2048 + kh * 512 + nl * 32 + q * 8);       // this wave stores gate kh
+    // the saved operands of step s1, two per wave (wave 0: i, j; 1: f, o; 2: c, c_prev; 3: incoming dh as bf16 bits in A[0], A[1])
+    auto sload = [&](int s1, f32x4& A, f32x4& B) {
+        A = (f32x4){0.f, 0.f, 0.f, 0.f}; B = A;
+        if (nvalid && s1 < len) {
+            const int t1 = d == 0 ? s1 : len - 1 - s1;
+            const int tp = d == 0 ? t1 - 1 : t1 + 1;
+            const long row1 = (long)nn * T + t1;
+            if (kh < 2) {
+                const float* gsrc = a.gates + ((long)d * R + row1) * (4L * U) + (long)ub * 64 + q * 4 + kh * 32;
+                A = *(const f32x4*)gsrc; B = *(const f32x4*)(gsrc + 16);
+            } else if (kh == 2) {
+                A = *(const f32x4*)(a.cell + ((long)d * R + row1) * U + u0);
+                if (s1 > 0) B = *(const f32x4*)(a.cell + ((long)d * R + (long)nn * T + tp) * U + u0);
+            } else {
+                const u32x2 g2 = *(const u32x2*)(a.dhout + row1 * (2L * U) + (long)d * U + u0);
+                A[0] = __uint_as_float(g2.x); A[1] = __uint_as_float(g2.y);
+            }
+        }
+    };
+    f32x4 nA, nB;
+    sload(T - 1, nA, nB);
+    for (int s = T - 1, it = 0; s >= 0; --s, ++it) {
+        const int dbgi = it;
+        DBG_STAMP(0);
+        const bool active = nvalid && s < len;
+        const bool has_next = nvalid && (s + 1 < len);
+        const int t = active ? (d == 0 ? s : len - 1 - s) : s;
+        const long row = (long)nn * T + t;
+        bf16x8 z[KS];
+        if (it > 0) {
+            const unsigned roff = (unsigned)((it - 1) & (RING - 1)) * SLOT + rdl;
+            unsigned spins = 0;
+            for (int i = 0; i < presleep; ++i) __builtin_amdgcn_s_sleep(1);
+            while (true) {
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) z[kk] = load_pub<4>(rrsrc, roff, (unsigned)(kk * 2 * 2048));
+                __builtin_amdgcn_sched_barrier(0);
+                unsigned m = 0;
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) m = fold_fill(m, z[kk]);
+                if (dead || !__any(has_next && holds_fill(m))) break;
+                if (++spins > (SPIN_LIMIT >> 4)) { if (lane == 0) atomicExch(a.err, 1); dead = true; break; }
+            }
+            DBG_STAMP(1);
+            POLL_ADAPT();
+            if (!has_next) {
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) z[kk] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        f32x4 A = nA, B = nB;
+        asm volatile("" : "+v"(A), "+v"(B));                   // taken behind the poll
+        nA = (f32x4){0.f, 0.f, 0.f, 0.f}; nB = nA;
+        if (s > 0) sload(s - 1, nA, nB);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it > 0) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+            for (int k0 = 0; k0 < KS; k0 += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[k0 + 0], z[k0 + 0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[k0 + 1], z[k0 + 1], acc1, 0, 0, 0);
+            }
+            red[kh][lane] = acc0 + acc1;
+        }
+        if (kh < 3) { sv[2 * kh][lane] = A; sv[2 * kh + 1][lane] = B; }
+        else {
+            const unsigned gx = __float_as_uint(A[0]), gy = __float_as_uint(A[1]);
+            sv[6][lane] = (f32x4){bf_lo(gx), bf_hi(gx), bf_lo(gy), bf_hi(gy)};
+        }
+        __syncthreads();                                        // A
+        const float* so = (const float*)&sv[0][lane] + kh;     // [operand][lane][element kh]
+        const float gi = so[0], gj = so[256], gf = so[512], go = so[768], c = so[1024], cprev = so[1280];
+        float dh = so[1536];
+        if (it > 0 && has_next) {
+            const float* ro = (const float*)&red[0][lane] + kh;
+            dh += (ro[0] + ro[256]) + (ro[512] + ro[768]);
+        }
+        const float tc = tanhf_(c);
+        const float dc = dcs + dh * go * (1.f - tc * tc);
+        float dg[4];
+        dg[3] = dh * tc * go * (1.f - go);
+        dg[0] = dc * gj * gi * (1.f - gi);
+        dg[1] = dc * gi * (1.f - gj * gj);
+        dg[2] = dc * cprev * gf * (1.f - gf);
+        if (active) dcs = dc * gf;
+        float* oo = (float*)&outs[0][lane] + kh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) oo[g * 256] = active ? dg[g] : 0.f;
+        __syncthreads();                                        // B
+        DBG_STAMP(2);
+        if (nvalid) {
+            const f32x4 v = outs[kh][lane];
+            const u32x2 p = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *(u32x2*)(gring + (unsigned)(it & (RING - 1)) * SLOT + wr0) = p;
+            asm volatile("" ::: "memory");
+            if (it >= 2) *(u32x2*)(gring + (unsigned)((it - 2) & (RING - 1)) * SLOT + wr0) = (u32x2){0xFFFFFFFFu, 0xFFFFFFFFu};
+            asm volatile("" ::: "memory");
+            *(u32x2*)(a.dz + row * (8L * U) + (long)d * 4 * U + (long)kh * U + u0) = p;
+        }
+        DBG_STAMP(3);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // C ABI.  `sync` is a caller-owned device block of ocr_lstm_seq_sync_words(Nb, U) 32-bit words: the group counters, the
 // protocol-4 ring and, as its LAST word, an error word; the call's own fill launch initialises what its protocol needs
@@ -478,7 +769,7 @@ extern "C" int ocr_lstm_seq_debug(void* dbg) { g_lstm_dbg = (long long*)dbg; ret
 
 // environment knobs are looked up ONCE per process (the launch path runs every step when graphs are off)
 static int seq_env_int(const char* name, int slot, int dflt, bool tuning = false /* read by experiments builds only */) {
-    static int val[4], seen[4];
+    static int val[5], seen[5];
     if (!seen[slot]) { const char* e = tuning ? ocr_tune_env(name) : getenv(name); val[slot] = e ? atoi(e) : dflt; seen[slot] = 1; }
     return val[slot];
 }
@@ -508,6 +799,19 @@ static int seq_proto() {
     const int env = seq_env_int("OCR_LSTM_PROTO", 3, -1);
     if (env == 0 || env == 4) return env;
     return g_seq_proto >= 0 ? g_seq_proto : 4;
+}
+// waves per workgroup of the 16-row, protocol-4 kernels: 4 (default, round 4: lstm_*_seq4_kernel) or 1 (the one-wave kernels).  Environment
+// OCR_LSTM_KSPLIT wins over the setter (tests run both families in one process through the setter).
+static int g_seq_ksplit = -1;
+extern "C" int ocr_set_lstm_ksplit(int k) {
+    if (k != 1 && k != 4) return OCR_ERR_INVALID;
+    g_seq_ksplit = k;
+    return OCR_OK;
+}
+static int seq_ksplit() {
+    const int env = seq_env_int("OCR_LSTM_KSPLIT", 4, -1);
+    if (env == 1 || env == 4) return env;
+    return g_seq_ksplit >= 0 ? g_seq_ksplit : 4;
 }
 extern "C" int ocr_lstm_seq_supported(int Nb, int U) { return Nb > 0 && seq_rows_per_wg(Nb, U) != 0; }
 // int32 words the caller must provide in `sync`: group counters | ring (sized for the backward pass and the smallest tile) | tail
@@ -564,7 +868,9 @@ extern "C" int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, cons
                         (unsigned char*)((unsigned*)sync + cwords), (int*)sync + words - 1, Nb, T, forget_bias, g_lstm_dbg,
                         seq_env_int("OCR_LSTM_PRESLEEP_F", 0, 0, true)};
     const dim3 grid3(U / 16, 2, nz), grid1((U / 16) * 8 * ceil_div(2 * nz, 8));
-#define FWD(UU) do { if (proto == 0) launch_fwd<UU, 0>(a, rows, grid3, grid1, stream); else launch_fwd<UU, 4>(a, rows, grid3, grid1, stream); } while (0)
+#define FWD(UU) do { if (proto == 0) launch_fwd<UU, 0>(a, rows, grid3, grid1, stream); \
+                     else if (rows == 16 && seq_ksplit() == 4) lstm_fwd_seq4_kernel<UU><<<grid1, 256, 0, stream>>>(a); \
+                     else launch_fwd<UU, 4>(a, rows, grid3, grid1, stream); } while (0)
     if (U == 256) FWD(256); else FWD(512);
 #undef FWD
     OCR_CHECK_LAUNCH();
@@ -589,7 +895,9 @@ extern "C" int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, con
                         (unsigned*)sync, (unsigned char*)((unsigned*)sync + cwords), (int*)sync + words - 1, Nb, T, g_lstm_dbg,
                         seq_env_int("OCR_LSTM_PRESLEEP", 1, 4, true)};
     const dim3 grid3(U / 16, 2, nz), grid1((U / 16) * 8 * ceil_div(2 * nz, 8));
-#define BWD(UU) do { if (proto == 0) launch_bwd<UU, 0>(a, rows, grid3, grid1, stream); else launch_bwd<UU, 4>(a, rows, grid3, grid1, stream); } while (0)
+#define BWD(UU) do { if (proto == 0) launch_bwd<UU, 0>(a, rows, grid3, grid1, stream); \
+                     else if (rows == 16 && seq_ksplit() == 4) lstm_bwd_seq4_kernel<UU><<<grid1, 256, 0, stream>>>(a); \
+                     else launch_bwd<UU, 4>(a, rows, grid3, grid1, stream); } while (0)
     if (U == 256) BWD(256); else BWD(512);
 #undef BWD
     OCR_CHECK_LAUNCH();

@@ -503,6 +503,11 @@ def lstm_bwd_step(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, dc_sta
          ptr(dc_state), Nb, T, U, step, ndir, _st())
 
 
+def set_lstm_ksplit(waves):
+    """Waves per workgroup of the persistent LSTM kernels (4: default since round 4; 1: the one-wave kernels).  OCR_LSTM_KSPLIT wins."""
+    call("ocr_set_lstm_ksplit", int(waves))
+
+
 def lstm_seq_supported(Nb, U):
     return bool(nat.lib().ocr_lstm_seq_supported(Nb, U))
 

@@ -811,13 +811,25 @@ def test_lstm_fwd_bwd(dev, N, T, D, U, lens, persistent):
     fw = og.lstm_direction(xr, seq_len, Wr[0], br[0], False, True)
     bw = og.lstm_direction(xr, seq_len, Wr[1], br[1], True, True)
     ref = torch.cat([fw, bw], 2)
+    dh = bf(gen((N, T, 2 * U), 9))
+    ref.backward(dh)
+    # the persistent kernels come in two families (four waves per workgroup — the default since round 4 — and one): both through the same checks
+    for ksplit in ((4, 1) if persistent else (None,)):
+        if ksplit is not None:
+            ops.set_lstm_ksplit(ksplit)
+        try:
+            _lstm_device_checks(dev, N, T, D, U, x, seq_len, Ws, bs, Wr, br, xr, ref, dh, persistent)
+        finally:
+            if ksplit is not None:
+                ops.set_lstm_ksplit(4)
+
+
+def _lstm_device_checks(dev, N, T, D, U, x, seq_len, Ws, bs, Wr, br, xr, ref, dh, persistent):
     st = _lstm_device_forward(dev, x, seq_len, Ws, bs, U, persistent)
     got = st["hout"].float().cpu().reshape(N, T, 2 * U)
     # measured on MI355X (round 2): <= 3.9e-3 = one bf16 ulp of |h| in [0.5, 1) (a rounding flip of the stored h), usually 0 .. 1e-3
     assert maxerr(got, ref.detach()) < 8e-3, maxerr(got, ref.detach())
     # ---- backward
-    dh = bf(gen((N, T, 2 * U), 9))
-    ref.backward(dh)
     R = N * T
     whb = torch.empty((2, D + U, 4 * U), dtype=BF, device=dev)
     for d in range(2):
