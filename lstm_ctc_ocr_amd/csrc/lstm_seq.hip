@@ -474,7 +474,8 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
 //     its own element: 2-byte and 4-byte stores scattered over 16 rows cost ~0.1 us EACH to issue — the backward pass, with twelve
 //     of them, ran 163 us against the one-wave kernel's 133, `profiles/r04o_lstm_bench.jsonl`.)
 //   * the operands that do not depend on the recurrence (x-projection; saved gates, cells and the incoming dh) are loaded wide by ONE
-//     wave each, a step AHEAD, and handed to the owners through LDS under barrier A: vmcnt retires in issue order, so a load issued at
+//     wave each, a step AHEAD, and reach the owners through LDS under barrier A (the saved gates / cells as they are; the x-projection of
+//     gate g and the incoming dh added to the partial sums of the wave that loaded them): vmcnt retires in issue order, so a load issued at
 //     the top of a step (as the one-wave kernels do) has to return — from the Infinity Cache or HBM — before the first poll of that step
 //     can be looked at; issued right behind the previous step's successful poll it has a whole step.  For the same reason there is no
 //     counted wait at the top of a step: the poll's own wait covers every older store of the wave, the refill included, before this
@@ -487,12 +488,18 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
 // the other barrier before anybody writes the buffer again.
 // The sums over the contraction axis are taken in a different order than in the one-wave kernels (four partial sums of K / 4 each): equal up
 // to fp32 rounding, not bit-identical.
+// The activations with v_rcp_f32 (1 ulp) in place of the correctly rounded reciprocal of sigmoidf_ / tanhf_: the IEEE division is a chain of
+// ten dependent instructions, five of them per step sat on the forward recurrence's critical path (one wave per SIMD: nothing hides it).
+__device__ __forceinline__ float sigmoid_q(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_q(float x) {
+    const float e = __expf(-2.0f * fabsf(x));          // in (0, 1]: no overflow
+    return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+}
 template <int U>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_seq4_kernel(LstmSeqFwdArgs a) {
     constexpr int KS = U / 32 / 4, UB = U / 16;
     constexpr unsigned SLOT = (unsigned)UB * 512u;                       // ring bytes per step and group
-    __shared__ f32x4 red[4][4][64];                                      // [source wave][unit r of the lane's four][lane] = partial {i, j, f, o}
-    __shared__ f32x4 xs[4][64];                                          // [gate][lane] = x-projection of the lane's four units
+    __shared__ f32x4 red[4][4][64];                                      // [source wave][unit r of the lane's four][lane] = partial {i, j, f, o}; wave g's carries x of gate g
     __shared__ f32x4 outs[6][64];                                        // [h, i, j, f, o, c][lane] = results of the lane's four units (element r by wave r)
     const int lane = threadIdx.x & 63;
     const int kh = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -566,26 +573,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         xn = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s + 1 < T) xn = xload(s + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (s > 0) {
-            f32x4 acc[4];
+        f32x4 acc[4];                                          // x of gate kh rides on this wave's partial sums (branch-free: the others start at x * 0)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < 4; ++g) acc[g] = xc * (kh == g ? 1.f : 0.f);
+        if (s > 0) {
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g][kk], b[kk], acc[g], 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[kh][r][lane] = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
         }
-        xs[kh][lane] = xc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[kh][r][lane] = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
         __syncthreads();                                        // A
-        const float* xo = (const float*)&xs[0][lane] + kh;     // [gate][lane][element kh]
-        f32x4 z = {xo[0], xo[256], xo[512], xo[768]};           // gate pre-activations {i, j, f, o} of (row nl, unit ul0 + kh)
-        if (s > 0) z += (red[0][kh][lane] + red[1][kh][lane]) + (red[2][kh][lane] + red[3][kh][lane]);
-        const float gi = sigmoidf_(z[0]), gj = tanhf_(z[1]), gf = sigmoidf_(z[2] + a.forget_bias), go = sigmoidf_(z[3]);
+        // gate pre-activations {i, j, f, o} of (row nl, unit ul0 + kh)
+        const f32x4 z = (red[0][kh][lane] + red[1][kh][lane]) + (red[2][kh][lane] + red[3][kh][lane]);
+        const float gi = sigmoid_q(z[0]), gj = tanh_q(z[1]), gf = sigmoid_q(z[2] + a.forget_bias), go = sigmoid_q(z[3]);
         const float cn = gf * c + gi * gj;
-        const float hn = go * tanhf_(cn);
+        const float hn = go * tanh_q(cn);
         if (active) c = cn;
         float* oo = (float*)&outs[0][lane] + kh;
         oo[0] = active ? hn : 0.f; oo[256] = gi; oo[512] = gj; oo[768] = gf; oo[1024] = go; oo[1280] = c;
@@ -618,7 +623,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int KS = U / 32, UB = U / 16;                              // wave kh multiplies gate kh's columns of W_h: K = kh U .. (kh + 1) U of 4U
     constexpr unsigned SLOT = (unsigned)UB * 2048u;                      // ring bytes per step and group: [ub][gate][16 rows][16 units]
     __shared__ f32x4 red[4][64];                                         // [source wave][lane] = partial dh of the lane's four units
-    __shared__ f32x4 sv[7][64];                                          // [i, j, f, o, c, c_prev, dh_in][lane] = saved operands of the lane's four units
+    __shared__ f32x4 sv[6][64];                                          // [i, j, f, o, c, c_prev][lane] = saved operands of the lane's four units
     __shared__ f32x4 outs[4][64];                                        // [gate][lane] = gate gradients of the lane's four units (element r by wave r)
     const int lane = threadIdx.x & 63;
     const int kh = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -703,29 +708,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         nA = (f32x4){0.f, 0.f, 0.f, 0.f}; nB = nA;
         if (s > 0) sload(s - 1, nA, nB);
         __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;        // (rows without a successor step multiplied zeros)
         if (it > 0) {
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
             for (int k0 = 0; k0 < KS; k0 += 2) {
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[k0 + 0], z[k0 + 0], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[k0 + 1], z[k0 + 1], acc1, 0, 0, 0);
             }
-            red[kh][lane] = acc0 + acc1;
         }
         if (kh < 3) { sv[2 * kh][lane] = A; sv[2 * kh + 1][lane] = B; }
-        else {
+        else {                                                  // the incoming dh rides on this wave's partial sums
             const unsigned gx = __float_as_uint(A[0]), gy = __float_as_uint(A[1]);
-            sv[6][lane] = (f32x4){bf_lo(gx), bf_hi(gx), bf_lo(gy), bf_hi(gy)};
+            acc1 += (f32x4){bf_lo(gx), bf_hi(gx), bf_lo(gy), bf_hi(gy)};
         }
+        red[kh][lane] = acc0 + acc1;
         __syncthreads();                                        // A
         const float* so = (const float*)&sv[0][lane] + kh;     // [operand][lane][element kh]
         const float gi = so[0], gj = so[256], gf = so[512], go = so[768], c = so[1024], cprev = so[1280];
-        float dh = so[1536];
-        if (it > 0 && has_next) {
-            const float* ro = (const float*)&red[0][lane] + kh;
-            dh += (ro[0] + ro[256]) + (ro[512] + ro[768]);
-        }
-        const float tc = tanhf_(c);
+        const float* ro = (const float*)&red[0][lane] + kh;
+        const float dh = (ro[0] + ro[256]) + (ro[512] + ro[768]);
+        const float tc = tanh_q(c);
         const float dc = dcs + dh * go * (1.f - tc * tc);
         float dg[4];
         dg[3] = dh * tc * go * (1.f - go);
