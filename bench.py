@@ -158,8 +158,11 @@ def conv_roofline(eng, device, workload):
     if not cands:
         pmc_error = "no profiles/r*_pmc_step_%s.json for this workload" % workload
     else:
-        src = os.path.basename(cands[-1])
-        pm = json.load(open(cands[-1]))
+        # several rounds' summaries lie side by side: the one taken on the loaded build wins; without one, the last by name is named in the refusal
+        loaded = [(c, json.load(open(c))) for c in cands]
+        match = [cp for cp in loaded if cp[1].get("workload") == workload and cp[1].get("build_id") == build_id]
+        path, pm = (match or loaded)[-1]
+        src = os.path.basename(path)
         pmc_commit, pmc_build = pm.get("commit"), pm.get("build_id")
         conv = [k for k in pm.get("kernels", []) if k["symbol"].startswith(("_Z16conv_halo_kernel", "_Z14conv_k2_kernel", "_Z14conv_k3_kernel", "_Z15conv_k3w_kernel", "_Z15conv_k3b_kernel"))]
         if pm.get("workload") != workload:
