@@ -165,9 +165,10 @@ int ocr_conv1_pool_fwd(const float* x, const float* w, const float* bias, void* 
 /* training form.  codes (may be NULL; Cout == 64): uint32 [Nb * W/2 * H/2][8], 4 bits per pooled output = position of the window's first
  * maximum (bf16-rounded values, TF scan order) | ReLU bit << 2, consumed by ocr_conv1_pool_bwd_codes (bit-identical gradients without
  * recomputing the windows).  zero (may be NULL): fp32 [zero_n] cleared by the same launch (zero_n % 4 == 0, 16-byte aligned): the step's
- * flat gradient buffer. */
+ * flat gradient buffer.  ones (may be NULL): ones_n 32-bit words (% 4 == 0, 16-byte aligned) set to 0xFFFFFFFF by the same launch: the
+ * hand-off blocks of the step's persistent LSTM launches (OCR_LSTM_PREPARED below). */
 int ocr_conv1_pool_fwd_train(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout,
-                             void* codes, float* zero, long zero_n, void* stream);
+                             void* codes, float* zero, long zero_n, void* ones, long ones_n, void* stream);
 int ocr_conv1_pool_bwd_codes(const float* x, const float* w, const float* bias, const void* dp, float* dw, float* db,
                              int Nb, int W, int H, int Cout, const void* codes, void* stream);
 /* slab form: no atomics - block b leaves {dW [9][64] | db [64]} (fp32) in slab[b][640], b < ocr_conv1_pool_bwd_slab_rows(Nb, W, H); the rows
@@ -220,7 +221,8 @@ int ocr_cast_f32_bf16(const float* in, void* out, long n, void* stream);
 int ocr_u8_to_unit_f32(const void* in, float* out, long n, void* stream);
 /* What train.py:130,139 fetches after sess.run, gathered on the device into out[4] (doubles): mean per-sample CTC cost, sum w^2 of
  * the regularised parameters (scalars[1]) and the global gradient norm (scalars[7]) of the optimiser block (scalars may be NULL),
- * and a bit mask of the non-zero error words (word_addrs: device array of nwords <= 32 device addresses of int error words). */
+ * and a bit mask of the error words that read 1 — the persistent LSTM kernels' time-out mark; 0 and 0xFFFFFFFF (a caller-prepared block,
+ * OCR_LSTM_PREPARED) both mean "nothing happened" (word_addrs: device array of nwords <= 32 device addresses of int error words). */
 int ocr_step_report(const float* costs, int n, const double* scalars, const void* word_addrs, int nwords, double* out, void* stream);
 /* One launch binding a DEVICE-resident batch to the engine's fixed input buffers (the feed_dict of train.py:126-130 once the
  * batch is already in HBM): pixels -> x (uint8 / 255 when pixels_are_u8, else an fp32 copy; n_pixels % 4 == 0) and the
@@ -271,6 +273,15 @@ int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, const int* seq_
                      float* cell, int Nb, int T, int U, float forget_bias, void* sync, void* stream);
 int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
                      const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync, void* stream);
+/* The same launches with flags.  OCR_LSTM_PREPARED: the caller has set EVERY word of `sync` to 0xFFFFFFFF earlier on this stream (the
+ * training engine does that for all of a step's launches inside a kernel it runs anyway, ocr_conv1_pool_fwd_train) and the call's own
+ * fill launch is skipped — under the ring protocol (4) only; under the counter protocol the call prepares the block itself as before.
+ * The error word (last word of `sync`) of a caller-prepared block reads 0xFFFFFFFF when nothing happened and 1 after a time-out. */
+#define OCR_LSTM_PREPARED 1
+int ocr_lstm_fwd_seq2(const float* xproj, const void* whT_packed, const int* seq_len, void* hout, float* gates,
+                      float* cell, int Nb, int T, int U, float forget_bias, void* sync, int flags, void* stream);
+int ocr_lstm_bwd_seq2(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
+                      const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync, int flags, void* stream);
 /* hand-off protocol of the persistent kernels: 4 (default) = data-as-flag through a ring inside one XCD's L2, 2 = data-as-flag
  * through the output tensor inside one XCD's L2 — both need workgroups with equal (id & 7) on one XCD, see ocr_probe_xcc;
  * 0 = counters (sc1): placement independent */

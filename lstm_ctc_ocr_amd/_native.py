@@ -54,7 +54,7 @@ _SIGS = {
     "ocr_conv1_wgrad": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "ocr_eltwise_bf16": ([_I, _P, _P, _P, _L, _P], _I),
     "ocr_conv1_pool_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
-    "ocr_conv1_pool_fwd_train": ([_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _L, _P], _I),
+    "ocr_conv1_pool_fwd_train": ([_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P], _I),
     "ocr_conv1_pool_bwd_codes": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P], _I),
     "ocr_conv1_pool_bwd_slab_rows": ([_I, _I, _I], _I),
     "ocr_conv1_pool_bwd_slab": ([_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P], _I),
@@ -94,6 +94,8 @@ _SIGS = {
     "ocr_lstm_seq_sync_words": ([_I, _I], _L),
     "ocr_lstm_fwd_seq": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P], _I),
     "ocr_lstm_bwd_seq": ([_P, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
+    "ocr_lstm_fwd_seq2": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _P], _I),
+    "ocr_lstm_bwd_seq2": ([_P, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P], _I),
     "ocr_lstm_hprev": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "ocr_lstm_pack_bias": ([_P, _P, _P, _I, _I, _P], _I),
     "ocr_optim_scalar_count": ([], _I),

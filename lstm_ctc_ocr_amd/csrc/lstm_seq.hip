@@ -852,9 +852,13 @@ static void seq_prepare(int proto, void* sync, long words, long cwords, long rin
     }
 }
 
-extern "C" int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, const int* seq_len, void* hout,
-                                float* gates, float* cell, int Nb, int T, int U, float forget_bias, void* sync,
-                                void* stream_) {
+// flags & OCR_LSTM_PREPARED (1): the caller has set EVERY word of `sync` to 0xFFFFFFFF earlier on this stream (the training engine does it for
+// all of a step's launches inside a kernel it runs anyway: ocr_conv1_pool_fwd_train) — the call's own fill launch is skipped.  Honoured under
+// protocol 4 only (the counter protocol needs zeros: the call then prepares the block itself).  The error word of such a block reads
+// 0xFFFFFFFF when nothing happened, 1 after a time-out.
+extern "C" int ocr_lstm_fwd_seq2(const float* xproj, const void* whT_packed, const int* seq_len, void* hout,
+                                 float* gates, float* cell, int Nb, int T, int U, float forget_bias, void* sync,
+                                 int flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!xproj || !whT_packed || !seq_len || !hout || !gates || !cell || !sync) return OCR_ERR_INVALID;
     if (Nb <= 0 || T <= 0 || !ocr_lstm_seq_supported(Nb, U)) return OCR_ERR_INVALID;
@@ -864,8 +868,10 @@ extern "C" int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, cons
     const int proto = seq_proto();
     const int wpb = rows / 16;
     const long ring_words = (long)(2 * nz) * RING * ((long)(U / 16) * wpb * 512) / 4;
-    seq_prepare(proto, sync, words, cwords, ring_words, stream);
-    OCR_CHECK_LAUNCH();
+    if (!((flags & 1) && proto == 4)) {
+        seq_prepare(proto, sync, words, cwords, ring_words, stream);
+        OCR_CHECK_LAUNCH();
+    }
     LstmSeqFwdArgs a = {xproj, (const bf16_t*)whT_packed, seq_len, (bf16_t*)hout, gates, cell, (unsigned*)sync,
                         (unsigned char*)((unsigned*)sync + cwords), (int*)sync + words - 1, Nb, T, forget_bias, g_lstm_dbg,
                         seq_env_int("OCR_LSTM_PRESLEEP_F", 0, 0, true)};
@@ -879,9 +885,15 @@ extern "C" int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, cons
     return OCR_OK;
 }
 
-extern "C" int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
-                                const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync,
+extern "C" int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, const int* seq_len, void* hout,
+                                float* gates, float* cell, int Nb, int T, int U, float forget_bias, void* sync,
                                 void* stream_) {
+    return ocr_lstm_fwd_seq2(xproj, whT_packed, seq_len, hout, gates, cell, Nb, T, U, forget_bias, sync, 0, stream_);
+}
+
+extern "C" int ocr_lstm_bwd_seq2(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
+                                 const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync,
+                                 int flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!wh || !seq_len || !dhout || !gates || !cell || !dz || !sync) return OCR_ERR_INVALID;
     if (Nb <= 0 || T <= 0 || !ocr_lstm_seq_supported(Nb, U)) return OCR_ERR_INVALID;
@@ -891,8 +903,10 @@ extern "C" int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, con
     const int proto = seq_proto();
     const int wpb = rows / 16;
     const long ring_words = (long)(2 * nz) * RING * ((long)(U / 16) * wpb * 2048) / 4;
-    seq_prepare(proto, sync, words, cwords, ring_words, stream);
-    OCR_CHECK_LAUNCH();
+    if (!((flags & 1) && proto == 4)) {
+        seq_prepare(proto, sync, words, cwords, ring_words, stream);
+        OCR_CHECK_LAUNCH();
+    }
     LstmSeqBwdArgs a = {(const bf16_t*)wh, ldw, w_dir_stride, seq_len, (const bf16_t*)dhout, gates, cell, (bf16_t*)dz,
                         (unsigned*)sync, (unsigned char*)((unsigned*)sync + cwords), (int*)sync + words - 1, Nb, T, g_lstm_dbg,
                         seq_env_int("OCR_LSTM_PRESLEEP", 1, 4, true)};
@@ -904,4 +918,10 @@ extern "C" int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, con
 #undef BWD
     OCR_CHECK_LAUNCH();
     return OCR_OK;
+}
+
+extern "C" int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
+                                const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync,
+                                void* stream_) {
+    return ocr_lstm_bwd_seq2(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, Nb, T, U, sync, 0, stream_);
 }

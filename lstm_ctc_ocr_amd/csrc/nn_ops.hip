@@ -362,10 +362,12 @@ template <bool CODES>
 __device__ __forceinline__ void conv1_pool_fwd_body(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ bias, bf16_t* __restrict__ p,
                                                     int Nb, int W, int H, int Cout, f32x4* __restrict__ zero, long zero_n4,
-                                                    uint32_t* __restrict__ codes) {
+                                                    uint32_t* __restrict__ codes, u32x4* __restrict__ ones, long ones_n4) {
     // the step's flat gradient buffer is cleared by the FIRST kernel of the forward pass (round 4: it was a fill launch of its own): the
-    // stores go out here and drain beside the VALU-bound work below
+    // stores go out here and drain beside the VALU-bound work below.  Likewise `ones`: the hand-off blocks of the step's persistent LSTM
+    // launches, set to the all-ones pattern they start from (ocr_lstm_*_seq2 with OCR_LSTM_PREPARED: two fill launches less).
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n4; i += (long)gridDim.x * 256) zero[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ones_n4; i += (long)gridDim.x * 256) ones[i] = (u32x4){~0u, ~0u, ~0u, ~0u};
     const int groups = Cout >> 3, gq = threadIdx.x % groups, plane = threadIdx.x / groups, planes = 256 / groups;
     float wr[9][8], br[8];
 #pragma unroll
@@ -400,8 +402,8 @@ __device__ __forceinline__ void conv1_pool_fwd_body(const float* __restrict__ x,
 template <bool CODES>
 __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                              bf16_t* __restrict__ p, int Nb, int W, int H, int Cout, f32x4* __restrict__ zero,
-                                                             long zero_n4, uint32_t* __restrict__ codes) {
-    conv1_pool_fwd_body<CODES>(x, w, bias, p, Nb, W, H, Cout, zero, zero_n4, codes);
+                                                             long zero_n4, uint32_t* __restrict__ codes, u32x4* __restrict__ ones, long ones_n4) {
+    conv1_pool_fwd_body<CODES>(x, w, bias, p, Nb, W, H, Cout, zero, zero_n4, codes, ones, ones_n4);
 }
 template <bool CODES /* routing + ReLU bits from the forward pass: no window recomputation, and none of its 110 registers (weights, outputs) */>
 __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -1397,36 +1399,38 @@ extern "C" int ocr_eltwise_bf16(int op, const void* a, const void* b, void* out,
     return OCR_OK;
 }
 static int conv1_pool_fwd_impl(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout,
-                               float* zero, long zero_n, void* codes, void* stream) {
+                               float* zero, long zero_n, void* codes, void* ones, long ones_n, void* stream) {
     if (!x || !w || !bias || !p || (Cout & 7) || Cout > 1024 || 256 % (Cout >> 3) || (W & 1) || (H & 1)) return OCR_ERR_INVALID;
     if (zero_n < 0 || (zero_n & 3) || (zero_n && (!zero || ((size_t)zero & 15)))) return OCR_ERR_INVALID;
+    if (ones_n < 0 || (ones_n & 3) || (ones_n && (!ones || ((size_t)ones & 15)))) return OCR_ERR_INVALID;
     if (codes && (Cout != 64 || ((size_t)codes & 3))) return OCR_ERR_INVALID;            // the routing codes exist for the 64-filter layer the backward kernel handles
     long total = (long)Nb * (W / 2) * (H / 2) * (Cout >> 3);
 #ifdef OCR_EXPERIMENTS
-    if (!zero_n && !codes && !conv1_v1() && (long)Nb * (W / 2) * (H / 2) < 0x7fffffffL && (long)Nb * W * H < 0x7fffffffL && (long)W * H < 0x7fffffffL)
+    if (!zero_n && !ones_n && !codes && !conv1_v1() && (long)Nb * (W / 2) * (H / 2) < 0x7fffffffL && (long)Nb * W * H < 0x7fffffffL && (long)W * H < 0x7fffffffL)
         conv1_pool_fwd2_kernel<<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout);
     else
 #endif
     {
         if (codes) conv1_pool_fwd_kernel<true><<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout, (f32x4*)zero,
-                                                                                                          zero_n / 4, (uint32_t*)codes);
+                                                                                                          zero_n / 4, (uint32_t*)codes, (u32x4*)ones, ones_n / 4);
         else conv1_pool_fwd_kernel<false><<<grid_for(total, 2048), 256, 0, (hipStream_t)stream>>>(x, w, bias, (bf16_t*)p, Nb, W, H, Cout, (f32x4*)zero,
-                                                                                                 zero_n / 4, nullptr);
+                                                                                                 zero_n / 4, nullptr, (u32x4*)ones, ones_n / 4);
     }
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }
 extern "C" int ocr_conv1_pool_fwd(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout,
                                   void* stream) {
-    return conv1_pool_fwd_impl(x, w, bias, p, Nb, W, H, Cout, nullptr, 0, nullptr, stream);
+    return conv1_pool_fwd_impl(x, w, bias, p, Nb, W, H, Cout, nullptr, 0, nullptr, nullptr, 0, stream);
 }
 // The training form of the same launch.  codes (may be NULL; Cout == 64): uint32 [Nb * W/2 * H/2][8] — per pooled output 4 bits, the position
 // of the window's first maximum (on the bf16-rounded values, TF scan order) | ReLU bit << 2: ocr_conv1_pool_bwd_codes routes the gradient with
 // them instead of recomputing the window.  zero (may be NULL): fp32 [zero_n] cleared by the same launch (zero_n % 4 == 0, 16-byte aligned):
-// the flat gradient buffer of the step that begins.
+// the flat gradient buffer of the step that begins.  ones (may be NULL): ones_n 32-bit words (% 4 == 0, 16-byte aligned) set to 0xFFFFFFFF by
+// the same launch: the hand-off blocks of the step's persistent LSTM launches (ocr_lstm_fwd_seq2 / ocr_lstm_bwd_seq2 with OCR_LSTM_PREPARED).
 extern "C" int ocr_conv1_pool_fwd_train(const float* x, const float* w, const float* bias, void* p, int Nb, int W, int H, int Cout,
-                                        void* codes, float* zero, long zero_n, void* stream) {
-    return conv1_pool_fwd_impl(x, w, bias, p, Nb, W, H, Cout, zero, zero_n, codes, stream);
+                                        void* codes, float* zero, long zero_n, void* ones, long ones_n, void* stream) {
+    return conv1_pool_fwd_impl(x, w, bias, p, Nb, W, H, Cout, zero, zero_n, codes, ones, ones_n, stream);
 }
 // pooled pixels per block of the conv1 + pool backward kernel (a thread walks ppb / 32 of them, one memory round trip each).  With atomics
 // smaller blocks were slower (profiles/r04k_conv1_ppb_ab.log: 640 same-address atomics per block); the slab form pays 2.5 KB per block instead.
@@ -1705,7 +1709,7 @@ extern "C" int ocr_bind_batch(const void* pixels, int pixels_are_u8, float* x, l
 }
 // Everything the training loop reads back after a step, gathered into 4 doubles so that ONE 32-byte D2H copy follows:
 // out[0] = mean per-sample CTC cost (summed in double, fixed order), out[1] = scalars[1] (sum w^2 of the regularised range),
-// out[2] = scalars[7] (global gradient norm), out[3] = bit i set <=> error word i (last int of words[i]) is non-zero.
+// out[2] = scalars[7] (global gradient norm), out[3] = bit i set <=> error word i (last int of words[i]) is 1 (the persistent LSTM kernels' time-out mark).
 __global__ void step_report_kernel(const float* __restrict__ costs, int n, const double* __restrict__ scalars,
                                    const long long* __restrict__ words, int nwords, double* __restrict__ out) {
     double s = 0.0;
@@ -1714,7 +1718,7 @@ __global__ void step_report_kernel(const float* __restrict__ costs, int n, const
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (threadIdx.x == 0) {
         unsigned bits = 0;
-        for (int i = 0; i < nwords; ++i) if (*(const int*)words[i] != 0) bits |= 1u << i;
+        for (int i = 0; i < nwords; ++i) if (*(const int*)words[i] == 1) bits |= 1u << i;    // 0 or, in a caller-prepared block, all ones: no time-out
         out[0] = s / (double)n;
         out[1] = scalars ? scalars[1] : 0.0;
         out[2] = scalars ? scalars[7] : 0.0;

@@ -228,7 +228,9 @@ class _ConvOp(_Op):
         if self.fused_pool is not None:
             zero, e._zero_pending = (e.grads if e._zero_pending else None), False     # the gradient buffer's clear rides on this launch
             codes = sp.buf.get(self.key + '/codes') if e.training else None
-            ops.conv1_pool_fwd(x, e.param(self.name + '/weights'), bias, out=self.fused_pool.y(sp), zero=zero, codes=codes)
+            ones, e._ones_pending = e._ones_pending, None                              # ... and so does the fill of the LSTM hand-off blocks
+            ops.conv1_pool_fwd(x, e.param(self.name + '/weights'), bias, out=self.fused_pool.y(sp), zero=zero, codes=codes, ones=ones)
+            sp.rings_ready = ones is not None
             return
         y = self.y(sp)
         if self.kind == 'c1':
@@ -788,9 +790,10 @@ class _BiLstmOp(_Op):
         b[self.key + '/xh'] = torch.empty((ND, R, self.D + U), dtype=BF16, device=dev)
         if self.ND == 2:
             words = max(ops.lstm_seq_sync_words(N, U), 64) if self._persistent(N) else 64
+            words = (words + 3) // 4 * 4                   # 16-byte granules: the blocks of a plan become views of ONE arena (ShapePlan)
             b[self.key + '/sync_f'] = torch.zeros(words, dtype=I32, device=dev)
             b[self.key + '/sync_b'] = torch.zeros(words, dtype=I32, device=dev)
-            sp.lstm_sync = getattr(sp, 'lstm_sync', ()) + (b[self.key + '/sync_f'], b[self.key + '/sync_b'])
+            sp.lstm_sync_keys = getattr(sp, 'lstm_sync_keys', ()) + (self.key + '/sync_f', self.key + '/sync_b')
 
     def shadow_params(self):
         return [c + '/weights' for c in self.cells] + ([self.fc + '/weights'] if self.with_fc else [])
@@ -819,7 +822,7 @@ class _BiLstmOp(_Op):
         ops.gemm_nt(x, self.wxT, out=b[self.key + '/xproj'], bias=self.bias)
         if self._persistent(N):
             ops.lstm_fwd_seq(b[self.key + '/xproj'], self.whT, sp.seq_len, b[self.key + '/hout'], b[self.key + '/gates'],
-                             b[self.key + '/cell'], N, T, U, b[self.key + '/sync_f'], 1.0)
+                             b[self.key + '/cell'], N, T, U, b[self.key + '/sync_f'], 1.0, prepared=getattr(sp, 'rings_ready', False))
         else:
             for s in range(T):
                 ops.lstm_fwd_step(b[self.key + '/xproj'], self.whT, sp.seq_len, b[self.key + '/hout'],
@@ -846,7 +849,7 @@ class _BiLstmOp(_Op):
         stride = e.offset(self.cells[1] + '/weights') - e.offset(self.cells[0] + '/weights') if ND == 2 else 0
         if self._persistent(N):
             ops.lstm_bwd_seq(wsh[D:], 4 * U, stride, sp.seq_len, b[self.key + '/dhout'], b[self.key + '/gates'],
-                             b[self.key + '/cell'], b[self.key + '/dz'], N, T, U, b[self.key + '/sync_b'])
+                             b[self.key + '/cell'], b[self.key + '/dz'], N, T, U, b[self.key + '/sync_b'], prepared=getattr(sp, 'rings_ready', False))
         else:
             b[self.key + '/dc'].zero_()
             for s in range(T - 1, -1, -1):
@@ -900,6 +903,18 @@ class ShapePlan(object):
             s = self.oshape[op.prev.key]
             op.alloc(self, s)
             self.oshape[op.key] = op.out_shape(s)
+        # the hand-off blocks of all persistent LSTM launches of a step as views of ONE arena: a training step sets the whole arena to the
+        # pattern the kernels start from inside its first kernel (conv1 + pool forward) instead of one fill launch per LSTM launch
+        keys = getattr(self, 'lstm_sync_keys', ())
+        self.lstm_arena = None
+        if keys:
+            self.lstm_arena = torch.zeros(sum(self.buf[k].numel() for k in keys), dtype=I32, device=dev)
+            off = 0
+            for k in keys:
+                n = self.buf[k].numel()
+                self.buf[k] = self.lstm_arena[off:off + n]
+                off += n
+        self.lstm_sync = tuple(self.buf[k] for k in keys)
         # deferred weight-gradient reductions keep every layer's slabs until the end of the backward body: that pays while the slabs
         # still sit in the Infinity Cache when the merged reduction reads them (162 MB for the CRNN at 64 x 256: 18 + 4 x 36 MB).  A deep graph (configs[4]:
         # 32 layers, ~0.4 GB of slabs) would read them back from HBM — measured 3 % slower than reducing behind each layer — so
@@ -1265,8 +1280,14 @@ class Engine(object):
         self._zero_pending = bool(training) and self.grads.numel() % 4 == 0 and os.environ.get('OCR_FUSE_ZERO', '1') != '0'
         if training and not self._zero_pending:
             self.grads.zero_()
+        # likewise the fill of the persistent LSTM launches' hand-off blocks (OCR_FUSE_RINGFILL=0: every launch fills its own); a graph whose
+        # first kernel is not conv1 + pool never consumes it and its LSTM launches prepare their blocks themselves
+        sp.rings_ready = False
+        self._ones_pending = sp.lstm_arena if (training and getattr(sp, 'lstm_arena', None) is not None
+                                               and os.environ.get('OCR_FUSE_RINGFILL', '1') != '0') else None
         for op in self.ops:
             op.fwd(sp)
+        self._ones_pending = None
         if self._zero_pending:
             self.grads.zero_()
             self._zero_pending = False

@@ -264,16 +264,18 @@ def eltwise(op, a, b, out):
     return out
 
 
-def conv1_pool_fwd(x, w, bias, out=None, zero=None, codes=None):
+def conv1_pool_fwd(x, w, bias, out=None, zero=None, codes=None, ones=None):
     """zero (fp32 tensor, numel % 4 == 0): cleared by the same launch (the step's flat gradient buffer).  codes (int32 [Nb * W/2 * H/2, 8]):
-    receives the pool routing + ReLU bits for conv1_pool_bwd(codes=...)."""
+    receives the pool routing + ReLU bits for conv1_pool_bwd(codes=...).  ones (int32 tensor, numel % 4 == 0): set to 0xFFFFFFFF by the
+    same launch (the hand-off blocks of the step's persistent LSTM launches, lstm_*_seq(prepared=True))."""
     Nb, W, H = x.shape
     Cout = w.shape[-1]
     if out is None:
         out = torch.empty((Nb, W // 2, H // 2, Cout), dtype=BF16, device=x.device)
-    if zero is not None or codes is not None:
+    if zero is not None or codes is not None or ones is not None:
         call("ocr_conv1_pool_fwd_train", ptr(_dev(x)), ptr(w), ptr(bias), ptr(out), Nb, W, H, Cout, ptr(codes),
-             ptr(_dev(zero)) if zero is not None else None, 0 if zero is None else zero.numel(), _st())
+             ptr(_dev(zero)) if zero is not None else None, 0 if zero is None else zero.numel(),
+             ptr(_dev(ones)) if ones is not None else None, 0 if ones is None else ones.numel(), _st())
     else:
         call("ocr_conv1_pool_fwd", ptr(_dev(x)), ptr(w), ptr(bias), ptr(out), Nb, W, H, Cout, _st())
     return out
@@ -517,14 +519,17 @@ def lstm_seq_sync_words(Nb, U):
     return int(nat.lib().ocr_lstm_seq_sync_words(Nb, U))
 
 
-def lstm_fwd_seq(xproj, whT, seq_len, hout, gates, cell, Nb, T, U, sync, forget_bias=1.0):
-    call("ocr_lstm_fwd_seq", ptr(_dev(xproj)), ptr(whT), ptr(seq_len), ptr(hout),
-         ptr(gates), ptr(cell), Nb, T, U, float(forget_bias), ptr(sync), _st())
+LSTM_PREPARED = 1       # OCR_LSTM_PREPARED: every word of `sync` was set to 0xFFFFFFFF earlier on this stream; the call skips its own fill launch
 
 
-def lstm_bwd_seq(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, Nb, T, U, sync):
-    call("ocr_lstm_bwd_seq", ptr(_dev(wh)), ldw, w_dir_stride, ptr(seq_len),
-         ptr(dhout), ptr(gates), ptr(cell), ptr(dz), Nb, T, U, ptr(sync), _st())
+def lstm_fwd_seq(xproj, whT, seq_len, hout, gates, cell, Nb, T, U, sync, forget_bias=1.0, prepared=False):
+    call("ocr_lstm_fwd_seq2", ptr(_dev(xproj)), ptr(whT), ptr(seq_len), ptr(hout),
+         ptr(gates), ptr(cell), Nb, T, U, float(forget_bias), ptr(sync), LSTM_PREPARED if prepared else 0, _st())
+
+
+def lstm_bwd_seq(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, Nb, T, U, sync, prepared=False):
+    call("ocr_lstm_bwd_seq2", ptr(_dev(wh)), ldw, w_dir_stride, ptr(seq_len),
+         ptr(dhout), ptr(gates), ptr(cell), ptr(dz), Nb, T, U, ptr(sync), LSTM_PREPARED if prepared else 0, _st())
 
 
 def lstm_hprev(hout, seq_len, hprev, Nb, T, U, ndir=2):

@@ -181,7 +181,7 @@ def test_round4_fusions_match_the_unfused_schedule(dev, monkeypatch):
     N, W = 64, 128
     x, labels, ll, sl = make_batch(N, W, 2, 5, 21, varlen=True)
     off = dict(OCR_FUSE_BN_STATS='0', OCR_FUSE_BN_POOL='0', OCR_FUSE_BN_BWD='0', OCR_TN_JOBS='0', OCR_FUSE_ZERO='0', OCR_CONV1_CODES='0',
-               OCR_W9_FLUSH_MB='0')
+               OCR_W9_FLUSH_MB='0', OCR_FUSE_RINGFILL='0')
 
     def run(env):
         for k in off:
@@ -195,12 +195,15 @@ def test_round4_fusions_match_the_unfused_schedule(dev, monkeypatch):
         eng._run(sp, 'fb')                            # the captured graph
         torch.cuda.synchronize()
         active = dict(stats=sum(1 for v in getattr(sp, 'bn_stat_rows', {}).values() if v), bwd=sum(1 for v in getattr(sp, 'bn_bwd_rows', {}).values() if v),
-                      pool=sum(1 for op in eng.ops if getattr(op, 'bn_pool', None) is not None), codes=sum(k.endswith('/codes') for k in sp.buf))
+                      pool=sum(1 for op in eng.ops if getattr(op, 'bn_pool', None) is not None), codes=sum(k.endswith('/codes') for k in sp.buf),
+                      rings=int(bool(getattr(sp, 'rings_ready', False))))
+        # the LSTM hand-off blocks' error words: 0 where the launches prepared their own blocks, -1 (untouched all-ones) where the conv1 launch did; 1 = time-out
+        assert [int(w[-1]) for w in sp.lstm_sync] == [-1 if active['rings'] else 0] * len(sp.lstm_sync)
         return {n: eng.grad(n).clone() for n in eng.specs}, float(sp.costs.double().mean()), active
 
     g0, c0, a0 = run(off)
     g1, c1, a1 = run({})
-    assert a0 == dict(stats=0, bwd=0, pool=0, codes=0) and a1 == dict(stats=2, bwd=1, pool=1, codes=1), (a0, a1)
+    assert a0 == dict(stats=0, bwd=0, pool=0, codes=0, rings=0) and a1 == dict(stats=2, bwd=1, pool=1, codes=1, rings=1), (a0, a1)
     assert abs(c1 - c0) < 1e-5 * abs(c0)
     for n in g0:
         ref = g0[n].double()

@@ -516,7 +516,9 @@ def _conv1_pool_fused_equals_unfused(dev, Nb, W, H):
     # backward pass that consumes the codes instead of recomputing the 2 x 2 windows sums the same terms in the same order
     codes = torch.full((Nb * (W // 2) * (H // 2), 8), -1, dtype=torch.int32, device=dev)
     junk = torch.full((4096 + 8,), 7.0, device=dev)
-    p2 = ops.conv1_pool_fwd(x, w, b, zero=junk[:4096], codes=codes)
+    ones = torch.zeros(4096 + 64, dtype=torch.int32, device=dev)
+    p2 = ops.conv1_pool_fwd(x, w, b, zero=junk[:4096], codes=codes, ones=ones[:4096])
+    assert bool((ones[:4096] == -1).all()) and bool((ones[4096:] == 0).all())                 # the all-ones fill: exactly the words it was given
     assert torch.equal(p2, p) and float(junk[:4096].abs().max()) == 0.0 and float(junk[4096:].min()) == 7.0
     dw2 = torch.zeros_like(w); db2 = torch.zeros(Co, device=dev)
     ops.conv1_pool_bwd(x, w, b, dp, dw2, db2, codes=codes)
@@ -764,7 +766,7 @@ def test_small_ops(dev):
 
 
 # ------------------------------------------------------------------------------------------- LSTM
-def _lstm_device_forward(dev, x, seq_len, Ws, bs, U, persistent=False):
+def _lstm_device_forward(dev, x, seq_len, Ws, bs, U, persistent=False, prepared=False):
     """Runs the hoisted projection + per-step kernels exactly as the executor does. x: [N,T,D] bf16-rounded fp32."""
     N, T, D = x.shape
     R = N * T
@@ -783,10 +785,13 @@ def _lstm_device_forward(dev, x, seq_len, Ws, bs, U, persistent=False):
     gates = torch.zeros((2, R, 4 * U), device=dev); cell = torch.zeros((2, R, U), device=dev)
     if persistent:
         assert ops.lstm_seq_supported(N, U)
-        sync = torch.zeros(ops.lstm_seq_sync_words(N, U), dtype=torch.int32, device=dev)
-        ops.lstm_fwd_seq(xproj, whT, sl, hout, gates, cell, N, T, U, sync)
+        # prepared: the caller has set every word of the hand-off block to 0xFFFFFFFF (what the training engine does inside its first
+        # kernel) and the call skips its own fill launch; the error word then reads -1 (untouched) or 1 (time-out)
+        sync = torch.full((ops.lstm_seq_sync_words(N, U),), -1 if prepared else 0, dtype=torch.int32, device=dev)
+        ops.lstm_fwd_seq(xproj, whT, sl, hout, gates, cell, N, T, U, sync, prepared=prepared)
         torch.cuda.synchronize()
-        assert int(sync[-1]) == 0, "persistent LSTM forward: spin timeout"
+        # (under the counter protocol the flag is ignored and the call prepares — zeroes — the block itself)
+        assert int(sync[-1]) in ((-1, 0) if prepared else (0,)), "persistent LSTM forward: spin timeout"
     else:
         for s in range(T):
             ops.lstm_fwd_step(xproj, whT, sl, hout, gates, cell, N, T, U, s)
@@ -814,18 +819,19 @@ def test_lstm_fwd_bwd(dev, N, T, D, U, lens, persistent):
     dh = bf(gen((N, T, 2 * U), 9))
     ref.backward(dh)
     # the persistent kernels come in two families (four waves per workgroup — the default since round 4 — and one): both through the same checks
-    for ksplit in ((4, 1) if persistent else (None,)):
+    # ... and with the hand-off block prepared by the caller instead of by the call's own fill launch
+    for ksplit, prepared in (((4, False), (4, True), (1, False)) if persistent else ((None, False),)):
         if ksplit is not None:
             ops.set_lstm_ksplit(ksplit)
         try:
-            _lstm_device_checks(dev, N, T, D, U, x, seq_len, Ws, bs, Wr, br, xr, ref, dh, persistent)
+            _lstm_device_checks(dev, N, T, D, U, x, seq_len, Ws, bs, Wr, br, xr, ref, dh, persistent, prepared)
         finally:
             if ksplit is not None:
                 ops.set_lstm_ksplit(4)
 
 
-def _lstm_device_checks(dev, N, T, D, U, x, seq_len, Ws, bs, Wr, br, xr, ref, dh, persistent):
-    st = _lstm_device_forward(dev, x, seq_len, Ws, bs, U, persistent)
+def _lstm_device_checks(dev, N, T, D, U, x, seq_len, Ws, bs, Wr, br, xr, ref, dh, persistent, prepared=False):
+    st = _lstm_device_forward(dev, x, seq_len, Ws, bs, U, persistent, prepared)
     got = st["hout"].float().cpu().reshape(N, T, 2 * U)
     # measured on MI355X (round 2): <= 3.9e-3 = one bf16 ulp of |h| in [0.5, 1) (a rounding flip of the stored h), usually 0 .. 1e-3
     assert maxerr(got, ref.detach()) < 8e-3, maxerr(got, ref.detach())
@@ -838,10 +844,10 @@ def _lstm_device_checks(dev, N, T, D, U, x, seq_len, Ws, bs, Wr, br, xr, ref, dh
     dc = torch.zeros((2, N, U), device=dev)
     dhd = dh.to(dev).to(BF).reshape(R, 2 * U)
     if persistent:
-        sync = torch.zeros(ops.lstm_seq_sync_words(N, U), dtype=torch.int32, device=dev)
-        ops.lstm_bwd_seq(whb[:, D:], 4 * U, (D + U) * 4 * U, st["sl"], dhd, st["gates"], st["cell"], dz, N, T, U, sync)
+        sync = torch.full((ops.lstm_seq_sync_words(N, U),), -1 if prepared else 0, dtype=torch.int32, device=dev)
+        ops.lstm_bwd_seq(whb[:, D:], 4 * U, (D + U) * 4 * U, st["sl"], dhd, st["gates"], st["cell"], dz, N, T, U, sync, prepared=prepared)
         torch.cuda.synchronize()
-        assert int(sync[-1]) == 0, "persistent LSTM backward: spin timeout"
+        assert int(sync[-1]) in ((-1, 0) if prepared else (0,)), "persistent LSTM backward: spin timeout"
     else:
         for s in range(T - 1, -1, -1):
             ops.lstm_bwd_step(whb[:, D:], 4 * U, (D + U) * 4 * U, st["sl"], dhd, st["gates"], st["cell"], dz, dc, N, T, U, s)

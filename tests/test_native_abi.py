@@ -103,3 +103,18 @@ def test_job_table_records_match_the_c_structs():
     nb, deferred = ctypes.c_int(0), ctypes.c_int(0)
     assert lib.ocr_conv3x3_wgrad_defer_bf16(None, None, None, None, 8, 8, 8, 64, 64, None, 0, ctypes.cast(job, ctypes.c_void_p),
                                             ctypes.byref(nb), ctypes.byref(deferred), None) == 2
+
+
+def test_persistent_lstm_entry_points_check_their_arguments_on_the_host():
+    """The persistent LSTM launches (plain and with flags) and their knobs refuse bad arguments before any launch; a kernel-family setter accepts
+    only the two families that exist."""
+    lib = nat.lib()
+    assert lib.ocr_lstm_fwd_seq2(None, None, None, None, None, None, 64, 63, 256, 1.0, None, 1, None) == 2
+    assert lib.ocr_lstm_bwd_seq2(None, 1024, 0, None, None, None, None, None, 64, 63, 256, None, 1, None) == 2
+    assert lib.ocr_lstm_fwd_seq(None, None, None, None, None, None, 64, 63, 256, 1.0, None, None) == 2
+    assert lib.ocr_set_lstm_ksplit(2) == 2 and lib.ocr_set_lstm_ksplit(4) == 0
+    assert lib.ocr_lstm_seq_supported(64, 256) == 1 and lib.ocr_lstm_seq_supported(64, 100) == 0
+    # the training form of conv1 + pool: the all-ones region must be 16-byte granules
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.ocr_conv1_pool_fwd_train(p, p, p, p, 1, 8, 8, 64, None, None, 0, p, 6, None) == 2
