@@ -300,7 +300,8 @@ def test_bind_batch_and_step_report(dev):
     costs = torch.rand(64, generator=g) * 30
     sc = torch.arange(16, dtype=torch.float64) * 1.5
     words = [torch.zeros(65, dtype=torch.int32, device=dev) for _ in range(3)]
-    words[1][-1] = 7
+    words[1][-1] = 1                      # the persistent LSTM kernels' time-out mark
+    words[2][-1] = -1                     # a block the caller prepared (all ones) that nothing touched: not an error
     addrs = torch.tensor([w[-1:].data_ptr() for w in words], dtype=torch.int64, device=dev)
     out = torch.zeros(4, dtype=torch.float64, device=dev)
     ops.step_report(costs.to(dev), sc.to(dev), addrs, out)

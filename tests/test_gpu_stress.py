@@ -36,5 +36,5 @@ def test_repeated_runs_agree(dev, N, W, ragged, reps):
         torch.cuda.synchronize()
         assert torch.equal(sp.costs, costs), "costs of repetition %d deviate" % i
         assert float((eng.grads - grads).abs().max()) < 1e-3 * scale, "gradients of repetition %d deviate" % i
-    for word in getattr(sp, 'lstm_sync', ()):             # error word of the persistent LSTM kernels: a wait timed out
-        assert int(word[-1].item()) == 0
+    for word in getattr(sp, 'lstm_sync', ()):             # error word of the persistent LSTM kernels: 1 = a wait timed out (0, or -1 in a
+        assert int(word[-1].item()) != 1                   # block the step prepared inside its first kernel: nothing happened)
