@@ -11,6 +11,7 @@ live with HIP events on the launch stream; `cpu_baseline` is the CPU oracle (a t
 reference TF1 graph — the TF reference itself cannot run here) on a bounded sample of the same workload.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -57,6 +58,18 @@ def synth_batches(n_batches, seed, device):
         sl = torch.full((BATCH,), T, dtype=torch.int32, device=device)
         out.append((x, labels, ll, sl))
     return out
+
+
+def pick_pmc_summary(profiles_dir, workload, build_id):
+    """The whole-step counter summary (tools/pmc_step_summary.py) bench.py may quote for `workload` on the library build `build_id`:
+    several rounds' summaries lie side by side in profiles/ — the one taken on this workload AND this build wins (the last by name if
+    there are several); without one, the last by name is returned so that the refusal can name what it found.  (None, None): no file."""
+    cands = sorted(glob.glob(os.path.join(profiles_dir, "r*_pmc_step_%s.json" % workload)))
+    if not cands:
+        return None, None
+    loaded = [(c, json.load(open(c))) for c in cands]
+    match = [cp for cp in loaded if cp[1].get("workload") == workload and cp[1].get("build_id") == build_id]
+    return (match or loaded)[-1]
 
 
 def conv_roofline(eng, device, workload):
@@ -146,7 +159,6 @@ def conv_roofline(eng, device, workload):
     # (tools/prof_step_pmc.sh -> profiles/rNN_pmc_step.json; FETCH_SIZE doubled: the guide's gfx950 correction).  The file names the
     # commit it was taken at and its kernel symbols: numbers whose symbols are not in the library loaded now are refused.
     traffic, mfma_busy, src, pmc_commit, pmc_error, pmc_build, pmc_clock, pmc_avg_us = None, None, None, None, None, None, None, None
-    import glob
     build_id = nat.build_id()
     try:
         build_commit = open(os.path.join(ROOT, ".build_commit")).read().strip()
@@ -154,14 +166,10 @@ def conv_roofline(eng, device, workload):
         build_commit = None
     # the newest profile of THIS workload; it must name the workload and the build id (source hash) of the library that is loaded now —
     # anything else is refused, not borrowed (the varwidth / deep lines used to print the headline's counters)
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_%s.json" % workload)))
-    if not cands:
+    path, pm = pick_pmc_summary(os.path.join(ROOT, "profiles"), workload, build_id)
+    if pm is None:
         pmc_error = "no profiles/r*_pmc_step_%s.json for this workload" % workload
     else:
-        # several rounds' summaries lie side by side: the one taken on the loaded build wins; without one, the last by name is named in the refusal
-        loaded = [(c, json.load(open(c))) for c in cands]
-        match = [cp for cp in loaded if cp[1].get("workload") == workload and cp[1].get("build_id") == build_id]
-        path, pm = (match or loaded)[-1]
         src = os.path.basename(path)
         pmc_commit, pmc_build = pm.get("commit"), pm.get("build_id")
         conv = [k for k in pm.get("kernels", []) if k["symbol"].startswith(("_Z16conv_halo_kernel", "_Z14conv_k2_kernel", "_Z14conv_k3_kernel", "_Z15conv_k3w_kernel", "_Z15conv_k3b_kernel"))]
