@@ -94,7 +94,7 @@ def conv_roofline(eng, device, workload):
     plain_t = 0.0                 # the same launches with the batch-norm work taken out of their write-outs again (secondary figure)
     # shader clock the kernel really runs at: workgroup 0 stamps {shader-clock counter, 100 MHz wall clock} at entry and exit
     from lstm_ctc_ocr_amd import _native as nat
-    clk = torch.zeros(4, dtype=torch.int64, device=device)
+    clk = torch.zeros(8, dtype=torch.int64, device=device)
     nat.call("ocr_conv_halo_clock_debug", clk.data_ptr())
     clk_cycles = clk_ticks = 0.0
     for (N, W, H, Ci, Co, has_dgrad, pool, fwd_stats, dgrad_bnb) in shapes:
@@ -159,6 +159,7 @@ def conv_roofline(eng, device, workload):
     # (tools/prof_step_pmc.sh -> profiles/rNN_pmc_step.json; FETCH_SIZE doubled: the guide's gfx950 correction).  The file names the
     # commit it was taken at and its kernel symbols: numbers whose symbols are not in the library loaded now are refused.
     traffic, mfma_busy, src, pmc_commit, pmc_error, pmc_build, pmc_clock, pmc_avg_us = None, None, None, None, None, None, None, None
+    mfma_window, pmc_own_clock = None, None
     build_id = nat.build_id()
     try:
         build_commit = open(os.path.join(ROOT, ".build_commit")).read().strip()
@@ -184,8 +185,14 @@ def conv_roofline(eng, device, workload):
             tm = float(sum(k["launches"] * k["avg_us"] for k in conv))
             if all("read_mb" in k and "write_mb" in k for k in conv):
                 traffic = sum(k["launches"] * (k["read_mb"] + k["write_mb"]) for k in conv) / nl * 1e6
-            if all("mfma_busy_frac" in k for k in conv):
-                mfma_busy = sum(k["launches"] * k["avg_us"] * k["mfma_busy_frac"] for k in conv) / tm
+            # matrix-pipe occupancy over the kernels' OWN cycles (busy cycles / (1024 SIMDs x duration x the shader clock stamped inside the
+            # convolution launches of the counter pass)); the GRBM-window quotient of rounds 3-4 is kept under its own name (a lower bound)
+            if all("mfma_busy_frac_own_cycles" in k for k in conv):
+                mfma_busy = sum(k["launches"] * k["sq_pass_avg_us"] * k["mfma_busy_frac_own_cycles"] for k in conv) / sum(k["launches"] * k["sq_pass_avg_us"] for k in conv)
+                pmc_own_clock = conv[0].get("own_clock_mhz")
+            wkey = "mfma_busy_frac_grbm_window" if all("mfma_busy_frac_grbm_window" in k for k in conv) else "mfma_busy_frac"
+            if all(wkey in k for k in conv):
+                mfma_window = sum(k["launches"] * k["avg_us"] * k[wkey] for k in conv) / tm
             if all("clock_mhz" in k for k in conv):
                 pmc_clock = sum(k["launches"] * k["avg_us"] * k["clock_mhz"] for k in conv) / tm
             pmc_avg_us = tm / nl
@@ -199,20 +206,21 @@ def conv_roofline(eng, device, workload):
             "executed_flop_frac": exe_fl / tot_fl, "achieved_executed": exe_fl / tot_t / 1e12,
             "executed_note": "`achieved` counts 2*M*K*N of every launch (SURVEY 8d) including the SAME-padding taps the plane-layout kernels "
                              "(conv_k3 / conv_k3w) never issue: 2/(3H) of a layer's MFMAs (H=4: a sixth); `achieved_executed` counts only issued MFMAs",
-            "traffic": traffic, "mfma_busy_frac": mfma_busy, "pmc_clock_mhz": pmc_clock, "pmc_avg_launch_us": pmc_avg_us, "pmc_commit": pmc_commit, "pmc_build_id": pmc_build, "build_id": build_id,
+            "traffic": traffic, "mfma_busy_frac": mfma_busy, "pmc_shader_clock_mhz": pmc_own_clock,
+            "mfma_busy_frac_grbm_window_lower_bound": mfma_window, "pmc_grbm_window_clock_mhz": pmc_clock, "pmc_avg_launch_us": pmc_avg_us, "pmc_commit": pmc_commit, "pmc_build_id": pmc_build, "build_id": build_id,
             "build_commit": build_commit, "pmc_error": pmc_error,
             "shader_clock_mhz": mhz, "frac_of_peak_at_that_clock": (ach / (MFMA_BF16_PEAK * mhz / PEAK_CLOCK_MHZ)) if mhz else None,
             "executed_frac_of_peak_at_that_clock": (exe_fl / tot_t / (MFMA_BF16_PEAK * mhz / PEAK_CLOCK_MHZ)) if mhz else None,
             "clock_note": "shader clock measured inside EVERY timed convolution launch (s_memtime / s_memrealtime of workgroup 0 of conv_k3 / conv_k3w / "
                           "conv_halo, time-weighted); `peak` is the guide's dense bf16 figure at %d MHz; executed_frac_of_peak_at_that_clock is the "
-                          "matrix-pipe occupancy of THIS run (issued MFMA cycles / available SIMD cycles) and is what mfma_busy_frac measures in the "
-                          "separate counter run at that run's clock (profiles/r04_mfma_busy_calibration.md)" % PEAK_CLOCK_MHZ,
-            "traffic_note": "HBM bytes per launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) and SQ_VALU_MFMA_BUSY_CYCLES / "
-                            "(1024 SIMDs x GRBM_GUI_ACTIVE / 8) of the same kernels inside this script's train step, from profiles/%s.  "
-                            "mfma_busy_frac is a LOWER bound for these 20-60 us launches: GRBM_GUI_ACTIVE / 8 of a profiled dispatch exceeds "
-                            "the kernel's own cycles (pmc_clock_mhz = GRBM cycles / kernel duration comes out above the chip's 2400 MHz); the busy CYCLES "
-                            "themselves are exact (16 per issued MFMA: profiles/r04_mfma_busy_calibration.md), so the occupancy over the kernel's "
-                            "own duration is executed_frac_of_peak_at_that_clock above" % src}
+                          "matrix-pipe occupancy of THIS run (issued MFMA cycles / available SIMD cycles); mfma_busy_frac is the same quantity from "
+                          "the separate counter run, over the kernels' own cycles at THAT run's stamped clock (pmc_shader_clock_mhz)" % PEAK_CLOCK_MHZ,
+            "traffic_note": "HBM bytes per launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of the same kernels inside this script's train "
+                            "step, from profiles/%s.  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel duration x shader clock), the clock "
+                            "stamped (s_memtime / s_memrealtime) inside the convolution launches of the counter pass itself (bench.py --stamp-clock); the busy "
+                            "cycles are exact (16 per issued MFMA: profiles/r04_mfma_busy_calibration.md).  mfma_busy_frac_grbm_window_lower_bound divides "
+                            "by GRBM_GUI_ACTIVE / 8 instead — the window of a profiled 20-60 us dispatch is longer than the kernel "
+                            "(pmc_grbm_window_clock_mhz = window / duration reads above the chip's 2400 MHz), kept for continuity with rounds 3-4 only" % src}
 
 
 def cpu_baseline(budget_s=12.0):
@@ -273,18 +281,23 @@ def self_launch(n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE under a launcher, else 1)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the live per-launch timing of the dominant kernel (profiling runs)")
+    ap.add_argument("--stamp-clock", action="store_true",
+                    help="workgroup 0 of every convolution launch of the run adds its lifetime in shader clocks and wall ticks to a device "
+                         "block; the line carries conv_clock = {mhz, launches} (the counter passes of tools/prof_step_pmc.sh use it)")
     ap.add_argument("--workload", choices=["fixed", "varwidth", "deep"], default="fixed",
                     help="fixed = BASELINE configs[1] (the headline metric); varwidth = configs[3] (W in [80,320] padded per "
                          "batch); deep = configs[4] (ResNet-34-style extractor + 2 x BiLSTM(512 per direction), 96 classes, bs=32/GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus is None:               # `torchrun --nproc-per-node N bench.py` without --gpus: the launcher's world is the answer
+        args.gpus = world
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -335,6 +348,11 @@ def main():
         x, labels, ll, sl = batches[i % len(batches)]
         eng.train_step(x, labels, ll, sl, fetch_loss=False)
 
+    stamp = None
+    if args.stamp_clock:
+        from lstm_ctc_ocr_amd import _native as nat
+        stamp = torch.zeros(8, dtype=torch.int64, device=device)
+        nat.call("ocr_conv_halo_clock_debug", stamp.data_ptr())
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -405,11 +423,21 @@ def main():
                                     "bs=32/GPU (BASELINE.json configs[4]; bf16 MFMA operands where BASELINE says fp16: same MFMA rate, fp32 accumulation)"),
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world, "hipgraph": not args.no_graphs},
             "final_loss": loss,
+            "fake_comm": ({"cus": int(os.environ["OCR_FAKE_COMM_CUS"]), "us_per_25mb": float(os.environ.get("OCR_FAKE_COMM_US", "250")),
+                           "lds_kb": int(os.environ.get("OCR_FAKE_COMM_LDS_KB", "96")), "fake_world": int(os.environ["OCR_FAKE_WORLD"]),
+                           "note": "one-GPU emulation: every all-reduce = a doubling kernel + `cus` resident workgroups holding CUs for the time a "
+                                   "ring all-reduce of that range would run, on the communication stream (lstm_ctc_ocr_amd/dist.py)"}
+                          if os.environ.get("OCR_FAKE_WORLD") and int(os.environ.get("OCR_FAKE_COMM_CUS", "0") or 0) > 0 else None),
             "dp_check": dp_check, "dp_host_enqueue_us": dp_host,
             "with_loss_fetch_every_step": {"value": BATCH * world * args.steps / dt_fetch, "ms_per_step": dt_fetch / args.steps * 1e3},
             "with_loss_read_one_step_behind": {"value": BATCH * world * args.steps / dt_lag, "ms_per_step": dt_lag / args.steps * 1e3},
             "model_tflops_per_gpu": value / world * TRAIN_GFLOP_PER_IMG * 1e9 / 1e12,
         }
+        if stamp is not None:
+            nat.call("ocr_conv_halo_clock_debug", None)
+            c = stamp.cpu().numpy()
+            line["conv_clock"] = {"mhz": (float(c[4]) / float(c[5]) * 100.0) if c[5] else None, "launches": int(c[6]),
+                                  "note": "shader clocks / 100 MHz wall ticks of workgroup 0, summed over every convolution launch of this process"}
         if args.workload != "fixed":
             line["metric"] = "captcha images/sec training (%s workload)" % args.workload
             line.pop("model_tflops_per_gpu")

@@ -94,8 +94,8 @@ int ocr_conv3x3_kernel_choice(int Nb, int W, int H, int Cin, int Cout, int flags
 /* non-zero: ocr_conv3x3_bf16 accepts OCR_EPI_ACCUM for this shape (y (bf16) += result: the data gradient of a tensor with several
  * consumers is added to what was already delivered, no scratch tensor + add pass) */
 int ocr_conv3x3_accum_supported(int Nb, int W, int H, int Cin, int Cout);
-/* diagnostic: workgroup 0 of the convolution kernels (conv_halo, conv_k3 / conv_k3w) stamps {shader clock counter, 100 MHz wall clock} at entry and exit into
- * dbg (device int64[4]; NULL = off) */
+/* diagnostic: workgroup 0 of the convolution kernels (conv_halo, conv_k3 / conv_k3w) stamps {shader clock counter, 100 MHz wall clock} at entry ([0], [1]) and exit ([2], [3])
+ * into dbg (device int64[8]; NULL = off) and adds its lifetime to [4] (shader clocks), [5] (wall ticks), [6] (launches) */
 int ocr_conv_halo_clock_debug(void* dbg);
 /* conv3x3 + bias + ReLU AND the max-pool behind it from one epilogue (LSTM_train.py:26-33): y [Nb,W,H,Cout] and pooled
  * [Nb, W/kw, H/kh, Cout]; (kw, kh) = (1, 2) (feature axis) or (2, 2).  ocr_conv3x3_pool_supported() != 0 tells whether the shape is
@@ -282,6 +282,14 @@ int ocr_lstm_fwd_seq2(const float* xproj, const void* whT_packed, const int* seq
                       float* cell, int Nb, int T, int U, float forget_bias, void* sync, int flags, void* stream);
 int ocr_lstm_bwd_seq2(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
                       const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync, int flags, void* stream);
+/* The forward recurrence WITH the input projection inside (no projection GEMM, no fp32 projection tensor): x bf16 [Nb * T][D] (the layer's
+ * input rows, batch-major), wxT_packed bf16 [2][4U][D] and bias_packed fp32 [2][4U] exactly as the projection GEMM takes them
+ * (ocr_pack_transpose with lstm_units, ocr_lstm_pack_bias).  Covered: ring protocol, 16-row tiles, four-wave workgroups, D = 512 / 1024,
+ * U = 256 / 512 — ocr_lstm_fwd_seq_x_supported; otherwise OCR_ERR_INVALID (run the GEMM + ocr_lstm_fwd_seq2).  flags as above. */
+int ocr_lstm_fwd_seq_x_supported(int Nb, int U, int D);
+int ocr_lstm_fwd_seq_x(const void* x, const void* wxT_packed, const float* bias_packed, int D, const void* whT_packed,
+                       const int* seq_len, void* hout, float* gates, float* cell, int Nb, int T, int U, float forget_bias,
+                       void* sync, int flags, void* stream);
 /* hand-off protocol of the persistent kernels: 4 (default) = data-as-flag through a ring inside one XCD's L2, 2 = data-as-flag
  * through the output tensor inside one XCD's L2 — both need workgroups with equal (id & 7) on one XCD, see ocr_probe_xcc;
  * 0 = counters (sc1): placement independent */
@@ -312,6 +320,10 @@ int ocr_wgrad9_debug(void* dbg);
 int ocr_probe_tr16(const int* addr /* 64 */, int* out /* 64*4 */, void* stream);
 /* out[id] = XCC_ID of workgroup id of a 1-D grid, out[nblocks + id] = its HW_ID register (evidence for id & 7 == XCD) */
 int ocr_probe_xcc(int* out /* 2*nblocks */, int nblocks, int threads, void* stream);
+/* one-GPU stand-in for the CUs a concurrent RCCL collective holds (torch.distributed all_reduce over xGMI: lib/lstm/train.py has no
+ * counterpart — the reference is single-device): nblocks workgroups of `threads` threads with lds_bytes of LDS each stay
+ * resident for `us` microseconds without issuing work.  Used by the OCR_FAKE_COMM_CUS / OCR_FAKE_COMM_US emulation (lstm_ctc_ocr_amd/dist.py). */
+int ocr_occupy_cus(int nblocks, int threads, int lds_bytes, float us, void* stream);
 /* counter calibration: every wave issues iters x 8 back-to-back v_mfma_f32_16x16x32_bf16 (a saturated matrix pipe with an exactly known
  * instruction count); clk[4] = {shader clock, 100 MHz clock} of workgroup 0 at loop entry and exit, or NULL (tools/mfma_busy_probe.py) */
 int ocr_mfma_busy_probe(float* out, int nblocks, int threads /* multiple of 64, <= 512 */, int iters, long long* clk, void* stream);

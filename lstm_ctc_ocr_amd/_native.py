@@ -39,6 +39,7 @@ _SIGS = {
     "ocr_set_wgrad_engine": ([_I], _I),
     "ocr_conv3x3_bf16": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P], _I),
     "ocr_conv_halo_clock_debug": ([_P], _I),
+    "ocr_occupy_cus": ([_I, _I, _I, _F, _P], _I),
     "ocr_conv3x3_accum_supported": ([_I, _I, _I, _I, _I], _I),
     "ocr_conv3x3_kernel_choice": ([_I, _I, _I, _I, _I, _I, _I, _I], _I),
     "ocr_conv3x3_pool_supported": ([_I, _I, _I, _I, _I, _I, _I], _I),
@@ -95,6 +96,8 @@ _SIGS = {
     "ocr_lstm_fwd_seq": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P], _I),
     "ocr_lstm_bwd_seq": ([_P, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
     "ocr_lstm_fwd_seq2": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _P], _I),
+    "ocr_lstm_fwd_seq_x_supported": ([_I, _I, _I], _I),
+    "ocr_lstm_fwd_seq_x": ([_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _P], _I),
     "ocr_lstm_bwd_seq2": ([_P, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P], _I),
     "ocr_lstm_hprev": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "ocr_lstm_pack_bias": ([_P, _P, _P, _I, _I, _P], _I),

@@ -87,4 +87,17 @@ static inline const char* ocr_tune_env(const char* name) {
     (void)name; return nullptr;
 #endif
 }
+// Clock diagnostic of the convolution kernels (ocr_conv_halo_clock_debug, device int64[8]): workgroup 0's first thread stamps
+// {shader-clock counter (s_memtime), 100 MHz wall clock (s_memrealtime)} into [0], [1] at entry and [2], [3] at exit, and ADDS its lifetime to
+// [4] (shader clocks), [5] (wall ticks), [6] (launches): launches of one stream are serial, so plain adds do.  MHz = [4] / [5] * 100 over
+// every stamped launch of a run — the counter passes divide the matrix pipes' busy cycles by the kernels' OWN cycles with it.
+__device__ __forceinline__ long long ocr_wall_clock() { return (long long)__builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ void ocr_clk_enter(long long* clk) {
+    clk[0] = (long long)__builtin_amdgcn_s_memtime(); clk[1] = ocr_wall_clock();
+}
+__device__ __forceinline__ void ocr_clk_exit(long long* clk) {
+    const long long c = (long long)__builtin_amdgcn_s_memtime(), t = ocr_wall_clock();
+    clk[2] = c; clk[3] = t;
+    clk[4] += c - clk[0]; clk[5] += t - clk[1]; clk[6] += 1;
+}
 __host__ __device__ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -58,7 +58,7 @@ void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 8 * NW */
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int H = g.cH, C = g.C;
     long long* const clk = g_halo_clk;
-    if (clk && blockIdx.x == 0 && tid == 0) { clk[0] = (long long)__builtin_amdgcn_s_memtime(); clk[1] = (long long)wall_clock64(); }
+    if (clk && blockIdx.x == 0 && tid == 0) ocr_clk_enter(clk);
     // co-resident workgroups of a launch start in phase (their prologue DMA, K steps and epilogue stores coincide instead of
     // overlapping — the short-K layers run at half their MFMA-only rate): optional start offset for every other workgroup of a CU
     if (g.stagger > 0 && ((blockIdx.x >> 3) & g.stagger_bit))
@@ -284,7 +284,7 @@ void conv_halo_kernel(HaloArgs g, int NRpad /* halo rows rounded up to 8 * NW */
             }
         }
     }
-    if (clk && blockIdx.x == 0 && tid == 0) { clk[2] = (long long)__builtin_amdgcn_s_memtime(); clk[3] = (long long)wall_clock64(); }
+    if (clk && blockIdx.x == 0 && tid == 0) ocr_clk_exit(clk);
 }
 
 // (A variant on v_mfma_f32_32x32x16_bf16 — same tiles, 32-row fragments, row swizzle (r & 7) ^ ((r >> 3) & 1) — was written in round 2,

@@ -110,7 +110,7 @@ __device__ __forceinline__ void k3_body(const K3Args& g) {
     const int tid = threadIdx.x, lane = tid & 63;
     K3_PHASE(0);
     long long* const clk = g_k3_clk;
-    if (clk && blockIdx.x == 0 && tid == 0) { clk[0] = (long long)__builtin_amdgcn_s_memtime(); clk[1] = (long long)wall_clock64(); }
+    if (clk && blockIdx.x == 0 && tid == 0) ocr_clk_enter(clk);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = wave >> 2, wm = (wave & 3) / WN, wn = (wave & 3) % WN;
     const int C = g.C;
@@ -474,7 +474,7 @@ __device__ __forceinline__ void k3_body(const K3Args& g) {
         }
     };
     if (kh) tail(std::integral_constant<int, 1>{}); else tail(std::integral_constant<int, 0>{});
-    if (clk && blockIdx.x == 0 && tid == 0) { clk[2] = (long long)__builtin_amdgcn_s_memtime(); clk[3] = (long long)wall_clock64(); }
+    if (clk && blockIdx.x == 0 && tid == 0) ocr_clk_exit(clk);
 #ifdef OCR_EXPERIMENTS
     K3_PHASE(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

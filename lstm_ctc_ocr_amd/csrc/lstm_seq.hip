@@ -20,6 +20,7 @@
 //     the caller then uses the per-step kernels).  Spins are bounded and report through an error word instead of hanging.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef unsigned long long u64;
 
@@ -618,6 +619,177 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// ---- the forward recurrence WITH the input projection (round 5) -----------------------------------------------------------------------------------
+// x_t W_x does not depend on the recurrence: the four-wave kernel above takes it from a tensor that a GEMM launch wrote (33 MB of fp32 at
+// N = 64, T = 63, U = 256: written once, read once, 17 - 21 us of igemm in front of the kernel).  Here each wave also holds ITS quarter of the
+// input features' W_x slice in registers (the same 64 packed gate rows as its W_h slice: D / 4 columns = 64 VGPRs at D = 512), loads the bf16
+// x_t fragments of its quarter one step ahead, and issues the D / 32 / 4 x 4 MFMAs of the input part BETWEEN issuing a step's first poll and
+// looking at it — the poll's L2 round trip (~0.5 us) is longer than those 16 MFMAs (256 clocks), so the projection costs no time on the
+// recurrence's critical path, and its launch, its tensor and their traffic are gone.  The partial sums of input and recurrent part share the
+// accumulators (the input part is their start value) and meet in the same LDS exchange; the bias is added by the owning lane.
+struct LstmSeqFwdXArgs {
+    const bf16_t* x; const bf16_t* wxT; const float* bias; const bf16_t* whT; const int* seq_len; bf16_t* hout; float* gates; float* cell;
+    unsigned char* ring; int* err;
+    int Nb, T; float forget_bias; long long* dbg; int presleep;
+};
+template <int U, int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_seq4x_kernel(LstmSeqFwdXArgs a) {
+    constexpr int KS = U / 32 / 4, KX = D / 32 / 4, UB = U / 16;
+    constexpr unsigned SLOT = (unsigned)UB * 512u;                       // ring bytes per step and group
+    __shared__ f32x4 red[4][4][64];                                      // [source wave][unit r of the lane's four][lane] = partial {i, j, f, o}
+    __shared__ f32x4 outs[6][64];                                        // [h, i, j, f, o, c][lane] = results of the lane's four units (element r by wave r)
+    const int lane = threadIdx.x & 63;
+    const int kh = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int ub, d, zb;
+    const int nzb = (a.Nb + 15) / 16;
+    if (!seq_decode<4, UB>(2 * nzb, ub, d, zb)) return;
+    const int T = a.T;
+    const int nl = lane & 15, q = lane >> 4;
+    const int n = zb * 16 + nl;
+    const bool nvalid = n < a.Nb;
+    const int nn = nvalid ? n : 0;
+    const int len = min(a.seq_len[nn], T);
+    const long R = (long)a.Nb * T;
+    const int ul0 = q * 4;
+
+    bf16x8 w[4][KS], wx[4][KX];
+    {
+        const bf16_t* wbase = a.whT + ((long)d * 4 * U + (long)ub * 64 + nl) * U + kh * (KS * 32) + q * 8;
+        const bf16_t* xbase = a.wxT + ((long)d * 4 * U + (long)ub * 64 + nl) * D + kh * (KX * 32) + q * 8;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) w[g][kk] = *(const bf16x8*)(wbase + (long)g * 16 * U + kk * 32);
+#pragma unroll
+            for (int kk = 0; kk < KX; ++kk) wx[g][kk] = *(const bf16x8*)(xbase + (long)g * 16 * D + kk * 32);
+        }
+    }
+    // bias of the four gates of the unit this lane finishes (packed gate-column order, as the projection GEMM's bias vector)
+    f32x4 bo;
+    {
+        const float* bp = a.bias + (long)d * 4 * U + ub * 64 + ul0 + kh;
+        bo = (f32x4){bp[0], bp[16], bp[32], bp[48]};
+    }
+    float c = 0.f;                                                       // cell state of (row nl, unit ul0 + kh)
+    int presleep = a.presleep, streak = 0;
+    bool dead = false;
+    unsigned char* const gring = a.ring + (size_t)(zb * 2 + d) * RING * SLOT;
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)gring, 0, (int)(RING * SLOT), 0x00020000);
+    const unsigned rd0 = (unsigned)((kh * KS * 2 + (q >> 1)) * 512 + nl * 32 + (q & 1) * 16);
+    const unsigned wr0 = (unsigned)(ub * 512 + nl * 32 + q * 8);
+    // this wave's quarter of the input row of step s1 as MFMA B fragments (zeros for rows past their length)
+    auto xload = [&](int s1, bf16x8 (&xb)[KX]) {
+#pragma unroll
+        for (int kk = 0; kk < KX; ++kk) xb[kk] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (nvalid && s1 < len) {
+            const int t1 = d == 0 ? s1 : len - 1 - s1;
+            const bf16_t* xp = a.x + ((long)nn * T + t1) * D + kh * (KX * 32) + q * 8;
+#pragma unroll
+            for (int kk = 0; kk < KX; ++kk) xb[kk] = *(const bf16x8*)(xp + kk * 32);
+        }
+    };
+    bf16x8 xn[KX];
+    xload(0, xn);
+    // One step.  The first one (no recurrent part, no poll) is a copy of its own: with `if (s > 0)` around the poll the compiler merges a path
+    // with and a path without poll loads in flight and then waits for ALL vector-memory operations before the input fragments are used —
+    // i.e. for the poll, which the input part is meant to overlap.
+    auto step = [&](const int s, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const int dbgi = s;
+        DBG_STAMP(0);
+        const bool active = nvalid && s < len;
+        const int t = active ? (d == 0 ? s : len - 1 - s) : s;
+        const long row = (long)nn * T + t;
+        bf16x8 b[KS];
+        const unsigned hoff = (unsigned)((s - 1) & (RING - 1)) * SLOT + rd0;
+        if (!FIRST) {
+            for (int i = 0; i < presleep; ++i) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) b[kk] = load_pub<4>(rrsrc, hoff + kk * 1024u);          // the first poll goes out ...
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ... and the input part is multiplied while it is under way: its fragments were requested a step ago (vmcnt retires in order, so
+        // they — and the last step's stores — land before the poll's data in any case)
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KX; ++kk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wx[g][kk], xn[kk], acc[g], 0, 0, 0);
+        // pinned HERE: the products are pure register arithmetic whose results are needed only behind the poll, and the compiler otherwise
+        // sinks all sixteen MFMAs below the polling loop (seen in the ISA) — behind the wait they are meant to fill
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) :: "memory");
+        if (!FIRST) {
+            unsigned spins = 0;
+            while (true) {
+                unsigned m = 0;
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) m = fold_fill(m, b[kk]);
+                if (dead || !__any(active && holds_fill(m))) break;
+                if (++spins > (SPIN_LIMIT >> 4)) { if (lane == 0) atomicExch(a.err, 1); dead = true; break; }
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) b[kk] = load_pub<4>(rrsrc, hoff + kk * 1024u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            DBG_STAMP(1);
+            POLL_ADAPT();
+            if (!active) {
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) b[kk] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+            // the operands are final HERE, in front of the next step's loads: sunk below them (as the compiler did) the selects above waited
+            // for those loads — on the critical path
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+v"(b[kk]) :: "memory");
+        }
+        if (s + 1 < T) xload(s + 1, xn);                       // next step's fragments: behind the poll, in front of this step's stores
+        __builtin_amdgcn_sched_barrier(0);
+        if (!FIRST) {
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g][kk], b[kk], acc[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[kh][r][lane] = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        __syncthreads();                                        // A
+        // gate pre-activations {i, j, f, o} of (row nl, unit ul0 + kh)
+        f32x4 z = (red[0][kh][lane] + red[1][kh][lane]) + (red[2][kh][lane] + red[3][kh][lane]);
+        if (active) z += bo;                                   // (rows past their length: x = 0 and no bias — throw-away values in rows nobody reads)
+        const float gi = sigmoid_q(z[0]), gj = tanh_q(z[1]), gf = sigmoid_q(z[2] + a.forget_bias), go = sigmoid_q(z[3]);
+        const float cn = gf * c + gi * gj;
+        const float hn = go * tanh_q(cn);
+        if (active) c = cn;
+        float* oo = (float*)&outs[0][lane] + kh;
+        oo[0] = active ? hn : 0.f; oo[256] = gi; oo[512] = gj; oo[768] = gf; oo[1024] = go; oo[1280] = c;
+        __syncthreads();                                        // B
+        DBG_STAMP(2);
+        if (nvalid) {
+            if (kh == 0) {
+                const f32x4 h = outs[0][lane];
+                const u32x2 hp = {pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
+                *(u32x2*)(gring + (unsigned)(s & (RING - 1)) * SLOT + wr0) = hp;               // the hand-off payload goes out FIRST
+                asm volatile("" ::: "memory");
+                if (s >= 2) *(u32x2*)(gring + (unsigned)((s - 2) & (RING - 1)) * SLOT + wr0) = (u32x2){0xFFFFFFFFu, 0xFFFFFFFFu};
+                asm volatile("" ::: "memory");
+                *(u32x2*)(a.hout + row * (2L * U) + (long)d * U + ub * 16 + ul0) = hp;
+            } else if (kh == 3) {
+                *(f32x4*)(a.cell + ((long)d * R + row) * U + ub * 16 + ul0) = outs[5][lane];
+            } else {
+                float* gdst = a.gates + ((long)d * R + row) * (4L * U) + (long)ub * 64 + ul0 + (kh - 1) * 32;
+                *(f32x4*)(gdst + 0) = outs[2 * kh - 1][lane];
+                *(f32x4*)(gdst + 16) = outs[2 * kh][lane];
+            }
+        }
+        DBG_STAMP(3);
+    };
+    step(0, std::true_type{});
+    for (int s = 1; s < T; ++s) step(s, std::false_type{});
+}
+
 template <int U>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_seq4_kernel(LstmSeqBwdArgs a) {
     constexpr int KS = U / 32, UB = U / 16;                              // wave kh multiplies gate kh's columns of W_h: K = kh U .. (kh + 1) U of 4U
@@ -924,4 +1096,36 @@ extern "C" int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, con
                                 const float* gates, const float* cell, void* dz, int Nb, int T, int U, void* sync,
                                 void* stream_) {
     return ocr_lstm_bwd_seq2(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, Nb, T, U, sync, 0, stream_);
+}
+
+// The forward recurrence with the input projection inside (lstm_fwd_seq4x_kernel): x bf16 [Nb * T][D], wxT_packed bf16 [2][4U][D] and bias
+// fp32 [2][4U] in the packed gate order of the projection GEMM's operands (ocr_pack_transpose with lstm_units / ocr_lstm_pack_bias).
+// Covered: the ring protocol, 16-row tiles, four-wave workgroups, D = 512 or 1024, U = 256 or 512 (ocr_lstm_fwd_seq_x_supported); otherwise
+// OCR_ERR_INVALID and the caller runs the projection GEMM + ocr_lstm_fwd_seq2.
+extern "C" int ocr_lstm_fwd_seq_x_supported(int Nb, int U, int D) {
+    return Nb > 0 && (D == 512 || D == 1024) && (U == 256 || U == 512) && seq_rows_per_wg(Nb, U) == 16 && seq_proto() == 4 && seq_ksplit() == 4;
+}
+extern "C" int ocr_lstm_fwd_seq_x(const void* x, const void* wxT_packed, const float* bias_packed, int D, const void* whT_packed,
+                                  const int* seq_len, void* hout, float* gates, float* cell, int Nb, int T, int U, float forget_bias,
+                                  void* sync, int flags, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !wxT_packed || !bias_packed || !whT_packed || !seq_len || !hout || !gates || !cell || !sync) return OCR_ERR_INVALID;
+    if (Nb <= 0 || T <= 0 || !ocr_lstm_fwd_seq_x_supported(Nb, U, D)) return OCR_ERR_INVALID;
+    const int nz = ceil_div(Nb, 16);
+    const long words = ocr_lstm_seq_sync_words(Nb, U), cwords = seq_counter_words(Nb);
+    const long ring_words = (long)(2 * nz) * RING * ((long)(U / 16) * 512) / 4;
+    if (!(flags & 1)) {
+        seq_prepare(4, sync, words, cwords, ring_words, stream);
+        OCR_CHECK_LAUNCH();
+    }
+    LstmSeqFwdXArgs a = {(const bf16_t*)x, (const bf16_t*)wxT_packed, bias_packed, (const bf16_t*)whT_packed, seq_len, (bf16_t*)hout, gates, cell,
+                         (unsigned char*)((unsigned*)sync + cwords), (int*)sync + words - 1, Nb, T, forget_bias, g_lstm_dbg,
+                         seq_env_int("OCR_LSTM_PRESLEEP_F", 0, 0, true)};
+    const dim3 grid1((U / 16) * 8 * ceil_div(2 * nz, 8));
+    if (U == 256 && D == 512) lstm_fwd_seq4x_kernel<256, 512><<<grid1, 256, 0, stream>>>(a);
+    else if (U == 512 && D == 512) lstm_fwd_seq4x_kernel<512, 512><<<grid1, 256, 0, stream>>>(a);
+    else if (U == 256) lstm_fwd_seq4x_kernel<256, 1024><<<grid1, 256, 0, stream>>>(a);
+    else lstm_fwd_seq4x_kernel<512, 1024><<<grid1, 256, 0, stream>>>(a);       // configs[4]'s second BiLSTM layer: 255 VGPRs + 54 AGPRs, no scratch
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
 }

@@ -67,6 +67,30 @@ extern "C" int ocr_mfma_busy_probe(float* out, int nblocks, int threads, int ite
     return OCR_OK;
 }
 
+// One-GPU stand-in for the CUs a concurrent RCCL collective occupies (OCR_FAKE_WORLD's doubling kernel is a ~10 us
+// elementwise pass and cannot show what a 0.2-0.3 ms all-reduce kernel does to the convolution launches running beside it).  `nblocks`
+// workgroups of `threads` threads, each holding `lds_bytes` of LDS, stay resident for `us` microseconds (100 MHz wall clock, s_sleep
+// between looks: no issue slots, no memory traffic — the CU's LDS and wave slots are what is taken, as by RCCL's long-running channel
+// kernels, one workgroup per channel).  A workgroup with more than half of a CU's LDS keeps every 160 KB convolution tile off its CU.
+__global__ void occupy_kernel(long long ticks, int* __restrict__ sink) {
+    extern __shared__ int occ_lds[];
+    const long long t0 = ocr_wall_clock();
+    if (sink == (int*)1) occ_lds[threadIdx.x] = 1;          // (never: keeps the dynamic LDS allocation referenced)
+    while (ocr_wall_clock() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (sink == (int*)1) sink[0] = occ_lds[0];
+}
+extern "C" int ocr_occupy_cus(int nblocks, int threads, int lds_bytes, float us, void* stream) {
+    if (nblocks <= 0 || nblocks > 1024 || threads <= 0 || threads > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024 || !(us >= 0.f) || us > 1e5f) return OCR_ERR_INVALID;
+    static int attr = 0;
+    if (lds_bytes > attr) {
+        if (hipFuncSetAttribute((const void*)occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return OCR_ERR_EXEC;
+        attr = 160 * 1024;
+    }
+    occupy_kernel<<<nblocks, threads, lds_bytes, (hipStream_t)stream>>>((long long)(us * 100.0f), nullptr);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+
 extern "C" const char* ocr_status_string(int status) {
     switch (status) {
         case OCR_OK: return "no error";

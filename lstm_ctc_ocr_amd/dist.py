@@ -20,6 +20,15 @@ def allreduce_sum_(flat, group=None, force=False):
     fake = os.environ.get('OCR_FAKE_WORLD')
     if fake:                # single-GPU emulation of `fake` ranks holding identical data: the sum is a multiplication
         flat.mul_(float(fake))      # (a real kernel on the current stream, so stream ordering is exercised like RCCL's)
+        # ... and, with OCR_FAKE_COMM_CUS=n, n workgroups that HOLD CUs for as long as a ring all-reduce of this range would run
+        # (OCR_FAKE_COMM_US = microseconds per 25 MB, scaled by the range; >= 20 us): the doubling kernel alone is a ~10 us elementwise
+        # pass and cannot show what RCCL's channel kernels do to the 256-tile convolution grids of the concurrent backward graph
+        cus = int(os.environ.get('OCR_FAKE_COMM_CUS', '0') or 0)
+        if cus > 0 and flat.is_cuda:
+            from . import _native as nat
+            us = max(20.0, float(os.environ.get('OCR_FAKE_COMM_US', '250')) * flat.numel() * flat.element_size() / 25e6)
+            lds = int(os.environ.get('OCR_FAKE_COMM_LDS_KB', '96')) * 1024      # > half a CU's 160 KB: no convolution tile fits beside it
+            nat.call("ocr_occupy_cus", cus, 256, lds, us, nat.stream())
         return flat
     if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
         if flat.is_cuda and dist.get_backend(group) == 'gloo':

@@ -39,6 +39,17 @@ def _round_up(x, m):
 
 
 # ====================================================================================================== ops
+def _take_ring(sp, key):
+    """True once per fill: the hand-off block `key` still holds the all-ones pattern the conv1 + pool launch of THIS forward pass wrote.
+    The persistent LSTM launch that asks consumes it — a second launch on the same block (a repeated backward pass without a new
+    training forward) gets False and fills the block itself."""
+    ready = getattr(sp, 'rings_ready', None)
+    if not ready or key not in ready:
+        return False
+    ready.discard(key)
+    return True
+
+
 class _Op(object):
     mask_in_consumer = False      # True: output has a fused ReLU whose backward the consumer must apply
 
@@ -196,6 +207,9 @@ class _ConvOp(_Op):
                     rows = 0
             sp.bn_bwd_rows = getattr(sp, 'bn_bwd_rows', {})
             if isinstance(p, _ConvOp):
+                # the producer's backward sums come EITHER from this layer's data-gradient write-out (partial rows) OR from its own passes
+                # routing a pooled gradient — never both: ocr_bn_train_bwd2 takes one form per launch
+                assert p.bn_pool is None or not rows, (p.key, rows)
                 sp.bn_bwd_rows[p.key] = rows
         if self.kind == '3x3':      # scratch of the slab weight-gradient kernel
             need = ops.conv3x3_wgrad_workspace_bytes(s[0], s[1], s[2], self.ci, self.co)
@@ -203,7 +217,14 @@ class _ConvOp(_Op):
             if need and self.eng.defer_w9:
                 # one buffer PER LAYER: the slabs stay until the end of the backward pass, where ONE launch reduces all layers'
                 # (Engine._flush_w9) — ~20 MB per layer of 288 GB against four dependent launches less per step
-                sp.buf[self.key + '/w9ws'] = torch.empty(need, dtype=torch.uint8, device=dev)
+                # ... shared by the plans of an engine (plans run one at a time on one stream and no slab outlives its backward body): a
+                # variable-width run makes one plan per padded width — a narrower plan takes a view of the widest workspace allocated so
+                # far instead of slabs of its own (9-61 plans x ~0.4 GB for the deep net otherwise)
+                pool = self.eng.w9_ws_pool
+                have_ws = pool.get(self.key)
+                if have_ws is None or have_ws.numel() < need:
+                    have_ws = pool[self.key] = torch.empty(need, dtype=torch.uint8, device=dev)      # (older plans keep the block their graphs captured)
+                sp.buf[self.key + '/w9ws'] = have_ws[:need]
             elif need and (have is None or have.numel() < need):     # one buffer per plan, shared by all layers (one stream)
                 sp.buf['wgrad_ws'] = torch.empty(need, dtype=torch.uint8, device=dev)
 
@@ -230,7 +251,8 @@ class _ConvOp(_Op):
             codes = sp.buf.get(self.key + '/codes') if e.training else None
             ones, e._ones_pending = e._ones_pending, None                              # ... and so does the fill of the LSTM hand-off blocks
             ops.conv1_pool_fwd(x, e.param(self.name + '/weights'), bias, out=self.fused_pool.y(sp), zero=zero, codes=codes, ones=ones)
-            sp.rings_ready = ones is not None
+            # every hand-off block of the plan is armed now; each persistent launch consumes (and thereby dirties) its own block ONCE
+            sp.rings_ready = set(getattr(sp, 'lstm_sync_keys', ())) if ones is not None else set()
             return
         y = self.y(sp)
         if self.kind == 'c1':
@@ -819,11 +841,18 @@ class _BiLstmOp(_Op):
         R = N * T
         b = sp.buf
         x = self.prev.y(sp).view(R, D)
-        ops.gemm_nt(x, self.wxT, out=b[self.key + '/xproj'], bias=self.bias)
-        if self._persistent(N):
+        if (self._persistent(N) and ND == 2 and os.environ.get('OCR_LSTM_FUSE_X', '1') != '0' and x.is_contiguous()
+                and ops.lstm_fwd_seq_x_supported(N, U, D)):
+            # the input projection inside the recurrent kernel (its MFMAs run while a step's first poll is under way): no projection GEMM,
+            # no fp32 projection tensor
+            ops.lstm_fwd_seq_x(x, self.wxT, self.bias, self.whT, sp.seq_len, b[self.key + '/hout'], b[self.key + '/gates'],
+                               b[self.key + '/cell'], N, T, U, b[self.key + '/sync_f'], 1.0, prepared=_take_ring(sp, self.key + '/sync_f'))
+        elif self._persistent(N):
+            ops.gemm_nt(x, self.wxT, out=b[self.key + '/xproj'], bias=self.bias)
             ops.lstm_fwd_seq(b[self.key + '/xproj'], self.whT, sp.seq_len, b[self.key + '/hout'], b[self.key + '/gates'],
-                             b[self.key + '/cell'], N, T, U, b[self.key + '/sync_f'], 1.0, prepared=getattr(sp, 'rings_ready', False))
+                             b[self.key + '/cell'], N, T, U, b[self.key + '/sync_f'], 1.0, prepared=_take_ring(sp, self.key + '/sync_f'))
         else:
+            ops.gemm_nt(x, self.wxT, out=b[self.key + '/xproj'], bias=self.bias)
             for s in range(T):
                 ops.lstm_fwd_step(b[self.key + '/xproj'], self.whT, sp.seq_len, b[self.key + '/hout'],
                                   b[self.key + '/gates'], b[self.key + '/cell'], N, T, U, s, 1.0, ND)
@@ -849,7 +878,7 @@ class _BiLstmOp(_Op):
         stride = e.offset(self.cells[1] + '/weights') - e.offset(self.cells[0] + '/weights') if ND == 2 else 0
         if self._persistent(N):
             ops.lstm_bwd_seq(wsh[D:], 4 * U, stride, sp.seq_len, b[self.key + '/dhout'], b[self.key + '/gates'],
-                             b[self.key + '/cell'], b[self.key + '/dz'], N, T, U, b[self.key + '/sync_b'], prepared=getattr(sp, 'rings_ready', False))
+                             b[self.key + '/cell'], b[self.key + '/dz'], N, T, U, b[self.key + '/sync_b'], prepared=_take_ring(sp, self.key + '/sync_b'))
         else:
             b[self.key + '/dc'].zero_()
             for s in range(T - 1, -1, -1):
@@ -971,7 +1000,8 @@ class Engine(object):
         # OCR_W9_DEFER=0: every 3x3 weight gradient reduces its slabs right behind its own kernel (five reduce launches per step
         # for the CRNN); default: one merged reduction per backward body (bit-identical sums)
         self.defer_w9 = os.environ.get('OCR_W9_DEFER', '1') != '0'
-        self.w9_defer_max_bytes = int(os.environ.get('OCR_W9_DEFER_MAX_MB', self.W9_DEFER_MAX_BYTES >> 20)) << 20
+        self.w9_defer_max_bytes = int(os.environ.get('OCR_W9_DEFER_MAX_MB', self.W9_DEFER_MAX_BYTES >> 20)) << 20     # only consulted with OCR_W9_FLUSH_MB=0
+        self.w9_ws_pool = {}          # layer key -> the largest slab workspace any plan asked for so far (shared by the plans)
         self.comm_stream = torch.cuda.Stream(device=self.device)
         self.dp_host_s = [0.0, 0.0, 0.0, 0.0, 0.0, 0]      # host enqueue seconds of the data-parallel schedule's phases + step count (train_step)
         self._lower(net)                                 # operators first: the parameter layout follows their EXECUTION order
@@ -1282,7 +1312,7 @@ class Engine(object):
             self.grads.zero_()
         # likewise the fill of the persistent LSTM launches' hand-off blocks (OCR_FUSE_RINGFILL=0: every launch fills its own); a graph whose
         # first kernel is not conv1 + pool never consumes it and its LSTM launches prepare their blocks themselves
-        sp.rings_ready = False
+        sp.rings_ready = set()
         self._ones_pending = sp.lstm_arena if (training and getattr(sp, 'lstm_arena', None) is not None
                                                and os.environ.get('OCR_FUSE_RINGFILL', '1') != '0') else None
         for op in self.ops:

@@ -527,6 +527,17 @@ def lstm_fwd_seq(xproj, whT, seq_len, hout, gates, cell, Nb, T, U, sync, forget_
          ptr(gates), ptr(cell), Nb, T, U, float(forget_bias), ptr(sync), LSTM_PREPARED if prepared else 0, _st())
 
 
+def lstm_fwd_seq_x_supported(Nb, U, D):
+    return bool(nat.lib().ocr_lstm_fwd_seq_x_supported(Nb, U, D))
+
+
+def lstm_fwd_seq_x(x, wxT, bias, whT, seq_len, hout, gates, cell, Nb, T, U, sync, forget_bias=1.0, prepared=False):
+    """The forward recurrence with the input projection inside: x bf16 [Nb * T, D]; wxT [2 * 4U, D] / bias [2 * 4U] as gemm_nt takes them."""
+    D = x.shape[-1]
+    call("ocr_lstm_fwd_seq_x", ptr(_dev(x)), ptr(wxT), ptr(bias), D, ptr(whT), ptr(seq_len), ptr(hout), ptr(gates), ptr(cell),
+         Nb, T, U, float(forget_bias), ptr(sync), LSTM_PREPARED if prepared else 0, _st())
+
+
 def lstm_bwd_seq(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, Nb, T, U, sync, prepared=False):
     call("ocr_lstm_bwd_seq2", ptr(_dev(wh)), ldw, w_dir_stride, ptr(seq_len),
          ptr(dhout), ptr(gates), ptr(cell), ptr(dz), Nb, T, U, ptr(sync), LSTM_PREPARED if prepared else 0, _st())

@@ -349,18 +349,22 @@ def convert(prefix, out_path, wanted=None, iteration=None, verify=False, output_
                 arrays[slot + name] = tf_vars[src + suffix].astype(np.float32)
                 used.add(src + suffix)
     if 'beta1_power' in tf_vars and 'beta2_power' in tf_vars and any(k.startswith('slot1/') for k in arrays):
-        # Adam's step count: the reference's global_step variable (train.py:71,85) if it was saved; else from the float32 powers —
-        # beta2^t first (0.9^t underflows float32 after ~830 steps, 0.999^t after ~87 000).  The device keeps the powers in double.
+        # Adam's step count: the reference's global_step variable (train.py:71,85) if it was saved; else from the float32 powers Adam
+        # itself multiplied up — beta2^t first (0.9^t underflows float32 after ~830 steps, 0.999^t after ~87 000).  TF keeps beta^t in
+        # FLOAT32 and multiplies by float32(0.999) = 0.99900001287 each step, so the logarithm is taken to THAT base: to the base 0.999 the
+        # estimate under-counts by 1.3e-5 per step and rounds wrongly from step 38 539 on — inside the reference's default 40 000-iteration
+        # run.  To the float32 base a float32 simulation of the product is off by < 0.01 of a step all the way to the underflow
+        # (tests/test_tf_bundle.py replays it at 40 000 and 86 000 steps).  The device keeps the powers in double.
         b1t, b2t = float(np.asarray(tf_vars['beta1_power']).reshape(-1)[0]), float(np.asarray(tf_vars['beta2_power']).reshape(-1)[0])
         step_var = next((k for k in ('global_step', 'Variable_1') if k in tf_vars and np.asarray(tf_vars[k]).size == 1
                          and np.issubdtype(np.asarray(tf_vars[k]).dtype, np.integer)), None)
         if step_var is not None:
             step = int(np.asarray(tf_vars[step_var]).reshape(-1)[0])
             used.add(step_var)
-        elif 0 < b2t < 1:                                                # exact: what Adam itself multiplied up
-            step = int(round(np.log(b2t) / np.log(0.999)))
+        elif 0 < b2t < 1:
+            step = int(round(np.log(b2t) / np.log(float(np.float32(0.999)))))
         elif 0 < b1t < 1:
-            step = int(round(np.log(b1t) / np.log(0.9)))
+            step = int(round(np.log(b1t) / np.log(float(np.float32(0.9)))))
         elif re.search(r'_iter_(\d+)', os.path.basename(prefix)):        # both powers underflowed: the Saver's file name (train.py:27-36)
             step = max(0, int(re.search(r'_iter_(\d+)', os.path.basename(prefix)).group(1)) - 1)
         else:

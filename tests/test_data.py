@@ -54,6 +54,54 @@ def test_one_channel_renderer_equals_the_rgb_path_up_to_rounding(monkeypatch):
     assert lab_gray == lab_rgb and im_gray.shape == im_rgb.shape and np.abs(im_gray.astype(int) - im_rgb.astype(int)).max() <= 3
 
 
+REF_FONT = '/root/reference/fonts/Ubuntu-M.ttf'          # the reference's own font asset (lib/lstm/config.py:26); never copied into this repo
+
+
+@pytest.mark.skipif(not __import__('os').path.exists(REF_FONT), reason='the reference tree (and its font asset) is not on this box')
+def test_renders_with_the_reference_font_and_keeps_the_reference_geometry(monkeypatch, capsys):
+    """with the reference's fonts/Ubuntu-M.ttf ($OCR_FONT, test side only) both renderers produce ImageCaptcha's
+    160 x 60 canvas (gen.py:31-37) without the substitute-font warning, the gray conversion is the reference's BGR-weights-on-RGB quirk
+    (gen.py:77-78), and groupBatch turns it into the [85 -> 88, 32] float rows the kernels receive: resize to H = 32 with
+    nw = int(32 / 60 * 160) = 85, right padding with 0 up to a multiple of POOL_SCALE, values / 255, time steps 85 // 4 - 1 (gen.py:41-67)."""
+    import random
+    monkeypatch.setenv('OCR_FONT', REF_FONT)
+    monkeypatch.setenv('OCR_STRICT_FONT', '1')
+    gen._font_path.clear(); gen._FONT_CACHE.clear(); gen._MASK_CACHE.clear()
+    try:
+        assert gen.resolve_font() == REF_FONT
+        random.seed(11)
+        chars = 'aZ3k'
+        st = random.getstate()
+        rgb = np.array(gen.render_captcha(chars, 160, 60))
+        random.setstate(st)
+        gray = np.array(gen.render_captcha_gray(chars, 160, 60))
+        assert rgb.shape == (60, 160, 3) and rgb.dtype == np.uint8 and gray.shape == (60, 160) and gray.dtype == np.uint8
+        ref_gray = gen.to_gray_reference(rgb)
+        assert np.abs(ref_gray.astype(int) - gray.astype(int)).max() <= 3        # one-channel path = gray(RGB path) up to 8-bit rounding
+        # light background (238..255 per channel), dark ink (10..200): both present, ink covers a plausible share of the canvas
+        assert ref_gray.max() >= 236 and ref_gray.min() <= 205
+        ink = float((ref_gray < 215).mean())
+        assert 0.03 < ink < 0.6, ink
+        # Q8: the weights are cv2's BGR2GRAY applied to an RGB array — a pure-red pixel reads 29, not 76
+        px = np.zeros((1, 1, 3), np.uint8); px[0, 0, 0] = 255
+        assert int(gen.to_gray_reference(px)[0, 0]) == 29
+        batch, label_vec, label_len, steps = gen.groupBatch([gray.copy(), gray[:, :120].copy()], [chars, 'ab'])
+        assert batch[0].shape == (88, 32) and batch[1].shape == (88, 32) and batch[0].dtype == np.float32
+        assert steps == [85 // 4 - 1, 64 // 4 - 1] and label_len == [4, 2]
+        assert np.all(batch[0][85:] == 0) and np.all(batch[1][64:] == 0)          # pad value 0 (black), on the right (time axis)
+        assert 0.0 <= float(batch[0].min()) and float(batch[0][:85].max()) <= 1.0 and float(batch[0][:85].max()) > 0.9
+        # row t of the batch is image column t (the image is transposed: time = width, gen.py:63-64)
+        from PIL import Image
+        small = np.array(Image.fromarray(gray).resize((85, 32), Image.BILINEAR)).astype(np.float32) / 255.
+        assert np.array_equal(batch[0][:85], small.swapaxes(0, 1))
+        assert 'WARNING' not in capsys.readouterr().err
+        # the generators feed exactly this path
+        imgs, labels, lens, st2 = next(gen.generator(batch_size=2))
+        assert imgs[0].shape == (88, 32) and st2 == [20, 20]
+    finally:
+        gen._font_path.clear(); gen._FONT_CACHE.clear(); gen._MASK_CACHE.clear()
+
+
 def test_enqueuer_threads():
     def counter():
         i = 0

@@ -156,15 +156,36 @@ def test_oracle_reproduces_headline_gradient_fixture():
         assert np.linalg.norm(got - ref) < 2e-3 * np.linalg.norm(ref), k      # thread-count dependent fp32 summation order + routing flips
 
 
+# Per-tensor bars for |g_dev - g_oracle|_2 / |g_oracle|_2 AT THE BENCHMARKED SIZE (N = 64): 3x the larger of the two measurements of
+# profiles/r04a_grad_parity.log (headline W = 256 / ragged W = 320 fixture; MI355X, round 4) — conv1..conv3_2 3.0e-3..3.6e-3, conv4_1 1.6e-3..2.3e-3,
+# conv4_2 1.3e-3..1.8e-3 (beta 1.3e-3, gamma 5.7e-4), conv5 3.6e-4..6.3e-4, logits/{fw,bw} 1.9e-4..7.5e-4, logits/weights 2.4e-4,
+# logits/biases 1.9e-5..9.3e-5.  (The N = 8 bars of tests/test_gpu_engine.py are ~10x looser: at N = 8 a single max-pool / ReLU routing flip
+# weighs 8x more.  THIS table is the whole-graph net at the size that is benchmarked; the tight per-kernel net is tests/test_gpu_kernels.py.)
+GRAD_L2_BAR_N64 = {'default': 1.1e-2,
+                   'conv4_1/weights': 7e-3, 'conv4_1/conv4_1/beta': 7e-3, 'conv4_1/conv4_1/gamma': 7e-3,
+                   'conv4_2/weights': 5.5e-3, 'conv4_2/conv4_2/beta': 4e-3, 'conv4_2/conv4_2/gamma': 1.8e-3,
+                   'conv5/weights': 2e-3, 'conv5/biases': 2e-3, 'logits/weights': 7.5e-4, 'logits/biases': 3e-4,
+                   'logits/fw/weights': 2e-3, 'logits/fw/biases': 2e-3, 'logits/bw/weights': 2e-3, 'logits/bw/biases': 2e-3}
+GRAD_NORM_RATIO_N64 = (0.995, 1.005)       # measured 0.9997 .. 1.0008
+
+
+def test_headline_gradient_bars_are_tighter_than_the_small_batch_bars():
+    """The N = 64 table must never be looser than the N = 8 one it replaced (a kernel wrong by 1 % at the benchmarked size fails it)."""
+    from test_gpu_engine import GRAD_L2_BAR
+    for k in set(GRAD_L2_BAR) | set(GRAD_L2_BAR_N64):
+        assert GRAD_L2_BAR_N64.get(k, GRAD_L2_BAR_N64['default']) <= GRAD_L2_BAR.get(k, GRAD_L2_BAR['default']), k
+    assert GRAD_L2_BAR_N64['default'] <= 1.1e-2
+
+
 def _device_gradient_parity(tag, N, W):
     """The benchmarked step's BACKWARD half at the size it is benchmarked (lib/lstm/train.py:79-83 over LSTM_train.py:22-38): per
-    parameter tensor, the device gradient against the committed sample of the bf16-simulating oracle's (relative L2 <= GRAD_L2_BAR of
-    tests/test_gpu_engine.py — the same per-tensor bars as the N = 8 test — and <= 20 % to the fp32 oracle's), full-tensor norm ratio
-    0.97..1.03, clip norm within 1 %; then ONE clip + Adam step from the same state against the oracle's post-step parameters."""
+    parameter tensor, the device gradient against the committed sample of the bf16-simulating oracle's (relative L2 <= GRAD_L2_BAR_N64
+    above = 3x what was measured at this size, and <= 20 % to the fp32 oracle's), full-tensor norm ratio 0.995..1.005, clip norm within
+    1 %; then ONE clip + Adam step from the same state against the oracle's post-step parameters."""
     from lstm_ctc_ocr_amd.config import cfg
     from lstm_ctc_ocr_amd.engine import Engine
     from lstm_ctc_ocr_amd.models import get_network
-    from test_gpu_engine import GRAD_L2_BAR, GRAD_L2_BAR_FP32
+    from test_gpu_engine import GRAD_L2_BAR_FP32
     mh, d, (x, labels, ll, sl) = _grad_fixture(tag)
     params = mh.fixture_params()
     lr, wd = float(d['lr']), float(d['wd'])
@@ -195,7 +216,8 @@ def _device_gradient_parity(tag, N, W):
             e_f32 = float(np.linalg.norm(got - ref32) / np.linalg.norm(ref32))
             nr = float(g.double().norm().cpu()) / float(d['grad_norm_bf16sim'][i])
             print('grad %-28s L2-rel vs bf16sim %.3e  vs fp32 %.3e  norm ratio %.4f' % (name, e_sim, e_f32, nr))
-            if not (e_sim < GRAD_L2_BAR.get(name, GRAD_L2_BAR['default']) and e_f32 < GRAD_L2_BAR_FP32 and 0.97 < nr < 1.03):
+            if not (e_sim < GRAD_L2_BAR_N64.get(name, GRAD_L2_BAR_N64['default']) and e_f32 < GRAD_L2_BAR_FP32
+                    and GRAD_NORM_RATIO_N64[0] < nr < GRAD_NORM_RATIO_N64[1]):
                 bad.append((name, e_sim, e_f32, nr))
         assert not bad, bad
         # ---- one optimisation step from the same state (captured graph: forward + CTC + backward + clip + Adam + re-pack)

@@ -131,13 +131,21 @@ def test_rccl_call_path_on_a_one_rank_group(dev, monkeypatch):
     assert float(diffs.max()) < 7e-3 and float(diffs.mean()) < 2e-5, (diffs.max(), diffs.mean())
 
 
-@pytest.mark.parametrize("overlap", ["1", "0"])
+@pytest.mark.parametrize("overlap", ["1", "0", "1+cus"])
 def test_data_parallel_schedule_on_emulated_ranks(dev, monkeypatch, overlap):
     """OCR_FAKE_WORLD=2 emulates two ranks holding the same batch on ONE GPU: every "all-reduce" is a doubling kernel issued
     exactly where the RCCL call would be (side stream for the late-layer gradient ranges, overlapped with the second backward
     graph; main stream for the early range), and the CTC gradient is scaled by 1/(N*2).  If a range were exchanged before
     its gradients were complete, twice, or not at all — or if the optimiser started before the side stream was joined — the
-    gradients would be off by a factor of two somewhere; the trajectory must instead be the single-GPU one."""
+    gradients would be off by a factor of two somewhere; the trajectory must instead be the single-GPU one.
+    "1+cus": additionally OCR_FAKE_COMM_CUS=16 — sixteen resident workgroups hold CUs on the communication stream for the time a ring
+    all-reduce of each range would take (round 5: the emulation's stand-in for RCCL's channel kernels); results must not move."""
+    cus = overlap.endswith("+cus")
+    overlap = overlap[0]
+    if cus:
+        monkeypatch.setenv('OCR_FAKE_COMM_CUS', '16'); monkeypatch.setenv('OCR_FAKE_COMM_US', '120')
+    else:
+        monkeypatch.delenv('OCR_FAKE_COMM_CUS', raising=False)
     batch = next(fixed_stream(8, 4))
     img, lab, ll, ts = (np.array(a) for a in batch)
 

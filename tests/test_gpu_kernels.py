@@ -67,6 +67,20 @@ def test_probe_tr16(dev):
     assert (got == exp).all(), "hypothesis H about ds_read_b64_tr_b16 does not hold — see gpurun_out/probe_tr16.json"
 
 
+def test_occupy_cus_holds_the_stream_for_the_asked_time(dev):
+    """ocr_occupy_cus (the CU stand-in of the one-GPU data-parallel emulation): resident for the asked time, not much longer."""
+    from lstm_ctc_ocr_amd import _native as nat
+    for blocks, lds in ((8, 96 * 1024), (32, 0)):
+        nat.call("ocr_occupy_cus", blocks, 256, lds, 10.0, nat.stream())       # warm-up (sets the LDS attribute)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        nat.call("ocr_occupy_cus", blocks, 256, lds, 400.0, nat.stream())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        assert 0.39 < ms < 0.6, (blocks, lds, ms)
+
+
 # ------------------------------------------------------------------------------------------- CTC
 def _ctc_case(dev, T, N, C, lens, in_lens, seed, blank=0, labels=None):
     rng = np.random.RandomState(seed)
@@ -496,6 +510,37 @@ def test_conv1_pool_second_generation_kernels(dev):
     assert out.returncode == 0 and 'V2_OK' in out.stdout, out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("Nb,W,H", [(5, 24, 32), (12, 64, 32)])
+def test_conv1_pool_train_kernels_against_torch(dev, Nb, W, H):
+    """The step's own conv1 launches — ocr_conv1_pool_fwd_train (pooled map + routing codes) and ocr_conv1_pool_bwd_slab (per-block partial
+    sums) — DIRECTLY against torch-CPU fp32 (LSTM_train.py:24-25: conv 3x3 SAME + ReLU, 2 x 2 max-pool; tf.gradients of both): the other
+    conv1 + pool tests compare device kernels with each other.  The reference rounds the activation to bf16 where the device stores it
+    (the pool routes on the bf16 values, first maximum wins: torch's max_pool2d scans the window in the same order — test_maxpool)."""
+    Co = 64
+    # operands on a 1/64 grid: every product is a multiple of 2^-12 and every 9-term sum is exact in fp32 whatever the order, so device and
+    # torch round the SAME value to bf16 and the pool routes identically — what is left in the backward sums is fp32 summation order
+    q = lambda t: torch.round(t * 64) / 64
+    x = q(gen((Nb, W, H), 1).abs()); w = q(gen((3, 3, 1, Co), 2, 0.3)); b = q(gen((Co,), 3, 0.1))
+    wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    z = _conv_ref(x.unsqueeze(3), wr, br)                                     # fp32 [Nb, W, H, Co]
+    yq = bf(torch.relu(z.detach())).requires_grad_(True)                      # what conv1 stores
+    p_ref = F.max_pool2d(yq.permute(0, 3, 1, 2), (2, 2), (2, 2)).permute(0, 2, 3, 1)
+    codes = torch.zeros((Nb * (W // 2) * (H // 2), 8), dtype=torch.int32, device=dev)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    p = ops.conv1_pool_fwd(xd, wd, bd, codes=codes)
+    assert maxerr(p.float().cpu(), p_ref.detach()) == 0.0
+    dp = bf(gen(tuple(p.shape), 4))
+    p_ref.backward(dp)
+    dz = yq.grad * (yq.detach() > 0)                                          # routed through the pool, masked by the ReLU
+    z.backward(dz)
+    rows = ops.conv1_pool_bwd_slab_rows(Nb, W, H)
+    for cd in (codes, None):                                                  # routing from the saved codes / from recomputed windows
+        slab = torch.full((rows, 640), float('nan'), device=dev)
+        ops.conv1_pool_bwd_slab(xd, wd, bd, dp.to(dev).to(BF), slab, codes=cd)
+        tot = slab.double().sum(0).cpu()
+        assert relerr(tot[:576].view(3, 3, 1, Co), wr.grad.double()) < 1e-4 and relerr(tot[576:], br.grad.double()) < 1e-4
+
+
 def _conv1_pool_fused_equals_unfused(dev, Nb, W, H):
     """(40, 250, 32): more pooled pixels than one sweep of the forward grid, so the kernels' next-iteration prefetch runs; W / 2 = 125
     and H / 2 = 6 are not powers of two (32-bit index arithmetic)."""
@@ -866,6 +911,44 @@ def _lstm_device_checks(dev, N, T, D, U, x, seq_len, Ws, bs, Wr, br, xr, ref, dh
         ops.cast2d_bf16(Ws[d].to(dev), 4 * U, wcat[:, d * 4 * U:], 8 * U, D, 4 * U)
     dx = ops.gemm_nt(dz, wcat)
     assert relerr(dx.float().cpu().reshape(N, T, D), xr.grad) < 1e-2
+
+
+@pytest.mark.parametrize("N,T,U,lens,D", [(64, 63, 256, None, 512), (8, 21, 256, None, 512), (3, 5, 256, [5, 1, 3], 512), (100, 12, 256, None, 512),
+                                         (32, 21, 512, None, 512), (32, 21, 512, None, 1024), (8, 9, 256, None, 1024)])
+def test_lstm_forward_with_the_input_projection_inside(dev, N, T, U, lens, D):
+    """ocr_lstm_fwd_seq_x (the projection's MFMAs inside the recurrent kernel, no projection tensor) against the projection GEMM +
+    ocr_lstm_fwd_seq2 on the same operands: same hidden states up to one bf16 rounding flip, same saved gates / cells up to fp32 summation
+    order (K = D + U summed in one accumulator chain instead of GEMM + add)."""
+    if not ops.lstm_fwd_seq_x_supported(N, U, D):
+        pytest.skip("shape / protocol not covered by the fused kernel on this device")
+    rng = np.random.RandomState(3)
+    seq_len = lens if lens is not None else rng.randint(max(1, T // 2), T + 1, N).tolist()
+    x = bf(gen((N, T, D), 1))
+    Ws = [gen((D + U, 4 * U), 2 + d, 0.08) for d in range(2)]
+    bs = [gen((4 * U,), 4 + d, 0.1) for d in range(2)]
+    ref = _lstm_device_forward(dev, x, seq_len, Ws, bs, U, persistent=True)
+    R = N * T
+    wxT = torch.empty((8 * U, D), dtype=BF, device=dev)
+    whT = torch.empty((2, 4 * U, U), dtype=BF, device=dev)
+    for d in range(2):
+        Wd = Ws[d].to(dev)
+        ops.pack_transpose(Wd[:D], wxT[d * 4 * U:(d + 1) * 4 * U], lstm_units=U, R=D, Cc=4 * U, ldin=4 * U)
+        ops.pack_transpose(Wd[D:], whT[d], lstm_units=U, R=U, Cc=4 * U, ldin=4 * U)
+    bias = torch.empty(8 * U, device=dev)
+    ops.lstm_pack_bias(bs[0].to(dev), bs[1].to(dev), bias, U)
+    for prepared in (False, True):
+        hout = torch.full((R, 2 * U), 7.0, dtype=BF, device=dev)
+        gates = torch.zeros((2, R, 4 * U), device=dev); cell = torch.zeros((2, R, U), device=dev)
+        sync = torch.full((ops.lstm_seq_sync_words(N, U),), -1 if prepared else 0, dtype=torch.int32, device=dev)
+        ops.lstm_fwd_seq_x(ref["xd"], wxT, bias, whT, ref["sl"], hout, gates, cell, N, T, U, sync, prepared=prepared)
+        torch.cuda.synchronize()
+        assert int(sync[-1]) == (-1 if prepared else 0), "spin timeout"
+        valid = (torch.arange(T, device=dev)[None, :] < ref["sl"][:, None]).reshape(R)         # rows past their length hold throw-away values
+        assert maxerr(hout.float()[valid].cpu(), ref["hout"].float()[valid].cpu()) < 8e-3
+        assert float(hout.float()[~valid].abs().max() if (~valid).any() else 0.0) == 0.0
+        for d in range(2):
+            assert maxerr(gates[d][valid].cpu(), ref["gates"][d][valid].cpu()) < 2e-3
+            assert maxerr(cell[d][valid].cpu(), ref["cell"][d][valid].cpu()) < 4e-3
 
 
 @pytest.mark.parametrize("env", [dict(OCR_LSTM_PROTO='0'), dict(OCR_LSTM_ROWS='32')])

@@ -40,6 +40,8 @@ def test_status_codes_and_host_side_validation():
     # NULL operands are rejected before any launch is attempted
     assert lib.ocr_ctc_loss(None, None, None, None, None, 64, 64, 63, 10, 0, None, None, None) == 2
     assert lib.ocr_gemm_nt_bf16(None, 0, None, 0, None, 0, 8, 8, 8, None, None, 0, 0, 1, 0, 0, 0, 0, None) == 2
+    assert lib.ocr_occupy_cus(0, 256, 0, ctypes.c_float(10.0), None) == 2 and lib.ocr_occupy_cus(8, 2048, 0, ctypes.c_float(10.0), None) == 2
+    assert lib.ocr_occupy_cus(8, 256, 161 * 1024, ctypes.c_float(10.0), None) == 2 and lib.ocr_occupy_cus(8, 256, 0, ctypes.c_float(-1.0), None) == 2
     assert lib.ocr_lstm_seq_supported(64, 256) == 1 and lib.ocr_lstm_seq_supported(64, 128) == 0
     assert lib.ocr_lstm_seq_supported(64 * 9, 256) == 0                            # would not be one workgroup per CU
     assert lib.ocr_lstm_seq_supported(64, 512) == 1 and lib.ocr_lstm_seq_supported(128, 512) == 1      # configs[4]: 512 units per direction
@@ -112,6 +114,8 @@ def test_persistent_lstm_entry_points_check_their_arguments_on_the_host():
     assert lib.ocr_lstm_fwd_seq2(None, None, None, None, None, None, 64, 63, 256, 1.0, None, 1, None) == 2
     assert lib.ocr_lstm_bwd_seq2(None, 1024, 0, None, None, None, None, None, 64, 63, 256, None, 1, None) == 2
     assert lib.ocr_lstm_fwd_seq(None, None, None, None, None, None, 64, 63, 256, 1.0, None, None) == 2
+    assert lib.ocr_lstm_fwd_seq_x(None, None, None, 512, None, None, None, None, None, 64, 63, 256, 1.0, None, 0, None) == 2
+    assert lib.ocr_lstm_fwd_seq_x_supported(64, 256, 512) == 1 and lib.ocr_lstm_fwd_seq_x_supported(64, 256, 1024) == 1 and lib.ocr_lstm_fwd_seq_x_supported(64, 256, 768) == 0
     assert lib.ocr_set_lstm_ksplit(2) == 2 and lib.ocr_set_lstm_ksplit(4) == 0
     assert lib.ocr_lstm_seq_supported(64, 256) == 1 and lib.ocr_lstm_seq_supported(64, 100) == 0
     # the training form of conv1 + pool: the all-ones region must be 16-byte granules

@@ -148,6 +148,18 @@ def test_conversion_to_a_snapshot(tmp_path):
     tb.write_bundle(plain, arrays)
     tb.convert(plain, out, wanted)
     assert np.load(out)['opt/scalars'][6] == 1234
+    # ... exactly, at the lengths the reference trains for: TF multiplies a FLOAT32 beta2_power by float32(0.999) every step, so the
+    # logarithm has to be taken to that base (to the base 0.999 the count is one short from step 38 539 on: ADVICE r4)
+    p2, at = np.float32(1.0), {}
+    for t in range(1, 86001):
+        p2 = np.float32(p2 * np.float32(0.999))
+        if t in (38539, 40000, 86000):
+            at[t] = p2
+    for t, v in at.items():
+        late = dict(arrays, beta1_power=np.float32(0.0), beta2_power=v)
+        tb.write_bundle(plain, late)
+        tb.convert(plain, out, wanted)
+        assert np.load(out)['opt/scalars'][6] == t, t
     # ... and from the Saver's file name only when both powers have underflowed (`_iter_2000` = 1999 completed steps: the reference's loop
     # starts at 1 and names a snapshot iter + 1, train.py:27-36,111)
     flushed = dict(arrays, beta1_power=np.float32(0.0), beta2_power=np.float32(0.0))

@@ -12,7 +12,7 @@ from lstm_ctc_ocr_amd import _native as nat  # noqa: E402
 from lstm_ctc_ocr_amd import ops  # noqa: E402
 
 dev = torch.device('cuda:0'); BF = torch.bfloat16
-dbg = torch.zeros(4, dtype=torch.int64, device=dev)
+dbg = torch.zeros(8, dtype=torch.int64, device=dev)
 nat.call("ocr_conv_halo_clock_debug", dbg.data_ptr())
 for name, W, H, Ci, Co in (("conv2", 128, 16, 64, 128), ("conv3_2", 64, 8, 256, 256), ("conv4_2", 64, 4, 512, 512)):
     x = torch.randn(64, W, H, Ci, device=dev).to(BF); wp = (torch.randn(Co, 3, 3, Ci, device=dev) * 0.05).to(BF)

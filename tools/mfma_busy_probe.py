@@ -23,7 +23,7 @@ def launch(path):
     from lstm_ctc_ocr_amd import _native as nat
     dev = torch.device('cuda', 0)
     out = torch.zeros(64, device=dev)
-    clk = torch.zeros(4, dtype=torch.int64, device=dev)
+    clk = torch.zeros(8, dtype=torch.int64, device=dev)
     rows = []
     nat.call('ocr_mfma_busy_probe', out.data_ptr(), 256, 256, 2000, None, nat.stream())       # warm-up (code load, clocks)
     torch.cuda.synchronize()
