@@ -253,6 +253,7 @@ class _ConvOp(_Op):
             ops.conv1_pool_fwd(x, e.param(self.name + '/weights'), bias, out=self.fused_pool.y(sp), zero=zero, codes=codes, ones=ones)
             # every hand-off block of the plan is armed now; each persistent launch consumes (and thereby dirties) its own block ONCE
             sp.rings_ready = set(getattr(sp, 'lstm_sync_keys', ())) if ones is not None else set()
+            sp.rings_armed = ones is not None         # (what the last forward pass did; rings_ready is consumed by the launches)
             return
         y = self.y(sp)
         if self.kind == 'c1':
@@ -1312,7 +1313,7 @@ class Engine(object):
             self.grads.zero_()
         # likewise the fill of the persistent LSTM launches' hand-off blocks (OCR_FUSE_RINGFILL=0: every launch fills its own); a graph whose
         # first kernel is not conv1 + pool never consumes it and its LSTM launches prepare their blocks themselves
-        sp.rings_ready = set()
+        sp.rings_ready, sp.rings_armed = set(), False
         self._ones_pending = sp.lstm_arena if (training and getattr(sp, 'lstm_arena', None) is not None
                                                and os.environ.get('OCR_FUSE_RINGFILL', '1') != '0') else None
         for op in self.ops:

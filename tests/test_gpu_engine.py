@@ -196,7 +196,7 @@ def test_round4_fusions_match_the_unfused_schedule(dev, monkeypatch):
         torch.cuda.synchronize()
         active = dict(stats=sum(1 for v in getattr(sp, 'bn_stat_rows', {}).values() if v), bwd=sum(1 for v in getattr(sp, 'bn_bwd_rows', {}).values() if v),
                       pool=sum(1 for op in eng.ops if getattr(op, 'bn_pool', None) is not None), codes=sum(k.endswith('/codes') for k in sp.buf),
-                      rings=int(bool(getattr(sp, 'rings_ready', False))))
+                      rings=int(bool(getattr(sp, 'rings_armed', False))))
         # the LSTM hand-off blocks' error words: 0 where the launches prepared their own blocks, -1 (untouched all-ones) where the conv1 launch did; 1 = time-out
         assert [int(w[-1]) for w in sp.lstm_sync] == [-1 if active['rings'] else 0] * len(sp.lstm_sync)
         return {n: eng.grad(n).clone() for n in eng.specs}, float(sp.costs.double().mean()), active
