@@ -173,7 +173,7 @@ def conv_roofline(eng, device, workload):
     else:
         src = os.path.basename(path)
         pmc_commit, pmc_build = pm.get("commit"), pm.get("build_id")
-        conv = [k for k in pm.get("kernels", []) if k["symbol"].startswith(("_Z16conv_halo_kernel", "_Z14conv_k2_kernel", "_Z14conv_k3_kernel", "_Z15conv_k3w_kernel", "_Z15conv_k3b_kernel"))]
+        conv = [k for k in pm.get("kernels", []) if k["symbol"].startswith(("_Z16conv_halo_kernel", "_Z14conv_k2_kernel", "_Z14conv_k3_kernel", "_Z15conv_k3w_kernel", "_Z15conv_k3b_kernel", "_Z14conv_ws_kernel"))]
         if pm.get("workload") != workload:
             pmc_error = "%s was taken on workload %r, this run is %r" % (src, pm.get("workload"), workload)
         elif pmc_build != build_id:
@@ -196,7 +196,7 @@ def conv_roofline(eng, device, workload):
             if all("clock_mhz" in k for k in conv):
                 pmc_clock = sum(k["launches"] * k["avg_us"] * k["clock_mhz"] for k in conv) / tm
             pmc_avg_us = tm / nl
-    return {"bound": "mfma", "kernel": "conv_k3_kernel / conv_k3b_kernel / conv_k2_kernel / conv_halo_kernel (implicit-GEMM 3x3 SAME conv, forward + data gradient, with their fused epilogues: %d launches/step)" % n_launch,
+    return {"bound": "mfma", "kernel": "conv_ws_kernel / conv_k3_kernel / conv_k3b_kernel / conv_k2_kernel / conv_halo_kernel (implicit-GEMM 3x3 SAME conv, forward + data gradient, with their fused epilogues: %d launches/step)" % n_launch,
             "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK,
             "avg_launch_us": tot_t / n_launch * 1e6, "algorithmic_gflop_per_launch": tot_fl / n_launch / 1e9,
             "frac_plain_write_outs": tot_fl / plain_t / MFMA_BF16_PEAK,

@@ -88,7 +88,7 @@ int ocr_conv3x3_bf16_stats(const void* x, const void* wpack, void* y, int Nb, in
                            float* partials, void* stream);
 /* Which kernel family the two convolution entry points run for a shape — a host-only query (nothing is launched, works without a GPU):
  * 0 generic GEMM engines, 1 conv_halo, 2 / 3 conv_k2 tile A (256 x 128) / D (256 x 64), 4 / 5 conv_k3 A / D, 6 / 7 conv_k3w (tiles that
- * cross image boundaries) A / D; a NEGATIVE value (-OCR_STATUS_INVALID) for non-positive sizes.  flags as for ocr_conv3x3_bf16;
+ * cross image boundaries) A / D, 8 conv_ws (weights in registers, persistent over the pixel tiles: Cin = 64 / 128 at H = 16 / 8); a NEGATIVE value (-OCR_STATUS_INVALID) for non-positive sizes.  flags as for ocr_conv3x3_bf16;
  * (kw, kh) = (0, 0) or the window of the fused max-pool. */
 int ocr_conv3x3_kernel_choice(int Nb, int W, int H, int Cin, int Cout, int flags, int kw, int kh);
 /* non-zero: ocr_conv3x3_bf16 accepts OCR_EPI_ACCUM for this shape (y (bf16) += result: the data gradient of a tensor with several

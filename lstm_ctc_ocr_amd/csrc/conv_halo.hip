@@ -322,6 +322,8 @@ static int launch_halo(const HaloArgs& g, hipStream_t stream) {
 
 int k2_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
                     const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind);
+int ws_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int H, int Cin, int Cout, const float* bias,
+                    const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind);
 #define K2_DEFAULT 1            // on since the weight prefetch distance went from 2 to 3 steps (profiles/r03n: the step 1.415 against 1.440 ms, three
                                 // interleaved runs each; with distance 2 it was an opt-in: no faster (tile D) or 1.4 % slower (tiles A + D) in the step,
                                 // profiles/r03l_bench_conv_ab.log, although 8 % faster back to back, profiles/r03j_conv_k2_final.log)
@@ -331,6 +333,12 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
                       const void* mask, int flags, hipStream_t stream, void* pool, int pool_kind) {
     if ((Cin & 63) || (Cout & 3) || M < 1024 || H > 30) return -1;
     if (flags & ~(IGH_BIAS | IGH_RELU | IGH_MASK | IGH_ACCUM)) return -1;
+    // seventh generation (conv_ws.hip: weights in registers, workgroups persistent over the pixel tiles) for the short-K layers it covers and
+    // chooses (Cin = 64 / 128 at H = 16 / 8 with at least two tiles per workgroup); A/B knob OCR_CONV_WS = 0 / 2 (never / every covered shape)
+    if (pool_kind < 3) {
+        const int rc = ws_try_dispatch(x, wpack, y, M, W, H, Cin, Cout, bias, mask, flags, stream, pool, pool_kind);
+        if (rc >= 0) return rc;
+    }
     if (pool_kind >= 3) {    // batch-norm statistics from the epilogue (3: forward, `pool` = float partial rows; 4: backward sums of a masked data
                              // gradient, `pool` = host K3BnBwd): the plane-layout kernels only
         if (pool_kind > 4 || !pool || (flags & IGH_ACCUM) || (M & 255)) return -1;
@@ -401,9 +409,10 @@ int halo_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, i
 }
 
 int k3_set_clock_debug(void* dbg);       // conv_k3.hip: the plane-layout kernels stamp the same block
-extern "C" int ocr_conv_halo_clock_debug(void* dbg /* device int64[4] or NULL */) {
+int ws_set_clock_debug(void* dbg);       // conv_ws.hip likewise
+extern "C" int ocr_conv_halo_clock_debug(void* dbg /* device int64[8] or NULL */) {
     long long* p = (long long*)dbg;
-    if (k3_set_clock_debug(dbg) != OCR_OK) return OCR_ERR_EXEC;
+    if (k3_set_clock_debug(dbg) != OCR_OK || ws_set_clock_debug(dbg) != OCR_OK) return OCR_ERR_EXEC;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_halo_clk), &p, sizeof(p)) == hipSuccess ? OCR_OK : OCR_ERR_EXEC;
 }
 

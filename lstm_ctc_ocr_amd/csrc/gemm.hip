@@ -301,7 +301,7 @@ extern "C" int ocr_conv3x3_accum_supported(int Nb, int W, int H, int Cin, int Co
 }
 // Which kernel family ocr_conv3x3_bf16 / ocr_conv3x3_relu_pool_bf16 would run for this shape (host-only: nothing is launched, no GPU is
 // needed): 0 the generic GEMM engines (igemm / gemm), 1 conv_halo, 2 / 3 conv_k2 tile A (256 x 128) / D (256 x 64), 4 / 5 conv_k3 A / D,
-// 6 / 7 conv_k3w (general width) A / D; -OCR_STATUS_INVALID (negative) for non-positive sizes.  flags as for ocr_conv3x3_bf16; (kw, kh) = (0, 0) or the window of a fused max-pool.
+// 6 / 7 conv_k3w (general width) A / D, 8 conv_ws (weight-stationary persistent); -OCR_STATUS_INVALID (negative) for non-positive sizes.  flags as for ocr_conv3x3_bf16; (kw, kh) = (0, 0) or the window of a fused max-pool.
 extern "C" int ocr_conv3x3_kernel_choice(int Nb, int W, int H, int Cin, int Cout, int flags, int kw, int kh) {
     if (Nb <= 0 || W <= 0 || H <= 0 || Cin <= 0 || Cout <= 0) return -OCR_ERR_INVALID;      // negative: 0..7 are kernel families
     const int pool_kind = (kw == 1 && kh == 2) ? 1 : ((kw == 2 && kh == 2) ? 2 : 0);

@@ -109,7 +109,7 @@ def gemm_nt(P, Q, out=None, *, M=None, N=None, K=None, ldp=None, ldq=None, ldo=N
     return out
 
 
-CONV_KERNEL_NAMES = ("gemm", "conv_halo", "conv_k2/A", "conv_k2/D", "conv_k3/A", "conv_k3/D", "conv_k3w/A", "conv_k3w/D")
+CONV_KERNEL_NAMES = ("gemm", "conv_halo", "conv_k2/A", "conv_k2/D", "conv_k3/A", "conv_k3/D", "conv_k3w/A", "conv_k3w/D", "conv_ws")
 
 
 def conv3x3_kernel_choice(Nb, W, H, Cin, Cout, *, bias=True, relu=True, mask=False, accumulate=False, pool=(0, 0)):

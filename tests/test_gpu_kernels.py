@@ -303,6 +303,9 @@ def _conv_ref(x, w, b):   # x [N,W,H,C], w HWIO
                                           (4, 128, 8, 128, 128), (6, 192, 4, 192, 64),       # plane-layout kernel: several tiles per image, 3 chunks
                                           (8, 48, 16, 128, 64), (16, 32, 16, 128, 128), (8, 64, 16, 64, 64),    # ... at H = 16 (one / two halo buffers)
                                           (32, 40, 4, 128, 128), (32, 24, 8, 64, 128), (16, 50, 8, 128, 64),    # ... tiles crossing image boundaries (general width)
+                                          # weight-stationary persistent kernel (conv_ws, round 5): small grids (fewer tiles than workgroups, three channel
+                                          # tiles = no XCD map, several images per workgroup run); taken by default only from two tiles per CU, forced with OCR_CONV_WS=2
+                                          (2, 32, 16, 64, 128), (3, 24, 16, 128, 192), (5, 48, 8, 128, 64), (40, 64, 16, 64, 64),
                                           # the EXACT shapes of the benchmarked step (BASELINE configs[1], N = 64, W = 256): conv2, conv3_1, conv3_2, conv4_2
                                           # (conv4_1 is (64, 64, 4, 256, 512) above) — the dispatcher's full-chip tiles / 64-split slabs only exist at this size
                                           (64, 128, 16, 64, 128), (64, 64, 8, 128, 256), (64, 64, 8, 256, 256), (64, 64, 4, 512, 512),
@@ -354,12 +357,13 @@ def test_conv3x3_fwd_dgrad_wgrad(dev, Nb, W, H, Ci, Co):
 
 @pytest.mark.parametrize("env", [dict(OCR_CONV_K2='1', OCR_K2_CFG='A'), dict(OCR_CONV_K2='1', OCR_K2_CFG='D'),
                                  dict(OCR_CONV_K2='1', OCR_K2_CFG='A', OCR_CONV_K3='0'), dict(OCR_CONV_K2='1', OCR_K2_CFG='D', OCR_CONV_K3='0'),
-                                 dict(OCR_CONV_K2='0')])
+                                 dict(OCR_CONV_K2='0'), dict(OCR_CONV_WS='2'), dict(OCR_CONV_WS='0')])
 def test_conv_kernel_generations_through_the_convolution_parity_tests(dev, env):
     """conv_k2.hip / conv_k3.hip (in-workgroup K split; tiles A 256 x 128 and D 256 x 64 pixels x channels; k3 = the plane layout of the
     halo, taken where it covers the shape) with each tile forced onto every shape it covers, conv_k2 alone (OCR_CONV_K3=0), and the
     conv_halo.hip kernels alone, through the same parity / fused-pool / accumulate tests (the knobs are read once per process; by default
-    the dispatcher mixes the kernels per layer)."""
+    the dispatcher mixes the kernels per layer).  OCR_CONV_WS=2: the weight-stationary persistent kernel (conv_ws.hip) on EVERY shape it
+    covers, whatever the grid; =0: none (the shapes it takes by default stay tested on the plane-layout kernels)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_kernels.py'), '-q', '-k', 'test_conv3x3'],
@@ -601,7 +605,9 @@ def test_maxpool(dev, kw, kh):
                                                (8, 64, 8, 64, 64, 2, 2), (16, 32, 4, 128, 192, 2, 2), (5, 26, 16, 64, 64, 1, 2),
                                                (3, 40, 10, 64, 128, 1, 2), (16, 64, 4, 128, 128, 2, 2), (16, 128, 8, 64, 128, 2, 2),
                                                (8, 32, 16, 64, 128, 2, 2), (8, 32, 16, 128, 64, 1, 2), (32, 40, 4, 64, 128, 2, 2),
-                                               (32, 24, 8, 64, 64, 1, 2)])
+                                               (32, 24, 8, 64, 64, 1, 2),
+                                               # conv_ws instances (OCR_CONV_WS=2 forces them at these sizes): both pools on each
+                                               (8, 32, 8, 128, 128, 1, 2), (8, 32, 8, 128, 64, 2, 2), (4, 32, 16, 64, 64, 1, 2), (4, 32, 16, 128, 64, 2, 2)])
 def test_conv3x3_relu_pool_fused_equals_unfused(dev, Nb, W, H, Ci, Co, kw, kh):
     """conv + bias + ReLU with the following max-pool written by the same epilogue (LSTM_train.py:26-33): the full-resolution output
     and the pooled tensor are bit-identical to conv3x3 followed by maxpool_fwd."""
