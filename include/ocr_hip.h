@@ -97,6 +97,9 @@ int ocr_conv3x3_accum_supported(int Nb, int W, int H, int Cin, int Cout);
 /* diagnostic: workgroup 0 of the convolution kernels (conv_halo, conv_k3 / conv_k3w) stamps {shader clock counter, 100 MHz wall clock} at entry ([0], [1]) and exit ([2], [3])
  * into dbg (device int64[8]; NULL = off) and adds its lifetime to [4] (shader clocks), [5] (wall ticks), [6] (launches) */
 int ocr_conv_halo_clock_debug(void* dbg);
+/* diagnostic: every workgroup of the weight-stationary convolution kernel (conv_ws) stamps the 100 MHz wall clock per phase and tile into
+ * dbg (device int64[workgroups * 64]; NULL = off) — tools/ws_phases.py */
+int ocr_conv_ws_debug(void* dbg);
 /* conv3x3 + bias + ReLU AND the max-pool behind it from one epilogue (LSTM_train.py:26-33): y [Nb,W,H,Cout] and pooled
  * [Nb, W/kw, H/kh, Cout]; (kw, kh) = (1, 2) (feature axis) or (2, 2).  ocr_conv3x3_pool_supported() != 0 tells whether the shape is
  * covered; otherwise run ocr_conv3x3_bf16 + ocr_maxpool_fwd (ocr_conv3x3_relu_pool_bf16 then returns 2). */

@@ -40,6 +40,7 @@ _SIGS = {
     "ocr_conv3x3_bf16": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P], _I),
     "ocr_conv_halo_clock_debug": ([_P], _I),
     "ocr_occupy_cus": ([_I, _I, _I, _F, _P], _I),
+    "ocr_conv_ws_debug": ([_P], _I),
     "ocr_conv3x3_accum_supported": ([_I, _I, _I, _I, _I], _I),
     "ocr_conv3x3_kernel_choice": ([_I, _I, _I, _I, _I, _I, _I, _I], _I),
     "ocr_conv3x3_pool_supported": ([_I, _I, _I, _I, _I, _I, _I], _I),

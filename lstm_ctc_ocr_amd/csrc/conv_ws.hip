@@ -40,16 +40,27 @@ struct WsArgs {
 typedef __attribute__((address_space(3))) void* ws_lptr_t;
 #define WS_OOB 0x80000000u                // lane offset of a row that does not exist: beyond any descriptor's range
 
+// diagnostic (ocr_conv_ws_debug; tools/ws_phases.py): 100 MHz wall-clock stamps of every workgroup's first thread — dbg[block * 64 + {0 entry,
+// 1 weights + first halo landed, then per tile i < 10: 2 + 6 i + {0 barrier passed, 1 next halo issued, 2 K loop issued, 3 pieces landed / old
+// stores acknowledged, 4 K halves exchanged, 5 write-out issued}}]
+__device__ long long* g_ws_dbg;
+extern "C" int ocr_conv_ws_debug(void* dbg) {
+    long long* q = (long long*)dbg;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_ws_dbg), &q, sizeof(q)) == hipSuccess ? OCR_OK : OCR_ERR_MEMOPS;
+}
+#define WS_PHASE(slot) do { if (wsdbg && tid == 0 && (slot) < 64) wsdbg[blockIdx.x * 64 + (slot)] = ocr_wall_clock(); } while (0)
 __device__ long long* g_ws_clk;          // ocr_conv_halo_clock_debug: workgroup 0 stamps the clocks (common.h)
 int ws_set_clock_debug(void* dbg) {
     long long* p = (long long*)dbg;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_ws_clk), &p, sizeof(p)) == hipSuccess ? OCR_OK : OCR_ERR_EXEC;
 }
 
-__device__ __forceinline__ uint32_t ws_max2(uint32_t a, uint32_t b) {           // packed bf16 max (exact)
-    const uint32_t lo = (bf_lo(b) > bf_lo(a)) ? (b & 0xffffu) : (a & 0xffffu);
-    const uint32_t hi = (bf_hi(b) > bf_hi(a)) ? (b & 0xffff0000u) : (a & 0xffff0000u);
-    return lo | hi;
+// packed bf16 max / ReLU as SIGNED 16-bit integer max (v_pk_max_i16, one instruction per pair): non-negative bf16 values order like their bit
+// patterns, every negative value (and -0) is a negative integer — so max(x, 0) is the ReLU of a bf16 pair and, on post-ReLU values, the integer
+// max is the float max (the single-wave write-out is VALU-issue-bound: the float-compare form of conv_k3 took ~10 instructions per pair here)
+typedef short ws_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t ws_max2(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ws_s16x2, a), __builtin_bit_cast(ws_s16x2, b)));
 }
 __device__ __forceinline__ u32x4 ws_max8(u32x4 a, u32x4 b) {
     u32x4 r = {ws_max2(a.x, b.x), ws_max2(a.y, b.y), ws_max2(a.z, b.z), ws_max2(a.w, b.w)};
@@ -92,7 +103,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     const int tid = threadIdx.x, lane = tid & 63, lane_id = lane;
     long long* const clk = g_ws_clk;
+    long long* const wsdbg = g_ws_dbg;
     if (clk && blockIdx.x == 0 && tid == 0) ocr_clk_enter(clk);
+    WS_PHASE(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pg = KSPLIT == 1 ? wave : (wave & 1), kh = KSPLIT == 1 ? 0 : (wave >> 1);      // pixel group; input chunk (= K half)
     const int C = g.C, N = g.N;
@@ -112,28 +125,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int rsub = lane >> 3;
     const unsigned lds0 = (unsigned)(size_t)(ws_lptr_t)smem;
 
-    // ---- the two zero planes of every chunk image of both buffers (never written again)
-    {
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        constexpr int ZU = PS * 8;                      // 16-byte units per plane
-        for (int i = tid; i < 2 * KSPLIT * 2 * ZU; i += 256) {
-            const int img = i / (2 * ZU), r = i % (2 * ZU);
-            const int off = img * G::CHB + (r < ZU ? 0 : (H + 1) * PS * 128) + (r % ZU) * 16;
-            *(u32x4*)(smem + off) = z;
-        }
-    }
-
-    // ---- this wave's weights: 64 output channels x chunk kh x nine taps, 72 A fragments (lane: channel row frow, k group fq)
-    u32x4 wq[4][18];
-    {
-        const bf16_t* q = g.Q + ((long)(n0 + frow) * 9 * C + kh * 64 + fq * 8);
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int s = 0; s < 18; ++s)
-                wq[a][s] = *(const u32x4*)(q + (long)a * 16 * 9 * C + (s >> 1) * C + (s & 1) * 32);
-    }
-
     // ---- DMA: this wave's pieces are q = j * 4 + wave; lane -> (plane row, 16-byte position); the swizzle key is the plane row's low bits.
     // The per-lane source offsets live in LDS as (offset / 16) << 2 | flags (bit 0: left halo column, bit 1: right halo column — masked where
     // the tile touches an image edge).
@@ -149,18 +140,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     if (tid < 64) ((float*)(smem + G::BOFF))[tid] = (g.flags & WS_BIAS) ? g.bias[n0 + tid] : 0.f;
     const long pbytes = (long)g.M * C * 2;
-    auto issue_halo = [&](int t, int buf) {
+    // issue_halo(t, buf, part): part < 0 all pieces now; else piece `part` only (the pieces of tile t + 1 are issued one per K sub-step of
+    // tile t, under its MFMAs; their table rows were read at the top of the tile — no LDS instruction may sit inside the K loop, whose
+    // fragment reads are waited for by COUNT)
+    unsigned e_[PI];
+    auto read_table = [&]() {
+#pragma unroll
+        for (int j = 0; j < PI; ++j) e_[j] = dtab[j * 64];
+    };
+    auto issue_halo = [&](int t, int buf, auto partc) {
+        constexpr int PART = decltype(partc)::value;
         const int col0 = t * NC;                        // first column of the tile, counted over the whole batch
         const bool edge_l = col0 % g.cW == 0, edge_r = (col0 + NC) % g.cW == 0;
         const long base = (long)(col0 - 1) * H * C * 2; // (the left halo column of the very first tile lies in front of the tensor: masked)
         long left = pbytes - base; if (left > 0x7fffffffL) left = 0x7fffffffL;
         const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)g.P + base), 0, (int)left, 0x00020000);
         const unsigned em = (edge_l ? 1u : 0u) | (edge_r ? 2u : 0u);
-        unsigned e_[PI];                                // all table rows first: an LDS-DMA may alias anything in LDS for the compiler, which
-#pragma unroll                                          // otherwise orders every table read behind the previous piece's issue
-        for (int j = 0; j < PI; ++j) e_[j] = dtab[j * 64];
 #pragma unroll
-        for (int j = 0; j < PI; ++j) {
+        for (int j = (PART < 0 ? 0 : PART); j < (PART < 0 ? PI : PART + 1); ++j) {
             const int q = j * 4 + wave;
             const unsigned e = e_[j];
             const unsigned v = (e & em) ? WS_OOB : ((e & ~3u) << 2);
@@ -183,8 +180,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's table rows
-    if (t_begin < t_end) issue_halo(t_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // weights + the first halo
+    read_table();
+    if (t_begin < t_end) issue_halo(t_begin, 0, std::integral_constant<int, -1>{});        // lands in buffer 0 while the weights arrive
+
+    // ---- this wave's weights: 64 output channels x chunk kh x nine taps = 72 A fragments (lane: channel row frow, k group fq), kept in
+    // registers for the whole launch.  Loaded ONCE per workgroup and chunk: the NSH waves that share a chunk fetch 72 / NSH fragments each
+    // from global memory and hand them round through LDS (buffer 1's space, R rounds of 36 KB).  (Every wave fetching all 72 itself — the
+    // same 147 KB from every CU of the chip, 64-byte row segments — took 9.5 us of a 33 us launch: profiles/r05c_ws_phases.log.)
+    u32x4 wq[4][18];
+    {
+        constexpr int NSH = 4 / KSPLIT, R = KSPLIT == 1 ? 2 : 4, FR = 72 / R, OWN = 72 / NSH;
+        static_assert(KSPLIT * FR * 1024 <= G::BUFB && FR % NSH == 0, "a round fits buffer 1");
+        const int rank = KSPLIT == 1 ? wave : pg;
+        const bf16_t* q = g.Q + ((long)(n0 + frow) * 9 * C + kh * 64 + fq * 8);
+        u32x4 own[OWN];
+#pragma unroll
+        for (int i = 0; i < OWN; ++i) {
+            const int f = i * NSH + rank, fa = f / 18, fs = f % 18;             // fragment f = a * 18 + s
+            own[i] = *(const u32x4*)(q + (long)fa * 16 * 9 * C + (fs >> 1) * C + (fs & 1) * 32);
+        }
+        u32x4* const wx = (u32x4*)(smem + G::BUFB) + kh * FR * 64 + lane;
+#pragma unroll
+        for (int rd = 0; rd < R; ++rd) {
+#pragma unroll
+            for (int i = rd * FR / NSH; i < (rd + 1) * FR / NSH; ++i) wx[(i * NSH + rank - rd * FR) * 64] = own[i];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int f = rd * FR; f < (rd + 1) * FR; ++f) wq[f / 18][f % 18] = wx[(f - rd * FR) * 64];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+    // ---- the two zero planes of every chunk image of both buffers (never written again; after the weights, which used buffer 1's space)
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        constexpr int ZU = PS * 8;                      // 16-byte units per plane
+        for (int i = tid; i < 2 * KSPLIT * 2 * ZU; i += 256) {
+            const int img = i / (2 * ZU), r = i % (2 * ZU);
+            const int off = img * G::CHB + (r < ZU ? 0 : (H + 1) * PS * 128) + (r % ZU) * 16;
+            *(u32x4*)(smem + off) = z;
+        }
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the first halo
+    WS_PHASE(1);
 
     constexpr bool has_mask = MASK;
     constexpr int NIT = NPE / 8;                        // 16-byte row units per lane in the write-out
@@ -196,7 +238,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 1 < t_end) issue_halo(t + 1, buf ^ 1);
+        const int ph0 = 2 + 6 * (t - t_begin);
+        WS_PHASE(ph0);
+        const bool more = t + 1 < t_end;
+        if (more) read_table();
         const int col0 = t * NC;
         // rows this wave writes out: NC columns x HWE feature rows from h_lo
         const int h_lo = pg * G::HW + (KSPLIT == 2 ? kh * HWE : 0);
@@ -211,7 +256,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(msrd, (ws_lptr_t)(smem + G::MOFF + wave * G::STW + it * 1024), 16, (int)v, 0, 0, 0);
             }
         }
-        // ---- K loop: 18 sub-steps (tap, k half), the fragments of sub-step s + 1 are read while s multiplies
+        WS_PHASE(ph0 + 1);
+        // ---- K loop: 18 sub-steps (tap, k half), the fragments of sub-step s + 1 are read while s multiplies; the accumulators start from the
+        //      bias (the first MFMA's C operand; the second K half of a split starts from zero)
+        f32x4 binit[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            binit[a] = *(const f32x4*)(smem + G::BOFF + (a * 16 + fq * 4) * 4);
+            if (KSPLIT == 2 && kh) binit[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(binit[0]), "+v"(binit[1]), "+v"(binit[2]), "+v"(binit[3]));      // (not inside the counted loop)
         f32x4 acc[4][4];
         u32x4 bfr[2][4];
 #define WS_RD(S_, DST_) do { \
@@ -225,13 +279,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             _Pragma("unroll") for (int b = 0; b < 4; ++b) \
             _Pragma("unroll") for (int a = 0; a < 4; ++a) \
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq[a][S_]), __builtin_bit_cast(bf16x8, SRC_[b]), \
-                                                                    (FIRST_) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[a][b], 0, 0, 0); \
+                                                                    (FIRST_) ? binit[a] : acc[a][b], 0, 0, 0); \
         } while (0)
 #define WS_WAIT(N_, SRC_) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(SRC_[0]), "+v"(SRC_[1]), "+v"(SRC_[2]), "+v"(SRC_[3]))
 #define WS_STEP(S_) do { \
             WS_RD((S_) + 1, bfr[((S_) + 1) & 1]); \
             WS_WAIT(4, bfr[(S_) & 1]);              /* the four reads of sub-step S_ have returned (LDS returns in order) */ \
             WS_MM(S_, bfr[(S_) & 1], (S_) == 0); \
+            if ((S_) >= 1 && (S_) <= PI && more) issue_halo(t + 1, buf ^ 1, std::integral_constant<int, ((S_) >= 1 && (S_) <= PI) ? (S_) - 1 : 0>{}); \
             __builtin_amdgcn_sched_barrier(0); \
         } while (0)
         WS_RD(0, bfr[0]);
@@ -244,7 +299,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef WS_WAIT
 #undef WS_MM
 #undef WS_RD
+        WS_PHASE(ph0 + 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of halo(t + 1) (issued a K loop ago), the mask rows, the stores of tile t - 1
+        WS_PHASE(ph0 + 3);
 
         // ---- write-out of this wave's NC x HWE pixels (KH selects the fragments a K-split wave keeps)
         auto tail = [&](auto khc) {
@@ -265,6 +322,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                     for (int i = 0; i < 2; ++i) acc[a][B0 + i] += theirs[(a * 2 + i) * 64 + lane_id];
             }
+            WS_PHASE(ph0 + 4);
             // (the write-out's lane arithmetic is re-derived per tile from an opaque copy of the lane id: hoisted out of the tile loop its ~20
             //  loop-invariant address registers do not fit beside the weights and came back as scratch reloads inside the loop)
             int lane = lane_id;
@@ -272,28 +330,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int frow = lane & 15, fq = lane >> 4;
             unsigned char* const S = smem + G::SOFF + wave * G::STW;
             const int colf = frow % CF, hsub = frow / CF;
+            const bool relu = (g.flags & WS_RELU) != 0;
 #pragma unroll
             for (int i = 0; i < G::NFE; ++i) {
                 const int row = colf * HWE + i * HF + hsub;
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    f32x4 v = acc[a][B0 + i] + *(const f32x4*)(smem + G::BOFF + (a * 16 + fq * 4) * 4);
-                    if (g.flags & WS_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    const f32x4 v = acc[a][B0 + i];
                     u32x2 pk;
                     pk.x = pack_bf2(v.x, v.y);
                     pk.y = pack_bf2(v.z, v.w);
+                    if (relu) { pk.x = ws_max2(pk.x, 0u); pk.y = ws_max2(pk.y, 0u); }      // ReLU after the rounding: the same values
                     const int slot = a * 4 + fq;                    // 8-byte slot of the 128-byte row; the column's low bits permute the 32-byte groups
                     *(u32x2*)(S + row * 128 + ((slot ^ ((colf & 3) << 2)) << 3)) = pk;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its own LDS writes are in order; nothing to wait for but the compiler's view)
+            u32x4 val[NIT], mkv[MASK ? NIT : 1];
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int idx = it * 64 + lane, row = idx >> 3, u = idx & 7;
-                const int col = row / HWE;
-                u32x4 v = *(const u32x4*)(S + row * 128 + ((u ^ ((col & 3) << 1)) << 4));
+                val[it] = *(const u32x4*)(S + row * 128 + ((u ^ (((row / HWE) & 3) << 1)) << 4));
+                if (has_mask) mkv[it] = *(const u32x4*)(smem + G::MOFF + wave * G::STW + idx * 16);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = it * 64 + lane, row = idx >> 3, u = idx & 7;
+                u32x4 v = val[it];
                 if (has_mask) {
-                    const u32x4 q = *(const u32x4*)(smem + G::MOFF + wave * G::STW + idx * 16);
+                    const u32x4 q = mkv[it];
                     if (!(bf_lo(q.x) > 0.f)) v.x &= 0xffff0000u;
                     if (!(bf_hi(q.x) > 0.f)) v.x &= 0x0000ffffu;
                     if (!(bf_lo(q.y) > 0.f)) v.y &= 0xffff0000u;
@@ -303,32 +368,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     if (!(bf_lo(q.w) > 0.f)) v.w &= 0xffff0000u;
                     if (!(bf_hi(q.w) > 0.f)) v.w &= 0x0000ffffu;
                 }
-                const long m = (long)(col0 + col) * H + h_lo + row % HWE;
+                const long m = (long)(col0 + row / HWE) * H + h_lo + row % HWE;
                 *(u32x4*)(g.out + m * N + n0 + u * 8) = v;
             }
             if (g.pool_kind == 1) {             // feature pairs (h, h + 1) of a column -> pooled row m / 2
-                constexpr int NQ = NC * (HWE / 2);
-                for (int idx = lane; idx < NQ * 8; idx += 64) {
-                    const int q = idx >> 3, u = idx & 7, col = q / (HWE / 2), ph = q % (HWE / 2);
+                constexpr int NQ = NC * (HWE / 2), PIT = NQ * 8 / 64;
+                static_assert(NQ * 8 % 64 == 0, "whole wave iterations");
+                u32x4 p0[PIT], p1[PIT];
+#pragma unroll
+                for (int it = 0; it < PIT; ++it) {
+                    const int idx = it * 64 + lane, q = idx >> 3, u = idx & 7, col = q / (HWE / 2), ph = q % (HWE / 2);
                     const unsigned char* r0 = S + (col * HWE + 2 * ph) * 128 + ((u ^ ((col & 3) << 1)) << 4);
-                    const u32x4 mx = ws_max8(*(const u32x4*)r0, *(const u32x4*)(r0 + 128));
+                    p0[it] = *(const u32x4*)r0; p1[it] = *(const u32x4*)(r0 + 128);
+                }
+#pragma unroll
+                for (int it = 0; it < PIT; ++it) {
+                    const int idx = it * 64 + lane, q = idx >> 3, u = idx & 7, col = q / (HWE / 2), ph = q % (HWE / 2);
                     const long pm = (long)(col0 + col) * (H / 2) + (h_lo >> 1) + ph;
-                    *(u32x4*)(g.pool + pm * N + n0 + u * 8) = mx;
+                    *(u32x4*)(g.pool + pm * N + n0 + u * 8) = ws_max8(p0[it], p1[it]);
                 }
             } else if (g.pool_kind == 2) {      // 2 x 2 window of columns (2c, 2c + 1) x rows (2p, 2p + 1)
-                constexpr int NQ = (NC / 2) * (HWE / 2);
-                for (int idx = lane; idx < NQ * 8; idx += 64) {
-                    const int q = idx >> 3, u = idx & 7, pc = q / (HWE / 2), ph = q % (HWE / 2);
+                constexpr int NQ = (NC / 2) * (HWE / 2), PIT = NQ * 8 / 64;
+                static_assert(NQ * 8 % 64 == 0, "whole wave iterations");
+                u32x4 p0[PIT], p1[PIT], p2[PIT], p3[PIT];
+#pragma unroll
+                for (int it = 0; it < PIT; ++it) {
+                    const int idx = it * 64 + lane, q = idx >> 3, u = idx & 7, pc = q / (HWE / 2), ph = q % (HWE / 2);
                     const int c0 = 2 * pc, c1 = c0 + 1;
                     const unsigned char* r0 = S + (c0 * HWE + 2 * ph) * 128 + ((u ^ ((c0 & 3) << 1)) << 4);
                     const unsigned char* r1 = S + (c1 * HWE + 2 * ph) * 128 + ((u ^ ((c1 & 3) << 1)) << 4);
-                    const u32x4 mx = ws_max8(ws_max8(*(const u32x4*)r0, *(const u32x4*)(r0 + 128)), ws_max8(*(const u32x4*)r1, *(const u32x4*)(r1 + 128)));
+                    p0[it] = *(const u32x4*)r0; p1[it] = *(const u32x4*)(r0 + 128); p2[it] = *(const u32x4*)r1; p3[it] = *(const u32x4*)(r1 + 128);
+                }
+#pragma unroll
+                for (int it = 0; it < PIT; ++it) {
+                    const int idx = it * 64 + lane, q = idx >> 3, u = idx & 7, pc = q / (HWE / 2), ph = q % (HWE / 2);
                     const long pm = (long)((col0 >> 1) + pc) * (H / 2) + (h_lo >> 1) + ph;
-                    *(u32x4*)(g.pool + pm * N + n0 + u * 8) = mx;
+                    *(u32x4*)(g.pool + pm * N + n0 + u * 8) = ws_max8(ws_max8(p0[it], p1[it]), ws_max8(p2[it], p3[it]));
                 }
             }
         };
         if (KSPLIT == 2 && kh) tail(std::integral_constant<int, 1>{}); else tail(std::integral_constant<int, 0>{});
+        WS_PHASE(ph0 + 5);
         const unsigned flip = buf ? (unsigned)-G::BUFB : (unsigned)G::BUFB;
 #pragma unroll
         for (int d = 0; d < 3; ++d)
