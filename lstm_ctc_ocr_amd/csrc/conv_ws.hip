@@ -140,9 +140,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     if (tid < 64) ((float*)(smem + G::BOFF))[tid] = (g.flags & WS_BIAS) ? g.bias[n0 + tid] : 0.f;
     const long pbytes = (long)g.M * C * 2;
-    // issue_halo(t, buf, part): part < 0 all pieces now; else piece `part` only (the pieces of tile t + 1 are issued one per K sub-step of
-    // tile t, under its MFMAs; their table rows were read at the top of the tile — no LDS instruction may sit inside the K loop, whose
-    // fragment reads are waited for by COUNT)
+    // issue_halo(t, buf, part): part < 0 all pieces now; else piece `part` only.  (Issuing the pieces of tile t + 1 one per K sub-step of
+    // tile t, "under" its MFMAs, was measured and rejected: the K loop went from 2.9 to 4.1 us for nine pieces that cost 0.4 us at the top of
+    // the tile — one wave per SIMD has no partner to issue vector-memory instructions beside its MFMAs: profiles/r05e_ws_phases.log)
     unsigned e_[PI];
     auto read_table = [&]() {
 #pragma unroll
@@ -240,8 +240,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("" ::: "memory");
         const int ph0 = 2 + 6 * (t - t_begin);
         WS_PHASE(ph0);
-        const bool more = t + 1 < t_end;
-        if (more) read_table();
+        if (t + 1 < t_end) { read_table(); issue_halo(t + 1, buf ^ 1, std::integral_constant<int, -1>{}); }
         const int col0 = t * NC;
         // rows this wave writes out: NC columns x HWE feature rows from h_lo
         const int h_lo = pg * G::HW + (KSPLIT == 2 ? kh * HWE : 0);
@@ -286,7 +285,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             WS_RD((S_) + 1, bfr[((S_) + 1) & 1]); \
             WS_WAIT(4, bfr[(S_) & 1]);              /* the four reads of sub-step S_ have returned (LDS returns in order) */ \
             WS_MM(S_, bfr[(S_) & 1], (S_) == 0); \
-            if ((S_) >= 1 && (S_) <= PI && more) issue_halo(t + 1, buf ^ 1, std::integral_constant<int, ((S_) >= 1 && (S_) <= PI) ? (S_) - 1 : 0>{}); \
             __builtin_amdgcn_sched_barrier(0); \
         } while (0)
         WS_RD(0, bfr[0]);
@@ -469,7 +467,10 @@ int ws_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int
         if (x && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         if (cus <= 0) cus = 256;
     }
-    if (mode == 1 && (long)(M / bm) * (Cout / 64) < 2L * (cus ? cus : 256)) return -1;       // fewer than two tiles per workgroup: the plane-layout kernels
+    // default policy (measured, profiles/r05e_ws_bench.log): the single-chunk instance (Cin = 64: conv2 forward 40.8 -> 32.3 us) from two tiles
+    // per workgroup on; the K-split instances (Cin = 128) are correct but lose to conv_k3 (conv2 data gradient 35 against 28 us, conv3_1 forward
+    // 32 against 21: their per-workgroup weight hand-round costs 7-8 us of a 4-tile run) — OCR_CONV_WS=2 runs them for the parity tests
+    if (mode == 1 && (Cin != 64 || (long)(M / bm) * (Cout / 64) < 2L * (cus ? cus : 256))) return -1;
     WsArgs g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, 0, 0, 0, 0};
     if (H == 16 && Cin == 64) return launch_ws<16, 16, 1>(g, cus, stream);
     if (H == 16) return launch_ws<16, 8, 2>(g, cus, stream);
