@@ -1048,22 +1048,24 @@ __device__ __forceinline__ void w9_reduce_body(float* __restrict__ dw, const flo
     const int cols = 256 / rows;
     const int col = threadIdx.x % cols, row = threadIdx.x / cols;
     const long i = (long)blk * cols + col;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, t = a;
     if (i < n4) {
         f32x4 b = {0.f, 0.f, 0.f, 0.f}, c = b, d = b;
         const f32x4* p = (const f32x4*)part + i;
+        // (round 5: the slabs are read exactly once — non-temporal loads keep them from displacing what the next kernels re-read from L2 — and
+        //  the running gradient is fetched BEFORE the rows meet, not behind the barrier; same summation order, bit-identical results)
+        if (row == 0) t = ((const f32x4*)dw)[i];
         int s = row;
         for (; s + 3 * rows < S; s += 4 * rows) {        // four slabs per round, the rounds independent of each other
-            a += p[(long)s * slab4];              b += p[(long)(s + rows) * slab4];
-            c += p[(long)(s + 2 * rows) * slab4]; d += p[(long)(s + 3 * rows) * slab4];
+            a += __builtin_nontemporal_load(p + (long)s * slab4);              b += __builtin_nontemporal_load(p + (long)(s + rows) * slab4);
+            c += __builtin_nontemporal_load(p + (long)(s + 2 * rows) * slab4); d += __builtin_nontemporal_load(p + (long)(s + 3 * rows) * slab4);
         }
-        for (; s < S; s += rows) a += p[(long)s * slab4];
+        for (; s < S; s += rows) a += __builtin_nontemporal_load(p + (long)s * slab4);
         a = (a + b) + (c + d);
     }
     red[row * cols + col] = a;
     __syncthreads();
     if (row == 0 && i < n4) {
-        f32x4 t = ((const f32x4*)dw)[i];
         for (int r = 0; r < rows; ++r) t += red[r * cols + col];
         ((f32x4*)dw)[i] = t;
     }
