@@ -988,6 +988,8 @@ class Engine(object):
         self.fuse_bn_stats = os.environ.get('OCR_FUSE_BN_STATS', '1') != '0'      # batch-norm statistics from the producing convolution's epilogue
         self.w9_flush_bytes = int(float(os.environ.get('OCR_W9_FLUSH_MB', '80')) * (1 << 20))    # slab bytes after which the pending reductions run (0: one at the end of the body); 80 MB: profiles/r04e
         self.tn_defer = os.environ.get('OCR_TN_JOBS', '1') != '0'                 # pairs of plain weight-gradient products as one gemm_tn3 launch
+        self.tn_side = os.environ.get('OCR_TN_SIDE', '0') != '0'                  # ... on a side stream beside the main chain's short kernels
+        self.side_stream = torch.cuda.Stream(device=self.device) if (self.tn_side and torch.device(self.device).type == 'cuda') else None
         self.group = group
         self.world = 1
         self._check_xcd_placement()
@@ -1340,6 +1342,7 @@ class Engine(object):
         for op in reversed(self.ops[self.split_op:]):
             op.bwd(sp)
         self._flush_tn(sp)                  # (always: the exchange of the late gradients may follow this body)
+        self._join_tn(sp)
         if flush:
             self._flush_w9(sp)
 
@@ -1347,6 +1350,7 @@ class Engine(object):
         for op in reversed(self.ops[:self.split_op]):
             op.bwd(sp)
         self._flush_tn(sp)
+        self._join_tn(sp)
         self._flush_w9(sp)
 
     def tn_push(self, sp, job, keep, fallback):
@@ -1364,10 +1368,25 @@ class Engine(object):
     def _flush_tn(self, sp):
         pend, sp.tn_pending = sp.tn_pending, []
         if len(pend) == 2:
-            ops.gemm_tn_jobs([pend[0][0], pend[1][0]])
+            if self.tn_side:
+                # the two plain weight-gradient products (47 us, operand-fill-bound on 160 of 256 CUs) are needed by the optimiser / the
+                # exchange only: they run on a side stream beside the short kernels that follow on the main chain (conv5's data gradient,
+                # col2im, conv4_2's batch-norm backward passes); _join_tn() at the end of the backward body
+                main = torch.cuda.current_stream(self.device)
+                self.side_stream.wait_stream(main)
+                with torch.cuda.stream(self.side_stream):
+                    ops.gemm_tn_jobs([pend[0][0], pend[1][0]])
+                sp.tn_side_open = True
+            else:
+                ops.gemm_tn_jobs([pend[0][0], pend[1][0]])
         else:
             for _, _, fallback in pend:
                 fallback()
+
+    def _join_tn(self, sp):
+        if getattr(sp, 'tn_side_open', False):
+            torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
+            sp.tn_side_open = False
 
     W9_DEFER_MAX_BYTES = 192 << 20       # total slab bytes of a plan up to which the reductions are deferred (Infinity Cache: 256 MB;
                                          # the headline plan has 162 MB); OCR_W9_DEFER_MAX_MB overrides
