@@ -287,6 +287,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the live per-launch timing of the dominant kernel (profiling runs)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="images per GPU and step (default: the workload's own — 64, deep 32).  Any other value is a SIDE measurement: the line "
+                         "says so in `metric` and `config` and is never the headline number")
     ap.add_argument("--stamp-clock", action="store_true",
                     help="workgroup 0 of every convolution launch of the run adds its lifetime in shader clocks and wall ticks to a device "
                          "block; the line carries conv_clock = {mhz, launches} (the counter passes of tools/prof_step_pmc.sh use it)")
@@ -339,6 +342,9 @@ def main():
     if args.workload == 'deep':
         # "2 x BiLSTM(512)" = 512 units per direction = TRAIN.NUM_HID 1024 (the reference's bi_lstm halves it: network.py:104-105)
         cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, cfg.TRAIN.NUM_HID, BATCH, net_name = 96, 2, 1024, 32, 'RESNET_train'
+    default_batch = BATCH
+    if args.batch is not None:
+        BATCH = args.batch
     eng = Engine(get_network(net_name), device=device, seed=cfg.RNG_SEED, use_graphs=not args.no_graphs)
     eng.setup_optimizer()
     # fixed and deep: W = 256 for every batch (what their config strings say); varwidth: W in [80, 320] padded per batch
@@ -433,6 +439,9 @@ def main():
             "with_loss_read_one_step_behind": {"value": BATCH * world * args.steps / dt_lag, "ms_per_step": dt_lag / args.steps * 1e3},
             "model_tflops_per_gpu": value / world * TRAIN_GFLOP_PER_IMG * 1e9 / 1e12,
         }
+        if BATCH != default_batch:
+            line["metric"] += " — SIDE MEASUREMENT at bs=%d/GPU (not the configuration BASELINE.json names)" % BATCH
+            line["config"]["workload"] += " — run at bs=%d/GPU instead of %d" % (BATCH, default_batch)
         if stamp is not None:
             nat.call("ocr_conv_halo_clock_debug", None)
             c = stamp.cpu().numpy()
@@ -446,6 +455,9 @@ def main():
         if not args.no_roofline:
             try:
                 line["roofline"] = conv_roofline(eng, device, args.workload)
+                if BATCH != default_batch:      # the committed counter summaries belong to the workload's own batch size
+                    line["roofline"].update({"traffic": None, "mfma_busy_frac": None, "mfma_busy_frac_grbm_window_lower_bound": None,
+                                             "pmc_error": "counter summaries are taken at the workload's own batch size (%d), this run is bs=%d" % (default_batch, BATCH)})
             except Exception as e:              # noqa: BLE001
                 line["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,31 @@
+#!/bin/bash
+# round 5, final validation at one build (ocr_build_id): full GPU suite, smoke, counter passes of all three workloads, the bench lines (headline with
+# cpu_baseline + roofline, varwidth, deep), rocprof kernel summaries, the emulated data-parallel schedule without / with held CUs, a bs=128 side line,
+# per-layer convolution times, conv_ws phase stamps, the live-generator training loop and the reference's own entry point end to end.
+#   usage (GPU box): bash tools/r05_final.sh [tag]
+T=${1:-r05_final}
+O=gpurun_out; mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+python -c "from lstm_ctc_ocr_amd import _native as n; print('build_id', n.build_id(), 'source', n.source_build_id())" | tee $O/${T}_build_id.txt
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error|FAILED|Error" | tail -12 | tee $O/${T}_gpu_suite.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $O/${T}_smoke.log
+line() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d.get('roofline') or {}; print('$1', round(d['value']), 'img/s', round(d['ms_per_step'],4), 'ms frac', r.get('frac'), 'traffic', r.get('traffic'), 'busy', r.get('mfma_busy_frac'), 'err', r.get('pmc_error'))"; }
+bash tools/prof_step_pmc.sh ${T} 2>&1 | tail -14
+bash tools/prof_step_pmc.sh ${T}_varwidth --workload varwidth 2>&1 | tail -3
+bash tools/prof_step_pmc.sh ${T}_deep --workload deep 2>&1 | tail -3
+cp $O/${T}_pmc_step_fixed.json $O/${T}_varwidth_pmc_step_varwidth.json $O/${T}_deep_pmc_step_deep.json profiles/ 2>/dev/null
+timeout 400 python bench.py > $O/${T}_bench_full.json 2> $O/${T}_bench.err; line headline < $O/${T}_bench_full.json
+timeout 300 python bench.py --workload varwidth --no-cpu-baseline > $O/${T}_varwidth.json 2>/dev/null; line varwidth < $O/${T}_varwidth.json
+timeout 300 python bench.py --workload deep --no-cpu-baseline > $O/${T}_deep.json 2>/dev/null; line deep < $O/${T}_deep.json
+timeout 300 python bench.py --batch 128 --no-cpu-baseline > $O/${T}_batch128_side.json 2>/dev/null; line "SIDE bs=128" < $O/${T}_batch128_side.json
+OCR_FAKE_WORLD=2 timeout 300 python bench.py --no-cpu-baseline --no-roofline > $O/${T}_fake_world2.json 2>/dev/null; line "FAKE_WORLD=2" < $O/${T}_fake_world2.json
+OCR_FAKE_WORLD=2 OCR_FAKE_COMM_CUS=16 timeout 300 python bench.py --no-cpu-baseline --no-roofline > $O/${T}_fake_world2_cus16.json 2>/dev/null; line "FAKE_WORLD=2 COMM_CUS=16" < $O/${T}_fake_world2_cus16.json
+bash tools/prof_bench.sh ${T} --no-roofline > /dev/null 2>&1; head -16 $O/${T}_kernel_stats.md | cut -c1-130; tail -1 $O/${T}_kernel_stats.md
+bash tools/prof_bench.sh ${T}_varwidth --no-roofline --workload varwidth --steps 100 > /dev/null 2>&1; tail -1 $O/${T}_varwidth_kernel_stats.md
+bash tools/prof_bench.sh ${T}_deep --no-roofline --workload deep --steps 100 > /dev/null 2>&1; tail -1 $O/${T}_deep_kernel_stats.md
+timeout 200 python tools/ws_bench.py 2>&1 | grep -v amdgpu.ids | tail -1 | tee $O/${T}_ws_bench.log
+timeout 200 python tools/ws_bench.py --cold 2>&1 | grep -v amdgpu.ids | tail -1 | tee -a $O/${T}_ws_bench.log
+OCR_CONV_WS=2 timeout 300 python tools/ws_phases.py 2>&1 | grep -v amdgpu.ids | tee $O/${T}_ws_phases.log
+timeout 600 python tools/cli_throughput.py --iters 1500 2>&1 | grep -v amdgpu.ids | tail -4 | tee $O/${T}_cli_throughput_live.log
+timeout 900 ./train.sh --iters 40000 2>&1 | grep -E "^iter: *[0-9]*000 |accuracy|done solving|speed" | tail -60 > $O/${T}_train_cli_40k.log; tail -4 $O/${T}_train_cli_40k.log
+ls -la $O/${T}*pmc_step_*.json
