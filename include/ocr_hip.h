@@ -307,12 +307,18 @@ int ocr_lstm_xh(const void* x, const void* hout, const int* seq_len, void* xh, i
 int ocr_lstm_pack_bias(const float* b_fw, const float* b_bw /* NULL when ndir == 1 */, float* out, int U, int ndir, void* stream);
 
 /* ---- optimiser (train.py:73-85: clip_by_global_norm 10.0 + Adam / Momentum / RMSProp; L2 of network.py:630-637) */
-int ocr_optim_scalar_count(void);   /* doubles in the caller-owned `scalars` block: 8 of state + per-step partial-sum bins */
+int ocr_optim_scalar_count(void);   /* doubles in the caller-owned `scalars` block: 8 of state + per-step partial-sum bins + 2 of the guard */
 int ocr_optim_init(void* scalars /* ocr_optim_scalar_count() doubles */, double lr, void* stream);
 int ocr_optim_set_lr(void* scalars, double lr, int multiply, void* stream);
 int ocr_optim_step(float* params, float* grads, float* state1, float* state2, long n, long reg_begin, long reg_end,
                    float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
                    void* scalars, void* stream);
+/* the same step behind a guard: guard_addrs = device array of nguard (<= 64) device addresses of int words that read 1 when a kernel of this step
+ * reported invalid results (the persistent LSTM launches' error words: a bounded inter-workgroup wait expired).  The update is then dropped on the
+ * device — moments, parameters and the bias-correction powers stay; scalars[72] = 1 for that step, scalars[73] counts the dropped steps. */
+int ocr_optim_step_guarded(float* params, float* grads, float* state1, float* state2, long n, long reg_begin, long reg_end,
+                           float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
+                           void* scalars, const void* guard_addrs, int nguard, void* stream);
 
 /* diagnostics: s_memtime stamps of workgroup 0 (NULL = off); device int64 [8 waves][64 steps][8] / [8][80][8] */
 int ocr_wgrad9_debug(void* dbg);

@@ -106,6 +106,7 @@ _SIGS = {
     "ocr_optim_init": ([_P, _D, _P], _I),
     "ocr_optim_set_lr": ([_P, _D, _I, _P], _I),
     "ocr_optim_step": ([_P, _P, _P, _P, _L, _L, _L, _F, _F, _I, _F, _F, _F, _P, _P], _I),
+    "ocr_optim_step_guarded": ([_P, _P, _P, _P, _L, _L, _L, _F, _F, _I, _F, _F, _F, _P, _P, _I, _P], _I),
     "ocr_wgrad9_debug": ([_P], _I),
     "ocr_probe_tr16": ([_P, _P, _P], _I),
     "ocr_set_lstm_proto": ([_I], _I),

@@ -27,18 +27,31 @@
 #define SC_BINS 32
 #define SC_NORM_BINS 8
 #define SC_REG_BINS 40
-#define SC_TOTAL 72
+// [72] 1 while the running step's update is dropped, [73] number of dropped updates so far (ocr_optim_step_guarded)
+#define SC_SKIP 72
+#define SC_SKIPPED 73
+#define SC_TOTAL 74
 // Round 4, measured and reverted (profiles/r04c_kernel_stats.md): folding the tick into the norm pass — last-arriving block by two-level
 // arrival tickets, __threadfence() between a block's bin atomics and its ticket — made optim_prep_kernel 62.8 us instead of 16.9 (+ 4.9 for
 // the tick launch it saved): a device-scope release fence on this chip writes the XCD's L2 back (the pass has just stored 22 MB of
 // gradients), once per block.  The tick stays a launch of its own.
 
-__global__ void optim_tick_kernel(double* sc, double beta1, double beta2) {
+// guard (round 5): device addresses of int words that read 1 when a kernel of this step reported that its results are invalid — the
+// persistent LSTM launches' error words (a bounded inter-workgroup wait expired: lstm_seq.hip).  The step is then DROPPED on the device:
+// no moment, no parameter and no bias-correction update (the host learns of it from the step report, one step later, and logs it) —
+// before, the garbage gradient was applied and the run died on the report.
+__global__ void optim_tick_kernel(double* sc, double beta1, double beta2, const long long* __restrict__ guard, int nguard) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double b1t = sc[SC_B1T] * beta1, b2t = sc[SC_B2T] * beta2;
-        sc[SC_B1T] = b1t; sc[SC_B2T] = b2t;
-        sc[SC_STEP] += 1.0;
-        sc[SC_LRT] = sc[SC_LR] * sqrt(1.0 - b2t) / (1.0 - b1t);
+        bool bad = false;
+        for (int i = 0; i < nguard; ++i) bad = bad || *(const int*)guard[i] == 1;
+        sc[SC_SKIP] = bad ? 1.0 : 0.0;
+        if (bad) sc[SC_SKIPPED] += 1.0;
+        else {
+            double b1t = sc[SC_B1T] * beta1, b2t = sc[SC_B2T] * beta2;
+            sc[SC_B1T] = b1t; sc[SC_B2T] = b2t;
+            sc[SC_STEP] += 1.0;
+            sc[SC_LRT] = sc[SC_LR] * sqrt(1.0 - b2t) / (1.0 - b1t);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < 2 * SC_BINS) sc[SC_NORM_BINS + threadIdx.x] = 0.0;
 }
@@ -112,6 +125,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p,
                                                           float beta1, float beta2, float eps, float clip,
                                                           double* sc, long reg0, long reg1, float wd) {
     const float gnorm = optim_gnorm(sc);
+    if (sc[SC_SKIP] != 0.0) return;                          // dropped step (uniform over the grid: written by the tick launch)
     const float scale = (clip > 0.f) ? clip / fmaxf(gnorm, clip) : 1.f;
     const float lrt = (float)sc[SC_LRT];
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -133,6 +147,7 @@ __global__ __launch_bounds__(256) void momentum_update_kernel(float* __restrict_
                                                               float* __restrict__ m, long n, float mom, float clip,
                                                               double* sc, long reg0, long reg1, float wd) {
     const float gnorm = optim_gnorm(sc);
+    if (sc[SC_SKIP] != 0.0) return;                          // dropped step (uniform over the grid: written by the tick launch)
     const float scale = (clip > 0.f) ? clip / fmaxf(gnorm, clip) : 1.f;
     const float lr = (float)sc[SC_LR];
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -152,6 +167,7 @@ __global__ __launch_bounds__(256) void rmsprop_update_kernel(float* __restrict__
                                                              float* __restrict__ ms, long n, float decay, float eps,
                                                              float clip, double* sc, long reg0, long reg1, float wd) {
     const float gnorm = optim_gnorm(sc);
+    if (sc[SC_SKIP] != 0.0) return;                          // dropped step (uniform over the grid: written by the tick launch)
     const float scale = (clip > 0.f) ? clip / fmaxf(gnorm, clip) : 1.f;
     const float lr = (float)sc[SC_LR];
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -170,7 +186,7 @@ __global__ __launch_bounds__(256) void rmsprop_update_kernel(float* __restrict__
 __global__ void optim_init_kernel(double* sc, double lr) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         sc[SC_NORM2] = 0; sc[SC_REG2] = 0; sc[SC_LR] = lr; sc[SC_LRT] = lr; sc[SC_B1T] = 1.0; sc[SC_B2T] = 1.0;
-        sc[SC_STEP] = 0; sc[SC_GNORM] = 0;
+        sc[SC_STEP] = 0; sc[SC_GNORM] = 0; sc[SC_SKIP] = 0; sc[SC_SKIPPED] = 0;
     }
     if (blockIdx.x == 0 && threadIdx.x < 2 * SC_BINS) sc[SC_NORM_BINS + threadIdx.x] = 0.0;
 }
@@ -200,16 +216,27 @@ extern "C" int ocr_optim_set_lr(void* scalars, double lr, int multiply, void* st
 }
 // solver: 0 Adam (beta1, beta2, eps), 1 Momentum (beta1 = momentum), 2 RMSProp (beta1 = decay, eps)
 // state1/state2: Adam m, v ; Momentum accumulator (state2 unused) ; RMSProp mean-square (state2 unused)
+extern "C" int ocr_optim_step_guarded(float* params, float* grads, float* state1, float* state2, long n, long reg_begin, long reg_end,
+                                      float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
+                                      void* scalars, const void* guard_addrs, int nguard, void* stream_);
 extern "C" int ocr_optim_step(float* params, float* grads, float* state1, float* state2, long n, long reg_begin, long reg_end,
                               float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
                               void* scalars, void* stream_) {
+    return ocr_optim_step_guarded(params, grads, state1, state2, n, reg_begin, reg_end, weight_decay, clip_norm, solver, beta1, beta2, eps, scalars,
+                                  nullptr, 0, stream_);
+}
+// ... with a guard: guard_addrs = device array of nguard device addresses of int words; the update is dropped when any of them reads 1
+extern "C" int ocr_optim_step_guarded(float* params, float* grads, float* state1, float* state2, long n, long reg_begin, long reg_end,
+                                      float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
+                                      void* scalars, const void* guard_addrs, int nguard, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (nguard < 0 || nguard > 64 || (nguard && !guard_addrs)) return OCR_ERR_INVALID;
     if (!params || !grads || !state1 || !scalars || n <= 0 || (n & 3) || (reg_begin & 3) || (reg_end & 3) || reg_begin < 0 ||
         reg_end < reg_begin || reg_end > n)
         return OCR_ERR_INVALID;
     if (solver == 0 && !state2) return OCR_ERR_INVALID;
     double* sc = (double*)scalars;
-    optim_tick_kernel<<<1, 64, 0, stream>>>(sc, (double)beta1, (double)beta2);
+    optim_tick_kernel<<<1, 64, 0, stream>>>(sc, (double)beta1, (double)beta2, (const long long*)guard_addrs, nguard);
     OCR_CHECK_LAUNCH();
     int blocks = (int)((n / 4 + 255) / 256); if (blocks > 2048) blocks = 2048;
     int pblocks = blocks > 1024 ? 1024 : blocks;       // the atomics at the end go to 32 bins, see SC_BINS

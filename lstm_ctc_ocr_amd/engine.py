@@ -1466,11 +1466,12 @@ class Engine(object):
             self._backward_early(sp)
 
         if getattr(sp, 'graph_step', None) is None:
+            self._guard(sp)                              # (its address table is uploaded here, outside the capture)
             fb()
 
             def body():
                 fb()
-                self._optim_body()
+                self._optim_body(sp)
             sp.graph_step = self._capture(body)
         sp.graph_step.replay()
 
@@ -1540,7 +1541,19 @@ class Engine(object):
         ops.optim_set_lr(self.scalars, gamma, multiply=True)
         self.lr *= gamma
 
-    def _optim_body(self):
+    def _guard(self, sp):
+        """Device addresses of the plan's persistent-LSTM error words for ocr_optim_step_guarded: a hand-off time-out inside the step drops the
+        step's update on the device instead of applying a garbage gradient (the report, one step later, logs it: report_wait).  Single GPU
+        only: with several ranks every replica would have to drop the same step — there the report raises as before."""
+        if sp is None or self.world > 1 or self.force_allreduce or os.environ.get('OCR_LSTM_TIMEOUT_GUARD', '1') == '0':
+            return None
+        g = getattr(sp, '_guard_addrs', None)
+        if g is None:
+            words = getattr(sp, 'lstm_sync', ())
+            g = sp._guard_addrs = (torch.tensor([w[-1:].data_ptr() for w in words], dtype=torch.int64, device=self.device) if words else False)
+        return g if g is not False else None
+
+    def _optim_body(self, sp=None):
         c = self.cfg.TRAIN
         if self.solver == 0:
             b1, b2, eps = 0.9, 0.999, 1e-8
@@ -1549,14 +1562,16 @@ class Engine(object):
         else:
             b1, b2, eps = 0.9, 0.0, 1e-10
         ops.optim_step(self.params, self.grads, self.state1, self.state2, self.reg_range, float(c.WEIGHT_DECAY), 10.0,
-                       self.solver, b1, b2, eps, self.scalars)
+                       self.solver, b1, b2, eps, self.scalars, guard=self._guard(sp))
         self.refresh_weights()
 
-    def optimizer_step(self):
+    def optimizer_step(self, sp=None):
+        """sp: the plan whose backward pass produced the gradients — its LSTM error words guard the update when the step runs eagerly
+        (the shared optimiser graph of the multi-graph schedules is plan-independent and unguarded)."""
         if not self.opt_ready:
             self.setup_optimizer()
         if not self.use_graphs:
-            self._optim_body()
+            self._optim_body(sp)
             return
         if self.graph_opt is None:
             # capture WITHOUT a warm-up run: the optimiser mutates state, so the first real step is the capture's replay
@@ -1610,7 +1625,7 @@ class Engine(object):
         else:
             self._run(sp, 'fb')
             self.allreduce_grads()
-            self.optimizer_step()
+            self.optimizer_step(sp)
         self.iteration += 1
         self.last_plan = sp
         if fetch_loss:
@@ -1678,6 +1693,15 @@ class Engine(object):
             self.last_ctc, self.last_reg, self.last_gnorm = ctc, reg, gnorm if opt_ready else 0.0
         if bits != 0.0:
             bad = [i for i in range(len(words)) if (int(bits) >> i) & 1]
+            # was the step's update dropped on the device (guarded optimiser step)?  scalars[73] counts the dropped steps: one blocking read on
+            # this rare path.  Then the parameters are intact and training goes on; the reported loss of that step is meaningless.
+            dropped = int(self.scalars[73].item()) if (opt_ready and self.scalars.numel() > 73) else 0
+            if dropped > getattr(self, '_dropped_seen', 0):
+                self._dropped_seen = dropped
+                import sys
+                sys.stderr.write('[engine] WARNING: persistent LSTM %s kernel reported an expired inter-workgroup wait; that step\'s update was '
+                                 'dropped on the device (%d dropped so far), parameters intact\n' % (('forward', 'backward')[bad[0] % 2], dropped))
+                return float('nan')
             # the sync block = group counters (64-word stride, at most 2 * ceil(N / 16) of them) | hand-off ring | error word: print the
             # counters only (the ring is hundreds of thousands of 0xFFFFFFFF words)
             w = words[bad[0]]

@@ -567,7 +567,9 @@ def optim_set_lr(scalars, lr, multiply=False):
     call("ocr_optim_set_lr", ptr(_dev(scalars)), float(lr), int(multiply), _st())
 
 
-def optim_step(params, grads, state1, state2, reg_range, weight_decay, clip_norm, solver, beta1, beta2, eps, scalars):
-    """reg_range = (begin, end) of the L2-regularised tensors inside the flat buffer."""
-    call("ocr_optim_step", ptr(_dev(params)), ptr(grads), ptr(state1), ptr(state2), params.numel(), int(reg_range[0]), int(reg_range[1]),
-         float(weight_decay), float(clip_norm), solver, float(beta1), float(beta2), float(eps), ptr(scalars), _st())
+def optim_step(params, grads, state1, state2, reg_range, weight_decay, clip_norm, solver, beta1, beta2, eps, scalars, guard=None):
+    """reg_range = (begin, end) of the L2-regularised tensors inside the flat buffer.  guard: device int64 tensor of addresses of int words
+    that read 1 when a kernel of the step reported invalid results — the update is then dropped on the device (ocr_optim_step_guarded)."""
+    call("ocr_optim_step_guarded", ptr(_dev(params)), ptr(grads), ptr(state1), ptr(state2), params.numel(), int(reg_range[0]), int(reg_range[1]),
+         float(weight_decay), float(clip_norm), solver, float(beta1), float(beta2), float(eps), ptr(scalars),
+         ptr(guard) if guard is not None else None, 0 if guard is None else int(guard.numel()), _st())

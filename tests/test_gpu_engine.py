@@ -350,3 +350,38 @@ def test_residual_stacked_network_parity(dev):
         assert l1 < l0
     finally:
         cfg.NCLASSES, cfg.TRAIN.NUM_LAYERS, cfg.TRAIN.WEIGHT_DECAY = old
+
+
+def test_lstm_handoff_timeout_drops_the_update_instead_of_applying_it(dev, capsys):
+    """Round 5: the persistent LSTM kernels bound their inter-workgroup waits and report through an error word (1 = results invalid).  Seen twice
+    in ~20 runs of the live-pipeline loop (tools/cli_throughput.py; also with round 4's kernels) — before, the garbage gradient was applied and the run died
+    on the report one step later.  Now the optimiser step is guarded on the device: with an error word at 1 neither parameters, nor moments, nor
+    the step count / bias-correction powers move, scalars[73] counts the dropped step, the report warns and returns NaN, and the next step is normal."""
+    eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3, use_graphs=False)
+    eng.setup_optimizer('Adam', 1e-3)
+    x, labels, ll, sl = make_batch(8, 88, 2, 4, 2)
+    l0 = eng.train_step(x, labels, ll, sl)
+    assert np.isfinite(l0) and float(eng.scalars[6]) == 1.0 and float(eng.scalars[73]) == 0.0
+    before, m1, m2, sc = eng.params.clone(), eng.state1.clone(), eng.state2.clone(), eng.scalars.clone()
+    sp = eng.plan(8, 88)
+    eng._bind(sp, x, sl, labels, ll)
+    eng._run(sp, 'fb')
+    assert len(sp.lstm_sync) == 2
+    sp.lstm_sync[0][-1] = 1                                  # fault injection: "the forward launch's wait expired"
+    eng.optimizer_step(sp)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.params, before) and torch.equal(eng.state1, m1) and torch.equal(eng.state2, m2)
+    assert float(eng.scalars[6]) == 1.0 and torch.equal(eng.scalars[2:7], sc[2:7])          # lr, lr_t, beta powers, step count untouched
+    assert float(eng.scalars[72]) == 1.0 and float(eng.scalars[73]) == 1.0
+    eng.last_plan = sp
+    v = eng.report_wait(eng.report_async())
+    assert np.isnan(v) and 'dropped on the device' in capsys.readouterr().err
+    l2 = eng.train_step(x, labels, ll, sl)                   # the next step is a normal one
+    assert np.isfinite(l2) and float(eng.scalars[6]) == 2.0 and float(eng.scalars[72]) == 0.0 and float(eng.scalars[73]) == 1.0
+    assert not torch.equal(eng.params, before)
+    # without the guard (several ranks, or OCR_LSTM_TIMEOUT_GUARD=0) the report raises as before
+    sp.lstm_sync[1][-1] = 1
+    eng.last_plan = sp
+    from lstm_ctc_ocr_amd._native import NativeError
+    with pytest.raises(NativeError):
+        eng.report_wait(eng.report_async())

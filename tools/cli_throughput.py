@@ -37,7 +37,17 @@ def run(eng, stream, iters, warm):
             eng.train_step(x, *rest, fetch_loss=False)              # iteration k is read while iteration k + 1 runs
             h = eng.report_async()
             if pending is not None:
-                losses.append(eng.report_wait(pending))
+                try:
+                    losses.append(eng.report_wait(pending))
+                except Exception as e:                              # diagnostic (round 5): what does the state look like when a time-out is reported?
+                    torch.cuda.synchronize()
+                    sp = eng.last_plan
+                    fin = lambda t: bool(torch.isfinite(t.float()).all())
+                    bufs = {k: fin(v) for k, v in sp.buf.items() if torch.is_tensor(v) and v.is_floating_point() and k.endswith(('/y', '/hout', '/z', '/dy'))}
+                    print('TIMEOUT-DIAG iteration %d: last losses %s | params finite %s grads finite %s | non-finite activation buffers %s | seq_len %s..%s labels_len %s..%s | %s'
+                          % (i, [round(v, 3) for v in losses[-5:]], fin(eng.params), fin(eng.grads), [k for k, ok in bufs.items() if not ok][:8],
+                             int(sp.seq_len.min()), int(sp.seq_len.max()), int(sp.labels_len.min()), int(sp.labels_len.max()), str(e)[:100]), flush=True)
+                    raise
             pending = h
         else:
             losses.append(eng.train_step(x, *rest))                 # one host sync per iteration at once (sess.run semantics)
@@ -55,6 +65,7 @@ def main():
     ap.add_argument('--legacy', action='store_true')
     ap.add_argument('--workers', type=int, default=0)
     ap.add_argument('--pool', type=int, default=0)
+    ap.add_argument('--only', default='', help='run one configuration only: W88 or W256')
     ap.add_argument('--no-lag', action='store_true', help='wait for every loss at once (OCR_LOSS_LAG=0 of the training loop)')
     a = ap.parse_args()
     global LAG
@@ -66,6 +77,8 @@ def main():
     except Exception:
         pass
     for name, kw in (('W88_4to6char', dict()), ('W256_10char', dict(min_len=10, max_len=10, width=480))):
+        if a.only and not name.startswith(a.only):
+            continue
         eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
         eng.setup_optimizer('Adam', 1e-4)
         if a.legacy:
