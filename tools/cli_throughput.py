@@ -56,7 +56,10 @@ def run(eng, stream, iters, warm):
         losses.append(eng.report_wait(pending))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return n / dt, dt / iters * 1e3, float(np.mean(losses[-50:]))
+    dropped = [k for k, v in enumerate(losses) if v != v]
+    if dropped:
+        print('steps dropped by the time-out guard at iterations %s' % dropped[:8], flush=True)
+    return n / dt, dt / iters * 1e3, float(np.nanmean(losses[-50:]))
 
 
 def main():

@@ -51,9 +51,10 @@ try:
             losses.append(eng.report_wait(pending))
         pending = h
     losses.append(eng.report_wait(pending))
-    print('%s W=%d len=T-%d FUSE_X=%s RINGFILL=%s: %d iterations clean, loss %.3f -> %.3f, %.1f s' % (
+    nan_at = [i for i, v in enumerate(losses) if v != v]
+    print('%s W=%d len=T-%d FUSE_X=%s RINGFILL=%s: %d iterations, %d steps dropped by the guard (device count %d; at iterations %s), loss %.3f -> %.3f, %.1f s' % (
         'live' if a.live else 'synthetic', a.width, a.short, os.environ.get('OCR_LSTM_FUSE_X', '1'), os.environ.get('OCR_FUSE_RINGFILL', '1'),
-        len(losses), losses[0], float(np.mean(losses[-20:])), time.time() - t0), flush=True)
+        len(losses), len(nan_at), int(eng.scalars[73].item()), nan_at[:8], losses[0], float(np.nanmean(losses[-20:])), time.time() - t0), flush=True)
 except nat.NativeError as e:
     print('%s W=%d len=T-%d FUSE_X=%s RINGFILL=%s: TIME-OUT reported at iteration %d (the report is one step behind); last losses %s; %s' % (
         'live' if a.live else 'synthetic', a.width, a.short, os.environ.get('OCR_LSTM_FUSE_X', '1'), os.environ.get('OCR_FUSE_RINGFILL', '1'),

@@ -26,6 +26,7 @@ bash tools/prof_bench.sh ${T}_deep --no-roofline --workload deep --steps 100 > /
 timeout 200 python tools/ws_bench.py 2>&1 | grep -v amdgpu.ids | tail -1 | tee $O/${T}_ws_bench.log
 timeout 200 python tools/ws_bench.py --cold 2>&1 | grep -v amdgpu.ids | tail -1 | tee -a $O/${T}_ws_bench.log
 OCR_CONV_WS=2 timeout 300 python tools/ws_phases.py 2>&1 | grep -v amdgpu.ids | tee $O/${T}_ws_phases.log
-timeout 600 python tools/cli_throughput.py --iters 1500 2>&1 | grep -v amdgpu.ids | tail -4 | tee $O/${T}_cli_throughput_live.log
+timeout 600 python tools/cli_throughput.py --iters 1500 2>&1 | grep -v amdgpu.ids | tail -5 | tee $O/${T}_cli_throughput_live.log
+timeout 300 python tools/lstm_timeout_probe.py --live --iters 20000 2>&1 | grep -v "amdgpu.ids" | tail -3 | tee $O/${T}_live_soak_20k.log
 timeout 900 ./train.sh --iters 40000 2>&1 | grep -E "^iter: *[0-9]*000 |accuracy|done solving|speed" | tail -60 > $O/${T}_train_cli_40k.log; tail -4 $O/${T}_train_cli_40k.log
 ls -la $O/${T}*pmc_step_*.json
