@@ -251,9 +251,15 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
                 if (active) c = cn;
                 u32x2 hp = {pack_bf2(hn[0], hn[1]), pack_bf2(hn[2], hn[3])};
                 if (!active) hp = (u32x2){0u, 0u};
-                *rdst = hp;                                 // the hand-off payload goes out FIRST
+                // (round 5) a workgroup whose rows are ALL past their length touches the ring no more: it polls nothing, so it runs free, and
+                // its stores would land in slots that a slower workgroup — still at the tile's last active step — is reading: the slot refill
+                // below destroyed the piece that workgroup was polling for (a time-out seen ~3 times in 30 000 live-pipeline iterations at
+                // W = 88, where every sequence is one step shorter than T), and three free steps later the payload of an inactive step (zeros)
+                // would overwrite the h it still needs.  Nothing polls these slots again in this launch; the next launch refills the ring.
+                const bool ring_live = __any(active);
+                if (ring_live) *rdst = hp;                  // the hand-off payload goes out FIRST
                 asm volatile("" ::: "memory");
-                if (s >= 2) {                               // recycle this wave's piece of the slot that nobody reads any more
+                if (s >= 2 && ring_live) {                  // recycle this wave's piece of the slot that nobody reads any more
                     const u32x2 f = {0xFFFFFFFFu, 0xFFFFFFFFu};
                     *(u32x2*)(gring + (unsigned)((s - 2) & (RING - 1)) * SLOT + wr0) = f;
                 }
@@ -602,9 +608,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (kh == 0) {
                 const f32x4 h = outs[0][lane];
                 const u32x2 hp = {pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
-                *(u32x2*)(gring + (unsigned)(s & (RING - 1)) * SLOT + wr0) = hp;               // the hand-off payload goes out FIRST
+                const bool ring_live = __any(active);          // a workgroup whose rows are all past their length leaves the ring alone: lstm_fwd_seq_kernel
+                if (ring_live) *(u32x2*)(gring + (unsigned)(s & (RING - 1)) * SLOT + wr0) = hp;               // the hand-off payload goes out FIRST
                 asm volatile("" ::: "memory");
-                if (s >= 2) *(u32x2*)(gring + (unsigned)((s - 2) & (RING - 1)) * SLOT + wr0) = (u32x2){0xFFFFFFFFu, 0xFFFFFFFFu};
+                if (s >= 2 && ring_live) *(u32x2*)(gring + (unsigned)((s - 2) & (RING - 1)) * SLOT + wr0) = (u32x2){0xFFFFFFFFu, 0xFFFFFFFFu};
                 asm volatile("" ::: "memory");
                 *(u32x2*)(a.hout + row * (2L * U) + (long)d * U + ub * 16 + ul0) = hp;
             } else if (kh == 3) {
@@ -771,9 +778,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (kh == 0) {
                 const f32x4 h = outs[0][lane];
                 const u32x2 hp = {pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
-                *(u32x2*)(gring + (unsigned)(s & (RING - 1)) * SLOT + wr0) = hp;               // the hand-off payload goes out FIRST
+                const bool ring_live = __any(active);          // a workgroup whose rows are all past their length leaves the ring alone: lstm_fwd_seq_kernel
+                if (ring_live) *(u32x2*)(gring + (unsigned)(s & (RING - 1)) * SLOT + wr0) = hp;               // the hand-off payload goes out FIRST
                 asm volatile("" ::: "memory");
-                if (s >= 2) *(u32x2*)(gring + (unsigned)((s - 2) & (RING - 1)) * SLOT + wr0) = (u32x2){0xFFFFFFFFu, 0xFFFFFFFFu};
+                if (s >= 2 && ring_live) *(u32x2*)(gring + (unsigned)((s - 2) & (RING - 1)) * SLOT + wr0) = (u32x2){0xFFFFFFFFu, 0xFFFFFFFFu};
                 asm volatile("" ::: "memory");
                 *(u32x2*)(a.hout + row * (2L * U) + (long)d * U + ub * 16 + ul0) = hp;
             } else if (kh == 3) {
