@@ -445,10 +445,17 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
                 for (int g = 0; g < 4; ++g) p[g] = (u32x2){0u, 0u};
             }
             if (PROTO == 4) {
+                // (round 5) as in the forward kernels: a workgroup none of whose rows is inside its sequence yet polls nothing and runs free — here
+                // through the FIRST iterations of a tile whose sequences are all shorter than T; it leaves the ring alone, so that a slot never
+                // holds the (zero) payload of a free iteration that a faster workgroup, already at its first polling iteration, could take
+                // for the gradient of four iterations later.  Rows only wait for pieces of iterations in which they were active (has_next).
+                const bool ring_live = __any(active);
+                if (ring_live) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) *(u32x2*)(rdst + g * 512) = p[g];
+                    for (int g = 0; g < 4; ++g) *(u32x2*)(rdst + g * 512) = p[g];
+                }
                 asm volatile("" ::: "memory");
-                if (it >= 2) {
+                if (it >= 2 && ring_live) {
                     const u32x2 f = {0xFFFFFFFFu, 0xFFFFFFFFu};
                     unsigned char* old = gring + (unsigned)((it - 2) & (RING - 1)) * SLOT + wr0;
 #pragma unroll
@@ -923,9 +930,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (nvalid) {
             const f32x4 v = outs[kh][lane];
             const u32x2 p = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            *(u32x2*)(gring + (unsigned)(it & (RING - 1)) * SLOT + wr0) = p;
+            const bool ring_live = __any(active);              // a workgroup none of whose rows is inside its sequence yet leaves the ring alone: lstm_bwd_seq_kernel
+            if (ring_live) *(u32x2*)(gring + (unsigned)(it & (RING - 1)) * SLOT + wr0) = p;
             asm volatile("" ::: "memory");
-            if (it >= 2) *(u32x2*)(gring + (unsigned)((it - 2) & (RING - 1)) * SLOT + wr0) = (u32x2){0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (it >= 2 && ring_live) *(u32x2*)(gring + (unsigned)((it - 2) & (RING - 1)) * SLOT + wr0) = (u32x2){0xFFFFFFFFu, 0xFFFFFFFFu};
             asm volatile("" ::: "memory");
             *(u32x2*)(a.dz + row * (8L * U) + (long)d * 4 * U + (long)kh * U + u0) = p;
         }

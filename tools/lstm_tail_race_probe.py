@@ -21,6 +21,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--reps', type=int, default=20000)
 ap.add_argument('--short', type=int, default=4)
 ap.add_argument('--width', type=int, default=88)
+ap.add_argument('--train', action='store_true', help='forward + CTC + backward: compare the backward recurrence\'s dz too')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
@@ -28,11 +29,20 @@ T = a.width // 4 - 1
 rng = np.random.RandomState(0)
 x = torch.from_numpy(rng.rand(64, a.width, 32).astype(np.float32)).to(dev)
 sl = torch.full((64,), T - a.short, dtype=torch.int32, device=dev)
-eng.forward(x, sl)
-torch.cuda.synchronize()
 sp = eng.plan(64, a.width)
+mode = 'fb' if a.train else 'fwd'
+if a.train:
+    ll = rng.randint(3, 5, 64).astype(np.int32)
+    labels = rng.randint(1, 63, int(ll.sum())).astype(np.int32)
+    eng._bind(sp, x, sl, labels, ll)
+else:
+    eng._bind(sp, x, sl)
+eng._run(sp, mode)
+torch.cuda.synchronize()
 key = [k for k in sp.buf if k.endswith('/hout')][0]
-ref = sp.buf[key].clone()
+keys = [key] + ([k for k in sp.buf if k.endswith('/dz') and 'logits' in k] if a.train else [])
+refs = [sp.buf[k].clone() for k in keys]
+ref = refs[0]
 stop = threading.Event()
 side = torch.cuda.Stream()
 big_a = torch.empty(256 << 20, dtype=torch.uint8, device=dev); big_b = torch.empty_like(big_a)
@@ -52,12 +62,15 @@ th = threading.Thread(target=noise); th.start()
 diff = torch.zeros(1, dtype=torch.int64, device=dev)
 errs = 0
 for i in range(a.reps):
-    eng._run(sp, 'fwd')
-    diff += (sp.buf[key] != ref).any().to(torch.int64)
+    eng._run(sp, mode)
+    bad = (sp.buf[key] != ref).any()
+    for k, r in zip(keys[1:], refs[1:]):
+        bad = bad | (sp.buf[k] != r).any()
+    diff += bad.to(torch.int64)
     if i % 500 == 499:
         torch.cuda.synchronize()
         errs += sum(int(w[-1].item() == 1) for w in sp.lstm_sync)
 stop.set(); th.join()
 torch.cuda.synchronize()
-print('build %s: W=%d T=%d len=T-%d, %d forwards beside an HBM-copy stream: BiLSTM output differed from the first launch in %d, expired waits seen at %d of %d checks'
-      % (nat.build_id(), a.width, T, a.short, a.reps, int(diff.item()), errs, a.reps // 500), flush=True)
+print('build %s (%s): W=%d T=%d len=T-%d, %d runs beside an HBM-copy stream: BiLSTM output differed from the first launch in %d, expired waits seen at %d of %d checks'
+      % (nat.build_id(), 'forward + CTC + backward: hout and dz compared' if a.train else 'inference forward: hout compared', a.width, T, a.short, a.reps, int(diff.item()), errs, a.reps // 500), flush=True)
