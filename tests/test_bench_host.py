@@ -44,3 +44,35 @@ def test_committed_counter_summaries_belong_to_the_sources_in_the_tree():
     for wl in ("fixed", "varwidth", "deep"):
         path, pm = b.pick_pmc_summary(os.path.join(ROOT, "profiles"), wl, bid)
         assert pm is not None and pm.get("build_id") == bid and pm.get("workload") == wl, (wl, path, pm and pm.get("build_id"), bid)
+
+
+def test_counter_summary_divides_busy_cycles_by_the_kernels_own_cycles(tmp_path):
+    """tools/pmc_step_summary.py (round 5): mfma_busy_frac_own_cycles = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x the kernel's duration IN THE PASS THAT
+    COUNTED IT x the shader clock bench.py --stamp-clock reported for that pass); the GRBM-window quotient keeps its own name; non-convolution
+    kernels get no own-cycles figure (their launches are not stamped)."""
+    import subprocess
+    import sys
+    txt = tmp_path / "pmc.txt"
+    txt.write_text(
+        "_Z14conv_ws_kernelILi16ELi16ELi1ELb0EEv6WsArgs.kd launches=11 avg_us=30.0\n"
+        "    FETCH_SIZE avg 1000.0\n"
+        "_Z14conv_ws_kernelILi16ELi16ELi1ELb0EEv6WsArgs.kd launches=11 avg_us=32.0\n"
+        "    SQ_VALU_MFMA_BUSY_CYCLES avg 2.0e7\n"
+        "    GRBM_GUI_ACTIVE avg 8.0e5\n"
+        "_Z18adam_update_kernelPfPKfS_S_lffffPdllf.kd launches=11 avg_us=33.0\n"
+        "    SQ_VALU_MFMA_BUSY_CYCLES avg 0.0\n"
+        "    GRBM_GUI_ACTIVE avg 9.0e5\n")
+    log = tmp_path / "pmc3.log"
+    log.write_text('noise\n{"metric": "x", "conv_clock": {"mhz": 2000.0, "launches": 110}}\n')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_step_summary.py"), str(txt), ROOT, "fixed", str(log)],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-800:]
+    d = json.loads(out.stdout)
+    assert d["workload"] == "fixed" and d["conv_clock"]["mhz"] == 2000.0
+    k = {r["symbol"]: r for r in d["kernels"]}
+    ws = k["_Z14conv_ws_kernelILi16ELi16ELi1ELb0EEv6WsArgs"]
+    assert ws["sq_pass_avg_us"] == 32.0 and ws["avg_us"] == 30.0                      # the duration of the pass that held the counter
+    assert abs(ws["mfma_busy_frac_own_cycles"] - 2.0e7 / (1024.0 * 32.0 * 2000.0)) < 1e-12
+    assert abs(ws["mfma_busy_frac_grbm_window"] - 2.0e7 / (1024.0 * 8.0e5 / 8.0)) < 1e-12
+    assert abs(ws["read_mb"] - 2.0 * 1000.0 * 1024 / 1e6) < 1e-9                      # FETCH_SIZE in KB, doubled (gfx950 correction)
+    assert "mfma_busy_frac_own_cycles" not in k["_Z18adam_update_kernelPfPKfS_S_lffffPdllf"]
