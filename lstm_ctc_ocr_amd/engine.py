@@ -1531,6 +1531,7 @@ class Engine(object):
         self.state1 = torch.ones_like(self.params) if self.solver == 2 else torch.zeros_like(self.params)
         self.state2 = torch.zeros_like(self.params) if self.solver == 0 else None
         self.scalars.zero_()                             # in place: captured graphs keep pointing at it
+        self._dropped_seen = 0                           # host mirror of scalars[73] (steps dropped by the guarded optimiser step)
         ops.optim_init(self.scalars, self.lr)
         self.opt_ready = True
         self.graph_opt = None                            # captured optimiser graphs hold the old slot tensors
