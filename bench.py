@@ -359,9 +359,14 @@ def main():
         from lstm_ctc_ocr_amd import _native as nat
         stamp = torch.zeros(8, dtype=torch.int64, device=device)
         nat.call("ocr_conv_halo_clock_debug", stamp.data_ptr())
+    # steps the guarded optimiser launch DROPPED (a persistent LSTM hand-off wait expired: the update kernels return early) and expired waits it
+    # saw — device counters (scalars[73], [74]), read outside the timed region.  A dropped step is work skipped inside the timed region: the line
+    # proves there was none, or carries no `value`
+    g0 = eng.guard_counters()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    g1 = eng.guard_counters()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -373,6 +378,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    g2 = eng.guard_counters()
     dp_host = None
     if eng.dp_host_s[5]:
         n = float(eng.dp_host_s[5])
@@ -414,6 +420,11 @@ def main():
     torch.cuda.synchronize()
     dt_lag = time.perf_counter() - t2
 
+    g3 = eng.guard_counters()
+    guard = torch.tensor([g1[0] - g0[0], g2[0] - g1[0], g3[0] - g2[0], g1[1] - g0[1], g2[1] - g1[1], g3[1] - g2[1]], dtype=torch.float64, device=device)
+    if world > 1:                       # (every rank drops the same steps; the time-out counts are per rank: the line carries the maximum)
+        guard = reduce_(guard, dist.ReduceOp.MAX)
+    guard = [int(v) for v in guard.tolist()]
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = BATCH * world * args.steps / dt
@@ -429,6 +440,9 @@ def main():
                                     "bs=32/GPU (BASELINE.json configs[4]; bf16 MFMA operands where BASELINE says fp16: same MFMA rate, fp32 accumulation)"),
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world, "hipgraph": not args.no_graphs},
             "final_loss": loss,
+            "dropped_steps": {"warmup": guard[0], "timed": guard[1], "side_loops": guard[2]},
+            "lstm_timeouts": {"warmup": guard[3], "timed": guard[4], "side_loops": guard[5]},
+            "guard": ("device-guarded optimiser step (ocr_optim_step_guarded2): on" if eng._guard_on() else "off (OCR_LSTM_TIMEOUT_GUARD=0): a time-out raises at the next report"),
             "fake_comm": ({"cus": int(os.environ["OCR_FAKE_COMM_CUS"]), "us_per_25mb": float(os.environ.get("OCR_FAKE_COMM_US", "250")),
                            "lds_kb": int(os.environ.get("OCR_FAKE_COMM_LDS_KB", "96")), "fake_world": int(os.environ["OCR_FAKE_WORLD"]),
                            "note": "one-GPU emulation: every all-reduce = a doubling kernel + `cus` resident workgroups holding CUs for the time a "
@@ -439,9 +453,13 @@ def main():
             "with_loss_read_one_step_behind": {"value": BATCH * world * args.steps / dt_lag, "ms_per_step": dt_lag / args.steps * 1e3},
             "model_tflops_per_gpu": value / world * TRAIN_GFLOP_PER_IMG * 1e9 / 1e12,
         }
-        if BATCH != default_batch:
-            line["metric"] += " — SIDE MEASUREMENT at bs=%d/GPU (not the configuration BASELINE.json names)" % BATCH
-            line["config"]["workload"] += " — run at bs=%d/GPU instead of %d" % (BATCH, default_batch)
+        if guard[1] or guard[4]:
+            # work was skipped inside the timed region: no number
+            line["value"] = None
+            line["ms_per_step"] = None
+            line.pop("model_tflops_per_gpu", None)
+            line["error"] = ("%d of the %d timed steps were dropped on the device after %d expired persistent-LSTM hand-off waits: the timed region "
+                             "did not do the work of %d steps — no value is reported" % (guard[1], args.steps, guard[4], args.steps))
         if stamp is not None:
             nat.call("ocr_conv_halo_clock_debug", None)
             c = stamp.cpu().numpy()
@@ -449,7 +467,10 @@ def main():
                                   "note": "shader clocks / 100 MHz wall ticks of workgroup 0, summed over every convolution launch of this process"}
         if args.workload != "fixed":
             line["metric"] = "captcha images/sec training (%s workload)" % args.workload
-            line.pop("model_tflops_per_gpu")
+            line.pop("model_tflops_per_gpu", None)
+        if BATCH != default_batch:          # (after the workload's own metric string: ADVICE r5)
+            line["metric"] += " — SIDE MEASUREMENT at bs=%d/GPU (not the configuration BASELINE.json names)" % BATCH
+            line["config"]["workload"] += " — run at bs=%d/GPU instead of %d" % (BATCH, default_batch)
         # the timed number above is complete at this point: a failure in the two side measurements must not cost the line (it is
         # reported inside the line instead of being swallowed)
         if not args.no_roofline:

@@ -225,7 +225,8 @@ int ocr_u8_to_unit_f32(const void* in, float* out, long n, void* stream);
 /* What train.py:130,139 fetches after sess.run, gathered on the device into out[4] (doubles): mean per-sample CTC cost, sum w^2 of
  * the regularised parameters (scalars[1]) and the global gradient norm (scalars[7]) of the optimiser block (scalars may be NULL),
  * and a bit mask of the error words that read 1 — the persistent LSTM kernels' time-out mark; 0 and 0xFFFFFFFF (a caller-prepared block,
- * OCR_LSTM_PREPARED) both mean "nothing happened" (word_addrs: device array of nwords <= 32 device addresses of int error words). */
+ * OCR_LSTM_PREPARED) both mean "nothing happened" (word_addrs: device array of nwords <= 32 device addresses of int error words); 2^40 is added
+ * when the update of the step the report follows was dropped on the device (scalars[72], ocr_optim_step_guarded*). */
 int ocr_step_report(const float* costs, int n, const double* scalars, const void* word_addrs, int nwords, double* out, void* stream);
 /* One launch binding a DEVICE-resident batch to the engine's fixed input buffers (the feed_dict of train.py:126-130 once the
  * batch is already in HBM): pixels -> x (uint8 / 255 when pixels_are_u8, else an fp32 copy; n_pixels % 4 == 0) and the
@@ -272,6 +273,12 @@ int ocr_lstm_bwd_step(const void* wh, long ldw, long w_dir_stride, const int* se
 int ocr_lstm_seq_supported(int Nb, int U);
 long ocr_lstm_seq_sync_words(int Nb, int U);
 int ocr_lstm_seq_debug(void* dbg /* device int64[4*T] phase stamps of workgroup 0, NULL = off */);
+/* test hook: in the persistent launches that follow, unit block 0 of EVERY (direction, batch tile) group sleeps units x 64 shader clocks at the
+ * top of iteration `at` (at < 0: of every iteration; units 0 = off, the default; 0 .. 4096) — the skew between the workgroups of a group that HBM
+ * contention produces once in ~10^4 launches, made deterministic: the ring hand-off that stands in for the dependent op sequence of
+ * network.py:104-109 must be right for any relative speed of its workgroups (tests/test_gpu_stress.py, tools/lstm_ring_model.py).  Baked into a
+ * captured graph at capture time. */
+int ocr_lstm_seq_test_skew(int units, int at);
 int ocr_lstm_fwd_seq(const float* xproj, const void* whT_packed, const int* seq_len, void* hout, float* gates,
                      float* cell, int Nb, int T, int U, float forget_bias, void* sync, void* stream);
 int ocr_lstm_bwd_seq(const void* wh, long ldw, long w_dir_stride, const int* seq_len, const void* dhout,
@@ -319,6 +326,14 @@ int ocr_optim_step(float* params, float* grads, float* state1, float* state2, lo
 int ocr_optim_step_guarded(float* params, float* grads, float* state1, float* state2, long n, long reg_begin, long reg_end,
                            float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
                            void* scalars, const void* guard_addrs, int nguard, void* stream);
+/* ... and / or behind a drop flag (data parallel, train.py:79-83 applied by every replica or by none): drop_flag = a device float, > 0 => drop
+ * (NULL: none).  ocr_guard_flag writes 1.0f / 0.0f (any of the nguard words reads 1 / none does) into flag_out; a rank puts that word at the end of
+ * its late gradient bucket, the SUM all-reduce turns it into the number of ranks whose step timed out, and every rank drops the SAME step.
+ * scalars[74] counts the expired waits the guard has seen (error words that read 1 + ranks that raised the flag). */
+int ocr_optim_step_guarded2(float* params, float* grads, float* state1, float* state2, long n, long reg_begin, long reg_end,
+                            float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
+                            void* scalars, const void* guard_addrs, int nguard, const float* drop_flag, void* stream);
+int ocr_guard_flag(const void* guard_addrs, int nguard, float* flag_out, void* stream);
 
 /* diagnostics: s_memtime stamps of workgroup 0 (NULL = off); device int64 [8 waves][64 steps][8] / [8][80][8] */
 int ocr_wgrad9_debug(void* dbg);

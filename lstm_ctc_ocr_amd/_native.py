@@ -93,6 +93,7 @@ _SIGS = {
     "ocr_lstm_bwd_step": ([_P, _L, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
     "ocr_lstm_seq_supported": ([_I, _I], _I),
     "ocr_lstm_seq_debug": ([_P], _I),
+    "ocr_lstm_seq_test_skew": ([_I, _I], _I),
     "ocr_lstm_seq_sync_words": ([_I, _I], _L),
     "ocr_lstm_fwd_seq": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P], _I),
     "ocr_lstm_bwd_seq": ([_P, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
@@ -107,6 +108,8 @@ _SIGS = {
     "ocr_optim_set_lr": ([_P, _D, _I, _P], _I),
     "ocr_optim_step": ([_P, _P, _P, _P, _L, _L, _L, _F, _F, _I, _F, _F, _F, _P, _P], _I),
     "ocr_optim_step_guarded": ([_P, _P, _P, _P, _L, _L, _L, _F, _F, _I, _F, _F, _F, _P, _P, _I, _P], _I),
+    "ocr_optim_step_guarded2": ([_P, _P, _P, _P, _L, _L, _L, _F, _F, _I, _F, _F, _F, _P, _P, _I, _P, _P], _I),
+    "ocr_guard_flag": ([_P, _I, _P, _P], _I),
     "ocr_wgrad9_debug": ([_P], _I),
     "ocr_probe_tr16": ([_P, _P, _P], _I),
     "ocr_set_lstm_proto": ([_I], _I),

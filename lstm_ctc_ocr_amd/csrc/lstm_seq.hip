@@ -29,6 +29,19 @@ typedef unsigned long long u64;
 #define RING 4            // slots of the protocol-4 exchange ring (see there why 4)
 // optional phase timestamps (wall_clock64, 100 MHz) of workgroup 0: dbg[step*4 + {0 loop top, 1 after wait, 2 after MFMA, 3 after arrive}]
 #define DBG_STAMP(slot) do { if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) a.dbg[dbgi * 4 + (slot)] = wall_clock64(); } while (0)
+// Test hooks.  SKEW_HOOK: ocr_lstm_seq_test_skew(n, at) makes unit block 0 of EVERY group sleep n x 64 clocks at the top of iteration `at` (at < 0:
+// of every iteration) — the skew between workgroups that HBM contention provides once in ~10^4 launches, made deterministic
+// (tests/test_gpu_stress.py: the hand-off must be right for ANY relative speed of the workgroups).  A delay in EVERY iteration is absorbed by the
+// other workgroups' adaptive pre-poll sleep (they slow down with it, free iterations included — measured: the round-4 rule survives it); the delay at
+// ONE iteration (the tile's last active step forward, the first iteration backward) is what lets the others run ahead.  RING_LIVE: the round-5 rule (a workgroup none of whose rows is inside its sequence leaves the
+// ring alone); the experiments build can be told to follow the rule of rounds 3-4 again (OCR_LSTM_RING_RULE=always: every iteration stores and
+// refills) so that the same tests can be shown to FAIL on it — the product library has no such switch.
+#define SKEW_HOOK() do { if (a.skew && ub == 0 && (a.skew_at < 0 || a.skew_at == dbgi)) for (int i_ = 0; i_ < a.skew; ++i_) __builtin_amdgcn_s_sleep(1); } while (0)
+#ifdef OCR_EXPERIMENTS
+#define RING_LIVE(act) (__any(act) || a.ring_always)
+#else
+#define RING_LIVE(act) (__any(act))
+#endif
 
 __device__ __forceinline__ void store_wt8(void* p, u32x2 v) {
     u64 x = ((u64)v.y << 32) | (u64)v.x;
@@ -115,7 +128,7 @@ template <int PROTO, int UB> __device__ __forceinline__ bool seq_decode(int ngro
 struct LstmSeqFwdArgs {
     const float* xproj; const bf16_t* whT; const int* seq_len; bf16_t* hout; float* gates; float* cell;
     unsigned* counters; unsigned char* ring; int* err;
-    int Nb, T; float forget_bias; long long* dbg; int presleep;
+    int Nb, T; float forget_bias; long long* dbg; int presleep; int skew; int skew_at; int ring_always;
 };
 
 // U: hidden units per direction; WPB: batch sub-tiles (waves) per workgroup; KSP: waves that share the contraction axis of one
@@ -165,6 +178,7 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
     for (int s = 0; s < T; ++s) {
         const int dbgi = s;
         DBG_STAMP(0);
+        SKEW_HOOK();
         // last step's slot refill (and everything older) has landed: stores retire in issue order, the six issued behind it may stay in flight
         if (PROTO == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         const bool active = nvalid && s < len;
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
                 // below destroyed the piece that workgroup was polling for (a time-out seen ~3 times in 30 000 live-pipeline iterations at
                 // W = 88, where every sequence is one step shorter than T), and three free steps later the payload of an inactive step (zeros)
                 // would overwrite the h it still needs.  Nothing polls these slots again in this launch; the next launch refills the ring.
-                const bool ring_live = __any(active);
+                const bool ring_live = RING_LIVE(active);
                 if (ring_live) *rdst = hp;                  // the hand-off payload goes out FIRST
                 asm volatile("" ::: "memory");
                 if (s >= 2 && ring_live) {                  // recycle this wave's piece of the slot that nobody reads any more
@@ -301,7 +315,7 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
 struct LstmSeqBwdArgs {
     const bf16_t* wh; long ldw; long w_dir_stride; const int* seq_len; const bf16_t* dhout; const float* gates;
     const float* cell; bf16_t* dz; unsigned* counters; unsigned char* ring; int* err;
-    int Nb, T; long long* dbg; int presleep;
+    int Nb, T; long long* dbg; int presleep; int skew; int skew_at; int ring_always;
 };
 
 template <int U, int WPB, int KSP, int PROTO>
@@ -344,6 +358,7 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
     for (int s = T - 1, it = 0; s >= 0; --s, ++it) {
         const int dbgi = it;
         DBG_STAMP(0);
+        SKEW_HOOK();
         if (PROTO == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // as in the forward kernel: the four dz stores sit behind the refill
         const bool active = nvalid && s < len;
         const bool has_next = nvalid && (s + 1 < len);
@@ -449,7 +464,7 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
                 // through the FIRST iterations of a tile whose sequences are all shorter than T; it leaves the ring alone, so that a slot never
                 // holds the (zero) payload of a free iteration that a faster workgroup, already at its first polling iteration, could take
                 // for the gradient of four iterations later.  Rows only wait for pieces of iterations in which they were active (has_next).
-                const bool ring_live = __any(active);
+                const bool ring_live = RING_LIVE(active);
                 if (ring_live) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) *(u32x2*)(rdst + g * 512) = p[g];
@@ -557,6 +572,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int s = 0; s < T; ++s) {
         const int dbgi = s;
         DBG_STAMP(0);
+        SKEW_HOOK();
         const bool active = nvalid && s < len;
         const int t = active ? (d == 0 ? s : len - 1 - s) : s;
         const long row = (long)nn * T + t;
@@ -615,7 +631,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (kh == 0) {
                 const f32x4 h = outs[0][lane];
                 const u32x2 hp = {pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
-                const bool ring_live = __any(active);          // a workgroup whose rows are all past their length leaves the ring alone: lstm_fwd_seq_kernel
+                const bool ring_live = RING_LIVE(active);          // a workgroup whose rows are all past their length leaves the ring alone: lstm_fwd_seq_kernel
                 if (ring_live) *(u32x2*)(gring + (unsigned)(s & (RING - 1)) * SLOT + wr0) = hp;               // the hand-off payload goes out FIRST
                 asm volatile("" ::: "memory");
                 if (s >= 2 && ring_live) *(u32x2*)(gring + (unsigned)((s - 2) & (RING - 1)) * SLOT + wr0) = (u32x2){0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -644,7 +660,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 struct LstmSeqFwdXArgs {
     const bf16_t* x; const bf16_t* wxT; const float* bias; const bf16_t* whT; const int* seq_len; bf16_t* hout; float* gates; float* cell;
     unsigned char* ring; int* err;
-    int Nb, T; float forget_bias; long long* dbg; int presleep;
+    int Nb, T; float forget_bias; long long* dbg; int presleep; int skew; int skew_at; int ring_always;
 };
 template <int U, int D>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_seq4x_kernel(LstmSeqFwdXArgs a) {
@@ -711,6 +727,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr bool FIRST = decltype(first_tag)::value;
         const int dbgi = s;
         DBG_STAMP(0);
+        SKEW_HOOK();
         const bool active = nvalid && s < len;
         const int t = active ? (d == 0 ? s : len - 1 - s) : s;
         const long row = (long)nn * T + t;
@@ -785,7 +802,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (kh == 0) {
                 const f32x4 h = outs[0][lane];
                 const u32x2 hp = {pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
-                const bool ring_live = __any(active);          // a workgroup whose rows are all past their length leaves the ring alone: lstm_fwd_seq_kernel
+                const bool ring_live = RING_LIVE(active);          // a workgroup whose rows are all past their length leaves the ring alone: lstm_fwd_seq_kernel
                 if (ring_live) *(u32x2*)(gring + (unsigned)(s & (RING - 1)) * SLOT + wr0) = hp;               // the hand-off payload goes out FIRST
                 asm volatile("" ::: "memory");
                 if (s >= 2 && ring_live) *(u32x2*)(gring + (unsigned)((s - 2) & (RING - 1)) * SLOT + wr0) = (u32x2){0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -864,6 +881,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int s = T - 1, it = 0; s >= 0; --s, ++it) {
         const int dbgi = it;
         DBG_STAMP(0);
+        SKEW_HOOK();
         const bool active = nvalid && s < len;
         const bool has_next = nvalid && (s + 1 < len);
         const int t = active ? (d == 0 ? s : len - 1 - s) : s;
@@ -930,7 +948,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (nvalid) {
             const f32x4 v = outs[kh][lane];
             const u32x2 p = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            const bool ring_live = __any(active);              // a workgroup none of whose rows is inside its sequence yet leaves the ring alone: lstm_bwd_seq_kernel
+            const bool ring_live = RING_LIVE(active);              // a workgroup none of whose rows is inside its sequence yet leaves the ring alone: lstm_bwd_seq_kernel
             if (ring_live) *(u32x2*)(gring + (unsigned)(it & (RING - 1)) * SLOT + wr0) = p;
             asm volatile("" ::: "memory");
             if (it >= 2 && ring_live) *(u32x2*)(gring + (unsigned)((it - 2) & (RING - 1)) * SLOT + wr0) = (u32x2){0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -957,6 +975,20 @@ static long long* g_lstm_dbg = nullptr;
 // test/diagnostic hook: device buffer of 4*T int64 receiving wall-clock stamps of workgroup 0 (NULL = off)
 extern "C" int ocr_lstm_seq_debug(void* dbg) { g_lstm_dbg = (long long*)dbg; return OCR_OK; }
 
+// test hook (SKEW_HOOK above): unit block 0 of every group sleeps `units` x 64 clocks at iteration `at` (every iteration if at < 0) in the launches that
+// follow (units 0 = off, the default)
+static int g_lstm_skew = 0, g_lstm_skew_at = -1;
+extern "C" int ocr_lstm_seq_test_skew(int units, int at) {
+    if (units < 0 || units > 4096) return OCR_ERR_INVALID;
+    g_lstm_skew = units; g_lstm_skew_at = at;
+    return OCR_OK;
+}
+// experiments build only: OCR_LSTM_RING_RULE=always restores the ring rule of rounds 3-4 (RING_LIVE above); the product library always returns 0
+static int seq_ring_always() {
+    static int v = -1;
+    if (v < 0) { const char* e = ocr_tune_env("OCR_LSTM_RING_RULE"); v = (e && e[0] == 'a') ? 1 : 0; }
+    return v;
+}
 // environment knobs are looked up ONCE per process (the launch path runs every step when graphs are off)
 static int seq_env_int(const char* name, int slot, int dflt, bool tuning = false /* read by experiments builds only */) {
     static int val[5], seen[5];
@@ -1062,7 +1094,7 @@ extern "C" int ocr_lstm_fwd_seq2(const float* xproj, const void* whT_packed, con
     }
     LstmSeqFwdArgs a = {xproj, (const bf16_t*)whT_packed, seq_len, (bf16_t*)hout, gates, cell, (unsigned*)sync,
                         (unsigned char*)((unsigned*)sync + cwords), (int*)sync + words - 1, Nb, T, forget_bias, g_lstm_dbg,
-                        seq_env_int("OCR_LSTM_PRESLEEP_F", 0, 0, true)};
+                        seq_env_int("OCR_LSTM_PRESLEEP_F", 0, 0, true), g_lstm_skew, g_lstm_skew_at, seq_ring_always()};
     const dim3 grid3(U / 16, 2, nz), grid1((U / 16) * 8 * ceil_div(2 * nz, 8));
 #define FWD(UU) do { if (proto == 0) launch_fwd<UU, 0>(a, rows, grid3, grid1, stream); \
                      else if (rows == 16 && seq_ksplit() == 4) lstm_fwd_seq4_kernel<UU><<<grid1, 256, 0, stream>>>(a); \
@@ -1097,7 +1129,7 @@ extern "C" int ocr_lstm_bwd_seq2(const void* wh, long ldw, long w_dir_stride, co
     }
     LstmSeqBwdArgs a = {(const bf16_t*)wh, ldw, w_dir_stride, seq_len, (const bf16_t*)dhout, gates, cell, (bf16_t*)dz,
                         (unsigned*)sync, (unsigned char*)((unsigned*)sync + cwords), (int*)sync + words - 1, Nb, T, g_lstm_dbg,
-                        seq_env_int("OCR_LSTM_PRESLEEP", 1, 4, true)};
+                        seq_env_int("OCR_LSTM_PRESLEEP", 1, 4, true), g_lstm_skew, g_lstm_skew_at, seq_ring_always()};
     const dim3 grid3(U / 16, 2, nz), grid1((U / 16) * 8 * ceil_div(2 * nz, 8));
 #define BWD(UU) do { if (proto == 0) launch_bwd<UU, 0>(a, rows, grid3, grid1, stream); \
                      else if (rows == 16 && seq_ksplit() == 4) lstm_bwd_seq4_kernel<UU><<<grid1, 256, 0, stream>>>(a); \
@@ -1136,7 +1168,7 @@ extern "C" int ocr_lstm_fwd_seq_x(const void* x, const void* wxT_packed, const f
     }
     LstmSeqFwdXArgs a = {(const bf16_t*)x, (const bf16_t*)wxT_packed, bias_packed, (const bf16_t*)whT_packed, seq_len, (bf16_t*)hout, gates, cell,
                          (unsigned char*)((unsigned*)sync + cwords), (int*)sync + words - 1, Nb, T, forget_bias, g_lstm_dbg,
-                         seq_env_int("OCR_LSTM_PRESLEEP_F", 0, 0, true)};
+                         seq_env_int("OCR_LSTM_PRESLEEP_F", 0, 0, true), g_lstm_skew, g_lstm_skew_at, seq_ring_always()};
     const dim3 grid1((U / 16) * 8 * ceil_div(2 * nz, 8));
     if (U == 256 && D == 512) lstm_fwd_seq4x_kernel<256, 512><<<grid1, 256, 0, stream>>>(a);
     else if (U == 512 && D == 512) lstm_fwd_seq4x_kernel<512, 512><<<grid1, 256, 0, stream>>>(a);

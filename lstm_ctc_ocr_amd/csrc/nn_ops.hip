@@ -1709,7 +1709,8 @@ extern "C" int ocr_bind_batch(const void* pixels, int pixels_are_u8, float* x, l
 }
 // Everything the training loop reads back after a step, gathered into 4 doubles so that ONE 32-byte D2H copy follows:
 // out[0] = mean per-sample CTC cost (summed in double, fixed order), out[1] = scalars[1] (sum w^2 of the regularised range),
-// out[2] = scalars[7] (global gradient norm), out[3] = bit i set <=> error word i (last int of words[i]) is 1 (the persistent LSTM kernels' time-out mark).
+// out[2] = scalars[7] (global gradient norm), out[3] = bit i set <=> error word i (last int of words[i]) is 1 (the persistent LSTM kernels' time-out mark),
+// bit 40 set <=> the update of this step was dropped on the device (scalars[72]).
 __global__ void step_report_kernel(const float* __restrict__ costs, int n, const double* __restrict__ scalars,
                                    const long long* __restrict__ words, int nwords, double* __restrict__ out) {
     double s = 0.0;
@@ -1722,7 +1723,9 @@ __global__ void step_report_kernel(const float* __restrict__ costs, int n, const
         out[0] = s / (double)n;
         out[1] = scalars ? scalars[1] : 0.0;
         out[2] = scalars ? scalars[7] : 0.0;
-        out[3] = (double)bits;
+        // + 2^40 when THIS step's update was dropped by the guarded optimiser step (scalars[72]: the report is queued right behind the step, so the
+        // word is the step's own — the host decides per step instead of comparing a global counter: ADVICE r5)
+        out[3] = (double)bits + ((scalars && scalars[72] != 0.0) ? 1099511627776.0 : 0.0);
     }
 }
 extern "C" int ocr_step_report(const float* costs, int n, const double* scalars, const void* word_addrs, int nwords, double* out, void* stream) {

@@ -28,9 +28,11 @@
 #define SC_NORM_BINS 8
 #define SC_REG_BINS 40
 // [72] 1 while the running step's update is dropped, [73] number of dropped updates so far (ocr_optim_step_guarded)
+// [74] number of expired hand-off waits the guard has seen so far (error words that read 1; with a drop flag: ranks that raised it)
 #define SC_SKIP 72
 #define SC_SKIPPED 73
-#define SC_TOTAL 74
+#define SC_TIMEOUTS 74
+#define SC_TOTAL 76
 // Round 4, measured and reverted (profiles/r04c_kernel_stats.md): folding the tick into the norm pass — last-arriving block by two-level
 // arrival tickets, __threadfence() between a block's bin atomics and its ticket — made optim_prep_kernel 62.8 us instead of 16.9 (+ 4.9 for
 // the tick launch it saved): a device-scope release fence on this chip writes the XCD's L2 back (the pass has just stored 22 MB of
@@ -40,12 +42,19 @@
 // persistent LSTM launches' error words (a bounded inter-workgroup wait expired: lstm_seq.hip).  The step is then DROPPED on the device:
 // no moment, no parameter and no bias-correction update (the host learns of it from the step report, one step later, and logs it) —
 // before, the garbage gradient was applied and the run died on the report.
-__global__ void optim_tick_kernel(double* sc, double beta1, double beta2, const long long* __restrict__ guard, int nguard) {
+// drop_flag (round 6, data parallel): a float that is > 0 when ANY rank's step reported such a time-out — every rank writes 1.0 / 0.0 into a
+// word that rides at the end of the late gradient bucket (ocr_guard_flag), the SUM all-reduce makes it the number of ranks that raised it, and
+// every rank then drops the SAME step: the replicas stay bit-identical (before: the guard was single-GPU only; with several ranks the garbage
+// gradient was all-reduced and applied everywhere, and the job died on the report one step later).
+__global__ void optim_tick_kernel(double* sc, double beta1, double beta2, const long long* __restrict__ guard, int nguard,
+                                  const float* __restrict__ drop_flag) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        bool bad = false;
-        for (int i = 0; i < nguard; ++i) bad = bad || *(const int*)guard[i] == 1;
+        int nbad = 0;
+        for (int i = 0; i < nguard; ++i) nbad += *(const int*)guard[i] == 1;
+        if (drop_flag) { const float f = *drop_flag; if (f > 0.f) nbad += (int)(f + 0.5f); }
+        const bool bad = nbad > 0;
         sc[SC_SKIP] = bad ? 1.0 : 0.0;
-        if (bad) sc[SC_SKIPPED] += 1.0;
+        if (bad) { sc[SC_SKIPPED] += 1.0; sc[SC_TIMEOUTS] += (double)nbad; }
         else {
             double b1t = sc[SC_B1T] * beta1, b2t = sc[SC_B2T] * beta2;
             sc[SC_B1T] = b1t; sc[SC_B2T] = b2t;
@@ -54,6 +63,14 @@ __global__ void optim_tick_kernel(double* sc, double beta1, double beta2, const 
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < 2 * SC_BINS) sc[SC_NORM_BINS + threadIdx.x] = 0.0;
+}
+// out[0] = 1.0f if any of the nguard int words reads 1, else 0.0f (written EVERY step: the word needs no clearing)
+__global__ void guard_flag_kernel(const long long* __restrict__ guard, int nguard, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        bool bad = false;
+        for (int i = 0; i < nguard; ++i) bad = bad || *(const int*)guard[i] == 1;
+        out[0] = bad ? 1.0f : 0.0f;
+    }
 }
 // totals of the two bin arrays, computed by every block of an update kernel (64 cached loads); block 0 also publishes them
 __device__ __forceinline__ float optim_gnorm(double* sc) {
@@ -186,7 +203,7 @@ __global__ __launch_bounds__(256) void rmsprop_update_kernel(float* __restrict__
 __global__ void optim_init_kernel(double* sc, double lr) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         sc[SC_NORM2] = 0; sc[SC_REG2] = 0; sc[SC_LR] = lr; sc[SC_LRT] = lr; sc[SC_B1T] = 1.0; sc[SC_B2T] = 1.0;
-        sc[SC_STEP] = 0; sc[SC_GNORM] = 0; sc[SC_SKIP] = 0; sc[SC_SKIPPED] = 0;
+        sc[SC_STEP] = 0; sc[SC_GNORM] = 0; sc[SC_SKIP] = 0; sc[SC_SKIPPED] = 0; sc[SC_TIMEOUTS] = 0;
     }
     if (blockIdx.x == 0 && threadIdx.x < 2 * SC_BINS) sc[SC_NORM_BINS + threadIdx.x] = 0.0;
 }
@@ -198,7 +215,7 @@ __global__ void optim_scale_lr_kernel(double* sc, double gamma) {
 }
 
 // ------------------------------------------------------------------------------------------
-// C ABI.  `scalars` is a caller-owned device block of ocr_optim_scalar_count() = 72 doubles (layout above).
+// C ABI.  `scalars` is a caller-owned device block of ocr_optim_scalar_count() doubles (layout above).
 // ------------------------------------------------------------------------------------------
 extern "C" int ocr_optim_scalar_count(void) { return SC_TOTAL; }
 extern "C" int ocr_optim_init(void* scalars, double lr, void* stream) {
@@ -216,19 +233,26 @@ extern "C" int ocr_optim_set_lr(void* scalars, double lr, int multiply, void* st
 }
 // solver: 0 Adam (beta1, beta2, eps), 1 Momentum (beta1 = momentum), 2 RMSProp (beta1 = decay, eps)
 // state1/state2: Adam m, v ; Momentum accumulator (state2 unused) ; RMSProp mean-square (state2 unused)
-extern "C" int ocr_optim_step_guarded(float* params, float* grads, float* state1, float* state2, long n, long reg_begin, long reg_end,
-                                      float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
-                                      void* scalars, const void* guard_addrs, int nguard, void* stream_);
+extern "C" int ocr_optim_step_guarded2(float* params, float* grads, float* state1, float* state2, long n, long reg_begin, long reg_end,
+                                       float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
+                                       void* scalars, const void* guard_addrs, int nguard, const float* drop_flag, void* stream_);
 extern "C" int ocr_optim_step(float* params, float* grads, float* state1, float* state2, long n, long reg_begin, long reg_end,
                               float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
                               void* scalars, void* stream_) {
-    return ocr_optim_step_guarded(params, grads, state1, state2, n, reg_begin, reg_end, weight_decay, clip_norm, solver, beta1, beta2, eps, scalars,
-                                  nullptr, 0, stream_);
+    return ocr_optim_step_guarded2(params, grads, state1, state2, n, reg_begin, reg_end, weight_decay, clip_norm, solver, beta1, beta2, eps, scalars,
+                                   nullptr, 0, nullptr, stream_);
 }
 // ... with a guard: guard_addrs = device array of nguard device addresses of int words; the update is dropped when any of them reads 1
 extern "C" int ocr_optim_step_guarded(float* params, float* grads, float* state1, float* state2, long n, long reg_begin, long reg_end,
                                       float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
                                       void* scalars, const void* guard_addrs, int nguard, void* stream_) {
+    return ocr_optim_step_guarded2(params, grads, state1, state2, n, reg_begin, reg_end, weight_decay, clip_norm, solver, beta1, beta2, eps, scalars,
+                                   guard_addrs, nguard, nullptr, stream_);
+}
+// ... and / or with a drop flag: a device float, > 0 => drop (data parallel: the all-reduced ocr_guard_flag word)
+extern "C" int ocr_optim_step_guarded2(float* params, float* grads, float* state1, float* state2, long n, long reg_begin, long reg_end,
+                                       float weight_decay, float clip_norm, int solver, float beta1, float beta2, float eps,
+                                       void* scalars, const void* guard_addrs, int nguard, const float* drop_flag, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (nguard < 0 || nguard > 64 || (nguard && !guard_addrs)) return OCR_ERR_INVALID;
     if (!params || !grads || !state1 || !scalars || n <= 0 || (n & 3) || (reg_begin & 3) || (reg_end & 3) || reg_begin < 0 ||
@@ -236,7 +260,7 @@ extern "C" int ocr_optim_step_guarded(float* params, float* grads, float* state1
         return OCR_ERR_INVALID;
     if (solver == 0 && !state2) return OCR_ERR_INVALID;
     double* sc = (double*)scalars;
-    optim_tick_kernel<<<1, 64, 0, stream>>>(sc, (double)beta1, (double)beta2, (const long long*)guard_addrs, nguard);
+    optim_tick_kernel<<<1, 64, 0, stream>>>(sc, (double)beta1, (double)beta2, (const long long*)guard_addrs, nguard, drop_flag);
     OCR_CHECK_LAUNCH();
     int blocks = (int)((n / 4 + 255) / 256); if (blocks > 2048) blocks = 2048;
     int pblocks = blocks > 1024 ? 1024 : blocks;       // the atomics at the end go to 32 bins, see SC_BINS
@@ -247,6 +271,14 @@ extern "C" int ocr_optim_step_guarded(float* params, float* grads, float* state1
     else if (solver == 1) momentum_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, n, beta1, clip_norm, sc, r0, r1, weight_decay);
     else if (solver == 2) rmsprop_update_kernel<<<blocks, 256, 0, stream>>>(params, grads, state1, n, beta1, eps, clip_norm, sc, r0, r1, weight_decay);
     else return OCR_ERR_INVALID;
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}
+// flag_out[0] := 1.0f if any of the nguard int words (device addresses in guard_addrs) reads 1, else 0.0f — the word a data-parallel rank appends to
+// its late gradient bucket so that the SUM all-reduce tells every rank whether ANY rank's persistent LSTM launch timed out in this step
+extern "C" int ocr_guard_flag(const void* guard_addrs, int nguard, float* flag_out, void* stream) {
+    if (nguard < 0 || nguard > 64 || (nguard && !guard_addrs) || !flag_out) return OCR_ERR_INVALID;
+    guard_flag_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const long long*)guard_addrs, nguard, flag_out);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }

@@ -1062,8 +1062,15 @@ class Engine(object):
         self.split_layer, self.reg_range, self.late_begin = lay.split_layer, lay.reg_range, lay.late_begin
         dev = self.device
         self.params = torch.zeros(self.n_total, dtype=F32, device=dev)
-        self.grads = torch.zeros(self.n_total, dtype=F32, device=dev)
+        # the gradient buffer has a hidden tail of GUARD_PAD floats behind the n_total gradients: word 0 of it is the data-parallel DROP FLAG (1.0 when
+        # a persistent LSTM launch of this rank's step timed out, ocr_guard_flag); it rides at the end of the late bucket's all-reduce, so after
+        # the exchange it is > 0 on EVERY rank iff any rank raised it, and every rank's optimiser launch drops the same step (_optim_body)
+        self._grads_store = torch.zeros(self.n_total + self.GUARD_PAD, dtype=F32, device=dev)
+        self.grads = self._grads_store[:self.n_total]
+        self.drop_flag = self._grads_store[self.n_total:self.n_total + 1]
         self.params_bf16 = torch.zeros(self.n_total, dtype=BF16, device=dev)
+
+    GUARD_PAD = 64         # floats behind the gradients (256 B: the exchanged range stays 256-B granular)
 
     def offset(self, name):
         return self.offsets[name]
@@ -1440,6 +1447,7 @@ class Engine(object):
         def body1():
             self._forward(sp, training=True)
             self._loss_and_backward(sp)
+            self._publish_guard(sp)
 
         def body2():
             self._backward_early(sp)
@@ -1484,6 +1492,7 @@ class Engine(object):
             if which == 'fb':
                 self._loss_and_backward(sp, flush=False)
                 self._backward_early(sp)
+                self._publish_guard(sp)
 
         if not self.use_graphs:
             body()
@@ -1531,7 +1540,6 @@ class Engine(object):
         self.state1 = torch.ones_like(self.params) if self.solver == 2 else torch.zeros_like(self.params)
         self.state2 = torch.zeros_like(self.params) if self.solver == 0 else None
         self.scalars.zero_()                             # in place: captured graphs keep pointing at it
-        self._dropped_seen = 0                           # host mirror of scalars[73] (steps dropped by the guarded optimiser step)
         ops.optim_init(self.scalars, self.lr)
         self.opt_ready = True
         self.graph_opt = None                            # captured optimiser graphs hold the old slot tensors
@@ -1542,17 +1550,38 @@ class Engine(object):
         ops.optim_set_lr(self.scalars, gamma, multiply=True)
         self.lr *= gamma
 
-    def _guard(self, sp):
-        """Device addresses of the plan's persistent-LSTM error words for ocr_optim_step_guarded: a hand-off time-out inside the step drops the
-        step's update on the device instead of applying a garbage gradient (the report, one step later, logs it: report_wait).  Single GPU
-        only: with several ranks every replica would have to drop the same step — there the report raises as before."""
-        if sp is None or self.world > 1 or self.force_allreduce or os.environ.get('OCR_LSTM_TIMEOUT_GUARD', '1') == '0':
+    def _guard_on(self):
+        return os.environ.get('OCR_LSTM_TIMEOUT_GUARD', '1') != '0'
+
+    def _dp(self):
+        return self.world > 1 or self.force_allreduce
+
+    def _guard_addrs(self, sp):
+        """Device addresses of the plan's persistent-LSTM error words (None: the plan has no persistent launch)."""
+        if sp is None:
             return None
         g = getattr(sp, '_guard_addrs', None)
         if g is None:
             words = getattr(sp, 'lstm_sync', ())
             g = sp._guard_addrs = (torch.tensor([w[-1:].data_ptr() for w in words], dtype=torch.int64, device=self.device) if words else False)
         return g if g is not False else None
+
+    def _guard(self, sp):
+        """Single GPU: the error words themselves guard the update — a hand-off time-out inside the step drops the step's update on the device
+        instead of applying a garbage gradient (ocr_optim_step_guarded2; the report, one step later, logs it: report_wait).  With several ranks
+        every replica has to drop the SAME step: there the words are folded into the drop flag that rides on the late bucket (_publish_guard)."""
+        if sp is None or self._dp() or not self._guard_on():
+            return None
+        return self._guard_addrs(sp)
+
+    def _publish_guard(self, sp):
+        """Data parallel: one tiny launch at the end of the backward graph that holds the LSTM (both error words are final there) writes this
+        rank's 1.0 / 0.0 into the drop flag — the word right behind the late bucket, which the all-reduce that follows sums over the ranks."""
+        hook = getattr(self, '_fault_hook', None)          # fault injection (tests): runs between the LSTM launches and the flag launch
+        if hook is not None:
+            hook(sp)
+        if self._dp() and self._guard_on():
+            ops.guard_flag(self._guard_addrs(sp), self.drop_flag)
 
     def _optim_body(self, sp=None):
         c = self.cfg.TRAIN
@@ -1563,12 +1592,13 @@ class Engine(object):
         else:
             b1, b2, eps = 0.9, 0.0, 1e-10
         ops.optim_step(self.params, self.grads, self.state1, self.state2, self.reg_range, float(c.WEIGHT_DECAY), 10.0,
-                       self.solver, b1, b2, eps, self.scalars, guard=self._guard(sp))
+                       self.solver, b1, b2, eps, self.scalars, guard=self._guard(sp),
+                       drop_flag=self.drop_flag if (self._dp() and self._guard_on()) else None)
         self.refresh_weights()
 
     def optimizer_step(self, sp=None):
-        """sp: the plan whose backward pass produced the gradients — its LSTM error words guard the update when the step runs eagerly
-        (the shared optimiser graph of the multi-graph schedules is plan-independent and unguarded)."""
+        """sp: the plan whose backward pass produced the gradients — its LSTM error words guard the update when the step runs eagerly on one GPU
+        (the shared optimiser graph of the multi-graph schedules is plan-independent: it is guarded by the exchanged drop flag)."""
         if not self.opt_ready:
             self.setup_optimizer()
         if not self.use_graphs:
@@ -1585,8 +1615,10 @@ class Engine(object):
         clip then sees the same global norm a single GPU would see at the global batch size."""
         if self.world > 1 or self.force_allreduce:
             hi = self.n_total if hi is None else hi
+            if hi == self.n_total and self._guard_on():
+                hi += self.GUARD_PAD              # the range that ends the buffer carries the drop flag (_publish_guard)
             if hi > lo:
-                ocr_dist.allreduce_sum_(self.grads[lo:hi], self.group, force=self.force_allreduce)
+                ocr_dist.allreduce_sum_(self._grads_store[lo:hi], self.group, force=self.force_allreduce)
 
     def train_step(self, data, labels, labels_len, seq_len, fetch_loss=True):
         """One optimisation step on a batch laid out as gen.py:41-67 produces it.  Returns the total loss
@@ -1692,20 +1724,31 @@ class Engine(object):
         reg = 0.5 * float(self.cfg.TRAIN.WEIGHT_DECAY) * reg2 if (self.cfg.TRAIN.WEIGHT_DECAY > 0 and opt_ready) else 0.0
         if update_mirrors:
             self.last_ctc, self.last_reg, self.last_gnorm = ctc, reg, gnorm if opt_ready else 0.0
-        if bits != 0.0:
-            bad = [i for i in range(len(words)) if (int(bits) >> i) & 1]
-            # was the step's update dropped on the device (guarded optimiser step)?  scalars[73] counts the dropped steps: one blocking read on
-            # this rare path.  Then the parameters are intact and training goes on; the reported loss of that step is meaningless.
-            dropped = int(self.scalars[73].item()) if (opt_ready and self.scalars.numel() > 73) else 0
-            if dropped > getattr(self, '_dropped_seen', 0):
-                self._dropped_seen = dropped
-                import sys
-                sys.stderr.write('[engine] WARNING: persistent LSTM %s kernel reported an expired inter-workgroup wait; that step\'s update was '
-                                 'dropped on the device (%d dropped so far), parameters intact\n' % (('forward', 'backward')[bad[0] % 2], dropped))
-                return float('nan')
+        bits = int(bits)
+        dropped, bits = bool(bits >> 40 & 1), bits & 0xFFFFFFFF
+        if dropped:
+            # THIS step's update was dropped on the device (the step's own scalars[72], exported by the report kernel — not a comparison of the global
+            # counter: a second report covering the same step, or two dropped steps in a row, used to raise — ADVICE r5): parameters and moments are
+            # intact on every rank, training goes on; the reported loss of that step is meaningless.  bits == 0 here means ANOTHER rank timed out.
+            self.dropped_reports = getattr(self, 'dropped_reports', 0) + 1
+            bad = [i for i in range(len(words)) if (bits >> i) & 1]
+            import sys
+            sys.stderr.write('[engine] WARNING: %s reported an expired inter-workgroup wait; that step\'s update was dropped on the device%s, parameters intact\n'
+                             % (('the persistent LSTM %s kernel' % ('forward', 'backward')[bad[0] % 2]) if bad else 'another rank\'s persistent LSTM kernel',
+                                ' on every rank' if self._dp() else ''))
+            return float('nan')
+        if bits != 0:
+            bad = [i for i in range(len(words)) if (bits >> i) & 1]
             # the sync block = group counters (64-word stride, at most 2 * ceil(N / 16) of them) | hand-off ring | error word: print the
             # counters only (the ring is hundreds of thousands of 0xFFFFFFFF words)
             w = words[bad[0]]
             raise NativeError('persistent LSTM %s kernel: inter-workgroup wait timed out (results invalid); group counters %s, error word %d'
                               % (('forward', 'backward')[bad[0] % 2], w[:64 * 16:64].tolist(), int(w[-1])))
         return ctc + reg
+
+    def guard_counters(self):
+        """(steps dropped by the guarded optimiser step, expired hand-off waits it saw) since setup_optimizer — two device doubles, one blocking read."""
+        if not self.opt_ready:
+            return 0, 0
+        v = self.scalars[73:75].cpu().numpy()
+        return int(v[0]), int(v[1])

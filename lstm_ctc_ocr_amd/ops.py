@@ -472,7 +472,7 @@ def bind_batch(pixels, x, seq_len, seq_len_dst, labels=None, labels_dst=None, la
 
 
 def step_report(costs, scalars, word_addrs, out):
-    """out[0..3] (double) = mean cost, scalars[1], scalars[7], bit mask of non-zero error words (see ocr_step_report)."""
+    """out[0..3] (double) = mean cost, scalars[1], scalars[7], bit mask of the error words that read 1 (+ 2^40: this step's update was dropped) — ocr_step_report."""
     nw = 0 if word_addrs is None else word_addrs.numel()
     call("ocr_step_report", ptr(_dev(costs)), costs.numel(), ptr(scalars), ptr(word_addrs) if nw else None, nw, ptr(out), _st())
     return out
@@ -508,6 +508,12 @@ def lstm_bwd_step(wh, ldw, w_dir_stride, seq_len, dhout, gates, cell, dz, dc_sta
 def set_lstm_ksplit(waves):
     """Waves per workgroup of the persistent LSTM kernels (4: default since round 4; 1: the one-wave kernels).  OCR_LSTM_KSPLIT wins."""
     call("ocr_set_lstm_ksplit", int(waves))
+
+
+def lstm_seq_test_skew(units, at=-1):
+    """Test hook: unit block 0 of every group of the persistent LSTM launches that follow sleeps units x 64 clocks at iteration `at` (< 0: every
+    iteration; units 0: off)."""
+    call("ocr_lstm_seq_test_skew", int(units), int(at))
 
 
 def lstm_seq_supported(Nb, U):
@@ -567,9 +573,16 @@ def optim_set_lr(scalars, lr, multiply=False):
     call("ocr_optim_set_lr", ptr(_dev(scalars)), float(lr), int(multiply), _st())
 
 
-def optim_step(params, grads, state1, state2, reg_range, weight_decay, clip_norm, solver, beta1, beta2, eps, scalars, guard=None):
+def optim_step(params, grads, state1, state2, reg_range, weight_decay, clip_norm, solver, beta1, beta2, eps, scalars, guard=None, drop_flag=None):
     """reg_range = (begin, end) of the L2-regularised tensors inside the flat buffer.  guard: device int64 tensor of addresses of int words
-    that read 1 when a kernel of the step reported invalid results — the update is then dropped on the device (ocr_optim_step_guarded)."""
-    call("ocr_optim_step_guarded", ptr(_dev(params)), ptr(grads), ptr(state1), ptr(state2), params.numel(), int(reg_range[0]), int(reg_range[1]),
+    that read 1 when a kernel of the step reported invalid results — the update is then dropped on the device; drop_flag: a device float, > 0 =>
+    drop (data parallel: the all-reduced guard_flag word, so every rank drops the same step) — ocr_optim_step_guarded2."""
+    call("ocr_optim_step_guarded2", ptr(_dev(params)), ptr(grads), ptr(state1), ptr(state2), params.numel(), int(reg_range[0]), int(reg_range[1]),
          float(weight_decay), float(clip_norm), solver, float(beta1), float(beta2), float(eps), ptr(scalars),
-         ptr(guard) if guard is not None else None, 0 if guard is None else int(guard.numel()), _st())
+         ptr(guard) if guard is not None else None, 0 if guard is None else int(guard.numel()),
+         ptr(drop_flag) if drop_flag is not None else None, _st())
+
+
+def guard_flag(guard, out):
+    """out[0] (device float) := 1.0 if any of the int words whose addresses `guard` holds reads 1, else 0.0 (ocr_guard_flag)."""
+    call("ocr_guard_flag", ptr(guard) if guard is not None else None, 0 if guard is None else int(guard.numel()), ptr(_dev(out)), _st())

@@ -49,7 +49,29 @@ def main():
     params = eng.params.clone().cpu()
     theirs = [torch.zeros_like(params) for _ in range(2)]
     dist.all_gather(theirs, params)
-    np.savez(out, losses=np.array(losses), exchanged=exchanged.numpy(), sum_local=(both[0] + both[1]).numpy(),
+    # fault injection on ONE rank (VERDICT r5 #1c): rank 0's backward LSTM launch "times out" in the next step.  The word rides on the late bucket's
+    # all-reduce, BOTH replicas drop the step (parameters, moments, step count untouched), both reports say so, and training goes on bit-identically.
+    eng.use_graphs = False                              # the hook below runs between the LSTM launches and the flag launch (eager bodies)
+    if rank == 0:
+        eng._fault_hook = lambda sp_: sp_.lstm_sync[1][-1:].fill_(1)
+    before, m1 = eng.params.clone(), eng.state1.clone()
+    steps_before = float(eng.scalars[6])
+    b = batches[1]
+    fault_loss = eng.train_step(b[0], b[1], b[2], b[3])
+    eng._fault_hook = None
+    torch.cuda.synchronize()
+    fault_unchanged = bool(torch.equal(eng.params, before) and torch.equal(eng.state1, m1) and float(eng.scalars[6]) == steps_before)
+    fault_counters = eng.guard_counters()
+    b = batches[2]
+    post_loss = eng.train_step(b[0], b[1], b[2], b[3])
+    torch.cuda.synchronize()
+    post_params = eng.params.clone().cpu()
+    post_theirs = [torch.zeros_like(post_params) for _ in range(2)]
+    dist.all_gather(post_theirs, post_params)
+    np.savez(out, fault_loss=float(fault_loss), fault_unchanged=fault_unchanged, fault_dropped=fault_counters[0], fault_timeouts=fault_counters[1],
+             post_loss=float(post_loss), post_changed=bool(not torch.equal(post_params, before.cpu())),
+             post_replicas_equal=bool(torch.equal(post_theirs[0], post_theirs[1])), post_steps=float(eng.scalars[6]) - steps_before,
+             losses=np.array(losses), exchanged=exchanged.numpy(), sum_local=(both[0] + both[1]).numpy(),
              local_differs=float((both[0] - both[1]).abs().max()), replicas_equal=bool(torch.equal(theirs[0], theirs[1])),
              params=params.numpy(), late_begin=eng.late_begin, n_total=eng.n_total)
     dist.barrier()

@@ -50,6 +50,13 @@ def test_two_ranks_exchange_the_sum_of_their_local_gradients_and_stay_identical(
         assert bool(r0['replicas_equal']) and bool(r1['replicas_equal'])
         assert np.array_equal(r0['params'], r1['params'])
         assert np.all(np.isfinite(r0['losses'])) and not np.allclose(r0['losses'], r1['losses'])     # local losses differ
+        # a time-out injected on rank 0 ONLY: both replicas dropped that step (nothing moved, NaN reported on both), counted it once, took the next
+        # step normally and are still bit-identical (the drop flag rides on the late bucket: engine._publish_guard, ocr_optim_step_guarded2)
+        for r in (r0, r1):
+            assert bool(r['fault_unchanged']) and np.isnan(float(r['fault_loss'])), ov
+            assert int(r['fault_dropped']) == 1 and int(r['fault_timeouts']) == 1, ov
+            assert np.isfinite(float(r['post_loss'])) and bool(r['post_changed']) and float(r['post_steps']) == 1.0, ov
+            assert bool(r['post_replicas_equal']), ov
     # overlapped two-bucket schedule == plain one-exchange schedule (same sums; atomics order noise only)
     a, b = res['1'][0]['params'], res['0'][0]['params']
     assert float(np.abs(a - b).max()) < 5e-3 and float(np.abs(a - b).mean()) < 2e-5

@@ -376,9 +376,25 @@ def test_lstm_handoff_timeout_drops_the_update_instead_of_applying_it(dev, capsy
     eng.last_plan = sp
     v = eng.report_wait(eng.report_async())
     assert np.isnan(v) and 'dropped on the device' in capsys.readouterr().err
+    # a SECOND report that covers the same dropped step (the every-64-steps watchdog's, queued by train_step beside the loop's own) is a NaN too —
+    # the decision is the step's own scalars[72], exported by the report kernel, not a comparison of the global counter
+    assert np.isnan(eng.report_wait(eng.report_async(_slot='watch'), update_mirrors=False))
     l2 = eng.train_step(x, labels, ll, sl)                   # the next step is a normal one
     assert np.isfinite(l2) and float(eng.scalars[6]) == 2.0 and float(eng.scalars[72]) == 0.0 and float(eng.scalars[73]) == 1.0
     assert not torch.equal(eng.params, before)
+    # two dropped steps in a row, their reports read one step late (OCR_LOSS_LAG = 1): each is its own step's
+    handles = []
+    for word in (0, 1):
+        eng._bind(sp, x, sl, labels, ll)
+        eng._run(sp, 'fb')
+        sp.lstm_sync[word][-1] = 1
+        eng.optimizer_step(sp)
+        eng.last_plan = sp
+        handles.append(eng.report_async())
+    assert all(np.isnan(eng.report_wait(h)) for h in handles)
+    assert eng.guard_counters() == (3, 3) and float(eng.scalars[6]) == 2.0
+    l3 = eng.train_step(x, labels, ll, sl)
+    assert np.isfinite(l3) and float(eng.scalars[6]) == 3.0
     # without the guard (several ranks, or OCR_LSTM_TIMEOUT_GUARD=0) the report raises as before
     sp.lstm_sync[1][-1] = 1
     eng.last_plan = sp

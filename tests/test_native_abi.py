@@ -41,8 +41,11 @@ def test_status_codes_and_host_side_validation():
     assert lib.ocr_ctc_loss(None, None, None, None, None, 64, 64, 63, 10, 0, None, None, None) == 2
     assert lib.ocr_gemm_nt_bf16(None, 0, None, 0, None, 0, 8, 8, 8, None, None, 0, 0, 1, 0, 0, 0, 0, None) == 2
     f = ctypes.c_float
-    assert lib.ocr_optim_scalar_count() == 74
+    assert lib.ocr_optim_scalar_count() == 76
     assert lib.ocr_optim_step_guarded(None, None, None, None, 16, 0, 16, f(0.0), f(10.0), 0, f(0.9), f(0.999), f(1e-8), None, None, 0, None) == 2
+    assert lib.ocr_optim_step_guarded2(None, None, None, None, 16, 0, 16, f(0.0), f(10.0), 0, f(0.9), f(0.999), f(1e-8), None, None, 0, None, None) == 2
+    assert lib.ocr_guard_flag(None, 1, None, None) == 2 and lib.ocr_guard_flag(None, 0, None, None) == 2
+    assert lib.ocr_lstm_seq_test_skew(-1, -1) == 2 and lib.ocr_lstm_seq_test_skew(0, -1) == 0
     assert lib.ocr_occupy_cus(0, 256, 0, ctypes.c_float(10.0), None) == 2 and lib.ocr_occupy_cus(8, 2048, 0, ctypes.c_float(10.0), None) == 2
     assert lib.ocr_occupy_cus(8, 256, 161 * 1024, ctypes.c_float(10.0), None) == 2 and lib.ocr_occupy_cus(8, 256, 0, ctypes.c_float(-1.0), None) == 2
     assert lib.ocr_lstm_seq_supported(64, 256) == 1 and lib.ocr_lstm_seq_supported(64, 128) == 0
