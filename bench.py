@@ -91,6 +91,7 @@ def conv_roofline(eng, device, workload):
             dgrad_bnb = bool(getattr(sp, 'bn_bwd_rows', {}).get(op.prev.key, 0)) if hasattr(op, 'wdgrad') else False
             shapes.append((N, W, H, Ci, op.co, hasattr(op, 'wdgrad'), pool, fwd_stats, dgrad_bnb))
     tot_fl, exe_fl, tot_t, n_launch = 0.0, 0.0, 0.0, 0
+    per_launch = []               # one record per launch: what, kernel, K steps, us, fraction of peak, stamped clock, matrix-pipe occupancy at that clock
     plain_t = 0.0                 # the same launches with the batch-norm work taken out of their write-outs again (secondary figure)
     # shader clock the kernel really runs at: workgroup 0 stamps {shader-clock counter, 100 MHz wall clock} at entry and exit
     from lstm_ctc_ocr_amd import _native as nat
@@ -144,15 +145,49 @@ def conv_roofline(eng, device, workload):
                 fn()
             e1.record()
             torch.cuda.synchronize()
-            tot_t += e0.elapsed_time(e1) * 1e-3 / 10
-            plain_t += plain_dt if fi in plain else e0.elapsed_time(e1) * 1e-3 / 10
-            tot_fl += 2.0 * N * W * H * 9 * Ci * Co
-            exe_fl += 2.0 * N * W * H * 9 * Ci * Co * ((1.0 - 2.0 / (3.0 * H)) if kname.startswith("conv_k3") else 1.0)
+            dt_l = e0.elapsed_time(e1) * 1e-3 / 10
+            tot_t += dt_l
+            plain_t += plain_dt if fi in plain else dt_l
+            fl_l = 2.0 * N * W * H * 9 * Ci * Co
+            ex_l = fl_l * ((1.0 - 2.0 / (3.0 * H)) if kname.startswith("conv_k3") else 1.0)
+            tot_fl += fl_l
+            exe_fl += ex_l
             n_launch += 1
             c = clk.cpu().numpy()                       # last of the ten back-to-back launches
+            mhz_l = None
             if c[3] > c[1]:
                 clk_cycles += float(c[2] - c[0]); clk_ticks += float(c[3] - c[1])
+                mhz_l = float(c[2] - c[0]) / float(c[3] - c[1]) * 100.0
+            cin_l = Ci if fi == 0 else Co               # contraction channels of this launch (the data gradient contracts over C_out)
+            per_launch.append({"what": "%dx%dx%d %d->%d %s" % (N, W, H, Ci, Co, "forward" if fi == 0 else "data gradient"), "kernel": kname,
+                               "k_steps": 9 * cin_l // 64, "us": dt_l * 1e6, "gflop": fl_l / 1e9, "frac": fl_l / dt_l / MFMA_BF16_PEAK,
+                               "shader_clock_mhz": mhz_l,
+                               "executed_frac_of_peak_at_that_clock": (ex_l / dt_l / (MFMA_BF16_PEAK * mhz_l / PEAK_CLOCK_MHZ)) if mhz_l else None,
+                               "_exe": ex_l, "_cout": Co if fi == 0 else Ci, "_m": N * W * H})
     nat.call("ocr_conv_halo_clock_debug", None)
+    # Two-point decomposition t = fixed + k_steps x per_step for every kernel instance that runs at two depths on the same output tile grid
+    # (conv3_1 / conv3_2 forward on conv_k3/A at H = 8: 18 and 36 steps; conv4_1 / conv4_2 forward at H = 4: 36 and 72; ...): the fixed cost per
+    # launch (dispatch, prologue, K-half exchange, write-out) and the K loop's matrix-pipe occupancy at the stamped clock — the three factors of
+    # DESIGN section 9 (loop occupancy x non-fixed share x clock / 2400), per launch instead of argued.
+    groups = {}
+    for r in per_launch:
+        groups.setdefault((r["kernel"], r["what"].split(" ")[0], r["_cout"], r["what"].endswith("forward")), []).append(r)
+    for key, rs in groups.items():
+        ks = sorted(set(r["k_steps"] for r in rs))
+        if len(rs) == 2 and len(ks) == 2:
+            a, b = sorted(rs, key=lambda r: r["k_steps"])
+            per_step = (b["us"] - a["us"]) / (b["k_steps"] - a["k_steps"])
+            fixed = a["us"] - a["k_steps"] * per_step
+            for r in (a, b):
+                mhz_r = r["shader_clock_mhz"]
+                # executed MFMA clocks per K step and SIMD: executed flop of the launch / steps / (1024 SIMDs x 1024 flop per clock)
+                mfma_clk = r["_exe"] / r["k_steps"] / (1024.0 * 1024.0)
+                r["two_point"] = {"fixed_us": fixed, "per_k_step_us": per_step, "non_fixed_share": 1.0 - fixed / r["us"],
+                                  "loop_mfma_occupancy_at_clock": (mfma_clk / (per_step * mhz_r)) if (mhz_r and per_step > 0) else None,
+                                  "clock_over_2400": (mhz_r / PEAK_CLOCK_MHZ) if mhz_r else None}
+    for r in per_launch:
+        for k in ("_exe", "_cout", "_m"):
+            r.pop(k)
     ach = tot_fl / tot_t
     mhz = clk_cycles / clk_ticks * 100.0 if clk_ticks else None
     # HBM bytes per launch and matrix-pipe occupancy of the same kernels from the separate rocprofv3 --pmc passes over THIS script
@@ -206,6 +241,7 @@ def conv_roofline(eng, device, workload):
             "executed_flop_frac": exe_fl / tot_fl, "achieved_executed": exe_fl / tot_t / 1e12,
             "executed_note": "`achieved` counts 2*M*K*N of every launch (SURVEY 8d) including the SAME-padding taps the plane-layout kernels "
                              "(conv_k3 / conv_k3w) never issue: 2/(3H) of a layer's MFMAs (H=4: a sixth); `achieved_executed` counts only issued MFMAs",
+            "per_launch": per_launch,
             "traffic": traffic, "mfma_busy_frac": mfma_busy, "pmc_shader_clock_mhz": pmc_own_clock,
             "mfma_busy_frac_grbm_window_lower_bound": mfma_window, "pmc_grbm_window_clock_mhz": pmc_clock, "pmc_avg_launch_us": pmc_avg_us, "pmc_commit": pmc_commit, "pmc_build_id": pmc_build, "build_id": build_id,
             "build_commit": build_commit, "pmc_error": pmc_error,
@@ -221,6 +257,93 @@ def conv_roofline(eng, device, workload):
                             "cycles are exact (16 per issued MFMA: profiles/r04_mfma_busy_calibration.md).  mfma_busy_frac_grbm_window_lower_bound divides "
                             "by GRBM_GUI_ACTIVE / 8 instead — the window of a profiled 20-60 us dispatch is longer than the kernel "
                             "(pmc_grbm_window_clock_mhz = window / duration reads above the chip's 2400 MHz), kept for continuity with rounds 3-4 only" % src}
+
+
+def wgrad_roofline(eng, device, workload):
+    """The OTHER third of the convolution MFMA work: the 3x3 weight gradients of the timed workload (tf.gradients of network.py:166 at
+    train.py:81), launched as the step launches them — one slab kernel per layer (wgrad9p / wgrad9, deferred form) in backward order and the merged
+    slab reductions wherever the engine's flush policy puts them (OCR_W9_FLUSH_MB) — timed as ONE sequence with HIP events on the launch stream.
+    achieved = sum 2 M 9 C_in C_out / time of the whole sequence, reductions included (they compute nothing and are charged to the family)."""
+    from lstm_ctc_ocr_amd import ops
+    from lstm_ctc_ocr_amd import _native as nat
+    sp = max(eng.plans.values(), key=lambda p: p.W)
+    layers = []
+    for op in reversed(eng.ops):                    # backward order
+        if getattr(op, 'kind', None) == '3x3':
+            (N, W, H, Ci), _ = sp.shape[op.key]
+            need = ops.conv3x3_wgrad_workspace_bytes(N, W, H, Ci, op.co)
+            if need:
+                layers.append((N, W, H, Ci, op.co, need))
+    if not layers:
+        return None
+    bufs = []
+    for (N, W, H, Ci, Co, need) in layers:
+        bufs.append((torch.randn(N, W, H, Ci, device=device).to(torch.bfloat16), (torch.randn(N, W, H, Co, device=device) * 0.1).to(torch.bfloat16),
+                     torch.zeros(3, 3, Ci, Co, device=device), torch.zeros(Co, device=device), torch.empty(need, dtype=torch.uint8, device=device)))
+    tables = {}
+
+    def flush(pend):
+        raw = b''.join(j for j, _ in pend)
+        ent = tables.get(raw)
+        if ent is None:
+            tab = np.frombuffer(raw, dtype=eng.W9_JOB_DTYPE).copy()
+            start = 0
+            for i, (_, nblk) in enumerate(pend):
+                tab['block_start'][i] = start
+                start += nblk
+            ent = tables[raw] = (torch.from_numpy(tab.view(np.uint8).copy()).to(device), len(pend), start)
+        ops.wgrad9_reduce_jobs(*ent)
+
+    counts = {"slab_kernels": 0, "reductions": 0}
+
+    def sequence(count=False):
+        pend, pbytes = [], 0
+        for (x, dy, dw, db, ws) in bufs:
+            job, nblk = ops.conv3x3_wgrad_deferred(x, dy, dw, db, ws)
+            if count:
+                counts["slab_kernels"] += 1
+            if job is None:
+                continue
+            pend.append((job, nblk)); pbytes += ws.numel()
+            if eng.w9_flush_bytes and pbytes >= eng.w9_flush_bytes:
+                flush(pend); pend, pbytes = [], 0
+                if count:
+                    counts["reductions"] += 1
+        if pend:
+            flush(pend)
+            if count:
+                counts["reductions"] += 1
+
+    sequence(count=True)
+    for _ in range(2):
+        sequence()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        sequence()
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / 10
+    fl = sum(2.0 * N * W * H * 9 * Ci * Co for (N, W, H, Ci, Co, _) in layers)
+    slab_mb = sum(need for (*_, need) in layers) / 1e6
+    nl = counts["slab_kernels"] + counts["reductions"]
+    traffic = pmc_us = src = None
+    path, pm = pick_pmc_summary(os.path.join(ROOT, "profiles"), workload, nat.build_id())
+    if pm is not None and pm.get("workload") == workload and pm.get("build_id") == nat.build_id():
+        ks = [k for k in pm.get("kernels", []) if k["symbol"].startswith(("_Z14wgrad9p_kernel", "_Z13wgrad9_kernel", "_Z25wgrad9_reduce_jobs_kernel"))]
+        steps = max(1, min(k["launches"] for k in ks)) if ks else 1
+        if ks and all("read_mb" in k and "write_mb" in k for k in ks):
+            per_step_launches = sum(k["launches"] for k in ks) / float(steps)
+            traffic = sum(k["launches"] * (k["read_mb"] + k["write_mb"]) for k in ks) / float(steps) / per_step_launches * 1e6
+            pmc_us = sum(k["launches"] * k["avg_us"] for k in ks) / float(steps)
+            src = os.path.basename(path)
+    return {"kernel": "wgrad9p_kernel / wgrad9_kernel + wgrad9_reduce_jobs_kernel (3x3 weight gradients: %d slab launches + %d merged slab reductions per step)"
+                      % (counts["slab_kernels"], counts["reductions"]),
+            "achieved": fl / t / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / t / MFMA_BF16_PEAK,
+            "avg_launch_us": t / nl * 1e6, "sequence_us": t * 1e6, "launches": nl, "algorithmic_gflop": fl / 1e9,
+            "slab_mb_written_and_read_back": slab_mb, "traffic": traffic, "pmc_sequence_us_in_the_step": pmc_us, "pmc_source": src,
+            "note": "timed stand-alone, back to back, on random operands of the timed plan's shapes; `traffic` = HBM bytes per launch of the same kernels "
+                    "inside the train step (counter summary of this build; null without one)"}
 
 
 def cpu_baseline(budget_s=12.0):
@@ -448,6 +571,10 @@ def main():
                            "note": "one-GPU emulation: every all-reduce = a doubling kernel + `cus` resident workgroups holding CUs for the time a "
                                    "ring all-reduce of that range would run, on the communication stream (lstm_ctc_ocr_amd/dist.py)"}
                           if os.environ.get("OCR_FAKE_WORLD") and int(os.environ.get("OCR_FAKE_COMM_CUS", "0") or 0) > 0 else None),
+            "dp_schedule": (None if not (eng.world > 1 or eng.force_allreduce) else
+                            "one hipGraph per step, both bucket all-reduces captured on the communication stream (OCR_DP_GRAPH=1)" if (eng.dp_graph and eng.use_graphs and eng.overlap_allreduce)
+                            else "three hipGraphs per step, the two bucket all-reduces issued between them" if eng.overlap_allreduce
+                            else "two hipGraphs per step, one all-reduce between them (OCR_OVERLAP_ALLREDUCE=0)"),
             "dp_check": dp_check, "dp_host_enqueue_us": dp_host,
             "with_loss_fetch_every_step": {"value": BATCH * world * args.steps / dt_fetch, "ms_per_step": dt_fetch / args.steps * 1e3},
             "with_loss_read_one_step_behind": {"value": BATCH * world * args.steps / dt_lag, "ms_per_step": dt_lag / args.steps * 1e3},
@@ -476,6 +603,19 @@ def main():
         if not args.no_roofline:
             try:
                 line["roofline"] = conv_roofline(eng, device, args.workload)
+                try:
+                    line["roofline"]["wgrad"] = wgrad_roofline(eng, device, args.workload)
+                    wg = line["roofline"]["wgrad"]
+                    if wg:
+                        # forward + data gradient + weight gradient of every 3x3 layer: all convolution MFMA work of the step
+                        r = line["roofline"]
+                        tot_fl = sum(p["gflop"] for p in r["per_launch"]) * 1e9
+                        tot_t = sum(p["us"] for p in r["per_launch"]) * 1e-6 + wg["sequence_us"] * 1e-6
+                        r["all_conv_mfma_work"] = {"achieved": (tot_fl + wg["algorithmic_gflop"] * 1e9) / tot_t / 1e12,
+                                                   "frac": (tot_fl + wg["algorithmic_gflop"] * 1e9) / tot_t / MFMA_BF16_PEAK,
+                                                   "us_per_step": tot_t * 1e6}
+                except Exception as e:          # noqa: BLE001
+                    line["roofline"]["wgrad"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 if BATCH != default_batch:      # the committed counter summaries belong to the workload's own batch size
                     line["roofline"].update({"traffic": None, "mfma_busy_frac": None, "mfma_busy_frac_grbm_window_lower_bound": None,
                                              "pmc_error": "counter summaries are taken at the workload's own batch size (%d), this run is bs=%d" % (default_batch, BATCH)})

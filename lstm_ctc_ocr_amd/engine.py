@@ -383,6 +383,26 @@ class _ConvOp(_Op):
                 finish()
 
 
+class _FcOp(_ConvOp):
+    """Network.fc (network.py:415-447) on a row tensor [N, T, d]: y = relu?(x W + b) over the last axis = the GEMMs of a 1 x 1 convolution
+    (`weights [dim, num_out]` has the memory layout of a [1, 1, dim, num_out] filter), so forward, data gradient, weight gradient, bf16 shadow and
+    re-pack are _ConvOp's '1x1' paths on the flattened rows."""
+
+    def __init__(self, eng, node, prev):
+        super(_FcOp, self).__init__(eng, node, prev)
+        assert self.kind == '1x1'
+
+    def out_shape(self, s):
+        return tuple(s[:-1]) + (self.co,)
+
+    def alloc(self, sp, s):
+        o = self.out_shape(s)
+        rows = int(np.prod(s[:-1]))
+        sp.shape[self.key] = ((rows, 1, 1, s[-1]), (rows, 1, 1, self.co))      # what the 1x1 paths multiply out
+        sp.buf[self.key + '/y'] = torch.empty(o, dtype=BF16, device=self.eng.device)
+        sp.buf[self.key + '/dy'] = torch.empty(o, dtype=BF16, device=self.eng.device)
+
+
 class _PoolOp(_Op):
     def __init__(self, eng, node, prev):
         super(_PoolOp, self).__init__(eng, node, prev)
@@ -1000,6 +1020,11 @@ class Engine(object):
             self.world = int(os.environ['OCR_FAKE_WORLD'])
             self.force_allreduce = True
         self.overlap_allreduce = os.environ.get('OCR_OVERLAP_ALLREDUCE', '1') != '0'
+        # OCR_DP_GRAPH=1 (round 6, opt-in): the WHOLE data-parallel step as ONE hipGraph — the two bucket all-reduces are captured on the communication
+        # stream (fork behind the late backward, join in front of the optimiser) instead of being issued by Python between three graphs: no graph
+        # boundaries, no host enqueue between them.  Opt-in because a captured RCCL collective cannot be validated on more than one rank here; the
+        # engine checks at start-up that a captured collective replays correctly on THIS group and falls back to the three-graph schedule otherwise.
+        self.dp_graph = os.environ.get('OCR_DP_GRAPH', '0') == '1'
         # OCR_W9_DEFER=0: every 3x3 weight gradient reduces its slabs right behind its own kernel (five reduce launches per step
         # for the CRNN); default: one merged reduction per backward body (bit-identical sums)
         self.defer_w9 = os.environ.get('OCR_W9_DEFER', '1') != '0'
@@ -1023,6 +1048,8 @@ class Engine(object):
                     if owner == op.name:
                         assert (self.offsets[name] >= self.late_begin) == (i >= self.split_op), (op.name, name)
         self.plans = {}
+        if self.dp_graph and (self.world > 1 or self.force_allreduce):
+            self.dp_graph = self._check_graph_collectives()
         self.training = False                            # set by the run bodies: dropout keeps everything outside training steps
         self.train_keep_prob = 0.5                       # what the reference feeds in training steps (train.py:126)
         # optimiser scalars live from the start (all zero until setup_optimizer): graphs captured before the optimiser exists read the
@@ -1152,7 +1179,7 @@ class Engine(object):
     def _lower(self, net):
         """Topological lowering of the plan reachable from 'logits' (a chain for the shipped models, a DAG with residual
         adds for deeper extractors).  Only data edges count: the second input of bi_lstm is the time_step_len slot."""
-        table = {'conv': _ConvOp, 'max_pool': _PoolOp, 'reshape_squeeze': _ViewOp, 'dropout': _DropoutOp, 'bi_lstm': _BiLstmOp, 'lstm': _BiLstmOp,
+        table = {'conv': _ConvOp, 'fc': _FcOp, 'max_pool': _PoolOp, 'reshape_squeeze': _ViewOp, 'dropout': _DropoutOp, 'bi_lstm': _BiLstmOp, 'lstm': _BiLstmOp,
                  'add': _AddOp, 'relu': _ReluOp, 'batch_norm': _BatchNormOp, 'avg_pool': _AvgPoolOp, 'concat': _ConcatOp,
                  'softmax': _SoftmaxOp}
         data_op = _InputOp(self)
@@ -1461,6 +1488,78 @@ class Engine(object):
         sp.graph_fb1.replay()
         return sp.graph_fb2.replay
 
+    def _check_graph_collectives(self):
+        """Can a collective of this group be captured in a hipGraph and replayed?  One eager all-reduce (communicator set-up), then a captured one on
+        the communication stream replayed twice: the buffer must hold world^2 x its start value.  Every rank must agree (an eager MIN all-reduce of
+        the verdict), else nobody uses the captured schedule.  gloo (tests: ranks sharing one GPU, staged through the host) is never capturable."""
+        import torch.distributed as dist
+        fake = bool(os.environ.get('OCR_FAKE_WORLD'))
+        if not fake:
+            if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(self.group) != 'nccl':
+                return False
+        ok = True
+        try:
+            t = torch.ones(256, dtype=F32, device=self.device)
+            main = torch.cuda.current_stream(self.device)
+            self.comm_stream.wait_stream(main)
+            with torch.cuda.stream(self.comm_stream):
+                ocr_dist.allreduce_sum_(t, self.group, force=self.force_allreduce)
+            main.wait_stream(self.comm_stream)
+            torch.cuda.synchronize()
+
+            def body():
+                cur = torch.cuda.current_stream(self.device)
+                self.comm_stream.wait_stream(cur)
+                with torch.cuda.stream(self.comm_stream):
+                    ocr_dist.allreduce_sum_(t, self.group, force=self.force_allreduce)
+                cur.wait_stream(self.comm_stream)
+            g = self._capture(body)
+            t.fill_(1.0)
+            g.replay(); g.replay()
+            torch.cuda.synchronize()
+            w = float(self.world if (fake or self.world > 1) else 1)
+            ok = bool(float(t[0]) == w * w and float(t[-1]) == w * w)
+        except Exception as e:       # noqa: BLE001
+            import sys
+            sys.stderr.write('[engine] OCR_DP_GRAPH=1: a captured collective failed on this group (%s: %s) — three-graph schedule instead\n' % (type(e).__name__, e))
+            ok = False
+        if not fake and dist.get_world_size(self.group) > 1:
+            v = torch.tensor([1.0 if ok else 0.0], device=self.device)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN, group=self.group)
+            ok = bool(float(v[0]) == 1.0)
+        return ok
+
+    def _run_dp_graph(self, sp):
+        """The whole data-parallel step of this shape as ONE hipGraph (OCR_DP_GRAPH=1): forward, CTC, backward of the late layers, the drop flag ->
+        [communication stream: all-reduce of the late bucket] || backward of the early layers -> [communication stream: all-reduce of the early
+        bucket] -> join -> clip + optimiser + re-pack.  Same kernels, same order, same two buckets as the three-graph schedule of train_step."""
+        if not self.opt_ready:
+            self.setup_optimizer()
+
+        def exchange(lo, hi):
+            cur = torch.cuda.current_stream(self.device)
+            self.comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self.comm_stream):
+                self.allreduce_grads(lo, hi)
+
+        def body():
+            self._forward(sp, training=True)
+            self._loss_and_backward(sp)
+            self._publish_guard(sp)
+            exchange(self.late_begin, self.n_total)
+            self._backward_early(sp)
+            exchange(0, self.late_begin)
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+            self._optim_body(None)
+
+        if getattr(sp, 'graph_dp', None) is None:
+            # warm-up outside capture: forward + backward only (lazy module loads) — the optimiser mutates state, its first run is the first replay
+            self._forward(sp, training=True)
+            self._loss_and_backward(sp)
+            self._backward_early(sp)
+            sp.graph_dp = self._capture(body)
+        sp.graph_dp.replay()
+
     def _run_step(self, sp):
         """Whole training step of this shape as one hipGraph (no exchange between backward and optimiser on a single GPU: the
         graph boundary cost ~8 us of idle GPU per step).  Only the forward/backward part is warmed up eagerly — the optimiser
@@ -1545,6 +1644,7 @@ class Engine(object):
         self.graph_opt = None                            # captured optimiser graphs hold the old slot tensors
         for sp in getattr(self, 'plans', {}).values():
             sp.graph_step = None
+            sp.graph_dp = None
 
     def scale_lr(self, gamma):
         ops.optim_set_lr(self.scalars, gamma, multiply=True)
@@ -1628,7 +1728,9 @@ class Engine(object):
         runs -> the early gradients are all-reduced on the same stream -> join -> graph 3 (clip + optimiser + re-pack)."""
         sp = self.plan(data.shape[0], data.shape[1])
         self._bind(sp, data, seq_len, labels, labels_len)
-        if (self.world > 1 or self.force_allreduce) and self.overlap_allreduce and self.split_op > 0:
+        if (self.world > 1 or self.force_allreduce) and self.overlap_allreduce and self.split_op > 0 and self.dp_graph and self.use_graphs:
+            self._run_dp_graph(sp)
+        elif (self.world > 1 or self.force_allreduce) and self.overlap_allreduce and self.split_op > 0:
             main = torch.cuda.current_stream(self.device)
             pc = time.perf_counter
             t0 = pc()

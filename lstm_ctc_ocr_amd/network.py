@@ -281,8 +281,28 @@ class Network(object):
 
     @layer
     def fc(self, input, num_out, name, relu=True, trainable=True):
-        raise NotImplementedError('`fc` belongs to the detection leftovers of the reference (network.py:432-459) '
-                                  'and is not on the OCR path')
+        """tf.nn.relu_layer / xw_plus_b over the LAST axis — network.py:415-447: `weights [dim, num_out]` truncated-normal(0.01) (0.001 for
+        'bbox_pred'), L2-regularised, `biases [num_out]` zeros.  Lowered as the GEMMs of a 1 x 1 convolution (igemm forward / data gradient, the
+        plain weight-gradient product).  What is covered is the reference's non-4-D branch (`feed_in, dim = input, input_shape[-1]`) on the row
+        tensors this graph has: the [N, T, d] output of reshape_squeeze_layer (the same per-time-step product bi_lstm does itself at
+        network.py:118-126), possibly behind dropout / relu / another fc.  A 4-D feature map is refused: the reference flattens the WHOLE static
+        map there (`dim = prod(input_shape[1:])` after a transpose), and this graph's width is dynamic (placeholder [None, None, 32],
+        LSTM_train.py:10) — TensorFlow raises on the `None` dimension as well."""
+        from .config import cfg
+        if isinstance(input, (list, tuple)):        # "only use the first input" (network.py:418-419)
+            input = input[0]
+        nd = input
+        while nd.op in ('fc', 'dropout', 'relu'):
+            nd = nd.inputs[0]
+        if nd.op != 'reshape_squeeze':
+            raise NotImplementedError('fc %r: the input must be a row tensor [N, T, d] (reshape_squeeze_layer, optionally behind dropout / relu / fc); '
+                                      'a 4-D map of dynamic width has no static flattened size (network.py:421-425)' % name)
+        dim = input.channels
+        self.make_var(name + '/weights', [dim, num_out], ('truncated_normal', 0.001 if name == 'bbox_pred' else 0.01), trainable,
+                      regularizer=self.l2_regularizer(cfg.TRAIN.WEIGHT_DECAY))
+        self.make_var(name + '/biases', [num_out], 'zeros', trainable)
+        return Node('fc', name, [input], k_h=1, k_w=1, c_o=num_out, s_h=1, s_w=1, c_i=dim, bn=False, biased=True, relu=relu, padding='VALID',
+                    channels=num_out)
 
     @layer
     def softmax(self, input, name):

@@ -70,6 +70,12 @@ def forward(net, params, x, seq_len, sim_bf16=False, keep=False, keep_prob=1.0, 
             if a['relu']:
                 z = torch.relu(z)
             out = og.qa(z, sim)
+        elif nd.op == 'fc':                  # xw_plus_b / relu_layer over the last axis (network.py:415-447)
+            h = ev(nd.inputs[0])
+            z = h.reshape(-1, h.shape[-1]) @ og.q(params[nd.name + '/weights'], sim) + params[nd.name + '/biases']
+            if nd.attrs['relu']:
+                z = torch.relu(z)
+            out = og.qa(z.reshape(tuple(h.shape[:-1]) + (z.shape[-1],)), sim)
         elif nd.op == 'max_pool':
             out = og.qa(og.max_pool(ev(nd.inputs[0]), nd.attrs['k_h'], nd.attrs['k_w']), sim, fwd=False)
         elif nd.op == 'add':

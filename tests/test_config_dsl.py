@@ -257,3 +257,54 @@ def test_unidirectional_lstm_layer_plan_and_oracle():
     assert float(h0[1, 4:].abs().max()) == 0.0 and float(h0[1, :4].abs().max()) > 0.0
     # past its length a sample's logits are the FC bias alone
     assert torch.allclose(logits[4:, 1], params['logits/biases'].expand(11, -1), atol=1e-6)
+
+
+def test_fc_layer_plan_and_oracle():
+    """Network.fc (network.py:415-447) on the row tensor: TF variable names / shapes / initialisers / regulariser, its place in the execution
+    order and the parameter layout, the refusal of a 4-D map of dynamic width, and the plan-walking oracle against a plain torch product."""
+    import torch
+    from lstm_ctc_ocr_amd.config import cfg
+    from lstm_ctc_ocr_amd.layout import FlatLayout, execution_order, host_parameters
+    from lstm_ctc_ocr_amd.network import Network
+    from oracle import plan_exec
+
+    class Net(Network):
+        def __init__(self):
+            self.inputs = []
+            self.layers = {'data': self.placeholder('data', 'float32', [None, None, 32]),
+                           'time_step_len': self.placeholder('time_step_len', 'int32', [None])}
+            self.trainable = True
+            self.setup()
+
+        def setup(self):
+            (self.feed('data').conv_single(3, 3, 64, 1, 1, name='c1', c_i=1).max_pool(2, 2, 2, 2, padding='VALID', name='p1')
+                 .max_pool(2, 2, 2, 2, padding='VALID', name='p2').max_pool(1, 2, 1, 2, padding='VALID', name='p3')
+                 .max_pool(1, 2, 1, 2, padding='VALID', name='p4')
+                 .conv_single(2, 2, 64, 1, 1, padding='VALID', name='c5', relu=False).reshape_squeeze_layer(d=64, name='rs')
+                 .fc(48, name='fc1').fc(40, name='bbox_pred', relu=False))
+            self.feed('bbox_pred', 'time_step_len').bi_lstm(32, 1, name='logits')
+
+    net = Net()
+    order = [nd.name for nd in execution_order(net.get_output('logits'))]
+    assert order[-4:] == ['rs', 'fc1', 'bbox_pred', 'logits']
+    sp = net.param_specs
+    assert tuple(sp['fc1/weights'].shape) == (64, 48) and sp['fc1/weights'].regularized and sp['fc1/weights'].init == ('truncated_normal', 0.01)
+    assert sp['bbox_pred/weights'].init == ('truncated_normal', 0.001) and tuple(sp['bbox_pred/biases'].shape) == (40,)
+    assert not sp['fc1/biases'].regularized and sp['fc1/biases'].init == 'zeros'
+    assert tuple(sp['logits/fw/weights'].shape) == (40 + 16, 64)           # the BiLSTM sees fc's num_out channels
+    lay = FlatLayout(sp.values(), 64, order=order)
+    assert lay.owner['fc1/weights'] == 'fc1'
+    with pytest.raises(NotImplementedError):
+        net.feed('p2').fc(10, name='bad')
+    with pytest.raises(RuntimeError):                                       # no inputs: the @layer contract (network.py:24-25)
+        net.feed('rs'); net.inputs = []; net.fc(10, name='bad2')
+    params = host_parameters(net, 5)
+    assert float(params['fc1/weights'].abs().max()) <= 0.02 + 1e-7         # truncated at two standard deviations
+    params['fc1/weights'] = params['fc1/weights'] * 20
+    params['fc1/biases'] = torch.linspace(-0.1, 0.1, 48)
+    x = torch.rand(3, 64, 32, generator=torch.Generator().manual_seed(0))
+    logits, inter = plan_exec.forward(net, params, x, [15, 4, 9], sim_bf16=False, keep=True)
+    assert tuple(logits.shape) == (15, 3, cfg.NCLASSES)
+    want = torch.relu(inter['rs'] @ params['fc1/weights'] + params['fc1/biases'])
+    assert tuple(inter['fc1'].shape) == (3, 15, 48) and torch.allclose(inter['fc1'], want, atol=1e-6)
+    assert torch.allclose(inter['bbox_pred'], want @ params['bbox_pred/weights'] + params['bbox_pred/biases'], atol=1e-6)      # relu=False: xw_plus_b

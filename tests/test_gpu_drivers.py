@@ -110,28 +110,34 @@ def test_rccl_call_path_on_a_one_rank_group(dev, monkeypatch):
     batch = next(fixed_stream(8, 3))
     img, lab, ll, ts = (np.array(a) for a in batch)
 
-    def run(force):
+    def run(force, graph=False):
         if force:
             monkeypatch.setenv('OCR_FORCE_ALLREDUCE', '1')
         else:
             monkeypatch.delenv('OCR_FORCE_ALLREDUCE', raising=False)
+        monkeypatch.setenv('OCR_DP_GRAPH', '1' if graph else '0')
         eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
         eng.setup_optimizer('Adam', 1e-3)
-        return [eng.train_step(img, lab, ll, ts) for _ in range(5)], eng.state_arrays()
+        return [eng.train_step(img, lab, ll, ts) for _ in range(5)], eng.state_arrays(), eng.dp_graph
 
-    base_losses, base_state = run(False)
+    base_losses, base_state, _ = run(False)
     dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
-        losses, state = run(True)
+        losses, state, _ = run(True)
+        # round 6 (OCR_DP_GRAPH=1): the same step with the RCCL collectives CAPTURED inside one hipGraph (fork / join on the communication stream)
+        glosses, gstate, captured = run(True, graph=True)
     finally:
         dist.destroy_process_group()
-    assert np.allclose(losses, base_losses, rtol=2e-3)
-    diffs = np.concatenate([np.abs(state[k] - base_state[k]).ravel() for k in state])
-    # Adam normalises the update, so entries whose gradient is summation-order noise may move by up to lr per step
-    assert float(diffs.max()) < 7e-3 and float(diffs.mean()) < 2e-5, (diffs.max(), diffs.mean())
+    print('RCCL collectives captured in the step graph on this stack: %s' % captured)
+    for ls, st in ((losses, state), (glosses, gstate)):
+        assert np.allclose(ls, base_losses, rtol=2e-3)
+        diffs = np.concatenate([np.abs(st[k] - base_state[k]).ravel() for k in st])
+        # Adam normalises the update, so entries whose gradient is summation-order noise may move by up to lr per step
+        assert float(diffs.max()) < 7e-3 and float(diffs.mean()) < 2e-5, (diffs.max(), diffs.mean())
+    assert captured, 'a captured RCCL all-reduce did not replay correctly on a 1-rank group: the engine fell back to the three-graph schedule'
 
 
-@pytest.mark.parametrize("overlap", ["1", "0", "1+cus"])
+@pytest.mark.parametrize("overlap", ["1", "0", "1+cus", "1+graph", "1+graph+cus"])
 def test_data_parallel_schedule_on_emulated_ranks(dev, monkeypatch, overlap):
     """OCR_FAKE_WORLD=2 emulates two ranks holding the same batch on ONE GPU: every "all-reduce" is a doubling kernel issued
     exactly where the RCCL call would be (side stream for the late-layer gradient ranges, overlapped with the second backward
@@ -141,6 +147,9 @@ def test_data_parallel_schedule_on_emulated_ranks(dev, monkeypatch, overlap):
     "1+cus": additionally OCR_FAKE_COMM_CUS=16 — sixteen resident workgroups hold CUs on the communication stream for the time a ring
     all-reduce of each range would take (round 5: the emulation's stand-in for RCCL's channel kernels); results must not move."""
     cus = overlap.endswith("+cus")
+    # "+graph": OCR_DP_GRAPH=1 — the whole step, collectives included, as ONE captured graph (round 6, opt-in)
+    monkeypatch.setenv('OCR_DP_GRAPH', '1' if '+graph' in overlap else '0')
+    graph = '+graph' in overlap
     overlap = overlap[0]
     if cus:
         monkeypatch.setenv('OCR_FAKE_COMM_CUS', '16'); monkeypatch.setenv('OCR_FAKE_COMM_US', '120')
@@ -157,6 +166,7 @@ def test_data_parallel_schedule_on_emulated_ranks(dev, monkeypatch, overlap):
             monkeypatch.delenv('OCR_FAKE_WORLD', raising=False)
         eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
         assert eng.split_layer == 'conv4_1' and 0 < eng.reg_range[0] < eng.late_begin < eng.reg_range[1] < eng.n_total
+        assert not fake or eng.dp_graph == graph                 # (the start-up check of a captured collective passed)
         eng.setup_optimizer('Adam', 0.0)                         # first step with lr = 0: the exchanged gradient itself
         eng.train_step(img, lab, ll, ts)
         grads = eng.grads.cpu().numpy().copy()

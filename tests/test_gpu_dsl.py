@@ -108,6 +108,82 @@ def test_wide_dsl_network_matches_oracle(dev):
         cfg.TRAIN.WEIGHT_DECAY = old
 
 
+class FcNet(WideDslNet):
+    """conv stack -> reshape_squeeze -> fc(256, relu) -> dropout slot -> fc(128, no relu) -> bi_lstm: `Network.fc` (network.py:415-447) on the
+    row tensor, twice, one of them feeding the other."""
+
+    def setup(self):
+        (self.feed('data').conv_single(3, 3, 64, 1, 1, name='c1', c_i=1).max_pool(2, 2, 2, 2, padding='VALID', name='p1')
+             .conv_single(3, 3, 64, 1, 1, name='c2').max_pool(2, 2, 2, 2, padding='VALID', name='p2')
+             .max_pool(1, 2, 1, 2, padding='VALID', name='p3').max_pool(1, 2, 1, 2, padding='VALID', name='p4')
+             .conv_single(2, 2, 128, 1, 1, padding='VALID', name='c5', relu=False)
+             .reshape_squeeze_layer(d=128, name='rs')
+             .fc(256, name='fc1')
+             .fc(128, name='fc2', relu=False))
+        self.feed('fc2', 'time_step_len').bi_lstm(64, 1, name='logits')
+
+
+def test_fc_layer_matches_oracle(dev):
+    old = cfg.TRAIN.WEIGHT_DECAY
+    cfg.TRAIN.WEIGHT_DECAY = 0.0
+    try:
+        net = FcNet()
+        assert net.param_specs['fc1/weights'].shape == (128, 256) and net.param_specs['fc1/weights'].regularized
+        assert net.param_specs['fc2/biases'].shape == (128,) and not net.param_specs['fc2/biases'].regularized
+        with pytest.raises(NotImplementedError):                    # a 4-D map of dynamic width has no static flattened size
+            net.feed('p2').fc(10, name='bad')
+        eng = Engine(net, device='cuda:0', seed=11)
+        g = torch.Generator().manual_seed(2)
+        arrays = {}
+        for name, spec in eng.specs.items():                        # the reference's stddev-0.01 init leaves fc gradients at the bf16 noise floor: widen it
+            v = eng.param(name).cpu()
+            if name.startswith('fc') and name.endswith('weights'):
+                v = 0.12 * torch.randn(spec.shape, generator=g)
+            elif name.endswith('biases'):
+                v = 0.1 * (torch.rand(spec.shape, generator=g) - 0.5)
+            arrays[name] = v.numpy()
+        eng.load_arrays(arrays)
+        params = {k: torch.from_numpy(v) for k, v in eng.state_arrays().items()}
+        rng = np.random.RandomState(5)
+        N, W = 16, 64
+        x = rng.rand(N, W, 32).astype(np.float32)
+        sl = np.full(N, W // 4 - 1, np.int32); sl[2] = 9; sl[7] = 4
+        ll = np.full(N, 3, np.int32)
+        lab = rng.randint(1, 63, N * 3).astype(np.int32)
+        logits = eng.forward(x, sl).float().cpu()
+        ref = plan_exec.forward(net, params, torch.from_numpy(x), sl.tolist(), sim_bf16=True)
+        assert tuple(logits.shape) == (W // 4 - 1, N, cfg.NCLASSES)
+        for n in range(N):
+            assert float((logits[:sl[n], n] - ref[:sl[n], n]).abs().max()) < 1e-2
+        leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        lg = plan_exec.forward(net, leaves, torch.from_numpy(x), sl.tolist(), sim_bf16=True)
+        costs = og._CTC.apply(lg, lab, ll, np.asarray(sl, np.int32))
+        costs.mean().backward()
+        sp = eng.plan(N, W)
+        eng._bind(sp, x, sl, lab, ll)
+        eng._run(sp, 'fb')
+        torch.cuda.synchronize()
+        dev_cost = float(sp.costs.cpu().numpy().mean())
+        assert abs(dev_cost - float(costs.mean())) / float(costs.mean()) < 2e-3, (dev_cost, float(costs.mean()))
+        bad = []
+        for name in eng.specs:
+            r = leaves[name].grad
+            if r is None or float(r.abs().max()) < 1e-9:
+                continue
+            e = l2(eng.grad(name).cpu(), r)
+            print('grad %-28s L2-rel %.3e' % (name, e))
+            if not e < 1e-2:
+                bad.append((name, e))
+        assert not bad, bad
+        assert float(eng.grad('fc1/weights').abs().max()) > 0 and float(eng.grad('fc2/biases').abs().max()) > 0
+        eng.setup_optimizer('Adam', 1e-3)
+        l0 = eng.train_step(x, lab, ll, sl)
+        l1 = [eng.train_step(x, lab, ll, sl) for _ in range(20)][-1]
+        assert np.isfinite(l1) and l1 < l0
+    finally:
+        cfg.TRAIN.WEIGHT_DECAY = old
+
+
 class UniLstmNet(WideDslNet):
     """conv stack -> `lstm` (network.py:130-152): two stacked unidirectional LSTMCell(64) + FC, ragged lengths."""
 

@@ -94,7 +94,7 @@ def _exp_library():
 @pytest.mark.parametrize("train,short,skews", [
     (False, 1, '64:last,96:last,128:last,192:last,256:last'),           # the live pipeline's case: an expired wait (the refill of slot s - 2 lands first)
     (False, 4, '96:last,128:last,192:last,256:last,384:last'),          # ... or a silently wrong h (the zero payload of free step s + 3 lands first)
-    (True, 6, '32:0,48:0,64:0,80:0,96:0,128:0,160:0'),                  # the backward twin: a free HEAD iteration's zero payload taken for a gradient
+    (True, 6, '160:0,224:0,288:0,384:0,96:0,128:0,512:0'),                  # the backward twin: a free HEAD iteration's zero payload taken for a gradient
 ])
 def test_the_handoff_cases_fail_on_the_round4_ring_rule(dev, train, short, skews):
     """The detector detects: the same runner against the experiments library told to follow the rule of rounds 3-4 again
