@@ -57,7 +57,10 @@ int ws_set_clock_debug(void* dbg) {
 
 // packed bf16 max / ReLU as SIGNED 16-bit integer max (v_pk_max_i16, one instruction per pair): non-negative bf16 values order like their bit
 // patterns, every negative value (and -0) is a negative integer — so max(x, 0) is the ReLU of a bf16 pair and, on post-ReLU values, the integer
-// max is the float max (the single-wave write-out is VALU-issue-bound: the float-compare form of conv_k3 took ~10 instructions per pair here)
+// max is the float max (the single-wave write-out is VALU-issue-bound: the float-compare form of conv_k3 took ~10 instructions per pair here).
+// NaN: a NaN with the sign bit set (0xFFxx) is a negative integer and becomes 0, a positive one (0x7Fxx) is kept — where conv_k3's float
+// compares and tf.nn.relu keep every NaN.  A diverged run therefore shows its NaNs one layer later at the latest (conv2's data gradient, conv3_1 and
+// the loss all run on conv_k3 / float arithmetic; the step report's loss is what the training loop checks), never as a silently finite loss.
 typedef short ws_s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t ws_max2(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ws_s16x2, a), __builtin_bit_cast(ws_s16x2, b)));
@@ -462,17 +465,19 @@ int ws_try_dispatch(const void* x, const void* wpack, void* y, int M, int W, int
     else return -1;
     if (W % nc || M % bm) return -1;
     if (pool_kind == 2 && (W & 1)) return -1;
+    // CU count of the device: latched only once the query SUCCEEDED (the host-only plan queries of the lowering — x == nullptr, possibly
+    // no device at all — came first and fixed the 256 fallback for the rest of the process); until then every call asks again
     if (!cus) {
         int dev = 0; hipDeviceProp_t prop;
-        if (x && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
+    const int ncu = cus > 0 ? cus : 256;                 // no device visible (CPU-only policy tests): the MI355X's count
     // default policy (measured, profiles/r05e_ws_bench.log): the single-chunk instance (Cin = 64: conv2 forward 40.8 -> 32.3 us) from two tiles
     // per workgroup on; the K-split instances (Cin = 128) are correct but lose to conv_k3 (conv2 data gradient 35 against 28 us, conv3_1 forward
     // 32 against 21: their per-workgroup weight hand-round costs 7-8 us of a 4-tile run) — OCR_CONV_WS=2 runs them for the parity tests
-    if (mode == 1 && (Cin != 64 || (long)(M / bm) * (Cout / 64) < 2L * (cus ? cus : 256))) return -1;
+    if (mode == 1 && (Cin != 64 || (long)(M / bm) * (Cout / 64) < 2L * ncu)) return -1;
     WsArgs g = {(const bf16_t*)x, (const bf16_t*)wpack, M, Cout, Cin, W, H, (bf16_t*)y, bias, (const bf16_t*)mask, flags, (bf16_t*)pool, pool_kind, 0, 0, 0, 0};
-    if (H == 16 && Cin == 64) return launch_ws<16, 16, 1>(g, cus, stream);
-    if (H == 16) return launch_ws<16, 8, 2>(g, cus, stream);
-    return launch_ws<8, 16, 2>(g, cus, stream);
+    if (H == 16 && Cin == 64) return launch_ws<16, 16, 1>(g, ncu, stream);
+    if (H == 16) return launch_ws<16, 8, 2>(g, ncu, stream);
+    return launch_ws<8, 16, 2>(g, ncu, stream);
 }

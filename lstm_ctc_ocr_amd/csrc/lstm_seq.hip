@@ -33,7 +33,9 @@ typedef unsigned long long u64;
 // of every iteration) — the skew between workgroups that HBM contention provides once in ~10^4 launches, made deterministic
 // (tests/test_gpu_stress.py: the hand-off must be right for ANY relative speed of the workgroups).  A delay in EVERY iteration is absorbed by the
 // other workgroups' adaptive pre-poll sleep (they slow down with it, free iterations included — measured: the round-4 rule survives it); the delay at
-// ONE iteration (the tile's last active step forward, the first iteration backward) is what lets the others run ahead.  RING_LIVE: the round-5 rule (a workgroup none of whose rows is inside its sequence leaves the
+// ONE iteration (the tile's last active step forward, the first iteration backward) is what lets the others run ahead.  The four-wave kernels carry the
+// hook in instances of their own (template parameter SKEW, launched only while a skew is set): compiled into the product instance the extra
+// block boundary at the top of every step cost the backward kernel 4 us per launch (95.9 against 91.5 us, profiles/r06a_kernel_stats.md).  RING_LIVE: the round-5 rule (a workgroup none of whose rows is inside its sequence leaves the
 // ring alone); the experiments build can be told to follow the rule of rounds 3-4 again (OCR_LSTM_RING_RULE=always: every iteration stores and
 // refills) so that the same tests can be shown to FAIL on it — the product library has no such switch.
 #define SKEW_HOOK() do { if (a.skew && ub == 0 && (a.skew_at < 0 || a.skew_at == dbgi)) for (int i_ = 0; i_ < a.skew; ++i_) __builtin_amdgcn_s_sleep(1); } while (0)
@@ -524,7 +526,7 @@ __device__ __forceinline__ float tanh_q(float x) {
     const float e = __expf(-2.0f * fabsf(x));          // in (0, 1]: no overflow
     return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
 }
-template <int U>
+template <int U, bool SKEW = false /* instance with the test hook (ocr_lstm_seq_test_skew); the product launch is the plain one */>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_seq4_kernel(LstmSeqFwdArgs a) {
     constexpr int KS = U / 32 / 4, UB = U / 16;
     constexpr unsigned SLOT = (unsigned)UB * 512u;                       // ring bytes per step and group
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int s = 0; s < T; ++s) {
         const int dbgi = s;
         DBG_STAMP(0);
-        SKEW_HOOK();
+        if constexpr (SKEW) SKEW_HOOK();
         const bool active = nvalid && s < len;
         const int t = active ? (d == 0 ? s : len - 1 - s) : s;
         const long row = (long)nn * T + t;
@@ -662,7 +664,7 @@ struct LstmSeqFwdXArgs {
     unsigned char* ring; int* err;
     int Nb, T; float forget_bias; long long* dbg; int presleep; int skew; int skew_at; int ring_always;
 };
-template <int U, int D>
+template <int U, int D, bool SKEW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_seq4x_kernel(LstmSeqFwdXArgs a) {
     constexpr int KS = U / 32 / 4, KX = D / 32 / 4, UB = U / 16;
     constexpr unsigned SLOT = (unsigned)UB * 512u;                       // ring bytes per step and group
@@ -727,7 +729,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr bool FIRST = decltype(first_tag)::value;
         const int dbgi = s;
         DBG_STAMP(0);
-        SKEW_HOOK();
+        if constexpr (SKEW) SKEW_HOOK();
         const bool active = nvalid && s < len;
         const int t = active ? (d == 0 ? s : len - 1 - s) : s;
         const long row = (long)nn * T + t;
@@ -822,7 +824,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int s = 1; s < T; ++s) step(s, std::false_type{});
 }
 
-template <int U>
+template <int U, bool SKEW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_seq4_kernel(LstmSeqBwdArgs a) {
     constexpr int KS = U / 32, UB = U / 16;                              // wave kh multiplies gate kh's columns of W_h: K = kh U .. (kh + 1) U of 4U
     constexpr unsigned SLOT = (unsigned)UB * 2048u;                      // ring bytes per step and group: [ub][gate][16 rows][16 units]
@@ -881,7 +883,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int s = T - 1, it = 0; s >= 0; --s, ++it) {
         const int dbgi = it;
         DBG_STAMP(0);
-        SKEW_HOOK();
+        if constexpr (SKEW) SKEW_HOOK();
         const bool active = nvalid && s < len;
         const bool has_next = nvalid && (s + 1 < len);
         const int t = active ? (d == 0 ? s : len - 1 - s) : s;
@@ -1097,7 +1099,7 @@ extern "C" int ocr_lstm_fwd_seq2(const float* xproj, const void* whT_packed, con
                         seq_env_int("OCR_LSTM_PRESLEEP_F", 0, 0, true), g_lstm_skew, g_lstm_skew_at, seq_ring_always()};
     const dim3 grid3(U / 16, 2, nz), grid1((U / 16) * 8 * ceil_div(2 * nz, 8));
 #define FWD(UU) do { if (proto == 0) launch_fwd<UU, 0>(a, rows, grid3, grid1, stream); \
-                     else if (rows == 16 && seq_ksplit() == 4) lstm_fwd_seq4_kernel<UU><<<grid1, 256, 0, stream>>>(a); \
+                     else if (rows == 16 && seq_ksplit() == 4) { if (a.skew) lstm_fwd_seq4_kernel<UU, true><<<grid1, 256, 0, stream>>>(a); else lstm_fwd_seq4_kernel<UU><<<grid1, 256, 0, stream>>>(a); } \
                      else launch_fwd<UU, 4>(a, rows, grid3, grid1, stream); } while (0)
     if (U == 256) FWD(256); else FWD(512);
 #undef FWD
@@ -1132,7 +1134,7 @@ extern "C" int ocr_lstm_bwd_seq2(const void* wh, long ldw, long w_dir_stride, co
                         seq_env_int("OCR_LSTM_PRESLEEP", 1, 4, true), g_lstm_skew, g_lstm_skew_at, seq_ring_always()};
     const dim3 grid3(U / 16, 2, nz), grid1((U / 16) * 8 * ceil_div(2 * nz, 8));
 #define BWD(UU) do { if (proto == 0) launch_bwd<UU, 0>(a, rows, grid3, grid1, stream); \
-                     else if (rows == 16 && seq_ksplit() == 4) lstm_bwd_seq4_kernel<UU><<<grid1, 256, 0, stream>>>(a); \
+                     else if (rows == 16 && seq_ksplit() == 4) { if (a.skew) lstm_bwd_seq4_kernel<UU, true><<<grid1, 256, 0, stream>>>(a); else lstm_bwd_seq4_kernel<UU><<<grid1, 256, 0, stream>>>(a); } \
                      else launch_bwd<UU, 4>(a, rows, grid3, grid1, stream); } while (0)
     if (U == 256) BWD(256); else BWD(512);
 #undef BWD
@@ -1170,7 +1172,8 @@ extern "C" int ocr_lstm_fwd_seq_x(const void* x, const void* wxT_packed, const f
                          (unsigned char*)((unsigned*)sync + cwords), (int*)sync + words - 1, Nb, T, forget_bias, g_lstm_dbg,
                          seq_env_int("OCR_LSTM_PRESLEEP_F", 0, 0, true), g_lstm_skew, g_lstm_skew_at, seq_ring_always()};
     const dim3 grid1((U / 16) * 8 * ceil_div(2 * nz, 8));
-    if (U == 256 && D == 512) lstm_fwd_seq4x_kernel<256, 512><<<grid1, 256, 0, stream>>>(a);
+    if (a.skew && U == 256 && D == 512) lstm_fwd_seq4x_kernel<256, 512, true><<<grid1, 256, 0, stream>>>(a);      // the test hook's instance (the stress tests' shape)
+    else if (U == 256 && D == 512) lstm_fwd_seq4x_kernel<256, 512><<<grid1, 256, 0, stream>>>(a);
     else if (U == 512 && D == 512) lstm_fwd_seq4x_kernel<512, 512><<<grid1, 256, 0, stream>>>(a);
     else if (U == 256) lstm_fwd_seq4x_kernel<256, 1024><<<grid1, 256, 0, stream>>>(a);
     else lstm_fwd_seq4x_kernel<512, 1024><<<grid1, 256, 0, stream>>>(a);       // configs[4]'s second BiLSTM layer: 255 VGPRs + 54 AGPRs, no scratch

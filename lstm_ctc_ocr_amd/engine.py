@@ -223,7 +223,15 @@ class _ConvOp(_Op):
                 pool = self.eng.w9_ws_pool
                 have_ws = pool.get(self.key)
                 if have_ws is None or have_ws.numel() < need:
-                    have_ws = pool[self.key] = torch.empty(need, dtype=torch.uint8, device=dev)      # (older plans keep the block their graphs captured)
+                    # sized ONCE for the widest batch this engine is expected to see (plans created in ascending width order — the usual
+                    # case for variable-width batches — each found the pool too small and allocated a block of their own): the slab bytes of a
+                    # layer grow with the split count, which is capped, so the need at OCR_MAX_WIDTH (default 320 = configs[3]'s widest) bounds them
+                    wmax = max(int(os.environ.get('OCR_MAX_WIDTH', '320')), sp.W)
+                    scale = max(1, wmax // sp.W + (1 if wmax % sp.W else 0))
+                    big = need
+                    if scale > 1:
+                        big = max(need, ops.conv3x3_wgrad_workspace_bytes(s[0], s[1] * scale, s[2], self.ci, self.co))
+                    have_ws = pool[self.key] = torch.empty(big, dtype=torch.uint8, device=dev)      # (older plans keep the block their graphs captured)
                 sp.buf[self.key + '/w9ws'] = have_ws[:need]
             elif need and (have is None or have.numel() < need):     # one buffer per plan, shared by all layers (one stream)
                 sp.buf['wgrad_ws'] = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -1483,7 +1491,7 @@ class Engine(object):
             body1()
             return body2
         if getattr(sp, 'graph_fb1', None) is None:
-            body1(); body2()                                    # warm-up outside capture
+            body1(); body2()                                    # warm-up outside capture (also uploads the drop flag's address table)
             sp.graph_fb1, sp.graph_fb2 = self._capture(body1), self._capture(body2)
         sp.graph_fb1.replay()
         return sp.graph_fb2.replay
@@ -1554,6 +1562,7 @@ class Engine(object):
 
         if getattr(sp, 'graph_dp', None) is None:
             # warm-up outside capture: forward + backward only (lazy module loads) — the optimiser mutates state, its first run is the first replay
+            self._guard_addrs(sp)                            # (the address table of the drop flag's words is uploaded here, outside the capture)
             self._forward(sp, training=True)
             self._loss_and_backward(sp)
             self._backward_early(sp)
