@@ -65,13 +65,62 @@ def _font(size):
     return _FONT_CACHE[key]
 
 
+# random.randint / random.choice cost ~2 us per call in CPython (three Python frames each) and the gray renderer makes ~85 of them per image: the
+# same draws inlined (random.randrange -> _randbelow_with_getrandbits: k = n.bit_length(), reject r >= n) — VALUE-IDENTICAL to the library calls for
+# the same generator state, so render_captcha (which keeps calling the library) and render_captcha_gray still see the same geometry
+_getrandbits = random.getrandbits          # (bound to the module-level generator: random.seed() reseeds it in place)
+
+
+def _rb(n):
+    """random._randbelow(n): uniform integer in [0, n)"""
+    k = n.bit_length()
+    r = _getrandbits(k)
+    while r >= n:
+        r = _getrandbits(k)
+    return r
+
+
+def _ri(a, b):
+    """random.randint(a, b)"""
+    return a + _rb(b - a + 1)
+
+
 def randRGB():
     return (random.randint(0, 255), random.randint(0, 255), random.randint(0, 255))
 
 
+def _rotate_mask(m, angle):
+    """m.rotate(angle, Image.BILINEAR, expand=1) for an 'L' image without PIL's Python layers (63 us per call of which 24 are the C transform: five
+    glyphs per captcha made it 40 % of an image): the same matrix, the same output size, the same core call — bit-identical
+    (tests/test_data.py::test_fast_render_path_is_bit_identical)."""
+    angle = angle % 360.0
+    if angle == 0 or angle == 180 or angle == 90 or angle == 270:
+        return m.rotate(angle, Image.BILINEAR, expand=1)
+    w, h = m.size
+    cx, cy = w / 2, h / 2
+    a = -math.radians(angle)
+    ca, sa = round(math.cos(a), 15), round(math.sin(a), 15)
+    m0, m1, m3, m4 = ca, sa, -sa, ca
+    m2 = m0 * -cx + m1 * -cy + 0.0 + cx
+    m5 = m3 * -cx + m4 * -cy + 0.0 + cy
+    xx, yy = [], []
+    for x, y in ((0, 0), (w, 0), (w, h), (0, h)):
+        xx.append(m0 * x + m1 * y + m2)
+        yy.append(m3 * x + m4 * y + m5)
+    nw = math.ceil(max(xx)) - math.floor(min(xx))
+    nh = math.ceil(max(yy)) - math.floor(min(yy))
+    tx, ty = -(nw - w) / 2.0, -(nh - h) / 2.0
+    m2, m5 = m0 * tx + m1 * ty + m2, m3 * tx + m4 * ty + m5
+    out = Image.new('L', (nw, nh), None)
+    out.im.transform((0, 0, nw, nh), m.im, 0, (m0, m1, m2, m3, m4, m5), 2, 1)      # Transform.AFFINE, Resampling.BILINEAR, fill
+    return out
+
+
 def gen_rand(min_len=None, max_len=None):
-    n = random.randint(cfg.MIN_LEN if min_len is None else min_len, cfg.MAX_LEN if max_len is None else max_len)
-    return "".join(random.choice(cfg.CHARSET) for _ in range(n))
+    n = _ri(cfg.MIN_LEN if min_len is None else min_len, cfg.MAX_LEN if max_len is None else max_len)
+    cs = cfg.CHARSET
+    k = len(cs)
+    return "".join([cs[_rb(k)] for _ in range(n)])
 
 
 def render_captcha(chars, width=160, height=60):
@@ -138,34 +187,39 @@ def render_captcha_gray(chars, width=160, height=60):
     SMOOTH kernel), hence gray(render_captcha(...)) up to the 8-bit rounding of the intermediate images (a few gray levels at glyph edges:
     tests/test_data.py).  About 3x cheaper per image: cached glyph masks instead of a FreeType render per glyph, 'L' instead of RGBA / RGB
     transforms, filter and resize, no float matmul for the gray conversion — the live generator is the training loop's bottleneck, not the GPU."""
-    bg = tuple(random.randint(238, 255) for _ in range(3))
-    fg = tuple(random.randint(10, 200) for _ in range(3))
+    bg = (_ri(238, 255), _ri(238, 255), _ri(238, 255))
+    fg = (_ri(10, 200), _ri(10, 200), _ri(10, 200))
     bgv, fgv = _gray_of(bg), _gray_of(fg)
     # A glyph of the RGB path is an RGBA image holding the full ink wherever its coverage is non-zero; PIL rotates RGBA with PREMULTIPLIED
     # alpha, so the rotated colour stays the ink and only the alpha is interpolated: pasting it = pasting the solid ink through the rotated mask.
     glyphs = []
     for ch in chars:
-        m = _glyph_mask(ch, random.choice((42, 50, 56)))
-        glyphs.append(m.rotate(random.uniform(-30, 30), Image.BILINEAR, expand=1))
+        m = _glyph_mask(ch, (42, 50, 56)[_rb(3)])
+        glyphs.append(_rotate_mask(m, random.uniform(-30, 30)))
     text_w = sum(a.size[0] for a in glyphs)
     avg = int(text_w / max(1, len(chars)))
     x = int(0.1 * avg)
     canvas_w = max(text_w, width)
     canvas = Image.new('L', (canvas_w, height), bgv)
+    cim = canvas.im
+    q = int(0.25 * avg)
     for a in glyphs:
-        y = int((height - a.size[1]) / 2) + random.randint(-4, 4)
-        canvas.paste(fgv, (x, max(0, y), x + a.size[0], max(0, y) + a.size[1]), a)
-        x += a.size[0] + random.randint(-int(0.25 * avg), 0)
+        y = int((height - a.size[1]) / 2) + _ri(-4, 4)
+        y0 = max(0, y)
+        cim.paste(fgv, (x, y0, x + a.size[0], y0 + a.size[1]), a.im)
+        x += a.size[0] + _ri(-q, 0)
     if canvas_w > width:
         canvas = canvas.resize((width, height))
     img = canvas.crop((0, 0, width, height)) if canvas.size != (width, height) else canvas
     d = ImageDraw.Draw(img)
+    ink = d._getink(fgv)[0]
+    lines = d.draw.draw_lines
     for _ in range(30):                                       # noise dots
-        px, py = random.randint(0, width), random.randint(0, height)
-        d.line(((px, py), (px - 1, py - 1)), fill=fgv, width=3)
-    x1, x2 = random.randint(0, int(width / 5)), random.randint(width - int(width / 5), width)   # noise curve
-    y1, y2 = random.randint(int(height / 5), height - int(height / 5)), random.randint(int(height / 5), height)
-    d.arc([x1, min(y1, y2), x2, max(y1, y2) + 1], random.randint(0, 20), random.randint(160, 200), fill=fgv)
+        px, py = _ri(0, width), _ri(0, height)
+        lines(((px, py), (px - 1, py - 1)), ink, 3)
+    x1, x2 = _ri(0, int(width / 5)), _ri(width - int(width / 5), width)   # noise curve
+    y1, y2 = _ri(int(height / 5), height - int(height / 5)), _ri(int(height / 5), height)
+    d.arc([x1, min(y1, y2), x2, max(y1, y2) + 1], _ri(0, 20), _ri(160, 200), fill=fgv)
     return img.filter(ImageFilter.SMOOTH)
 
 

@@ -250,3 +250,28 @@ def test_a_dead_generator_worker_is_reported_not_waited_for():
                     continue
     finally:
         ring.close()
+
+
+def test_fast_render_path_is_bit_identical():
+    """Round 6: the gray renderer's hot helpers — random draws inlined (`_ri` / `_rb`) and the glyph rotation without PIL's Python layers
+    (`_rotate_mask`) — give EXACTLY what the library calls they replace give, for the same generator state: the RGB path (which keeps calling
+    the library) and the gray path still see the same geometry, and rendered batches do not change with the speed-up."""
+    import random
+    from PIL import Image
+    from lstm_ctc_ocr_amd.utils import gen
+    random.seed(11)
+    ref = [random.randint(a, b) for a, b in ((0, 255), (-4, 4), (238, 255), (0, 160), (-13, 0), (0, 0), (10, 200), (3, 1000003))] * 50
+    st = random.getstate()
+    random.seed(11)
+    got = [gen._ri(a, b) for a, b in ((0, 255), (-4, 4), (238, 255), (0, 160), (-13, 0), (0, 0), (10, 200), (3, 1000003))] * 50
+    assert got == ref and random.getstate() == st
+    random.seed(5)
+    want = "".join(random.choice(cfg.CHARSET) for _ in range(40))
+    random.seed(5)
+    assert "".join(cfg.CHARSET[gen._rb(len(cfg.CHARSET))] for _ in range(40)) == want
+    rng = np.random.RandomState(0)
+    for ch, size in (('A', 42), ('g', 50), ('8', 56), ('W', 56), ('i', 42)):
+        m = gen._glyph_mask(ch, size)
+        for angle in list(rng.uniform(-30, 30, 12)) + [0.0, 90.0, -90.0, 180.0, 29.999999, -30.0, 1e-9]:
+            a, b = gen._rotate_mask(m, float(angle)), m.rotate(float(angle), Image.BILINEAR, expand=1)
+            assert a.size == b.size and a.mode == b.mode and np.array_equal(np.array(a), np.array(b)), (ch, size, angle)
