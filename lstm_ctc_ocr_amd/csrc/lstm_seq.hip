@@ -521,6 +521,8 @@ __global__ __launch_bounds__(64 * WPB * KSP) __attribute__((amdgpu_waves_per_eu(
 // to fp32 rounding, not bit-identical.
 // The activations with v_rcp_f32 (1 ulp) in place of the correctly rounded reciprocal of sigmoidf_ / tanhf_: the IEEE division is a chain of
 // ten dependent instructions, five of them per step sat on the forward recurrence's critical path (one wave per SIMD: nothing hides it).
+// the four units of this lane from an element-major LDS exchange array v[value][unit][lane] (four conflict-free 4-byte reads)
+#define OUTS4(v_) ((f32x4){outs[v_][0][lane], outs[v_][1][lane], outs[v_][2][lane], outs[v_][3][lane]})
 __device__ __forceinline__ float sigmoid_q(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_q(float x) {
     const float e = __expf(-2.0f * fabsf(x));          // in (0, 1]: no overflow
@@ -531,7 +533,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int KS = U / 32 / 4, UB = U / 16;
     constexpr unsigned SLOT = (unsigned)UB * 512u;                       // ring bytes per step and group
     __shared__ f32x4 red[4][4][64];                                      // [source wave][unit r of the lane's four][lane] = partial {i, j, f, o}; wave g's carries x of gate g
-    __shared__ f32x4 outs[6][64];                                        // [h, i, j, f, o, c][lane] = results of the lane's four units (element r by wave r)
+    __shared__ float outs[6][4][64];                                     // [h, i, j, f, o, c][unit r of the lane's four: written by wave r][lane] — element-major, so that the
+                                                                         // one-element writes of a wave are 64 consecutive words (round 6: as f32x4[lane] they were 8-way bank conflicts)
     const int lane = threadIdx.x & 63;
     const int kh = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int ub, d, zb;
@@ -624,14 +627,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float cn = gf * c + gi * gj;
         const float hn = go * tanh_q(cn);
         if (active) c = cn;
-        float* oo = (float*)&outs[0][lane] + kh;
-        oo[0] = active ? hn : 0.f; oo[256] = gi; oo[512] = gj; oo[768] = gf; oo[1024] = go; oo[1280] = c;
+        outs[0][kh][lane] = active ? hn : 0.f; outs[1][kh][lane] = gi; outs[2][kh][lane] = gj; outs[3][kh][lane] = gf; outs[4][kh][lane] = go; outs[5][kh][lane] = c;
         __syncthreads();                                        // B
         DBG_STAMP(2);
         if (nvalid) {
             // the one-wave kernel's stores, one part per wave (rows past their length store zeros / throw-away gate values into rows nobody reads)
             if (kh == 0) {
-                const f32x4 h = outs[0][lane];
+                const f32x4 h = OUTS4(0);
                 const u32x2 hp = {pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
                 const bool ring_live = RING_LIVE(active);          // a workgroup whose rows are all past their length leaves the ring alone: lstm_fwd_seq_kernel
                 if (ring_live) *(u32x2*)(gring + (unsigned)(s & (RING - 1)) * SLOT + wr0) = hp;               // the hand-off payload goes out FIRST
@@ -640,11 +642,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 asm volatile("" ::: "memory");
                 *(u32x2*)(a.hout + row * (2L * U) + (long)d * U + ub * 16 + ul0) = hp;
             } else if (kh == 3) {
-                *(f32x4*)(a.cell + ((long)d * R + row) * U + ub * 16 + ul0) = outs[5][lane];
+                *(f32x4*)(a.cell + ((long)d * R + row) * U + ub * 16 + ul0) = OUTS4(5);
             } else {
                 float* gdst = a.gates + ((long)d * R + row) * (4L * U) + (long)ub * 64 + ul0 + (kh - 1) * 32;
-                *(f32x4*)(gdst + 0) = outs[2 * kh - 1][lane];
-                *(f32x4*)(gdst + 16) = outs[2 * kh][lane];
+                *(f32x4*)(gdst + 0) = OUTS4(2 * kh - 1);
+                *(f32x4*)(gdst + 16) = OUTS4(2 * kh);
             }
         }
         DBG_STAMP(3);
@@ -669,7 +671,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int KS = U / 32 / 4, KX = D / 32 / 4, UB = U / 16;
     constexpr unsigned SLOT = (unsigned)UB * 512u;                       // ring bytes per step and group
     __shared__ f32x4 red[4][4][64];                                      // [source wave][unit r of the lane's four][lane] = partial {i, j, f, o}
-    __shared__ f32x4 outs[6][64];                                        // [h, i, j, f, o, c][lane] = results of the lane's four units (element r by wave r)
+    __shared__ float outs[6][4][64];                                     // [h, i, j, f, o, c][unit r of the lane's four: written by wave r][lane] — element-major, so that the
+                                                                         // one-element writes of a wave are 64 consecutive words (round 6: as f32x4[lane] they were 8-way bank conflicts)
     const int lane = threadIdx.x & 63;
     const int kh = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int ub, d, zb;
@@ -796,13 +799,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float cn = gf * c + gi * gj;
         const float hn = go * tanh_q(cn);
         if (active) c = cn;
-        float* oo = (float*)&outs[0][lane] + kh;
-        oo[0] = active ? hn : 0.f; oo[256] = gi; oo[512] = gj; oo[768] = gf; oo[1024] = go; oo[1280] = c;
+        outs[0][kh][lane] = active ? hn : 0.f; outs[1][kh][lane] = gi; outs[2][kh][lane] = gj; outs[3][kh][lane] = gf; outs[4][kh][lane] = go; outs[5][kh][lane] = c;
         __syncthreads();                                        // B
         DBG_STAMP(2);
         if (nvalid) {
             if (kh == 0) {
-                const f32x4 h = outs[0][lane];
+                const f32x4 h = OUTS4(0);
                 const u32x2 hp = {pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3])};
                 const bool ring_live = RING_LIVE(active);          // a workgroup whose rows are all past their length leaves the ring alone: lstm_fwd_seq_kernel
                 if (ring_live) *(u32x2*)(gring + (unsigned)(s & (RING - 1)) * SLOT + wr0) = hp;               // the hand-off payload goes out FIRST
@@ -811,11 +813,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 asm volatile("" ::: "memory");
                 *(u32x2*)(a.hout + row * (2L * U) + (long)d * U + ub * 16 + ul0) = hp;
             } else if (kh == 3) {
-                *(f32x4*)(a.cell + ((long)d * R + row) * U + ub * 16 + ul0) = outs[5][lane];
+                *(f32x4*)(a.cell + ((long)d * R + row) * U + ub * 16 + ul0) = OUTS4(5);
             } else {
                 float* gdst = a.gates + ((long)d * R + row) * (4L * U) + (long)ub * 64 + ul0 + (kh - 1) * 32;
-                *(f32x4*)(gdst + 0) = outs[2 * kh - 1][lane];
-                *(f32x4*)(gdst + 16) = outs[2 * kh][lane];
+                *(f32x4*)(gdst + 0) = OUTS4(2 * kh - 1);
+                *(f32x4*)(gdst + 16) = OUTS4(2 * kh);
             }
         }
         DBG_STAMP(3);
@@ -828,9 +830,12 @@ template <int U, bool SKEW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_seq4_kernel(LstmSeqBwdArgs a) {
     constexpr int KS = U / 32, UB = U / 16;                              // wave kh multiplies gate kh's columns of W_h: K = kh U .. (kh + 1) U of 4U
     constexpr unsigned SLOT = (unsigned)UB * 2048u;                      // ring bytes per step and group: [ub][gate][16 rows][16 units]
-    __shared__ f32x4 red[4][64];                                         // [source wave][lane] = partial dh of the lane's four units
-    __shared__ f32x4 sv[6][64];                                          // [i, j, f, o, c, c_prev][lane] = saved operands of the lane's four units
-    __shared__ f32x4 outs[4][64];                                        // [gate][lane] = gate gradients of the lane's four units (element r by wave r)
+    // element-major exchange arrays (round 6): every wave reads / writes ONE element of a lane's four per access — as f32x4[lane] those were 4-byte
+    // accesses at a 16-byte stride, 8-way bank conflicts on 14 LDS instructions per step (PMC: lds_conflict_frac 0.62); as [element][lane] they are
+    // 64 consecutive words, and the wide side pays four 4-byte accesses instead of one 16-byte one (the same LDS cycles)
+    __shared__ float red[4][4][64];                                      // [source wave][unit e of the lane's four][lane] = partial dh
+    __shared__ float sv[6][4][64];                                       // [i, j, f, o, c, c_prev][unit e][lane] = saved operands
+    __shared__ float outs[4][4][64];                                     // [gate][unit e: written by wave e][lane] = gate gradients
     const int lane = threadIdx.x & 63;
     const int kh = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int ub, d, zb;
@@ -923,17 +928,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[k0 + 1], z[k0 + 1], acc1, 0, 0, 0);
             }
         }
-        if (kh < 3) { sv[2 * kh][lane] = A; sv[2 * kh + 1][lane] = B; }
+        if (kh < 3) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sv[2 * kh][e][lane] = A[e]; sv[2 * kh + 1][e][lane] = B[e]; }
+        }
         else {                                                  // the incoming dh rides on this wave's partial sums
             const unsigned gx = __float_as_uint(A[0]), gy = __float_as_uint(A[1]);
             acc1 += (f32x4){bf_lo(gx), bf_hi(gx), bf_lo(gy), bf_hi(gy)};
         }
-        red[kh][lane] = acc0 + acc1;
+        {
+            const f32x4 part = acc0 + acc1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[kh][e][lane] = part[e];
+        }
         __syncthreads();                                        // A
-        const float* so = (const float*)&sv[0][lane] + kh;     // [operand][lane][element kh]
-        const float gi = so[0], gj = so[256], gf = so[512], go = so[768], c = so[1024], cprev = so[1280];
-        const float* ro = (const float*)&red[0][lane] + kh;
-        const float dh = (ro[0] + ro[256]) + (ro[512] + ro[768]);
+        const float gi = sv[0][kh][lane], gj = sv[1][kh][lane], gf = sv[2][kh][lane], go = sv[3][kh][lane], c = sv[4][kh][lane], cprev = sv[5][kh][lane];
+        const float dh = (red[0][kh][lane] + red[1][kh][lane]) + (red[2][kh][lane] + red[3][kh][lane]);
         const float tc = tanh_q(c);
         const float dc = dcs + dh * go * (1.f - tc * tc);
         float dg[4];
@@ -942,13 +952,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         dg[1] = dc * gi * (1.f - gj * gj);
         dg[2] = dc * cprev * gf * (1.f - gf);
         if (active) dcs = dc * gf;
-        float* oo = (float*)&outs[0][lane] + kh;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) oo[g * 256] = active ? dg[g] : 0.f;
+        for (int g = 0; g < 4; ++g) outs[g][kh][lane] = active ? dg[g] : 0.f;
         __syncthreads();                                        // B
         DBG_STAMP(2);
         if (nvalid) {
-            const f32x4 v = outs[kh][lane];
+            const f32x4 v = OUTS4(kh);
             const u32x2 p = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
             const bool ring_live = RING_LIVE(active);              // a workgroup none of whose rows is inside its sequence yet leaves the ring alone: lstm_bwd_seq_kernel
             if (ring_live) *(u32x2*)(gring + (unsigned)(it & (RING - 1)) * SLOT + wr0) = p;

@@ -40,9 +40,11 @@ def test_oracle_reproduces_headline_fixture():
     d, x, labels, ll, sl = c2_inputs()
     _, params = load_graph_fixture()
     lg = og.forward(params, torch.from_numpy(x), sl.tolist(), sim_bf16=True)
-    assert np.abs(lg.numpy() - d['logits_bf16sim']).max() < 1e-4
+    # 5e-4: on the machine that made the fixture the difference is 0; another CPU / BLAS thread count sums fp32 in another order and flips single bf16
+    # roundings of intermediate activations (measured 1.5e-4 on the GPU box's 256-core host) — an edit of the oracle's arithmetic shows as >= 1e-2
+    assert np.abs(lg.numpy() - d['logits_bf16sim']).max() < 5e-4
     costs = og._CTC.apply(lg, labels, ll, sl).numpy()
-    assert np.allclose(costs, d['costs'], rtol=1e-5)
+    assert np.allclose(costs, d['costs'], rtol=2e-4)
 
 
 def test_oracle_reproduces_ctc_fixture():
