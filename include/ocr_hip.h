@@ -223,7 +223,8 @@ int ocr_cast_f32_bf16(const float* in, void* out, long n, void* stream);
 /* uint8 pixels -> fp32 in [0, 1] (= u8 / 255, correctly rounded: identical to the host's `astype(float32) / 255.`, gen.py:59-65); n % 4 == 0 */
 int ocr_u8_to_unit_f32(const void* in, float* out, long n, void* stream);
 /* What train.py:130,139 fetches after sess.run, gathered on the device into out[4] (doubles): mean per-sample CTC cost, sum w^2 of
- * the regularised parameters (scalars[1]) and the global gradient norm (scalars[7]) of the optimiser block (scalars may be NULL),
+ * the regularised parameters (scalars[1]) and the global gradient norm (scalars[7]) of the optimiser block (scalars: NULL, or the WHOLE block of
+ * ocr_optim_scalar_count() doubles — entry [72] is read too),
  * and a bit mask of the error words that read 1 — the persistent LSTM kernels' time-out mark; 0 and 0xFFFFFFFF (a caller-prepared block,
  * OCR_LSTM_PREPARED) both mean "nothing happened" (word_addrs: device array of nwords <= 32 device addresses of int error words); 2^40 is added
  * when the update of the step the report follows was dropped on the device (scalars[72], ocr_optim_step_guarded*). */

@@ -474,6 +474,9 @@ def bind_batch(pixels, x, seq_len, seq_len_dst, labels=None, labels_dst=None, la
 def step_report(costs, scalars, word_addrs, out):
     """out[0..3] (double) = mean cost, scalars[1], scalars[7], bit mask of the error words that read 1 (+ 2^40: this step's update was dropped) — ocr_step_report."""
     nw = 0 if word_addrs is None else word_addrs.numel()
+    if scalars is not None and scalars.numel() < optim_scalar_count():
+        raise ValueError('step_report: `scalars` must be the whole optimiser block (%d doubles; the report reads entry 72), got %d'
+                         % (optim_scalar_count(), scalars.numel()))
     call("ocr_step_report", ptr(_dev(costs)), costs.numel(), ptr(scalars), ptr(word_addrs) if nw else None, nw, ptr(out), _st())
     return out
 

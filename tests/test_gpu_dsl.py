@@ -374,7 +374,8 @@ def test_bind_batch_and_step_report(dev):
     assert torch.equal(d_sl.cpu(), sl)
 
     costs = torch.rand(64, generator=g) * 30
-    sc = torch.arange(16, dtype=torch.float64) * 1.5
+    sc = torch.arange(ops.optim_scalar_count(), dtype=torch.float64) * 1.5       # the WHOLE optimiser block: the report reads [1], [7] and (round 6) [72]
+    sc[72] = 0.0
     words = [torch.zeros(65, dtype=torch.int32, device=dev) for _ in range(3)]
     words[1][-1] = 1                      # the persistent LSTM kernels' time-out mark
     words[2][-1] = -1                     # a block the caller prepared (all ones) that nothing touched: not an error
@@ -383,6 +384,9 @@ def test_bind_batch_and_step_report(dev):
     ops.step_report(costs.to(dev), sc.to(dev), addrs, out)
     o = out.cpu().numpy()
     assert abs(o[0] - float(costs.double().mean())) < 1e-12 and o[1] == 1.5 and o[2] == 10.5 and o[3] == 2.0
+    sc[72] = 1.0                          # the guarded optimiser launch dropped this step: bit 40 of the report's word (the host decides per step)
+    ops.step_report(costs.to(dev), sc.to(dev), addrs, out)
+    assert out.cpu().numpy()[3] == 2.0 + 2.0 ** 40
     ops.step_report(costs.to(dev), None, None, out)
     o = out.cpu().numpy()
     assert o[1] == 0.0 and o[2] == 0.0 and o[3] == 0.0
