@@ -419,8 +419,19 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(W9Args g) {
 #else
 #define W9P_PHASE(slot) do { } while (0)
 #endif
-template <int H, int LA = 2 /* A groups kept in flight ahead of the tap being multiplied */, bool CONT = false /* continuous read stream: see runc */>
+// GENW (round 6, configs[3]): any image width W >= NC — a step's NC columns may cross ONE image boundary: local column b of the step is the first
+// column of the next image.  The planes are staged exactly as for whole-image steps (plane row 1 + c = local column c, the two halo rows); what
+// differs is two elements of the contraction: the +1 tap of column b - 1 (the last column of image A) and the -1 tap of column b (the first of image
+// B) must read zeros — the lanes that SUPPLY those two pixels are redirected, for that tap only, to one of the zero rows every plane carries behind
+// its columns (rows NC + 2 .. PS - 1 arrive as zeros with every stage), so a fragment address stays "lane register + immediate" and nothing
+// touches the DMA.  Per step: a uniform branch; in the steps that cross a boundary (40 % at W = 80, NC = 32) four compares and four selects.
+// (First form, measured and replaced: conv_k3w's zero ROW inserted into the planes — the DMA lanes behind it fetch one column further left — cost
+// ~45 VALU instructions per crossing step and ran conv4_2 at W = 80 in 78 us; profiles/r06h_ab_varwidth_first_form.log, r06h2_ab_varwidth.log.)
+// Index algebra replayed on the CPU: tools/w9p_plane_model.py (a_fragment_rows_genw), tests/test_w9p_plane_model.py::test_general_width_boundary_redirect.
+template <int H, int LA = 2 /* A groups kept in flight ahead of the tap being multiplied */, bool CONT = false /* continuous read stream: see runc */,
+          bool GENW = false>
 __global__ __launch_bounds__(512) void wgrad9p_kernel(W9Args g) {
+    static_assert(!(CONT && GENW), "the continuous-stream schedule exists for whole-image steps only");
     constexpr int DMA_AT = 3, NSLOT = LA + 1;
     constexpr int NC = 128 / H;                         // image columns per step
     constexpr int PS = (NC + 2 + 7) / 8 * 8;            // rows per plane (40 / 24)
@@ -457,6 +468,9 @@ __global__ __launch_bounds__(512) void wgrad9p_kernel(W9Args g) {
                                                                           (int)(((long)g.M - kbeg + H) * g.Cin * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)(g.dY + (long)kbeg * g.Cout), 0,
                                                                           (int)(((long)g.M - kbeg) * g.Cout * 2), 0x00020000);
+    // GENW: zero rows of a plane the redirected lanes read: ZLO for the first read of a tap, ZHI + 16 (H = 4: the second read carries a 16-row immediate)
+    constexpr int ZLO = NC + 4, ZHI = H == 4 ? NC + 4 - 16 : NC + 4;
+    static_assert(NC + 2 <= ZLO && ZLO < PS, "a zero row exists behind the columns of every plane");
     unsigned voff[W9_NDMA], eL[W9_NDMA], eR[W9_NDMA];
 #pragma unroll
     for (int i = 0; i < W9_NDMA; ++i) {
@@ -498,6 +512,10 @@ __global__ __launch_bounds__(512) void wgrad9p_kernel(W9Args g) {
         baseA[d] = cp * 128 + ((cb ^ ((cp >> 1) & 3)) << 5) + (L & 3) * 8;
         zabs[d] = lds0 + ZOFF + baseA[d];
     }
+    const int clo = 4 * g4 + (L >> 2);                 // GENW: local column of the pixel this lane supplies (second read at H = 4: + 16)
+    // ... and where it reads instead when that pixel's dw = -1 / +1 neighbour belongs to another image: a zero row, at the 8-byte piece it would have read
+    const unsigned zlo0 = ZLO * 128 + (baseA[0] & 127), zlo2 = ZLO * 128 + (baseA[2] & 127);
+    const unsigned zhi0 = ZHI * 128 + (baseA[0] & 127), zhi2 = ZHI * 128 + (baseA[2] & 127);
     const int rowl = kh * 64 + 4 * g4 + (L >> 2);
 #pragma unroll
     for (int c = 0; c < 4; ++c) offB[c] = XROWS * 128 + rowl * 128 + ((c ^ ((rowl >> 1) & 3)) << 5) + (L & 3) * 8;
@@ -513,6 +531,7 @@ __global__ __launch_bounds__(512) void wgrad9p_kernel(W9Args g) {
     const unsigned offC = XROWS * 128 + csr * 128 + (((((csq >> 1) ^ ((csr >> 1) & 3)) << 1) | (csq & 1)) << 4);   // (csr + 64) >> 1 & 3 same
 
     int wcl = wc0;                                      // column of the next step to be loaded
+    int wcc = wc0;                                      // GENW: column of the step being multiplied
 #pragma unroll
     for (int p = 0; p < W9_NST - 1; ++p)
         if (p < nsteps) { stage_load(p, p, wcl); wcl += NC; if (wcl >= W) wcl -= W; }
@@ -526,9 +545,17 @@ __global__ __launch_bounds__(512) void wgrad9p_kernel(W9Args g) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const unsigned sb = lds0 + cur * W9_STAGE;
-            unsigned sbA[3], sbB[4];
+            unsigned sbA[3], sbAh[3], sbB[4];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) sbA[d] = sb + baseA[d];
+            for (int d = 0; d < 3; ++d) { sbA[d] = sb + baseA[d]; sbAh[d] = sbA[d]; }
+            if (GENW && W - wcc < NC) {
+                // (uniform branch) this step crosses an image boundary at local column bq: the -1 tap of column bq and the +1 tap of column bq - 1 read zeros
+                const int bq = W - wcc, chi = clo + (H == 4 ? 16 : 0);
+                if (clo == bq) sbA[0] = sb + zlo0;
+                if (clo == bq - 1) sbA[2] = sb + zlo2;
+                if (chi == bq) sbAh[0] = sb + zhi0;
+                if (chi == bq - 1) sbAh[2] = sb + zhi2;
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) sbB[c] = sb + offB[c];
             s16x4 alo[NSLOT], ahi[NSLOT], blo[2][4], bhi[2][4];
@@ -544,7 +571,7 @@ __global__ __launch_bounds__(512) void wgrad9p_kernel(W9Args g) {
                     constexpr int pl_ = W9P_PLANE(kb_, dh_, 0), ph_ = W9P_PLANE(kb_, dh_, 1); \
                     constexpr int il_ = W9P_OK(pl_) ? pl_ * PS * 128 : 0, ih_ = W9P_OK(ph_) ? ph_ * PS * 128 + (H == 4 ? 16 * 128 : 0) : (H == 4 ? 16 * 128 : 0); \
                     W9_TR(alo[m_ % NSLOT], W9P_OK(pl_) ? sbA[dw_] : zabs[dw_], il_); \
-                    W9_TR(ahi[m_ % NSLOT], W9P_OK(ph_) ? sbA[dw_] : zabs[dw_], ih_); \
+                    W9_TR(ahi[m_ % NSLOT], W9P_OK(ph_) ? sbAh[dw_] : zabs[dw_], ih_); \
                 } } while (0)
             // the read stream as compile-time positions (tables of wgrad9_kernel): issue everything up to tab.upto[n] before tap n
             auto issue_to = [&](auto fromc, auto toc) {
@@ -616,6 +643,7 @@ __global__ __launch_bounds__(512) void wgrad9p_kernel(W9Args g) {
                 cs[4] += bf_lo(v0.z) + bf_lo(v1.z); cs[5] += bf_hi(v0.z) + bf_hi(v1.z); cs[6] += bf_lo(v0.w) + bf_lo(v1.w); cs[7] += bf_hi(v0.w) + bf_hi(v1.w);
             }
             cur = (cur + 1 == W9_NST) ? 0 : cur + 1;
+            if (GENW) { wcc += NC; if (wcc >= W) wcc -= W; }
         }
     };
     // Continuous-stream schedule (CONT): the per-step barrier above stops the read stream — after it every wave first fetches B(0), A(0,0)..
@@ -1149,14 +1177,18 @@ int wgrad9_try_dispatch(const void* x, const void* dy, float* dw, float* dbias, 
     // plane-layout kernel where it covers the shape (A/B knob OCR_W9_PLANES = 0: wgrad9_kernel everywhere)
     static int planes = -1;
     if (planes < 0) { const char* e = getenv("OCR_W9_PLANES"); planes = e ? atoi(e) : 1; }
-    const bool use_p = planes && variant == 0 && (H == 4 || H == 8) && W % (128 / H) == 0 && M % 128 == 0 &&
+    // whole-image steps (W % NC == 0) or, round 6, any W >= NC through the zero-row instances (GENW)
+    static int genw = -1;                       // A/B knob OCR_W9P_GENW = 0: general widths stay on wgrad9_kernel; 2: the zero-row instances on whole-image shapes too (tests, timing)
+    if (genw < 0) { const char* e = getenv("OCR_W9P_GENW"); genw = e ? atoi(e) : 1; }
+    const bool whole = (H == 4 || H == 8) && W % (128 / H) == 0;
+    const bool use_p = planes && variant == 0 && (H == 4 || H == 8) && (whole || (genw && W >= 128 / H)) && M % 128 == 0 &&
                        (long)M * (Cin > Cout ? Cin : Cout) * 2 < 0x7fffffffL;
     if (use_p) {
         // (look-ahead 3 and 4 of the fragment read stream measured equal to 2: profiles/r03s_wgrad9p.log)
-#define W9P_LAUNCH(H_, LA_, C_) do { \
+#define W9P_LAUNCH(H_, LA_, C_, ...) do { \
             static bool attr = false; \
-            if (!attr) { if (hipFuncSetAttribute((const void*)wgrad9p_kernel<H_, LA_, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, W9_LDS) != hipSuccess) return OCR_ERR_EXEC; attr = true; } \
-            wgrad9p_kernel<H_, LA_, C_><<<grid, 512, W9_LDS, stream>>>(g); } while (0)
+            if (!attr) { if (hipFuncSetAttribute((const void*)wgrad9p_kernel<H_, LA_, C_, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, W9_LDS) != hipSuccess) return OCR_ERR_EXEC; attr = true; } \
+            wgrad9p_kernel<H_, LA_, C_, ##__VA_ARGS__><<<grid, 512, W9_LDS, stream>>>(g); } while (0)
         // (the continuous-read-stream schedule `runc` — barrier in the middle of a step, the next step's first fragments fetched by the
         // last taps — measured equal or slower, look-ahead 2 and 5: profiles/r03x_wgrad9p_cont.log; only `make EXPERIMENTS=1` builds it)
 #ifdef OCR_EXPERIMENTS
@@ -1167,7 +1199,8 @@ int wgrad9_try_dispatch(const void* x, const void* dy, float* dw, float* dbias, 
             else { if (cont == 1) W9P_LAUNCH(8, 2, true); else W9P_LAUNCH(8, 5, true); }
         } else
 #endif
-        if (H == 4) W9P_LAUNCH(4, 2, false); else W9P_LAUNCH(8, 2, false);
+        if (!whole || (genw == 2 && W >= 128 / H)) { if (H == 4) W9P_LAUNCH(4, 2, false, true); else W9P_LAUNCH(8, 2, false, true); }
+        else if (H == 4) W9P_LAUNCH(4, 2, false); else W9P_LAUNCH(8, 2, false);
 #undef W9P_LAUNCH
     } else
     switch (H == 2 ? 0 : variant) {             // H = 2 (a 4-row read block spans two image columns): only the redirecting default handles it

@@ -310,7 +310,10 @@ def _conv_ref(x, w, b):   # x [N,W,H,C], w HWIO
                                           # (conv4_1 is (64, 64, 4, 256, 512) above) — the dispatcher's full-chip tiles / 64-split slabs only exist at this size
                                           (64, 128, 16, 64, 128), (64, 64, 8, 128, 256), (64, 64, 8, 256, 256), (64, 64, 4, 512, 512),
                                           # ... and the extremes of configs[3] (W = 80 and W = 320 padded batches)
-                                          (64, 40, 16, 64, 128), (64, 20, 4, 512, 512), (64, 80, 8, 256, 256), (64, 80, 4, 256, 512)])
+                                          (64, 40, 16, 64, 128), (64, 20, 4, 512, 512), (64, 80, 8, 256, 256), (64, 80, 4, 256, 512),
+                                          # ... and widths that are no multiple of the weight-gradient kernel's step (round 6: wgrad9p's zero-row instances — every
+                                          # step of (32, 33, 4) / (16, 17, 8) crosses an image boundary at another column; W = 79 = a 316-pixel configs[3] batch)
+                                          (32, 33, 4, 64, 64), (16, 17, 8, 64, 64), (64, 79, 4, 256, 512), (64, 79, 8, 256, 256), (32, 47, 4, 128, 64)])
 def test_conv3x3_fwd_dgrad_wgrad(dev, Nb, W, H, Ci, Co):
     x = bf(gen((Nb, W, H, Ci), 1)); w = bf(gen((3, 3, Ci, Co), 2, 0.05)); b = gen((Co,), 3)
     ref = _conv_ref(x, w, b)

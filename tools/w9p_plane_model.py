@@ -75,3 +75,43 @@ def b_fragment_rows(g, kh, kk, lane):
     g4 = lane >> 4
     base = g.XROWS + kh * 64 + kk * 32
     return [base + 4 * g4 + e for e in range(4)] + [base + 16 + 4 * g4 + e for e in range(4)]
+
+
+# ---- general widths (round 6, wgrad9p_kernel<H, LA, CONT, GENW = true>): a step's NC columns may cross ONE image boundary (W >= NC) ---------------------
+# The planes are staged as for whole-image steps (dma_fill above works for any W: plane row 1 + c = local column c).  Where local column b of the step
+# is the first column of the next image, two contraction elements change: the +1 tap of column b - 1 and the -1 tap of column b read a ZERO ROW of the
+# plane (rows NC + 2 .. PS - 1 arrive as zeros with every stage) — the lane that supplies that pixel is redirected for that tap.
+def boundary_of(g, step_col0, W):
+    """first local column of the NEXT image inside this step, or NC if the step stays inside one image (W >= NC: at most one)"""
+    assert W >= g.NC
+    b = W - step_col0 % W
+    return b if b < g.NC else g.NC
+
+
+def zero_rows(g):
+    """(row read by a redirected FIRST read, base row of a redirected SECOND read before its immediate) — kernel constants ZLO, ZHI"""
+    zlo = g.NC + 4
+    return zlo, (zlo - 16 if g.H == 4 else zlo)
+
+
+def a_fragment_rows_genw(g, kh, kk, tap, lane, b):
+    """a_fragment_rows() with the boundary redirect: the lane SUPPLYING pixel column c = 4 g4 + e (+ 16 in the second read at H = 4) reads a zero row
+    when (c == b and dw == -1) or (c == b - 1 and dw == +1)"""
+    dw, dh = tap // 3 - 1, tap % 3 - 1
+    g4 = lane >> 4
+    pl, ph = planes_of(g, kh, kk, dh)
+    okl, okh = 0 <= pl < g.H, 0 <= ph < g.H
+    zlo, zhi = zero_rows(g)
+    nb = b < g.NC
+
+    def redirected(c):
+        return nb and ((c == b and dw == -1) or (c == b - 1 and dw == 1))
+    out = []
+    for e in range(4):
+        c = 4 * g4 + e
+        out.append((pl * g.PS + (zlo if redirected(c) else 1 + c + dw)) if okl else None)
+    for e in range(4):
+        c = 4 * g4 + e + (16 if g.H == 4 else 0)
+        imm = 16 if g.H == 4 else 0
+        out.append((ph * g.PS + ((zhi + imm) if redirected(c) else 1 + c + dw)) if okh else None)
+    return (okl or okh), out
