@@ -1243,8 +1243,19 @@ struct PackJob {            // 64 bytes, mirrored by lstm_ctc_ocr_amd/engine.py 
 
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int njobs) {
     __shared__ float tile[64][65];
+    // which job is this block's?  The last one whose block_start <= blockIdx.x — found by ALL threads at once (thread t looks at jobs t, t + 256, ...;
+    // wave maximum, then the four waves' through LDS).  Round 6: the serial scan `while (blockIdx.x >= jobs[j + 1].block_start) ++j` was one dependent
+    // L2 round trip per job in front of every block — ~110 of them for the last blocks of configs[4]'s table (its re-pack launch took 151 us at 1.7 TB/s
+    // where the headline's 20-job table runs at 5 TB/s).
+    __shared__ int jsel[4];
     int j = 0;
-    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block_start) ++j;
+    for (int k = threadIdx.x; k < njobs; k += 256)
+        if (jobs[k].block_start <= (int)blockIdx.x) j = k;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) j = max(j, __shfl_xor(j, off));
+    if ((threadIdx.x & 63) == 0) jsel[threadIdx.x >> 6] = j;
+    __syncthreads();
+    j = max(max(jsel[0], jsel[1]), max(jsel[2], jsel[3]));
     const PackJob jb = jobs[j];
     const int b = blockIdx.x - jb.block_start;
     if (jb.type == 0) {                                // fp32 [R][ldin] -> bf16 [Cc][R] (transposed), 64 x 64 tiles:

@@ -1118,8 +1118,17 @@ struct W9ReduceJob {        // 64 bytes, mirrored by lstm_ctc_ocr_amd/engine.py 
     int S, rows, Cout, block_start;
 };
 __global__ __launch_bounds__(256) void wgrad9_reduce_jobs_kernel(const W9ReduceJob* __restrict__ jobs, int njobs) {
+    // the block's job = the last one whose block_start <= blockIdx.x, looked up by all threads at once (round 6: the serial scan was one dependent L2
+    // round trip per job in front of every block; nn_ops.hip::pack_jobs_kernel)
+    __shared__ int jsel[4];
     int j = 0;
-    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block_start) ++j;
+    for (int k = threadIdx.x; k < njobs; k += 256)
+        if (jobs[k].block_start <= (int)blockIdx.x) j = k;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) j = max(j, __shfl_xor(j, off));
+    if ((threadIdx.x & 63) == 0) jsel[threadIdx.x >> 6] = j;
+    __syncthreads();
+    j = max(max(jsel[0], jsel[1]), max(jsel[2], jsel[3]));
     const W9ReduceJob jb = jobs[j];
     w9_reduce_body(jb.dw, jb.part, jb.n4, jb.slab4, jb.S, jb.rows, jb.dbias, jb.cs_part, jb.Cout, (int)blockIdx.x - jb.block_start);
 }
