@@ -336,6 +336,17 @@ int ocr_optim_step_guarded2(float* params, float* grads, float* state1, float* s
                             void* scalars, const void* guard_addrs, int nguard, const float* drop_flag, void* stream);
 int ocr_guard_flag(const void* guard_addrs, int nguard, float* flag_out, void* stream);
 
+/* ---- GPU-side captcha synthesis (the data side of the path: /root/reference/lib/lstm/utils/gen.py:31-37 generateImg — captcha.ImageCaptcha on 12
+ * worker processes — and :41-67 groupBatch: resize to height 32, [W, 32] rows, right-padded with 0) ---------------------------------------------
+ * One workgroup per image composes resident glyph masks in LDS with Pillow's own arithmetic (affine bilinear rotation, DIV255 paste, bicubic
+ * resize, noise dots + arc, 3 x 3 SMOOTH, bilinear resize) and writes out[n_images][W][out_h] uint8 — what ocr_bind_batch takes as pixels.
+ * params: int32 [n_images][words_per_image] records (lstm_ctc_ocr_amd/utils/synth.draw_params: every random draw + the integer geometry;
+ * max_glyphs glyph slots per record); atlas: concatenated 8-bit glyph masks (records hold byte offsets into it); stamp: n_stamp (dx, dy) int32
+ * pairs = the footprint of one noise dot; canvas_cap / width_cap >= every record's canvas_w / width (they size the LDS image:
+ * 60 * (canvas_cap + width_cap) + 34816 bytes <= 160 KB, else OCR_ERR_INVALID). */
+int ocr_captcha_synth(const int* params, int n_images, int words_per_image, int max_glyphs, const void* atlas, const int* stamp, int n_stamp,
+                      void* out, int W, int out_h, int canvas_cap, int width_cap, void* stream);
+
 /* diagnostics: s_memtime stamps of workgroup 0 (NULL = off); device int64 [8 waves][64 steps][8] / [8][80][8] */
 int ocr_wgrad9_debug(void* dbg);
 

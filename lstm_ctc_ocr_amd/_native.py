@@ -86,6 +86,7 @@ _SIGS = {
     "ocr_u8_to_unit_f32": ([_P, _P, _L, _P], _I),
     "ocr_step_report": ([_P, _I, _P, _P, _I, _P, _P], _I),
     "ocr_bind_batch": ([_P, _I, _P, _L, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P], _I),
+    "ocr_captcha_synth": ([_P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P], _I),
     "ocr_cast2d_f32_bf16": ([_P, _L, _P, _L, _I, _I, _P], _I),
     "ocr_tnc_to_ntc_bf16": ([_P, _P, _I, _I, _I, _F, _P], _I),
     "ocr_conv5_col2im": ([_P, _P, _I, _I, _I, _P], _I),

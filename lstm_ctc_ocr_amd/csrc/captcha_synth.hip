@@ -1,0 +1,254 @@
+// GPU-side captcha synthesis: the training images of the reference's generator
+// (/root/reference/lib/lstm/utils/gen.py:31-37 generateImg -> captcha.ImageCaptcha, :41-67 groupBatch: resize to height 32, [W, 32] rows,
+// right-padded with 0) composed on the device from a resident atlas of glyph masks.  One workgroup per image, the whole image in LDS:
+//
+//   A  canvas[60][canvas_w] = background; per glyph, in order: the rotated coverage (affine transform of the atlas mask with bilinear sampling,
+//      double arithmetic, (UINT8) truncation — Pillow's Geometry.c affine_transform + bilinear_filter8) blended in with the paste's
+//      DIV255(out * (255 - m) + ink * m)
+//   B  canvas wider than the captcha: horizontal bicubic resampling to [60][width] (Resample.c: double coefficients normalised per output
+//      column, quantised to 22 fractional bits, integer accumulation)
+//   C  30 noise dots (the footprint of ImageDraw's 3-wide diagonal line, passed in) and the noise arc (thin ellipse outline between the two
+//      end normals — the one primitive that is NOT Pillow's algorithm, see tools/synth_model.py arc_pixels)
+//   D  3 x 3 SMOOTH (Filter.c ImagingFilter3x3: float32, border pixels copied)
+//   E  bilinear resampling to [32][nw_out], horizontal pass then vertical pass, each rounded to 8 bits (Resample.c again)
+//   F  [W][32] uint8 rows to HBM, columns >= nw_out zero
+//
+// The parameters (every random draw and the integer geometry that follows) come from the host: lstm_ctc_ocr_amd/utils/synth.draw_params.
+// Bit-exact against the numpy model tools/synth_model.py, which is bit-exact against Pillow 12 itself without the arc (tests/test_synth.py,
+// tests/test_gpu_synth.py) — hence no floating-point contraction in this file: Pillow's C code is compiled without fused multiply-adds.
+// HBM traffic per image: ~400 bytes of parameters + <= 30 KB of atlas masks (L2-resident: the atlas is 285 KB) read, W * 32 bytes written.
+#include "common.h"
+#pragma clang fp contract(off)
+
+#define SY_H 60
+#define SY_HDR 32
+#define SY_NDOTS 30
+#define SY_GW 20
+#define SY_TAPS 32
+#define SY_PREC 22
+
+struct SynthArgs {
+    const int* params; int S; int G;
+    const uint8_t* atlas; const int* stamp; int nstamp;
+    uint8_t* out; int W; int ccap; int wcap; int out_h;
+};
+
+__device__ __forceinline__ double sy_dbl(const int* p) {
+    return __hiloint2double(p[1], p[0]);
+}
+__device__ __forceinline__ double sy_bicubic(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+__device__ __forceinline__ double sy_bilinear(double x) {
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return 1.0 - x;
+    return 0.0;
+}
+// Resample.c precompute_coeffs + normalize_coeffs_8bpc for output position xx: taps -> coef[k * 256 + slot], returns (first input index, count)
+template <bool BICUBIC>
+__device__ __forceinline__ void sy_coeffs(int in_size, int out_size, int xx, int slot, int* coef, int* cmin, int* cn) {
+    const double scale = (double)in_size / (double)out_size;
+    const double fs = scale < 1.0 ? 1.0 : scale;
+    const double support = (BICUBIC ? 2.0 : 1.0) * fs;
+    const double ss = 1.0 / fs;
+    const double center = (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    int n = xmax - xmin;
+    if (n > SY_TAPS) n = SY_TAPS;                       // (the host refuses such ratios: utils/synth.draw_params)
+    double ww = 0.0;
+    for (int x = 0; x < n; ++x) {
+        const double t = (x + xmin - center + 0.5) * ss;
+        ww += BICUBIC ? sy_bicubic(t) : sy_bilinear(t);
+    }
+    for (int x = 0; x < n; ++x) {
+        const double t = (x + xmin - center + 0.5) * ss;
+        double w = BICUBIC ? sy_bicubic(t) : sy_bilinear(t);
+        if (ww != 0.0) w = w / ww;
+        coef[x * 256 + slot] = w < 0 ? (int)(-0.5 + w * (double)(1 << SY_PREC)) : (int)(0.5 + w * (double)(1 << SY_PREC));
+    }
+    cmin[slot] = xmin; cn[slot] = n;
+}
+// One resampling pass over `lines` independent lines: element i of line r is src[r * s_line + i * s_pos]; output likewise in dst (LDS or HBM).
+template <bool BICUBIC>
+__device__ void sy_resample(const uint8_t* src, int s_line, int s_pos, int in_size, int lines,
+                            uint8_t* dst, int d_line, int d_pos, int out_size, int* coef, int* cmin, int* cn, bool lines_fastest) {
+    for (int c0 = 0; c0 < out_size; c0 += 256) {
+        const int nc = min(256, out_size - c0);
+        if ((int)threadIdx.x < nc) sy_coeffs<BICUBIC>(in_size, out_size, c0 + threadIdx.x, threadIdx.x, coef, cmin, cn);
+        __syncthreads();
+        const int total = nc * lines;
+        for (int idx = threadIdx.x; idx < total; idx += 256) {
+            int r, c;
+            if (lines_fastest) { r = idx % lines; c = idx / lines; } else { r = idx / nc; c = idx % nc; }
+            const int x0 = cmin[c], n = cn[c];
+            int acc = 1 << (SY_PREC - 1);
+            const uint8_t* s = src + (long)r * s_line + (long)x0 * s_pos;
+            for (int k = 0; k < n; ++k) acc += (int)s[(long)k * s_pos] * coef[k * 256 + c];
+            acc >>= SY_PREC;
+            dst[(long)r * d_line + (long)(c0 + c) * d_pos] = (uint8_t)(acc < 0 ? 0 : acc > 255 ? 255 : acc);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void captcha_synth_kernel(SynthArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint8_t* canvas = smem;                                   // [60][canvas_w]; later the smoothed image [60][width]
+    uint8_t* img = smem + SY_H * a.ccap;                      // [60][width]; later the horizontally reduced image [60][nw_out]
+    int* coef = (int*)(smem + SY_H * (a.ccap + a.wcap));      // [SY_TAPS][256]
+    int* cmin = coef + SY_TAPS * 256;
+    int* cn = cmin + 256;
+    const int tid = threadIdx.x;
+    const int* p = a.params + (long)blockIdx.x * a.S;
+    const int width = p[0], cw = p[1], nw_out = p[2];
+    const int L = min(p[3], a.G);
+    const int bg = p[4], fg = p[5];
+
+    // A: background, glyphs in order
+    for (int i = tid; i < SY_H * cw; i += 256) canvas[i] = (uint8_t)bg;
+    __syncthreads();
+    for (int g = 0; g < L; ++g) {
+        const int* q = p + SY_HDR + 2 * SY_NDOTS + g * SY_GW;
+        const uint8_t* mask = a.atlas + q[0];
+        const int mw = q[1], mh = q[2], px = q[3], py = q[4], nw = q[5], nh = q[6];
+        const double m0 = sy_dbl(q + 8), m1 = sy_dbl(q + 10), m2 = sy_dbl(q + 12), m3 = sy_dbl(q + 14), m4 = sy_dbl(q + 16), m5 = sy_dbl(q + 18);
+        for (int i = tid; i < nw * nh; i += 256) {
+            const int yo = i / nw, xo = i - yo * nw;
+            const int X = px + xo, Y = py + yo;
+            if (X < 0 || X >= cw || Y < 0 || Y >= SY_H) continue;
+            double xin = m0 * (xo + 0.5) + m1 * (yo + 0.5) + m2;
+            double yin = m3 * (xo + 0.5) + m4 * (yo + 0.5) + m5;
+            if (xin < 0.0 || xin >= (double)mw || yin < 0.0 || yin >= (double)mh) continue;       // fill 0: the blend leaves the pixel
+            xin -= 0.5; yin -= 0.5;
+            const int x = (int)floor(xin), y = (int)floor(yin);
+            const double dx = xin - x, dy = yin - y;
+            const int x0 = x < 0 ? 0 : x < mw ? x : mw - 1;
+            const int x1 = x + 1 < 0 ? 0 : x + 1 < mw ? x + 1 : mw - 1;
+            const int yc = y < 0 ? 0 : y < mh ? y : mh - 1;
+            const uint8_t* in = mask + yc * mw;
+            double v1 = (double)in[x0] + ((double)in[x1] - (double)in[x0]) * dx, v2 = v1;
+            if (y + 1 >= 0 && y + 1 < mh) {
+                in = mask + (y + 1) * mw;
+                v2 = (double)in[x0] + ((double)in[x1] - (double)in[x0]) * dx;
+            }
+            v1 = v1 + (v2 - v1) * dy;
+            const int m = (int)v1 & 255;
+            if (m == 0) continue;
+            const int t = (int)canvas[Y * cw + X] * (255 - m) + fg * m + 128;
+            canvas[Y * cw + X] = (uint8_t)(((t >> 8) + t) >> 8);
+        }
+        __syncthreads();
+    }
+
+    // B: to the captcha's width
+    if (cw > width) {
+        sy_resample<true>(canvas, cw, 1, cw, SY_H, img, width, 1, width, coef, cmin, cn, false);
+    } else {
+        for (int i = tid; i < SY_H * width; i += 256) img[i] = canvas[i];
+        __syncthreads();
+    }
+
+    // C: noise dots and noise arc (same ink everywhere: the order of the stores does not matter)
+    for (int i = tid; i < SY_NDOTS * a.nstamp; i += 256) {
+        const int d = i / a.nstamp, s = i - d * a.nstamp;
+        const int x = p[SY_HDR + 2 * d] + a.stamp[2 * s], y = p[SY_HDR + 2 * d + 1] + a.stamp[2 * s + 1];
+        if (x >= 0 && x < width && y >= 0 && y < SY_H) img[y * width + x] = (uint8_t)fg;
+    }
+    {
+        const int bx0 = p[6], by0 = p[7], bx1 = p[8], by1 = p[9];
+        const double start = (double)p[10], end = (double)p[11];
+        const double ea = (bx1 - bx0) / 2.0, eb = (by1 - by0) / 2.0, cx = (bx0 + bx1) / 2.0, cy = (by0 + by1) / 2.0;
+        const double l0 = sy_dbl(p + 16), l1 = sy_dbl(p + 18), l2 = sy_dbl(p + 20), r0 = sy_dbl(p + 22), r1 = sy_dbl(p + 24), r2 = sy_dbl(p + 26);
+        auto on_arc = [&](int ix, int iy) -> bool {
+            const double u = ix - cx, v = iy - cy;
+            double t = atan2(v / eb, u / ea) * (180.0 / 3.14159265358979323846);
+            if (t < 0.0) t += 360.0;
+            if (t <= start + 30.0 || t >= 330.0) return l0 * u + l1 * v + l2 >= 0.0;
+            if (end - 30.0 <= t && t <= end + 30.0) return r0 * u + r1 * v + r2 >= 0.0;
+            return start < t && t < end;
+        };
+        if (ea > 0.0 && eb > 0.0) {
+            const int xa = max(0, bx0), xb = min(width - 1, bx1), ya = max(0, by0), yb = min(SY_H - 1, by1);
+            const int ncol = max(0, xb - xa + 1), nrow = max(0, yb - ya + 1);
+            for (int i = tid; i < 2 * (ncol + nrow); i += 256) {
+                const double sg = (i & 1) ? -1.0 : 1.0;
+                const int j = i >> 1;
+                if (j < ncol) {                                        // flat stretches: one pixel per column
+                    const int x = xa + j;
+                    const double u = (x - cx) / ea;
+                    if (fabs(u) > 1.0) continue;
+                    const double s = sqrt(1.0 - u * u);
+                    if (fabs(u) * eb > s * ea) continue;
+                    const int yi = (int)floor(cy + sg * eb * s + 0.5);
+                    if (yi >= 0 && yi < SY_H && on_arc(x, yi)) img[yi * width + x] = (uint8_t)fg;
+                } else {                                               // steep stretches: one pixel per row
+                    const int y = ya + (j - ncol);
+                    const double v = (y - cy) / eb;
+                    if (fabs(v) > 1.0) continue;
+                    const double s = sqrt(1.0 - v * v);
+                    if (fabs(v) * ea >= s * eb) continue;
+                    const int xi = (int)floor(cx + sg * ea * s + 0.5);
+                    if (xi >= 0 && xi < width && on_arc(xi, y)) img[y * width + xi] = (uint8_t)fg;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // D: SMOOTH, img -> canvas region [60][width]
+    {
+        const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
+        uint8_t* sm = canvas;
+        for (int i = tid; i < SY_H * width; i += 256) {
+            const int y = i / width, x = i - y * width;
+            uint8_t o = img[i];
+            if (y > 0 && y < SY_H - 1 && x > 0 && x < width - 1) {
+                const uint8_t* c = img + i;
+                float ss = 0.5f;
+                ss += (float)c[width - 1] * k1 + (float)c[width] * k1 + (float)c[width + 1] * k1;
+                ss += (float)c[-1] * k1 + (float)c[0] * k5 + (float)c[1] * k1;
+                ss += (float)c[-width - 1] * k1 + (float)c[-width] * k1 + (float)c[-width + 1] * k1;
+                o = ss <= 0.0f ? 0 : ss >= 255.0f ? 255 : (uint8_t)(int)ss;
+            }
+            sm[i] = o;
+        }
+    }
+    __syncthreads();
+
+    // E: bilinear to [out_h][nw_out]: rows of the smoothed image first (-> img region, [60][nw_out]), then columns, straight to HBM as [W][out_h]
+    sy_resample<false>(canvas, width, 1, width, SY_H, img, nw_out, 1, nw_out, coef, cmin, cn, false);
+    uint8_t* o = a.out + (long)blockIdx.x * a.W * a.out_h;
+    sy_resample<false>(img, 1, nw_out, SY_H, nw_out, o, a.out_h, 1, a.out_h, coef, cmin, cn, false);
+    // F: right padding
+    for (int i = nw_out * a.out_h + tid; i < a.W * a.out_h; i += 256) o[i] = 0;
+}
+
+// params: [n_images][words_per_image] int32 records of utils/synth.draw_params (max_glyphs glyph slots each); atlas: the concatenated glyph masks;
+// stamp: n_stamp (dx, dy) pairs; out: [n_images][W][out_h] uint8.  canvas_cap / width_cap: upper bounds of the records' canvas_w / width
+// (they size the LDS image: 60 * (canvas_cap + width_cap) + 34816 bytes <= 160 KB).
+extern "C" int ocr_captcha_synth(const int* params, int n_images, int words_per_image, int max_glyphs, const void* atlas, const int* stamp,
+                                 int n_stamp, void* out, int W, int out_h, int canvas_cap, int width_cap, void* stream) {
+    if (!params || !atlas || !out || (n_stamp && !stamp) || n_images < 0 || max_glyphs < 0 || W <= 0 || out_h <= 0 || out_h > SY_H ||
+        words_per_image < SY_HDR + 2 * SY_NDOTS + SY_GW * max_glyphs || canvas_cap < width_cap || width_cap < 8)
+        return OCR_ERR_INVALID;
+    if (n_images == 0) return OCR_OK;
+    const int ccap = (canvas_cap + 15) & ~15, wcap = (width_cap + 15) & ~15;
+    const int lds = SY_H * (ccap + wcap) + (SY_TAPS * 256 + 512) * 4;
+    if (lds > 160 * 1024) return OCR_ERR_INVALID;
+    static int lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute((const void*)captcha_synth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return OCR_ERR_EXEC;
+        lds_set = lds;
+    }
+    SynthArgs a{params, words_per_image, max_glyphs, (const uint8_t*)atlas, stamp, n_stamp, (uint8_t*)out, W, ccap, wcap, out_h};
+    captcha_synth_kernel<<<n_images, 256, lds, (hipStream_t)stream>>>(a);
+    OCR_CHECK_LAUNCH();
+    return OCR_OK;
+}

@@ -471,6 +471,20 @@ def bind_batch(pixels, x, seq_len, seq_len_dst, labels=None, labels_dst=None, la
          0 if labels_len is None else labels_len.numel(), _st())
 
 
+def captcha_synth(params, n_images, words_per_image, atlas, stamp, out, W, stream=None, max_glyphs=None, canvas_cap=1024, width_cap=600,
+                  out_h=32):
+    """GPU-side captcha synthesis (csrc/captcha_synth.hip): params int32 [n_images * words_per_image (+ more)] device records of
+    utils.synth.draw_params -> out uint8 [n_images, W, out_h].  stream: a torch stream (default: the current one)."""
+    assert params.dtype == torch.int32 and atlas.dtype == torch.uint8 and stamp.dtype == torch.int32 and out.dtype == torch.uint8
+    assert params.numel() >= n_images * words_per_image and out.numel() >= n_images * W * out_h
+    if max_glyphs is None:
+        max_glyphs = (words_per_image - 92) // 20
+    st = _st() if stream is None else stream.cuda_stream
+    call("ocr_captcha_synth", ptr(_dev(params)), n_images, words_per_image, max_glyphs, ptr(_dev(atlas)), ptr(_dev(stamp)), stamp.numel() // 2,
+         ptr(_dev(out)), W, out_h, canvas_cap, width_cap, st)
+    return out
+
+
 def step_report(costs, scalars, word_addrs, out):
     """out[0..3] (double) = mean cost, scalars[1], scalars[7], bit mask of the error words that read 1 (+ 2^40: this step's update was dropped) — ocr_step_report."""
     nw = 0 if word_addrs is None else word_addrs.numel()

@@ -93,6 +93,9 @@ class SolverWrapper(object):
         if train_gen is None:
             if os.environ.get('OCR_PIPELINE', 'ring') == 'legacy':       # the reference's transport: 12 processes -> pickled float batches
                 train_gen = get_batch(num_workers=12, batch_size=cfg.TRAIN.BATCH_SIZE, vis=False)
+            elif os.environ.get('OCR_PIPELINE') == 'synth':              # the captchas are composed on the GPU (utils/synth.py): no PIL workers,
+                from .utils.synth import DeviceSynthStream               # the loop runs at the device's pace instead of the host's
+                train_gen = DeviceSynthStream(eng.device, cfg.TRAIN.BATCH_SIZE)
             else:                     # shared-memory ring + pinned asynchronous H2D, batches arrive device-resident (utils/pipeline.py)
                 from .utils.pipeline import DeviceBatchStream
                 train_gen = DeviceBatchStream(eng.device, cfg.TRAIN.BATCH_SIZE)

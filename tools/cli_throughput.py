@@ -66,6 +66,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=2000)
     ap.add_argument('--legacy', action='store_true')
+    ap.add_argument('--synth', action='store_true', help='GPU-side synthesis (utils/synth.DeviceSynthStream) instead of the PIL worker ring')
     ap.add_argument('--workers', type=int, default=0)
     ap.add_argument('--pool', type=int, default=0)
     ap.add_argument('--only', default='', help='run one configuration only: W88 or W256')
@@ -74,7 +75,7 @@ def main():
     global LAG
     LAG = not a.no_lag
     cfg_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lstm', 'lstm.yml'))
-    out = {'cpu_count': os.cpu_count(), 'affinity': len(os.sched_getaffinity(0)), 'pool': a.pool, 'loss_lag': LAG}
+    out = {'source': 'gpu synthesis' if a.synth else 'PIL workers', 'cpu_count': os.cpu_count(), 'affinity': len(os.sched_getaffinity(0)), 'pool': a.pool, 'loss_lag': LAG}
     try:
         out['cgroup_cpu_max'] = open('/sys/fs/cgroup/cpu.max').read().strip()
     except Exception:
@@ -87,11 +88,14 @@ def main():
         if a.legacy:
             from lstm_ctc_ocr_amd.utils.gen import get_batch
             stream = get_batch(num_workers=12, batch_size=64, vis=False, **kw)
+        elif a.synth:
+            from lstm_ctc_ocr_amd.utils.synth import DeviceSynthStream
+            stream = DeviceSynthStream('cuda:0', 64, **kw)
         else:
             from lstm_ctc_ocr_amd.utils.pipeline import DeviceBatchStream
             stream = DeviceBatchStream('cuda:0', 64, workers=a.workers or None, pool=a.pool, **kw)
             time.sleep(3.0)                                          # let the ring fill
-        nworkers = len(stream.ring.procs) if hasattr(stream, 'ring') else 12
+        nworkers = len(stream.ring.procs) if hasattr(stream, 'ring') else (0 if a.synth else 12)
         ips, ms, loss = run(eng, stream, a.iters, 50)
         # device-resident rate of the same shape: replay ONE batch that is already in HBM
         b = next(iter(stream))
