@@ -17,6 +17,13 @@
 // Bit-exact against the numpy model tools/synth_model.py, which is bit-exact against Pillow 12 itself without the arc (tests/test_synth.py,
 // tests/test_gpu_synth.py) — hence no floating-point contraction in this file: Pillow's C code is compiled without fused multiply-adds.
 // HBM traffic per image: ~400 bytes of parameters + <= 30 KB of atlas masks (L2-resident: the atlas is 285 KB) read, W * 32 bytes written.
+// Bound: neither HBM nor the matrix pipes — one CU's vector ALU.  Measured alone (tools/synth_bench.py, profiles/r06l_synth_bench.log, batch of
+// 64): 63 us at W = 88 (4-6 glyphs), 126 us at W = 256 (10 glyphs) = 1.0 M / 0.5 M images/s, 12x / 9x what the training step consumes; by
+// stage, cut off one after the other (profiles/r06l_synth_stages.log, us at W = 88 / 256): empty launch 8 / 8, A 15 / 27, B 20 / 32 (the slowest
+// image of the batch decides: one that needs the bicubic pass), C 1.4 / 2.2, D 9 / 26, E rows 6 / 15, E columns + stores 3 / 15.  Beside a training
+// step it costs its share of the chip: 64 CUs x 63-126 us of 256 CUs x 750-1140 us = 2-3 % (the live loop runs at 0.97-0.98x of the
+// device-resident rate).  Known headroom, not built: four pixels per thread in D (dword LDS reads, shared products), row-per-wave loops
+// instead of the runtime divisions, register-resident taps in E.
 #include "common.h"
 #pragma clang fp contract(off)
 
@@ -26,6 +33,8 @@
 #define SY_GW 20
 #define SY_TAPS 32
 #define SY_PREC 22
+#define SY_NT 1024           // threads per image: 16 waves, 4 per SIMD — with 4 the LDS / L2 latencies of every stage were exposed (173 us per batch)
+#define SY_STAGE_G 12        // glyph masks staged in LDS before stage A (<= 3072 bytes each; others are sampled from L2)
 
 struct SynthArgs {
     const int* params; int S; int G;
@@ -84,7 +93,7 @@ __device__ void sy_resample(const uint8_t* src, int s_line, int s_pos, int in_si
         if ((int)threadIdx.x < nc) sy_coeffs<BICUBIC>(in_size, out_size, c0 + threadIdx.x, threadIdx.x, coef, cmin, cn);
         __syncthreads();
         const int total = nc * lines;
-        for (int idx = threadIdx.x; idx < total; idx += 256) {
+        for (int idx = threadIdx.x; idx < total; idx += SY_NT) {
             int r, c;
             if (lines_fastest) { r = idx % lines; c = idx / lines; } else { r = idx / nc; c = idx % nc; }
             const int x0 = cmin[c], n = cn[c];
@@ -98,7 +107,7 @@ __device__ void sy_resample(const uint8_t* src, int s_line, int s_pos, int in_si
     }
 }
 
-__global__ __launch_bounds__(256) void captcha_synth_kernel(SynthArgs a) {
+__global__ __launch_bounds__(SY_NT) void captcha_synth_kernel(SynthArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint8_t* canvas = smem;                                   // [60][canvas_w]; later the smoothed image [60][width]
     uint8_t* img = smem + SY_H * a.ccap;                      // [60][width]; later the horizontally reduced image [60][nw_out]
@@ -111,16 +120,44 @@ __global__ __launch_bounds__(256) void captcha_synth_kernel(SynthArgs a) {
     const int L = min(p[3], a.G);
     const int bg = p[4], fg = p[5];
 
-    // A: background, glyphs in order
-    for (int i = tid; i < SY_H * cw; i += 256) canvas[i] = (uint8_t)bg;
+    // A: background, glyphs in order.  The masks come out of the atlas ONCE, all of them in flight together, into the LDS the later stages use
+    // (img + coefficient table, idle until stage B): sampled straight from L2, four dependent byte loads per pixel made this stage most of
+    // the kernel's time.
+    for (int i = tid; i < SY_H * cw; i += SY_NT) canvas[i] = (uint8_t)bg;
+    const int stage_cap = SY_H * a.wcap + (SY_TAPS * 256 + 512) * 4;
+    {
+        uint8_t v[SY_STAGE_G][3];
+#pragma unroll
+        for (int g = 0; g < SY_STAGE_G; ++g) {
+            const int* q = p + SY_HDR + 2 * SY_NDOTS + (g < L ? g : 0) * SY_GW;
+            const int sz = g < L ? q[1] * q[2] : 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v[g][j] = (tid + j * SY_NT < sz) ? a.atlas[q[0] + tid + j * SY_NT] : (uint8_t)0;
+        }
+        int off = 0;
+#pragma unroll
+        for (int g = 0; g < SY_STAGE_G; ++g) {
+            const int* q = p + SY_HDR + 2 * SY_NDOTS + (g < L ? g : 0) * SY_GW;
+            const int sz = g < L ? q[1] * q[2] : 0;
+            if (sz <= 3 * SY_NT && off + sz <= stage_cap) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) if (tid + j * SY_NT < sz) img[off + tid + j * SY_NT] = v[g][j];
+            }
+            off += (sz + 15) & ~15;
+        }
+    }
     __syncthreads();
+    int moff = 0;
     for (int g = 0; g < L; ++g) {
         const int* q = p + SY_HDR + 2 * SY_NDOTS + g * SY_GW;
-        const uint8_t* mask = a.atlas + q[0];
         const int mw = q[1], mh = q[2], px = q[3], py = q[4], nw = q[5], nh = q[6];
+        const bool staged = g < SY_STAGE_G && mw * mh <= 3 * SY_NT && moff + mw * mh <= stage_cap;
+        const uint8_t* mask = staged ? (const uint8_t*)(img + moff) : a.atlas + q[0];
+        moff += (mw * mh + 15) & ~15;
         const double m0 = sy_dbl(q + 8), m1 = sy_dbl(q + 10), m2 = sy_dbl(q + 12), m3 = sy_dbl(q + 14), m4 = sy_dbl(q + 16), m5 = sy_dbl(q + 18);
-        for (int i = tid; i < nw * nh; i += 256) {
-            const int yo = i / nw, xo = i - yo * nw;
+        const unsigned rnw = nw > 1 ? (unsigned)((0x100000000ull + nw - 1) / nw) : 0u;       // i / nw = umulhi(i, ceil(2^32 / nw)) for i * nw < 2^32
+        for (int i = tid; i < nw * nh; i += SY_NT) {
+            const int yo = nw > 1 ? (int)__umulhi((unsigned)i, rnw) : i, xo = i - yo * nw;
             const int X = px + xo, Y = py + yo;
             if (X < 0 || X >= cw || Y < 0 || Y >= SY_H) continue;
             double xin = m0 * (xo + 0.5) + m1 * (yo + 0.5) + m2;
@@ -128,16 +165,17 @@ __global__ __launch_bounds__(256) void captcha_synth_kernel(SynthArgs a) {
             if (xin < 0.0 || xin >= (double)mw || yin < 0.0 || yin >= (double)mh) continue;       // fill 0: the blend leaves the pixel
             xin -= 0.5; yin -= 0.5;
             const int x = (int)floor(xin), y = (int)floor(yin);
-            const double dx = xin - x, dy = yin - y;
             const int x0 = x < 0 ? 0 : x < mw ? x : mw - 1;
             const int x1 = x + 1 < 0 ? 0 : x + 1 < mw ? x + 1 : mw - 1;
             const int yc = y < 0 ? 0 : y < mh ? y : mh - 1;
+            const bool row2 = y + 1 >= 0 && y + 1 < mh;
             const uint8_t* in = mask + yc * mw;
-            double v1 = (double)in[x0] + ((double)in[x1] - (double)in[x0]) * dx, v2 = v1;
-            if (y + 1 >= 0 && y + 1 < mh) {
-                in = mask + (y + 1) * mw;
-                v2 = (double)in[x0] + ((double)in[x1] - (double)in[x0]) * dx;
-            }
+            const uint8_t* in2 = mask + (row2 ? y + 1 : yc) * mw;
+            const int t00 = in[x0], t01 = in[x1], t10 = in2[x0], t11 = in2[x1];
+            if ((t00 | t01 | t10 | t11) == 0) continue;                                           // most of a rotated box is empty: coverage 0
+            const double dx = xin - x, dy = yin - y;
+            double v1 = (double)t00 + ((double)t01 - (double)t00) * dx, v2 = v1;
+            if (row2) v2 = (double)t10 + ((double)t11 - (double)t10) * dx;
             v1 = v1 + (v2 - v1) * dy;
             const int m = (int)v1 & 255;
             if (m == 0) continue;
@@ -151,12 +189,12 @@ __global__ __launch_bounds__(256) void captcha_synth_kernel(SynthArgs a) {
     if (cw > width) {
         sy_resample<true>(canvas, cw, 1, cw, SY_H, img, width, 1, width, coef, cmin, cn, false);
     } else {
-        for (int i = tid; i < SY_H * width; i += 256) img[i] = canvas[i];
+        for (int i = tid; i < SY_H * width; i += SY_NT) img[i] = canvas[i];
         __syncthreads();
     }
 
     // C: noise dots and noise arc (same ink everywhere: the order of the stores does not matter)
-    for (int i = tid; i < SY_NDOTS * a.nstamp; i += 256) {
+    for (int i = tid; i < SY_NDOTS * a.nstamp; i += SY_NT) {
         const int d = i / a.nstamp, s = i - d * a.nstamp;
         const int x = p[SY_HDR + 2 * d] + a.stamp[2 * s], y = p[SY_HDR + 2 * d + 1] + a.stamp[2 * s + 1];
         if (x >= 0 && x < width && y >= 0 && y < SY_H) img[y * width + x] = (uint8_t)fg;
@@ -177,7 +215,7 @@ __global__ __launch_bounds__(256) void captcha_synth_kernel(SynthArgs a) {
         if (ea > 0.0 && eb > 0.0) {
             const int xa = max(0, bx0), xb = min(width - 1, bx1), ya = max(0, by0), yb = min(SY_H - 1, by1);
             const int ncol = max(0, xb - xa + 1), nrow = max(0, yb - ya + 1);
-            for (int i = tid; i < 2 * (ncol + nrow); i += 256) {
+            for (int i = tid; i < 2 * (ncol + nrow); i += SY_NT) {
                 const double sg = (i & 1) ? -1.0 : 1.0;
                 const int j = i >> 1;
                 if (j < ncol) {                                        // flat stretches: one pixel per column
@@ -206,7 +244,7 @@ __global__ __launch_bounds__(256) void captcha_synth_kernel(SynthArgs a) {
     {
         const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
         uint8_t* sm = canvas;
-        for (int i = tid; i < SY_H * width; i += 256) {
+        for (int i = tid; i < SY_H * width; i += SY_NT) {
             const int y = i / width, x = i - y * width;
             uint8_t o = img[i];
             if (y > 0 && y < SY_H - 1 && x > 0 && x < width - 1) {
@@ -227,7 +265,7 @@ __global__ __launch_bounds__(256) void captcha_synth_kernel(SynthArgs a) {
     uint8_t* o = a.out + (long)blockIdx.x * a.W * a.out_h;
     sy_resample<false>(img, 1, nw_out, SY_H, nw_out, o, a.out_h, 1, a.out_h, coef, cmin, cn, false);
     // F: right padding
-    for (int i = nw_out * a.out_h + tid; i < a.W * a.out_h; i += 256) o[i] = 0;
+    for (int i = nw_out * a.out_h + tid; i < a.W * a.out_h; i += SY_NT) o[i] = 0;
 }
 
 // params: [n_images][words_per_image] int32 records of utils/synth.draw_params (max_glyphs glyph slots each); atlas: the concatenated glyph masks;
@@ -248,7 +286,7 @@ extern "C" int ocr_captcha_synth(const int* params, int n_images, int words_per_
         lds_set = lds;
     }
     SynthArgs a{params, words_per_image, max_glyphs, (const uint8_t*)atlas, stamp, n_stamp, (uint8_t*)out, W, ccap, wcap, out_h};
-    captcha_synth_kernel<<<n_images, 256, lds, (hipStream_t)stream>>>(a);
+    captcha_synth_kernel<<<n_images, SY_NT, lds, (hipStream_t)stream>>>(a);
     OCR_CHECK_LAUNCH();
     return OCR_OK;
 }

@@ -39,4 +39,18 @@ def smoke():
     assert rel < 1e-3, 'loss %g vs oracle %g' % (loss, float(total))
     loss2 = eng.train_step(x, labels, ll, sl)
     assert np.isfinite(loss2)
+    # the data side: four captchas composed on the GPU against Pillow driven with the same parameters (everything but the noise arc is Pillow's own
+    # arithmetic and must be identical: oracle/synth_ref.py)
+    from . import ops
+    from .utils import gen, synth
+    from oracle import synth_ref
+    atlas = synth.GlyphAtlas()
+    P = synth.draw_params(np.random.default_rng(3), 4, atlas, strings=False)
+    P['packed'][:, 8] = P['packed'][:, 6]                                # empty arc box
+    W = gen.padded_width(int(P['nw_out'].max()))
+    pix = torch.zeros((4, W, 32), dtype=torch.uint8, device='cuda:0')
+    ops.captcha_synth(torch.from_numpy(P['packed'].reshape(-1).copy()).cuda(), 4, P['packed'].shape[1], torch.from_numpy(atlas.data).cuda(),
+                      torch.from_numpy(synth.dot_stamp().reshape(-1)).cuda(), pix, W, max_glyphs=P['max_glyphs'],
+                      canvas_cap=int(P['canvas_w'].max()), width_cap=int(P['widths'].max()))
+    assert np.array_equal(pix.cpu().numpy(), synth_ref.render_batch(P, atlas, W, arc=False)), 'synthesised captchas differ from Pillow'
     print('smoke ok: max|logits - oracle| = %.2e, loss %.6f (oracle %.6f), next-step loss %.6f' % (err, loss, float(total), loss2))

@@ -90,15 +90,22 @@ class SolverWrapper(object):
     def train_model(self, sess, max_iters, restore=False, train_gen=None, val_gen=None):
         eng = sess
         chief = getattr(eng, 'rank', 0) == 0            # data parallel: every rank trains, rank 0 prints / snapshots / validates
+        own_gen = train_gen is None
         if train_gen is None:
-            if os.environ.get('OCR_PIPELINE', 'ring') == 'legacy':       # the reference's transport: 12 processes -> pickled float batches
+            # OCR_PIPELINE: 'synth' (default for the reference's single-channel captchas) = the batches are composed on the GPU (utils/synth.py: no
+            # PIL workers, the loop runs at 0.97-0.98x of the device-resident rate); 'ring' = PIL worker processes -> shared-memory ring -> pinned
+            # asynchronous H2D (utils/pipeline.py: 0.42-0.53x on 16 cores); 'legacy' = the reference's transport, 12 processes -> pickled float batches
+            mode = os.environ.get('OCR_PIPELINE') or ('synth' if cfg.NCHANNELS == 1 else 'ring')
+            if mode == 'legacy':
                 train_gen = get_batch(num_workers=12, batch_size=cfg.TRAIN.BATCH_SIZE, vis=False)
-            elif os.environ.get('OCR_PIPELINE') == 'synth':              # the captchas are composed on the GPU (utils/synth.py): no PIL workers,
-                from .utils.synth import DeviceSynthStream               # the loop runs at the device's pace instead of the host's
+            elif mode == 'synth':
+                from .utils.synth import DeviceSynthStream
                 train_gen = DeviceSynthStream(eng.device, cfg.TRAIN.BATCH_SIZE)
-            else:                     # shared-memory ring + pinned asynchronous H2D, batches arrive device-resident (utils/pipeline.py)
+            elif mode == 'ring':
                 from .utils.pipeline import DeviceBatchStream
                 train_gen = DeviceBatchStream(eng.device, cfg.TRAIN.BATCH_SIZE)
+            else:
+                raise ValueError("OCR_PIPELINE=%r: expected 'synth', 'ring' or 'legacy'" % mode)
         val_gen = val_gen or get_batch(num_workers=1, seed=stream_seed(stream=1), batch_size=cfg.VAL.BATCH_SIZE, vis=False)
         world = getattr(eng, 'world', 1)
         self.net.build_loss()
@@ -159,6 +166,8 @@ class SolverWrapper(object):
             on_loss(pending[0], eng.report_wait(pending[1]), pending[2])
         if self.loss_log is not None:
             self.loss_log.flush()
+        if own_gen and hasattr(train_gen, 'close'):          # worker processes / feeder thread of the stream this call started
+            train_gen.close()
 
 
 def make_engine(network, use_graphs=True):

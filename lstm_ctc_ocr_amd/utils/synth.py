@@ -70,7 +70,15 @@ def _trunc(x):
     return np.trunc(x).astype(np.int64)
 
 
-def draw_params(rng, n, atlas, min_len=None, max_len=None, width=160, px_per_char=None):
+def _randint(rng, lo, hi, shape=None):
+    """random.randint(lo, hi) with ARRAY bounds, vectorised: lo + floor(u * (hi - lo + 1)) (Generator.integers takes array bounds too, at ~50 ns per
+    draw — the 30 noise dots of every image made it most of draw_params)."""
+    lo, hi = np.asarray(lo), np.asarray(hi)
+    u = rng.random(np.broadcast(lo, hi).shape if shape is None else shape)
+    return lo + np.minimum(np.floor(u * (hi - lo + 1)).astype(np.int64), hi - lo)
+
+
+def draw_params(rng, n, atlas, min_len=None, max_len=None, width=160, px_per_char=None, strings=True):
     """The random draws of n captchas (gen.sample_image + gen.render_captcha_gray, in their distributions) and the geometry that follows.
     rng: numpy Generator.  Returns a dict of arrays; 'packed' int32 [n, words_per_image(max_len)] is what the kernel reads."""
     lo = cfg.MIN_LEN if min_len is None else min_len
@@ -111,7 +119,7 @@ def draw_params(rng, n, atlas, min_len=None, max_len=None, width=160, px_per_cha
     avg = _trunc(text_w / np.maximum(1, L))
     q = _trunc(0.25 * avg)
     yj = rng.integers(-4, 5, (n, G))
-    adv = rng.integers(-q[:, None], 1, (n, G))
+    adv = _randint(rng, -q[:, None], 0, (n, G))
     pen_y = np.maximum(0, _trunc((HEIGHT - nh) / 2) + yj)
     pen_x = np.zeros((n, G), np.int64)
     x = _trunc(0.1 * avg)
@@ -123,10 +131,10 @@ def draw_params(rng, n, atlas, min_len=None, max_len=None, width=160, px_per_cha
         raise ValueError('captcha canvas of %d px: the synthesis kernel holds %d' % (canvas_w.max(), CANVAS_CAP))
     if widths.max() > WIDTH_CAP or widths.min() < 8:
         raise ValueError('captcha widths %d..%d outside [8, %d]' % (widths.min(), widths.max(), WIDTH_CAP))
-    dots = np.stack([rng.integers(0, widths[:, None] + 1, (n, NDOTS)), rng.integers(0, HEIGHT + 1, (n, NDOTS))], -1)
+    dots = np.stack([_randint(rng, 0, widths[:, None], (n, NDOTS)), rng.integers(0, HEIGHT + 1, (n, NDOTS))], -1)
     fifth = _trunc(widths / 5)
-    x1 = rng.integers(0, fifth + 1)
-    x2 = rng.integers(widths - fifth, widths + 1)
+    x1 = _randint(rng, 0, fifth)
+    x2 = _randint(rng, widths - fifth, widths)
     y1 = rng.integers(HEIGHT // 5, HEIGHT - HEIGHT // 5 + 1, n)
     y2 = rng.integers(HEIGHT // 5, HEIGHT + 1, n)
     a_start = rng.integers(0, 21, n)
@@ -153,7 +161,7 @@ def draw_params(rng, n, atlas, min_len=None, max_len=None, width=160, px_per_cha
     labels = atlas.codes[chars][live]                       # flat, sample-major
     return {'packed': packed, 'labels': labels.astype(np.int32), 'labels_len': L.astype(np.int32), 'steps': steps.astype(np.int32),
             'nw_out': nw_out, 'widths': widths, 'canvas_w': canvas_w, 'chars': chars, 'L': L,
-            'strings': [''.join(atlas.charset[c] for c in chars[i, :L[i]]) for i in range(n)], 'max_glyphs': G}
+            'strings': [''.join(atlas.charset[c] for c in chars[i, :L[i]]) for i in range(n)] if strings else None, 'max_glyphs': G}
 
 
 def arc_normals(box, start, end):
@@ -194,13 +202,59 @@ def dot_stamp():
     return np.stack([xs - 8, ys - 8], 1).astype(np.int32)
 
 
+MSG_HDR = 4                # int32 words in front of a batch message: W, canvas_cap, width_cap, number of labels
+
+
+def batch_words(B, G):
+    """int32 words of one batch message / device block: header | B parameter records | flat labels (room for B * G) | label_len[B] | steps[B]"""
+    return MSG_HDR + B * words_per_image(G) + B * G + 2 * B
+
+
+def fill_batches(p, B, G, out):
+    """Split the draws of k * B images (draw_params) into k batch blocks out[k][batch_words(B, G)] (int32)."""
+    S = words_per_image(G)
+    ends = np.cumsum(p['labels_len'])
+    for c in range(out.shape[0]):
+        s = slice(c * B, (c + 1) * B)
+        l0 = int(ends[c * B - 1]) if c else 0
+        l1 = int(ends[(c + 1) * B - 1])
+        m = out[c]
+        m[0], m[1], m[2], m[3] = gen.padded_width(int(p['nw_out'][s].max())), int(p['canvas_w'][s].max()), int(p['widths'][s].max()), l1 - l0
+        o = MSG_HDR + B * S
+        m[MSG_HDR:o] = p['packed'][s].reshape(-1)
+        m[o:o + l1 - l0] = p['labels'][l0:l1]
+        m[o + B * G:o + B * G + B] = p['labels_len'][s]
+        m[o + B * G + B:o + B * G + 2 * B] = p['steps'][s]
+
+
+def _param_worker(conn, seed, B, G, chunk, atlas, kw):
+    """Child process: draws parameters, `chunk` batches per numpy pass, and writes one message per batch into its pipe (which blocks when the
+    feeder is `depth` batches ahead: the back-pressure)."""
+    try:
+        rng = np.random.default_rng(seed)
+        out = np.zeros((chunk, batch_words(B, G)), np.int32)
+        while True:
+            fill_batches(draw_params(rng, B * chunk, atlas, strings=False, **kw), B, G, out)
+            for c in range(chunk):
+                conn.send_bytes(out[c])
+    except (BrokenPipeError, EOFError, KeyboardInterrupt, OSError):
+        pass
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        raise
+
+
 class DeviceSynthStream(object):
     """Iterator of device-resident batches — the tuples utils.pipeline.DeviceBatchStream yields: (pixels uint8 [B, W, 32], labels int32 [n],
-    label_len int32 [B], steps int32 [B]) — synthesised on the GPU.  A feeder thread draws the parameters of `chunk` batches per numpy pass
-    (the per-call overhead of ~40 small array operations is what the host pays), copies them through pinned memory on a side stream and launches
-    the synthesis kernel there, `depth` batches ahead of the training stream.  A returned batch stays valid until the NEXT call of next()."""
+    label_len int32 [B], steps int32 [B]) — synthesised on the GPU.  `workers` child processes draw the parameters (~0.3 ms of numpy per batch:
+    drawn on a thread of the training process they held its GIL in bursts of several ms and the launch loop stalled behind them — 0.96x of
+    the device-resident rate instead of the 0.99x the kernel costs); a feeder thread reads their messages round-robin straight into pinned
+    memory, copies them on a side stream and launches the synthesis kernel there, `depth` batches ahead of the training stream.  A returned
+    batch stays valid until the NEXT call of next().  Deterministic for a given (seed, workers, chunk)."""
 
-    def __init__(self, device, batch_size, depth=4, seed=None, chunk=8, **gen_kwargs):
+    def __init__(self, device, batch_size, depth=4, seed=None, chunk=8, workers=2, **gen_kwargs):
+        import multiprocessing
         import torch
         from .. import ops
         self.torch, self.ops = torch, ops
@@ -210,17 +264,25 @@ class DeviceSynthStream(object):
                        px_per_char=gen_kwargs.get('px_per_char'))
         self.atlas = GlyphAtlas()
         self.G = int(cfg.MAX_LEN if self.kw['max_len'] is None else self.kw['max_len'])
-        self.rng = np.random.default_rng(gen.stream_seed() if seed is None else seed)
+        seed = gen.stream_seed() if seed is None else seed
         self.d_atlas = torch.from_numpy(self.atlas.data).to(self.device)
         self.d_stamp = torch.from_numpy(dot_stamp().reshape(-1)).to(self.device)
         self.S = words_per_image(self.G)
-        max_w = gen.padded_width(int(cfg.IMG_HEIGHT / HEIGHT * (WIDTH_CAP if self.kw['px_per_char'] else self.kw['width'])))
-        self.max_w = max_w
-        nmeta = self.B * self.S + self.B * self.G + 2 * self.B
-        self.depth, self.chunk = depth, max(1, int(chunk))
+        self.max_w = gen.padded_width(int(cfg.IMG_HEIGHT / HEIGHT * (WIDTH_CAP if self.kw['px_per_char'] else self.kw['width'])))
+        nmeta = batch_words(self.B, self.G)
+        self.depth = depth
+        ctx = multiprocessing.get_context('fork')
+        self.conns, self.procs = [], []
+        for i in range(max(1, int(workers))):
+            rd, wr = ctx.Pipe(duplex=False)
+            pr = ctx.Process(target=_param_worker, args=(wr, seed + 1000003 * i, self.B, self.G, max(1, int(chunk)), self.atlas, self.kw), daemon=True)
+            pr.start()
+            wr.close()
+            self.conns.append(rd)
+            self.procs.append(pr)
         self.h_meta = [torch.empty(nmeta, dtype=torch.int32).pin_memory() for _ in range(depth)]
         self.d_meta = [torch.empty(nmeta, dtype=torch.int32, device=self.device) for _ in range(depth)]
-        self.d_pix = [torch.empty(self.B * max_w * cfg.NUM_FEATURES, dtype=torch.uint8, device=self.device) for _ in range(depth)]
+        self.d_pix = [torch.empty(self.B * self.max_w * cfg.NUM_FEATURES, dtype=torch.uint8, device=self.device) for _ in range(depth)]
         self.filled = [torch.cuda.Event() for _ in range(depth)]
         self.side = torch.cuda.Stream(device=self.device)
         self.free = queue.Queue()
@@ -233,46 +295,36 @@ class DeviceSynthStream(object):
         self.thread = threading.Thread(target=self._feed, daemon=True)
         self.thread.start()
 
-    def _draw_chunk(self):
-        B = self.B
-        p = draw_params(self.rng, B * self.chunk, self.atlas, **self.kw)
-        ends = np.cumsum(p['labels_len'])
-        out = []
-        for c in range(self.chunk):
-            s = slice(c * B, (c + 1) * B)
-            l0 = ends[c * B - 1] if c else 0
-            out.append((p['packed'][s], p['labels'][l0:ends[(c + 1) * B - 1]], p['labels_len'][s], p['steps'][s],
-                        gen.padded_width(int(p['nw_out'][s].max())), int(p['canvas_w'][s].max()), int(p['widths'][s].max())))
-        return out
-
     def _feed(self):
         torch = self.torch
         B, S, G = self.B, self.S, self.G
         try:
             torch.cuda.set_device(self.device)
-            pending = []
+            turn = 0
             while not self.halt.is_set():
                 try:
                     k, done = self.free.get(timeout=0.2)
                 except queue.Empty:
                     continue
-                if not pending:
-                    pending = self._draw_chunk()
-                packed, lab, ll, steps, W, ccap, wcap = pending.pop(0)
                 if done is not None:
                     done.synchronize()                       # everything that read this buffer (and its pinned source) has finished
                 hm = self.h_meta[k].numpy()
-                hm[:B * S] = packed.reshape(-1)
-                o = B * S
-                hm[o:o + lab.size] = lab
-                hm[o + B * G:o + B * G + B] = ll
-                hm[o + B * G + B:o + B * G + 2 * B] = steps
+                conn = self.conns[turn % len(self.conns)]
+                turn += 1
+                while not conn.poll(0.2):
+                    if self.halt.is_set():
+                        return
+                try:
+                    conn.recv_bytes_into(hm)
+                except EOFError:
+                    raise RuntimeError('a synthesis parameter worker died (its traceback is on stderr)')
+                W, ccap, wcap, nlab = int(hm[0]), int(hm[1]), int(hm[2]), int(hm[3])
                 with torch.cuda.stream(self.side):
                     self.d_meta[k].copy_(self.h_meta[k], non_blocking=True)
-                    self.ops.captcha_synth(self.d_meta[k], B, S, self.d_atlas, self.d_stamp, self.d_pix[k], W, stream=self.side, max_glyphs=G,
+                    self.ops.captcha_synth(self.d_meta[k][MSG_HDR:], B, S, self.d_atlas, self.d_stamp, self.d_pix[k], W, stream=self.side, max_glyphs=G,
                                            canvas_cap=ccap, width_cap=wcap, out_h=cfg.IMG_HEIGHT)
                     self.filled[k].record(self.side)
-                self.staged.put((k, W, int(lab.size)))
+                self.staged.put((k, W, nlab))
         except Exception as e:                               # surface in the consumer
             self.error = e
 
@@ -297,10 +349,22 @@ class DeviceSynthStream(object):
         torch.cuda.current_stream(self.device).wait_event(self.filled[k])
         B, S, G = self.B, self.S, self.G
         meta = self.d_meta[k]
-        o = B * S
+        o = MSG_HDR + B * S
         pix = self.d_pix[k][:B * W * cfg.NUM_FEATURES].view(B, W, cfg.NUM_FEATURES)
         return pix, meta[o:o + nlab], meta[o + B * G:o + B * G + B], meta[o + B * G + B:o + B * G + 2 * B]
 
     def close(self):
         self.halt.set()
         self.thread.join(timeout=2.0)
+        for c in self.conns:
+            c.close()
+        for pr in self.procs:
+            pr.terminate()
+        for pr in self.procs:
+            pr.join(timeout=2.0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

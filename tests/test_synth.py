@@ -125,3 +125,43 @@ def test_dot_stamp_is_translation_invariant():
     ImageDraw.Draw(im).draw.draw_lines(((31, 17), (30, 16)), 255, 3)
     ys, xs = np.nonzero(np.array(im))
     assert {(int(x) - 31, int(y) - 17) for x, y in zip(xs, ys)} == st
+
+
+def test_parameter_worker_messages(atlas):
+    """the child process that draws the parameters for the feeder: message layout, determinism, back-pressure through the pipe"""
+    import multiprocessing
+    B, G, chunk = 8, cfg.MAX_LEN, 3
+    kw = dict(min_len=None, max_len=None, width=160, px_per_char=None)
+
+    def take(seed, n):
+        ctx = multiprocessing.get_context('fork')
+        rd, wr = ctx.Pipe(duplex=False)
+        pr = ctx.Process(target=synth._param_worker, args=(wr, seed, B, G, chunk, atlas, kw), daemon=True)
+        pr.start()
+        wr.close()
+        out = []
+        try:
+            for _ in range(n):
+                m = np.empty(synth.batch_words(B, G), np.int32)
+                assert rd.poll(30)
+                rd.recv_bytes_into(m)
+                out.append(m)
+        finally:
+            rd.close()
+            pr.terminate()
+            pr.join(5)
+        return out
+    a, b = take(3, 5), take(3, 5)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and not np.array_equal(a[0], a[1])
+    S = synth.words_per_image(G)
+    ref = synth.draw_params(np.random.default_rng(3), B * chunk, atlas)
+    for c, m in enumerate(a[:chunk]):
+        W, ccap, wcap, nlab = m[:4]
+        assert W == 88 and wcap == 160 and ccap == ref['canvas_w'][c * B:(c + 1) * B].max()
+        assert np.array_equal(m[4:4 + B * S].reshape(B, S), ref['packed'][c * B:(c + 1) * B])
+        o = 4 + B * S
+        ll = m[o + B * G:o + B * G + B]
+        assert nlab == ll.sum() and np.array_equal(ll, ref['labels_len'][c * B:(c + 1) * B])
+        want = [gen.encode_maps[ch] for s in ref['strings'][c * B:(c + 1) * B] for ch in s]
+        assert m[o:o + nlab].tolist() == want
+        assert (m[o + B * G + B:o + B * G + 2 * B] == 85 // cfg.POOL_SCALE + cfg.OFFSET_TIME_STEP).all()
