@@ -17,13 +17,14 @@
 // Bit-exact against the numpy model tools/synth_model.py, which is bit-exact against Pillow 12 itself without the arc (tests/test_synth.py,
 // tests/test_gpu_synth.py) — hence no floating-point contraction in this file: Pillow's C code is compiled without fused multiply-adds.
 // HBM traffic per image: ~400 bytes of parameters + <= 30 KB of atlas masks (L2-resident: the atlas is 285 KB) read, W * 32 bytes written.
-// Bound: neither HBM nor the matrix pipes — one CU's vector ALU.  Measured alone (tools/synth_bench.py, profiles/r06l_synth_bench.log, batch of
-// 64): 63 us at W = 88 (4-6 glyphs), 126 us at W = 256 (10 glyphs) = 1.0 M / 0.5 M images/s, 12x / 9x what the training step consumes; by
-// stage, cut off one after the other (profiles/r06l_synth_stages.log, us at W = 88 / 256): empty launch 8 / 8, A 15 / 27, B 20 / 32 (the slowest
-// image of the batch decides: one that needs the bicubic pass), C 1.4 / 2.2, D 9 / 26, E rows 6 / 15, E columns + stores 3 / 15.  Beside a training
-// step it costs its share of the chip: 64 CUs x 63-126 us of 256 CUs x 750-1140 us = 2-3 % (the live loop runs at 0.97-0.98x of the
-// device-resident rate).  Known headroom, not built: four pixels per thread in D (dword LDS reads, shared products), row-per-wave loops
-// instead of the runtime divisions, register-resident taps in E.
+// Bound: neither HBM nor the matrix pipes — one CU's vector ALU per image.  Measured alone (tools/synth_bench.py, batch of 64): 57 us at W = 88
+// (4-6 glyphs), 104 us at W = 256 (10 glyphs) = 1.1 M / 0.6 M images/s, 13x / 11x what the training step consumes.  By stage, cut off one after
+// the other in the version before this one (63 / 126 us; profiles/r06l_synth_stages.log, us at W = 88 / 256): empty launch 8 / 8, A 15 / 27,
+// B 20 / 32 (the slowest image of the batch decides: one that needs the bicubic pass), C 1.4 / 2.2, D 9 / 26, E rows 6 / 15, E columns + stores
+// 3 / 15; this version took the runtime divisions out of the resampling loops (a wave per row), four pixels per thread in D and 16-byte stores
+// through LDS in F: -6 / -22 us, bit-identical.  Beside a training step the launch costs its share of the chip: 64 CUs x 57-104 us of 256 CUs x
+// 750-1140 us = 2 % (the live loop runs at 0.97-0.98x of the device-resident rate).  What is left is double-precision work Pillow's arithmetic
+// prescribes (coordinates and bilinear weights of every glyph pixel, a division per resampling tap).
 #include "common.h"
 #pragma clang fp contract(off)
 
@@ -84,24 +85,41 @@ __device__ __forceinline__ void sy_coeffs(int in_size, int out_size, int xx, int
     }
     cmin[slot] = xmin; cn[slot] = n;
 }
-// One resampling pass over `lines` independent lines: element i of line r is src[r * s_line + i * s_pos]; output likewise in dst (LDS or HBM).
-template <bool BICUBIC>
-__device__ void sy_resample(const uint8_t* src, int s_line, int s_pos, int in_size, int lines,
-                            uint8_t* dst, int d_line, int d_pos, int out_size, int* coef, int* cmin, int* cn, bool lines_fastest) {
+// One resampling pass over `lines` independent lines: element i of line r is src[r * s_line + i * s_pos]; output likewise in dst.  Both in LDS
+// (forced inline: the compiler then sees the address space and issues ds_ instead of flat_ accesses).  ROWS: a wave takes a line, its lanes the
+// output positions (horizontal passes: positions are contiguous bytes); otherwise a thread takes one (line, position) pair with the positions
+// fastest (vertical pass: 32 positions per line) — no runtime division in either loop (two per output were a third of the instructions).
+template <bool BICUBIC, bool ROWS>
+__device__ __forceinline__ void sy_resample(const uint8_t* src, int s_line, int s_pos, int in_size, int lines,
+                                            uint8_t* dst, int d_line, int d_pos, int out_size, int* coef, int* cmin, int* cn) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int c0 = 0; c0 < out_size; c0 += 256) {
         const int nc = min(256, out_size - c0);
         if ((int)threadIdx.x < nc) sy_coeffs<BICUBIC>(in_size, out_size, c0 + threadIdx.x, threadIdx.x, coef, cmin, cn);
         __syncthreads();
-        const int total = nc * lines;
-        for (int idx = threadIdx.x; idx < total; idx += SY_NT) {
-            int r, c;
-            if (lines_fastest) { r = idx % lines; c = idx / lines; } else { r = idx / nc; c = idx % nc; }
-            const int x0 = cmin[c], n = cn[c];
-            int acc = 1 << (SY_PREC - 1);
-            const uint8_t* s = src + (long)r * s_line + (long)x0 * s_pos;
-            for (int k = 0; k < n; ++k) acc += (int)s[(long)k * s_pos] * coef[k * 256 + c];
-            acc >>= SY_PREC;
-            dst[(long)r * d_line + (long)(c0 + c) * d_pos] = (uint8_t)(acc < 0 ? 0 : acc > 255 ? 255 : acc);
+        if (ROWS) {
+            for (int c = lane; c < nc; c += 64) {
+                const int x0 = cmin[c], n = cn[c];
+                for (int r = wave; r < lines; r += SY_NT / 64) {
+                    const uint8_t* s = src + r * s_line + x0 * s_pos;
+                    int acc = 1 << (SY_PREC - 1);
+                    for (int k = 0; k < n; ++k) acc += (int)s[k * s_pos] * coef[k * 256 + c];
+                    acc >>= SY_PREC;
+                    dst[r * d_line + (c0 + c) * d_pos] = (uint8_t)(acc < 0 ? 0 : acc > 255 ? 255 : acc);
+                }
+            }
+        } else {
+            const int total = nc * lines;
+            const bool pow32 = nc == 32;
+            for (int idx = threadIdx.x; idx < total; idx += SY_NT) {
+                const int r = pow32 ? idx >> 5 : idx / nc, c = pow32 ? idx & 31 : idx - (idx / nc) * nc;
+                const int x0 = cmin[c], n = cn[c];
+                const uint8_t* s = src + r * s_line + x0 * s_pos;
+                int acc = 1 << (SY_PREC - 1);
+                for (int k = 0; k < n; ++k) acc += (int)s[k * s_pos] * coef[k * 256 + c];
+                acc >>= SY_PREC;
+                dst[r * d_line + (c0 + c) * d_pos] = (uint8_t)(acc < 0 ? 0 : acc > 255 ? 255 : acc);
+            }
         }
         __syncthreads();
     }
@@ -119,6 +137,7 @@ __global__ __launch_bounds__(SY_NT) void captcha_synth_kernel(SynthArgs a) {
     const int width = p[0], cw = p[1], nw_out = p[2];
     const int L = min(p[3], a.G);
     const int bg = p[4], fg = p[5];
+    const int ws = (width + 3) & ~3;                          // row stride of img / the smoothed image: dword-aligned rows for stage D
 
     // A: background, glyphs in order.  The masks come out of the atlas ONCE, all of them in flight together, into the LDS the later stages use
     // (img + coefficient table, idle until stage B): sampled straight from L2, four dependent byte loads per pixel made this stage most of
@@ -187,9 +206,10 @@ __global__ __launch_bounds__(SY_NT) void captcha_synth_kernel(SynthArgs a) {
 
     // B: to the captcha's width
     if (cw > width) {
-        sy_resample<true>(canvas, cw, 1, cw, SY_H, img, width, 1, width, coef, cmin, cn, false);
+        sy_resample<true, true>(canvas, cw, 1, cw, SY_H, img, ws, 1, width, coef, cmin, cn);
     } else {
-        for (int i = tid; i < SY_H * width; i += SY_NT) img[i] = canvas[i];
+        for (int r = tid >> 6; r < SY_H; r += SY_NT / 64)
+            for (int x = tid & 63; x < width; x += 64) img[r * ws + x] = canvas[r * cw + x];
         __syncthreads();
     }
 
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(SY_NT) void captcha_synth_kernel(SynthArgs a) {
     for (int i = tid; i < SY_NDOTS * a.nstamp; i += SY_NT) {
         const int d = i / a.nstamp, s = i - d * a.nstamp;
         const int x = p[SY_HDR + 2 * d] + a.stamp[2 * s], y = p[SY_HDR + 2 * d + 1] + a.stamp[2 * s + 1];
-        if (x >= 0 && x < width && y >= 0 && y < SY_H) img[y * width + x] = (uint8_t)fg;
+        if (x >= 0 && x < width && y >= 0 && y < SY_H) img[y * ws + x] = (uint8_t)fg;
     }
     {
         const int bx0 = p[6], by0 = p[7], bx1 = p[8], by1 = p[9];
@@ -225,7 +245,7 @@ __global__ __launch_bounds__(SY_NT) void captcha_synth_kernel(SynthArgs a) {
                     const double s = sqrt(1.0 - u * u);
                     if (fabs(u) * eb > s * ea) continue;
                     const int yi = (int)floor(cy + sg * eb * s + 0.5);
-                    if (yi >= 0 && yi < SY_H && on_arc(x, yi)) img[yi * width + x] = (uint8_t)fg;
+                    if (yi >= 0 && yi < SY_H && on_arc(x, yi)) img[yi * ws + x] = (uint8_t)fg;
                 } else {                                               // steep stretches: one pixel per row
                     const int y = ya + (j - ncol);
                     const double v = (y - cy) / eb;
@@ -233,39 +253,73 @@ __global__ __launch_bounds__(SY_NT) void captcha_synth_kernel(SynthArgs a) {
                     const double s = sqrt(1.0 - v * v);
                     if (fabs(v) * ea >= s * eb) continue;
                     const int xi = (int)floor(cx + sg * ea * s + 0.5);
-                    if (xi >= 0 && xi < width && on_arc(xi, y)) img[y * width + xi] = (uint8_t)fg;
+                    if (xi >= 0 && xi < width && on_arc(xi, y)) img[y * ws + xi] = (uint8_t)fg;
                 }
             }
         }
     }
     __syncthreads();
 
-    // D: SMOOTH, img -> canvas region [60][width]
+    // D: SMOOTH, img -> canvas region [60][ws].  Four pixels per thread: three aligned dwords of each of the three rows instead of 36 byte reads, every
+    // product v * k formed once (the same product wherever it is used, so the sums are Filter.c's, term by term in its order).
     {
         const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
         uint8_t* sm = canvas;
-        for (int i = tid; i < SY_H * width; i += SY_NT) {
-            const int y = i / width, x = i - y * width;
-            uint8_t o = img[i];
-            if (y > 0 && y < SY_H - 1 && x > 0 && x < width - 1) {
-                const uint8_t* c = img + i;
-                float ss = 0.5f;
-                ss += (float)c[width - 1] * k1 + (float)c[width] * k1 + (float)c[width + 1] * k1;
-                ss += (float)c[-1] * k1 + (float)c[0] * k5 + (float)c[1] * k1;
-                ss += (float)c[-width - 1] * k1 + (float)c[-width] * k1 + (float)c[-width + 1] * k1;
-                o = ss <= 0.0f ? 0 : ss >= 255.0f ? 255 : (uint8_t)(int)ss;
+        const int wq = ws >> 2;
+        for (int y = tid >> 6; y < SY_H; y += SY_NT / 64) {
+            const bool edge_row = y == 0 || y == SY_H - 1;
+            const uint32_t* rm = (const uint32_t*)(img + (y > 0 ? y - 1 : y) * ws);
+            const uint32_t* r0 = (const uint32_t*)(img + y * ws);
+            const uint32_t* rp = (const uint32_t*)(img + (y < SY_H - 1 ? y + 1 : y) * ws);
+            for (int q = tid & 63; q < wq; q += 64) {
+                const uint32_t c0 = r0[q];
+                uint32_t outw = c0;
+                if (!edge_row) {
+                    const int ql = q > 0 ? q - 1 : q, qr = q < wq - 1 ? q + 1 : q;
+                    // bytes x0 - 1 .. x0 + 4 of the three rows as floats times k1 (and the centre row's own bytes times k5)
+                    float pm[6], pc[6], pp[6], pc5[4];
+                    const uint32_t m0 = rm[q], p0 = rp[q];
+                    const uint32_t ml = rm[ql], cl = r0[ql], pl = rp[ql], mr = rm[qr], cr = r0[qr], pr = rp[qr];
+                    pm[0] = (float)(ml >> 24) * k1; pc[0] = (float)(cl >> 24) * k1; pp[0] = (float)(pl >> 24) * k1;
+                    pm[5] = (float)(mr & 255) * k1; pc[5] = (float)(cr & 255) * k1; pp[5] = (float)(pr & 255) * k1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float vm = (float)((m0 >> (8 * j)) & 255), vc = (float)((c0 >> (8 * j)) & 255), vp = (float)((p0 >> (8 * j)) & 255);
+                        pm[j + 1] = vm * k1; pc[j + 1] = vc * k1; pp[j + 1] = vp * k1; pc5[j] = vc * k5;
+                    }
+                    outw = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int x = 4 * q + j;
+                        uint32_t o = (c0 >> (8 * j)) & 255;
+                        if (x > 0 && x < width - 1) {
+                            float ss = 0.5f;
+                            ss += pp[j] + pp[j + 1] + pp[j + 2];
+                            ss += pc[j] + pc5[j] + pc[j + 2];
+                            ss += pm[j] + pm[j + 1] + pm[j + 2];
+                            o = ss <= 0.0f ? 0u : ss >= 255.0f ? 255u : (uint32_t)(int)ss;
+                        }
+                        outw |= o << (8 * j);
+                    }
+                }
+                ((uint32_t*)(sm + y * ws))[q] = outw;
             }
-            sm[i] = o;
         }
     }
     __syncthreads();
 
-    // E: bilinear to [out_h][nw_out]: rows of the smoothed image first (-> img region, [60][nw_out]), then columns, straight to HBM as [W][out_h]
-    sy_resample<false>(canvas, width, 1, width, SY_H, img, nw_out, 1, nw_out, coef, cmin, cn, false);
+    // E: bilinear to [out_h][nw_out]: rows of the smoothed image first (-> img region, [60][nw_out]), then columns (-> canvas region as the
+    // [nw_out][out_h] rows the engine binds: the smoothed image is dead by then), F: 16-byte stores of those rows to HBM, right padding 0
+    sy_resample<false, true>(canvas, ws, 1, width, SY_H, img, nw_out, 1, nw_out, coef, cmin, cn);
+    sy_resample<false, false>(img, 1, nw_out, SY_H, nw_out, canvas, a.out_h, 1, a.out_h, coef, cmin, cn);
     uint8_t* o = a.out + (long)blockIdx.x * a.W * a.out_h;
-    sy_resample<false>(img, 1, nw_out, SY_H, nw_out, o, a.out_h, 1, a.out_h, coef, cmin, cn, false);
-    // F: right padding
-    for (int i = nw_out * a.out_h + tid; i < a.W * a.out_h; i += SY_NT) o[i] = 0;
+    const int nb = nw_out * a.out_h, tb = a.W * a.out_h;
+    if (((nb | tb) & 15) == 0 && (((size_t)o) & 15) == 0) {
+        for (int i = tid; i < (tb >> 4); i += SY_NT)
+            ((u32x4*)o)[i] = i < (nb >> 4) ? ((const u32x4*)canvas)[i] : (u32x4){0u, 0u, 0u, 0u};
+    } else {
+        for (int i = tid; i < tb; i += SY_NT) o[i] = i < nb ? canvas[i] : (uint8_t)0;
+    }
 }
 
 // params: [n_images][words_per_image] int32 records of utils/synth.draw_params (max_glyphs glyph slots each); atlas: the concatenated glyph masks;
