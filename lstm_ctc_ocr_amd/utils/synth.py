@@ -131,6 +131,10 @@ def draw_params(rng, n, atlas, min_len=None, max_len=None, width=160, px_per_cha
         raise ValueError('captcha canvas of %d px: the synthesis kernel holds %d' % (canvas_w.max(), CANVAS_CAP))
     if widths.max() > WIDTH_CAP or widths.min() < 8:
         raise ValueError('captcha widths %d..%d outside [8, %d]' % (widths.min(), widths.max(), WIDTH_CAP))
+    taps = 2 * np.ceil(2.0 * canvas_w / widths) + 1          # Resample.c: ksize of the bicubic pass canvas_w -> width
+    if taps.max() > TAPS_CAP:
+        raise ValueError('a %d px canvas on a %d px captcha needs %d resampling taps: the synthesis kernel holds %d'
+                         % (canvas_w[taps.argmax()], widths[taps.argmax()], taps.max(), TAPS_CAP))
     dots = np.stack([_randint(rng, 0, widths[:, None], (n, NDOTS)), rng.integers(0, HEIGHT + 1, (n, NDOTS))], -1)
     fifth = _trunc(widths / 5)
     x1 = _randint(rng, 0, fifth)
@@ -354,13 +358,16 @@ class DeviceSynthStream(object):
         return pix, meta[o:o + nlab], meta[o + B * G:o + B * G + B], meta[o + B * G + B:o + B * G + 2 * B]
 
     def close(self):
+        """Stop the feeder thread and the parameter workers (idempotent)."""
         self.halt.set()
-        self.thread.join(timeout=2.0)
-        for c in self.conns:
+        if self.thread.is_alive():
+            self.thread.join(timeout=2.0)
+        conns, procs, self.conns, self.procs = self.conns, self.procs, [], []
+        for c in conns:
             c.close()
-        for pr in self.procs:
+        for pr in procs:
             pr.terminate()
-        for pr in self.procs:
+        for pr in procs:
             pr.join(timeout=2.0)
 
     def __del__(self):

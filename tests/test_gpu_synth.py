@@ -120,3 +120,31 @@ def test_stream_is_reproducible_and_rank_dependent(atlas):
     for x, y in zip(a, b):
         assert all(torch.equal(u, v) for u, v in zip(x, y))
     assert not torch.equal(a[0][0], c[0][0])
+
+
+def test_stream_with_variable_widths(atlas):
+    """px_per_char batches: every batch padded to its own widest sample (gen.py:54-62), steps follow each sample's width, the engine re-plans per W"""
+    from lstm_ctc_ocr_amd.engine import Engine
+    from lstm_ctc_ocr_amd.models import get_network
+    st = synth.DeviceSynthStream('cuda:0', 16, seed=11, chunk=2, min_len=3, max_len=12, px_per_char=48)
+    try:
+        eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
+        eng.setup_optimizer('Adam', 1e-3)
+        seen = set()
+        for _ in range(6):
+            pix, lab, ll, steps = next(st)
+            B, W, H = pix.shape
+            seen.add(W)
+            assert B == 16 and H == 32 and W % cfg.POOL_SCALE == 0 and 76 <= W <= 320
+            s = steps.cpu().numpy()
+            nw = (s - cfg.OFFSET_TIME_STEP) * cfg.POOL_SCALE                      # each sample's own width, rounded down to the pool scale
+            assert nw.max() <= W and W - nw.max() < 2 * cfg.POOL_SCALE
+            host = pix.cpu().numpy()
+            for i in range(B):
+                assert not host[i, nw[i] + cfg.POOL_SCALE:].any() and host[i, :nw[i]].mean() > 100
+            assert np.isfinite(eng.train_step(pix, lab, ll, steps))
+        assert len(seen) >= 1
+        st.close()
+        st.close()                                                                # idempotent
+    finally:
+        st.close()

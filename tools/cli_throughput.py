@@ -69,7 +69,9 @@ def main():
     ap.add_argument('--synth', action='store_true', help='GPU-side synthesis (utils/synth.DeviceSynthStream) instead of the PIL worker ring')
     ap.add_argument('--workers', type=int, default=0)
     ap.add_argument('--pool', type=int, default=0)
-    ap.add_argument('--only', default='', help='run one configuration only: W88 or W256')
+    ap.add_argument('--only', default='', help='run one configuration only: W88, W256 or var')
+    ap.add_argument('--var', action='store_true', help='also run variable-width batches (3-12 characters at 48 px each: W = 76..312 after the resize, '
+                                                      'padded per batch - BASELINE configs[3] as the generators produce it)')
     ap.add_argument('--no-lag', action='store_true', help='wait for every loss at once (OCR_LOSS_LAG=0 of the training loop)')
     a = ap.parse_args()
     global LAG
@@ -80,7 +82,10 @@ def main():
         out['cgroup_cpu_max'] = open('/sys/fs/cgroup/cpu.max').read().strip()
     except Exception:
         pass
-    for name, kw in (('W88_4to6char', dict()), ('W256_10char', dict(min_len=10, max_len=10, width=480))):
+    confs = [('W88_4to6char', dict()), ('W256_10char', dict(min_len=10, max_len=10, width=480))]
+    if a.var or a.only == 'var':
+        confs.append(('varwidth_3to12char', dict(min_len=3, max_len=12, px_per_char=48)))
+    for name, kw in confs:
         if a.only and not name.startswith(a.only):
             continue
         eng = Engine(get_network('LSTM_train'), device='cuda:0', seed=3)
