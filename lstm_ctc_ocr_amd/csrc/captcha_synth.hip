@@ -17,14 +17,18 @@
 // Bit-exact against the numpy model tools/synth_model.py, which is bit-exact against Pillow 12 itself without the arc (tests/test_synth.py,
 // tests/test_gpu_synth.py) — hence no floating-point contraction in this file: Pillow's C code is compiled without fused multiply-adds.
 // HBM traffic per image: ~400 bytes of parameters + <= 30 KB of atlas masks (L2-resident: the atlas is 285 KB) read, W * 32 bytes written.
-// Bound: neither HBM nor the matrix pipes — one CU's vector ALU per image.  Measured alone (tools/synth_bench.py, batch of 64): 57 us at W = 88
-// (4-6 glyphs), 104 us at W = 256 (10 glyphs) = 1.1 M / 0.6 M images/s, 13x / 11x what the training step consumes.  By stage, cut off one after
-// the other in the version before this one (63 / 126 us; profiles/r06l_synth_stages.log, us at W = 88 / 256): empty launch 8 / 8, A 15 / 27,
-// B 20 / 32 (the slowest image of the batch decides: one that needs the bicubic pass), C 1.4 / 2.2, D 9 / 26, E rows 6 / 15, E columns + stores
-// 3 / 15; this version took the runtime divisions out of the resampling loops (a wave per row), four pixels per thread in D and 16-byte stores
-// through LDS in F: -6 / -22 us, bit-identical.  Beside a training step the launch costs its share of the chip: 64 CUs x 57-104 us of 256 CUs x
-// 750-1140 us = 2 % (the live loop runs at 0.97-0.98x of the device-resident rate).  What is left is double-precision work Pillow's arithmetic
-// prescribes (coordinates and bilinear weights of every glyph pixel, a division per resampling tap).
+// Bound: neither HBM nor the matrix pipes, and not the vector ALU's throughput either — the LATENCY of one workgroup's dependent work: counters of
+// the launch alone (tools/prof_synth_pmc.sh, profiles/r06*_synth_pmc.txt, average of the three workloads): 1.0 MB read + 0.44 MB written per launch
+// (0.015 TB/s), 4.6 M vector + 2.9 M scalar + 0.44 M LDS wave instructions, vector ALU active 30 % of the 64 busy CUs' cycles, waves waiting on
+// a dependency half of theirs (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.50), LDS bank conflicts 16 % of the LDS-active cycles.  Per image the critical
+// path is: glyph passes one after the other (a barrier each), double-precision coordinate / weight chains per pixel, one IEEE division per
+// resampling tap on the few waves that own a column — all prescribed by Pillow's arithmetic and order.  Measured alone (tools/synth_bench.py,
+// batch of 64): 57 us at W = 88 (4-6 glyphs), 104 us at W = 256 (10 glyphs) = 1.1 M / 0.6 M images/s, 13x / 11x what the training step consumes.
+// By stage, cut off one after the other in the version before this one (63 / 126 us; profiles/r06l_synth_stages.log, us at W = 88 / 256): empty
+// launch 8 / 8, A 15 / 27, B 20 / 32 (the slowest image of the batch decides: one that needs the bicubic pass), C 1.4 / 2.2, D 9 / 26, E rows
+// 6 / 15, E columns + stores 3 / 15; this version took the runtime divisions out of the resampling loops (a wave per row), four pixels per thread
+// in D and 16-byte stores through LDS in F: -6 / -22 us, bit-identical.  Beside a training step the launch holds 64 CUs' LDS and a third of their
+// issue slots for 57-104 us of a 750-1140 us step: the live loop runs at 0.97-0.98x of the device-resident rate.
 #include "common.h"
 #pragma clang fp contract(off)
 

@@ -34,6 +34,7 @@ timeout 600 python tools/lstm_tail_race_probe.py --width 320 --ragged --train --
 timeout 600 python tools/cli_throughput.py --iters 1500 2>&1 | grep -v amdgpu.ids | tail -5 | tee $O/${T}_cli_throughput_live.log
 timeout 600 python tools/cli_throughput.py --iters 1500 --synth 2>&1 | grep -v amdgpu.ids | tail -4 | tee $O/${T}_cli_throughput_synth.log
 timeout 300 python tools/synth_bench.py 2>&1 | grep -v "amdgpu.ids\|WARNING" | tee $O/${T}_synth_bench.log
+bash tools/prof_synth_pmc.sh ${T} > /dev/null 2>&1; head -30 $O/${T}_synth_pmc.txt | cut -c1-120
 timeout 300 python tools/lstm_timeout_probe.py --live --iters 20000 2>&1 | grep -v "amdgpu.ids" | tail -3 | tee $O/${T}_live_soak_20k.log
 ( time timeout 900 ./train.sh --iters 40000 2>&1 | grep -E "^iter: *[0-9]*000 |accuracy|done solving|speed" | tail -60 ) > $O/${T}_train_cli_40k.log 2>&1; tail -6 $O/${T}_train_cli_40k.log
 ( time OCR_PIPELINE=ring timeout 900 ./train.sh --iters 40000 2>&1 | grep -E "^iter: *[0-9]*000 |accuracy|done solving|speed" | tail -60 ) > $O/${T}_train_cli_40k_pil_ring.log 2>&1; tail -6 $O/${T}_train_cli_40k_pil_ring.log
