@@ -18,7 +18,6 @@ kernel against PIL, CPU) and tests/test_gpu_synth.py (the kernel against both). 
 (a thin parametric ellipse outline instead of ImagingDrawArc's clip tree); the tests bound what that costs in pixels.
 """
 import math
-import os
 import queue
 import threading
 
@@ -272,7 +271,7 @@ class DeviceSynthStream(object):
         self.d_atlas = torch.from_numpy(self.atlas.data).to(self.device)
         self.d_stamp = torch.from_numpy(dot_stamp().reshape(-1)).to(self.device)
         self.S = words_per_image(self.G)
-        self.max_w = gen.padded_width(int(cfg.IMG_HEIGHT / HEIGHT * (WIDTH_CAP if self.kw['px_per_char'] else self.kw['width'])))
+        self.max_w = gen.padded_width(int(cfg.IMG_HEIGHT / HEIGHT * (WIDTH_CAP if self.kw['px_per_char'] else self.kw['width'])))    # widest padded batch
         nmeta = batch_words(self.B, self.G)
         self.depth = depth
         ctx = multiprocessing.get_context('fork')
