@@ -17,8 +17,14 @@ The checker is PIL itself, driven with the SAME parameters (oracle/synth_ref.py,
 kernel against PIL, CPU) and tests/test_gpu_synth.py (the kernel against both).  The noise arc is the one primitive that is not PIL's algorithm
 (a thin parametric ellipse outline instead of ImagingDrawArc's clip tree); the tests bound what that costs in pixels.
 """
+import fcntl
 import math
+import os
+import pickle
 import queue
+import select
+import subprocess
+import sys
 import threading
 
 import numpy as np
@@ -230,16 +236,16 @@ def fill_batches(p, B, G, out):
         m[o + B * G + B:o + B * G + 2 * B] = p['steps'][s]
 
 
-def _param_worker(conn, seed, B, G, chunk, atlas, kw):
-    """Child process: draws parameters, `chunk` batches per numpy pass, and writes one message per batch into its pipe (which blocks when the
-    feeder is `depth` batches ahead: the back-pressure)."""
+def _param_worker(send, seed, B, G, chunk, atlas, kw):
+    """Worker loop: draws parameters, `chunk` batches per numpy pass, and hands one int32 message per batch to `send` (a pipe write that blocks
+    when the reader is behind: the back-pressure)."""
     try:
         rng = np.random.default_rng(seed)
         out = np.zeros((chunk, batch_words(B, G)), np.int32)
         while True:
             fill_batches(draw_params(rng, B * chunk, atlas, strings=False, **kw), B, G, out)
             for c in range(chunk):
-                conn.send_bytes(out[c])
+                send(out[c])
     except (BrokenPipeError, EOFError, KeyboardInterrupt, OSError):
         pass
     except BaseException:
@@ -248,16 +254,50 @@ def _param_worker(conn, seed, B, G, chunk, atlas, kw):
         raise
 
 
+_WORKER_CFG_KEYS = ('IMG_HEIGHT', 'POOL_SCALE', 'OFFSET_TIME_STEP', 'MIN_LEN', 'MAX_LEN')
+
+
+def _worker_main():
+    """`python -m lstm_ctc_ocr_amd.utils.synth`: a parameter worker of DeviceSynthStream as a process of its own.  The job (seed, batch geometry,
+    the glyph atlas, the few cfg values draw_params reads) arrives pickled on stdin, the batch messages leave as raw int32 on stdout.  A fresh
+    interpreter instead of a fork of the training process: forking a process that has tens of GB of device memory mapped copies its page tables
+    (8 s per worker inside the GPU test-suite's process), and the child would carry the HIP runtime's state for nothing."""
+    import pickle
+    import sys
+    job = pickle.load(sys.stdin.buffer)
+    for k, v in job['cfg'].items():
+        setattr(cfg, k, v)
+    out = sys.stdout.buffer
+
+    def send(row):
+        out.write(memoryview(row).cast('B'))
+        out.flush()
+    _param_worker(send, job['seed'], job['B'], job['G'], job['chunk'], job['atlas'], job['kw'])
+
+
+def spawn_worker(seed, B, G, chunk, atlas, kw):
+    """Start one parameter worker (_worker_main in a fresh interpreter); its stdout delivers batch_words(B, G) int32 words per batch."""
+    pkg_parent = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, PYTHONPATH=pkg_parent + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    pr = subprocess.Popen([sys.executable, '-m', 'lstm_ctc_ocr_amd.utils.synth'], stdin=subprocess.PIPE, stdout=subprocess.PIPE, bufsize=0, env=env)
+    try:
+        fcntl.fcntl(pr.stdout.fileno(), 1031, 1 << 20)                 # F_SETPIPE_SZ: room for a dozen batches ahead of the feeder
+    except OSError:
+        pass
+    pickle.dump({'seed': seed, 'B': B, 'G': G, 'chunk': chunk, 'atlas': atlas, 'kw': kw, 'cfg': {k: cfg[k] for k in _WORKER_CFG_KEYS}}, pr.stdin)
+    pr.stdin.close()
+    return pr
+
+
 class DeviceSynthStream(object):
     """Iterator of device-resident batches — the tuples utils.pipeline.DeviceBatchStream yields: (pixels uint8 [B, W, 32], labels int32 [n],
-    label_len int32 [B], steps int32 [B]) — synthesised on the GPU.  `workers` child processes draw the parameters (~0.3 ms of numpy per batch:
-    drawn on a thread of the training process they held its GIL in bursts of several ms and the launch loop stalled behind them — 0.96x of
-    the device-resident rate instead of the 0.99x the kernel costs); a feeder thread reads their messages round-robin straight into pinned
+    label_len int32 [B], steps int32 [B]) — synthesised on the GPU.  `workers` processes (fresh interpreters: _worker_main) draw the parameters
+    (~0.3 ms of numpy per batch: drawn on a thread of the training process they held its GIL in bursts of several ms and the launch loop stalled
+    behind them); a feeder thread reads their messages round-robin straight into pinned
     memory, copies them on a side stream and launches the synthesis kernel there, `depth` batches ahead of the training stream.  A returned
     batch stays valid until the NEXT call of next().  Deterministic for a given (seed, workers, chunk)."""
 
     def __init__(self, device, batch_size, depth=4, seed=None, chunk=8, workers=2, **gen_kwargs):
-        import multiprocessing
         import torch
         from .. import ops
         self.torch, self.ops = torch, ops
@@ -274,15 +314,7 @@ class DeviceSynthStream(object):
         self.max_w = gen.padded_width(int(cfg.IMG_HEIGHT / HEIGHT * (WIDTH_CAP if self.kw['px_per_char'] else self.kw['width'])))    # widest padded batch
         nmeta = batch_words(self.B, self.G)
         self.depth = depth
-        ctx = multiprocessing.get_context('fork')
-        self.conns, self.procs = [], []
-        for i in range(max(1, int(workers))):
-            rd, wr = ctx.Pipe(duplex=False)
-            pr = ctx.Process(target=_param_worker, args=(wr, seed + 1000003 * i, self.B, self.G, max(1, int(chunk)), self.atlas, self.kw), daemon=True)
-            pr.start()
-            wr.close()
-            self.conns.append(rd)
-            self.procs.append(pr)
+        self.procs = [spawn_worker(seed + 1000003 * i, self.B, self.G, max(1, int(chunk)), self.atlas, self.kw) for i in range(max(1, int(workers)))]
         self.h_meta = [torch.empty(nmeta, dtype=torch.int32).pin_memory() for _ in range(depth)]
         self.d_meta = [torch.empty(nmeta, dtype=torch.int32, device=self.device) for _ in range(depth)]
         self.d_pix = [torch.empty(self.B * self.max_w * cfg.NUM_FEATURES, dtype=torch.uint8, device=self.device) for _ in range(depth)]
@@ -312,15 +344,19 @@ class DeviceSynthStream(object):
                 if done is not None:
                     done.synchronize()                       # everything that read this buffer (and its pinned source) has finished
                 hm = self.h_meta[k].numpy()
-                conn = self.conns[turn % len(self.conns)]
+                pr = self.procs[turn % len(self.procs)]
                 turn += 1
-                while not conn.poll(0.2):
+                mv, got = memoryview(hm).cast('B'), 0
+                while got < len(mv):
+                    ready, _, _ = select.select([pr.stdout], [], [], 0.2)
                     if self.halt.is_set():
                         return
-                try:
-                    conn.recv_bytes_into(hm)
-                except EOFError:
-                    raise RuntimeError('a synthesis parameter worker died (its traceback is on stderr)')
+                    if not ready:
+                        continue
+                    n = pr.stdout.readinto(mv[got:])
+                    if not n:
+                        raise RuntimeError('a synthesis parameter worker died (exit status %s; its traceback is on stderr)' % pr.poll())
+                    got += n
                 W, ccap, wcap, nlab = int(hm[0]), int(hm[1]), int(hm[2]), int(hm[3])
                 with torch.cuda.stream(self.side):
                     self.d_meta[k].copy_(self.h_meta[k], non_blocking=True)
@@ -361,16 +397,22 @@ class DeviceSynthStream(object):
         self.halt.set()
         if self.thread.is_alive():
             self.thread.join(timeout=2.0)
-        conns, procs, self.conns, self.procs = self.conns, self.procs, [], []
-        for c in conns:
-            c.close()
+        procs, self.procs = self.procs, []
         for pr in procs:
             pr.terminate()
         for pr in procs:
-            pr.join(timeout=2.0)
+            try:
+                pr.wait(timeout=2.0)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+            pr.stdout.close()
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+
+if __name__ == '__main__':
+    _worker_main()

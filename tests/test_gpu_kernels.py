@@ -358,23 +358,44 @@ def test_conv3x3_fwd_dgrad_wgrad(dev, Nb, W, H, Ci, Co):
     assert relerr(dw2.cpu() - 1.0, wr.grad) < 1e-4
 
 
-@pytest.mark.parametrize("env", [dict(OCR_CONV_K2='1', OCR_K2_CFG='A'), dict(OCR_CONV_K2='1', OCR_K2_CFG='D'),
-                                 dict(OCR_CONV_K2='1', OCR_K2_CFG='A', OCR_CONV_K3='0'), dict(OCR_CONV_K2='1', OCR_K2_CFG='D', OCR_CONV_K3='0'),
-                                 dict(OCR_CONV_K2='0'), dict(OCR_CONV_WS='2'), dict(OCR_CONV_WS='0')])
-def test_conv_kernel_generations_through_the_convolution_parity_tests(dev, env):
+_CONV_GENERATION_ENVS = [dict(OCR_CONV_K2='1', OCR_K2_CFG='A'), dict(OCR_CONV_K2='1', OCR_K2_CFG='D'),
+                         dict(OCR_CONV_K2='1', OCR_K2_CFG='A', OCR_CONV_K3='0'), dict(OCR_CONV_K2='1', OCR_K2_CFG='D', OCR_CONV_K3='0'),
+                         dict(OCR_CONV_K2='0'), dict(OCR_CONV_WS='2'), dict(OCR_CONV_WS='0')]
+
+
+@pytest.fixture(scope='module')
+def conv_generation_runs():
+    """The seven knob settings below, each a pytest subprocess over the convolution parity tests (the knobs are read once per process) — started
+    together, four at a time: one after the other they were 200 s of the GPU suite, most of it the CPU references of a single process."""
+    import concurrent.futures
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(env):
+        # conv_ws forced onto every shape it covers changes WHICH kernel computes the unfused side of the "write-out fusion == separate passes,
+        # bit for bit" tests (those hold within one kernel family: same fp32 summation order): it runs the parity and fused-pool tests
+        sel = 'test_conv3x3_fwd_dgrad_wgrad or test_conv3x3_relu_pool' if env.get('OCR_CONV_WS') == '2' else 'test_conv3x3'
+        try:
+            out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_kernels.py'), '-q', '-k', sel],
+                                 env=dict(os.environ, OMP_NUM_THREADS='4', MKL_NUM_THREADS='4', **env), capture_output=True, text=True, timeout=1200, cwd=root)
+            return out.returncode, out.stdout[-3000:]
+        except subprocess.TimeoutExpired as e:
+            return -1, 'timed out: %s' % e
+    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
+        return list(ex.map(run, _CONV_GENERATION_ENVS))
+
+
+@pytest.mark.parametrize("env", range(len(_CONV_GENERATION_ENVS)), ids=['env%d' % i for i in range(len(_CONV_GENERATION_ENVS))])
+def test_conv_kernel_generations_through_the_convolution_parity_tests(dev, conv_generation_runs, env):
     """conv_k2.hip / conv_k3.hip (in-workgroup K split; tiles A 256 x 128 and D 256 x 64 pixels x channels; k3 = the plane layout of the
     halo, taken where it covers the shape) with each tile forced onto every shape it covers, conv_k2 alone (OCR_CONV_K3=0), and the
     conv_halo.hip kernels alone, through the same parity / fused-pool / accumulate tests (the knobs are read once per process; by default
     the dispatcher mixes the kernels per layer).  OCR_CONV_WS=2: the weight-stationary persistent kernel (conv_ws.hip) on EVERY shape it
     covers, whatever the grid; =0: none (the shapes it takes by default stay tested on the plane-layout kernels)."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # conv_ws forced onto every shape it covers changes WHICH kernel computes the unfused side of the "write-out fusion == separate passes,
-    # bit for bit" tests (those hold within one kernel family: same fp32 summation order): it runs the parity and fused-pool tests
-    sel = 'test_conv3x3_fwd_dgrad_wgrad or test_conv3x3_relu_pool' if env.get('OCR_CONV_WS') == '2' else 'test_conv3x3'
-    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_kernels.py'), '-q', '-k', sel],
-                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=1200, cwd=root)
-    assert out.returncode == 0, out.stdout[-3000:]
+    rc, tail = conv_generation_runs[env]
+    assert rc == 0, (_CONV_GENERATION_ENVS[env], tail)
 
 
 @pytest.mark.parametrize("Mk,I,J", [(4032, 512, 2048), (4032, 256, 1024), (4032, 512, 64), (100, 72, 136), (300, 128, 128), (1000, 256, 384)])

@@ -136,7 +136,7 @@ def test_parameter_worker_messages(atlas):
     def take(seed, n):
         ctx = multiprocessing.get_context('fork')
         rd, wr = ctx.Pipe(duplex=False)
-        pr = ctx.Process(target=synth._param_worker, args=(wr, seed, B, G, chunk, atlas, kw), daemon=True)
+        pr = ctx.Process(target=synth._param_worker, args=(wr.send_bytes, seed, B, G, chunk, atlas, kw), daemon=True)
         pr.start()
         wr.close()
         out = []
@@ -165,3 +165,31 @@ def test_parameter_worker_messages(atlas):
         want = [gen.encode_maps[ch] for s in ref['strings'][c * B:(c + 1) * B] for ch in s]
         assert m[o:o + nlab].tolist() == want
         assert (m[o + B * G + B:o + B * G + 2 * B] == 85 // cfg.POOL_SCALE + cfg.OFFSET_TIME_STEP).all()
+
+
+def test_parameter_worker_as_a_process_of_its_own(atlas):
+    """what DeviceSynthStream starts: `python -m lstm_ctc_ocr_amd.utils.synth`, job pickled on stdin, raw int32 batch messages on stdout — the same
+    messages the in-process worker loop produces for the seed"""
+    B, G, chunk = 8, cfg.MAX_LEN, 2
+    kw = dict(min_len=None, max_len=None, width=160, px_per_char=None)
+    pr = synth.spawn_worker(3, B, G, chunk, atlas, kw)
+    try:
+        nbytes = synth.batch_words(B, G) * 4
+        msgs = []
+        for _ in range(3):
+            buf = bytearray()
+            while len(buf) < nbytes:
+                part = pr.stdout.read(nbytes - len(buf))
+                assert part, 'worker ended early (exit status %s)' % pr.poll()
+                buf += part
+            msgs.append(np.frombuffer(bytes(buf), np.int32))
+    finally:
+        pr.terminate()
+        pr.wait(5)
+        pr.stdout.close()
+    ref = np.zeros((chunk, synth.batch_words(B, G)), np.int32)
+    rng = np.random.default_rng(3)
+    synth.fill_batches(synth.draw_params(rng, B * chunk, atlas, strings=False, **kw), B, G, ref)
+    assert np.array_equal(msgs[0], ref[0]) and np.array_equal(msgs[1], ref[1])
+    synth.fill_batches(synth.draw_params(rng, B * chunk, atlas, strings=False, **kw), B, G, ref)
+    assert np.array_equal(msgs[2], ref[0])
