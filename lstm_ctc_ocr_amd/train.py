@@ -93,7 +93,7 @@ class SolverWrapper(object):
         own_gen = train_gen is None
         if train_gen is None:
             # OCR_PIPELINE: 'synth' (default for the reference's single-channel captchas) = the batches are composed on the GPU (utils/synth.py: no
-            # PIL workers, the loop runs at 0.97-0.98x of the device-resident rate); 'ring' = PIL worker processes -> shared-memory ring -> pinned
+            # PIL workers, the loop runs at 0.96-0.98x of the device-resident rate); 'ring' = PIL worker processes -> shared-memory ring -> pinned
             # asynchronous H2D (utils/pipeline.py: 0.42-0.53x on 16 cores); 'legacy' = the reference's transport, 12 processes -> pickled float batches
             mode = os.environ.get('OCR_PIPELINE') or ('synth' if cfg.NCHANNELS == 1 else 'ring')
             if mode == 'legacy':

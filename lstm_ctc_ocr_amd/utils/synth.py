@@ -278,7 +278,9 @@ def _worker_main():
 def spawn_worker(seed, B, G, chunk, atlas, kw):
     """Start one parameter worker (_worker_main in a fresh interpreter); its stdout delivers batch_words(B, G) int32 words per batch."""
     pkg_parent = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, PYTHONPATH=pkg_parent + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    # one thread per worker: a fresh interpreter's BLAS / OpenMP pools would spin on the cores the training process's launch loop needs
+    env = dict(os.environ, PYTHONPATH=pkg_parent + os.pathsep + os.environ.get('PYTHONPATH', ''), OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1',
+               MKL_NUM_THREADS='1')
     pr = subprocess.Popen([sys.executable, '-m', 'lstm_ctc_ocr_amd.utils.synth'], stdin=subprocess.PIPE, stdout=subprocess.PIPE, bufsize=0, env=env)
     try:
         fcntl.fcntl(pr.stdout.fileno(), 1031, 1 << 20)                 # F_SETPIPE_SZ: room for a dozen batches ahead of the feeder
