@@ -148,3 +148,26 @@ def test_stream_with_variable_widths(atlas):
         st.close()                                                                # idempotent
     finally:
         st.close()
+
+
+def test_raw_ctypes_binding_of_the_entry_point(atlas):
+    """INTEGRATION.md's stub, verbatim in spirit: plain ctypes on the shared library, no ops / _native wrappers — and Pillow as the checker"""
+    import ctypes
+    from lstm_ctc_ocr_amd import _native as nat
+    lib = ctypes.CDLL(nat.LIB_PATH)
+    lib.ocr_captcha_synth.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.ocr_captcha_synth.restype = ctypes.c_int
+    P = synth.draw_params(np.random.default_rng(31), 8, atlas)
+    P['packed'][:, 8] = P['packed'][:, 6]                               # no arc: byte-identical to Pillow
+    W = gen.padded_width(int(P['nw_out'].max()))
+    n, S = P['packed'].shape
+    rec = torch.from_numpy(P['packed']).cuda()
+    atlas_dev = torch.from_numpy(atlas.data).cuda()
+    stamp_dev = torch.from_numpy(synth.dot_stamp().reshape(-1)).cuda()
+    pix = torch.empty((n, W, 32), dtype=torch.uint8, device='cuda')
+    rc = lib.ocr_captcha_synth(rec.data_ptr(), n, S, P['max_glyphs'], atlas_dev.data_ptr(), stamp_dev.data_ptr(), stamp_dev.numel() // 2,
+                               pix.data_ptr(), W, 32, int(P['canvas_w'].max()), int(P['widths'].max()), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(pix.cpu().numpy(), synth_ref.render_batch(P, atlas, W, arc=False))
