@@ -2,7 +2,7 @@
 (SURVEY.md 7 "GPU-side synthesis", 8 f2; reference: /root/reference/lib/lstm/utils/gen.py:31-67 generateImg + groupBatch).
 
 Why: PIL renders ~0.6-1.4 k captchas per second and core; the 16 cores of an MI355X box feed 0.42-0.53x of what ONE GPU trains
-(profiles/r06_final8_cli_throughput_live.log), so the live training loop ran at the generator's pace.  What a captcha costs is pixel work —
+(profiles/r06_final9_cli_throughput_live.log), so the live training loop ran at the generator's pace.  What a captcha costs is pixel work —
 five glyph rotations, a bicubic resize, a 3 x 3 filter, a bilinear resize — and none of it needs the host.
 
 Split:
