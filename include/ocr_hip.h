@@ -343,7 +343,9 @@ int ocr_guard_flag(const void* guard_addrs, int nguard, float* flag_out, void* s
  * params: int32 [n_images][words_per_image] records (lstm_ctc_ocr_amd/utils/synth.draw_params: every random draw + the integer geometry;
  * max_glyphs glyph slots per record); atlas: concatenated 8-bit glyph masks (records hold byte offsets into it); stamp: n_stamp (dx, dy) int32
  * pairs = the footprint of one noise dot; canvas_cap / width_cap >= every record's canvas_w / width (they size the LDS image:
- * 60 * (canvas_cap + width_cap) + 34816 bytes <= 160 KB, else OCR_ERR_INVALID). */
+ * 60 * (canvas_cap + width_cap) + 34816 bytes <= 160 KB, else OCR_ERR_INVALID).  The records live in device memory: that they respect the two
+ * caps, the atlas' extent and max_glyphs is the caller's contract and is NOT checked by the launch (utils/synth.draw_params produces records and
+ * caps together). */
 int ocr_captcha_synth(const int* params, int n_images, int words_per_image, int max_glyphs, const void* atlas, const int* stamp, int n_stamp,
                       void* out, int W, int out_h, int canvas_cap, int width_cap, void* stream);
 
